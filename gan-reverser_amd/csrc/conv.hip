@@ -1,0 +1,375 @@
+// conv.hip — 3x3 stride-1 pad-1 cross-correlation on gfx950 as implicit GEMM on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 products/accumulation, 256 FLOP/clk/CU).
+//
+// Replaces nn.SpatialConvolution / cudnn.SpatialConvolution(…,3,3,1,1,1,1) as instantiated at
+// reference models.lua:122,128,132 (G, with the preceding nn.SpatialUpSamplingNearest(2) folded
+// into the input addressing) and models.lua:409,414,419,426,431,436 (R): forward, backward-data
+// (same kernel on transposed+flipped weights) and backward-weight.
+//
+// GEMM view (forward):  M = Cout, N = B*H*W output pixels, K = 9*Cin.
+//   * one workgroup (4 waves) owns a tile of 256 output pixels of one image x CT = 32*MT output channels;
+//     wave w owns pixels [64w, 64w+64) as two 32-lane pixel groups x MT 32-channel row blocks.
+//   * K is walked in chunks of 8 input channels (72 k-values); per chunk the zero-padded input patch
+//     [8][rows+2][cols+2] and the k-major weight slice [72][CT] are staged global -> registers -> LDS,
+//     double buffered, one barrier per chunk.
+//   * k order inside a chunk is (tap, channel pair): the two halves of a wave (lanes 0-31 / 32-63) take
+//     adjacent input channels at the same tap, so the B operand read is patch[ci+h][pix + tap offset]
+//     (consecutive lanes -> consecutive LDS words) and the A operand read is wts[k+h][o] (same).
+#include "kernels.h"
+
+namespace gr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// blocks b and b+8 share an XCD (round-robin dispatch, observed): give each XCD a contiguous run of logical tiles
+// so that the o-tiles of one pixel tile and neighbouring pixel tiles hit the same L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  const int q = n >> 3, r = n & 7, xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+struct ConvArgs {
+  const float* in; const float* wt; const float* bias; float* out;
+  int B, Cin, Cout, H, W;
+  int up, nchunks, cout_pad, tiles_x, tiles_y, n_otiles;
+};
+
+template <int MT, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
+  constexpr int NG = 2, PT = 256, TR = PT / TW, PR = TR + 2, PC = TW + 2, PS = PR * PC, CK = CONV_CK, CT = MT * 32;
+  constexpr int NSLOT = (PS + 255) / 256;
+  constexpr int WROWS = 9 * CK;
+  constexpr int WV4 = WROWS * CT / 4;            // float4s of one weight chunk
+  constexpr int NWF = WV4 / 256, WREM = WV4 % 256;   // full rounds of 256 float4 loads + a partial one
+  static_assert((CK * PS * 4) % 16 == 0, "weight LDS region must stay 16-byte aligned");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* patch = smem;                 // [2][CK*PS]
+  float* wts = smem + 2 * CK * PS;     // [2][WROWS*CT]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * CT;
+  const int H = a.H, W = a.W;
+  const int Hs = a.up ? H >> 1 : H, Ws = a.up ? W >> 1 : W;
+  const size_t HWs = (size_t)Hs * Ws;
+
+  int src_off[NSLOT]; bool inb[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int e = tid + 256 * s, r = e / PC, c = e - r * PC, yy = y0 + r - 1, xx = x0 + c - 1;
+    inb[s] = e < PS && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    src_off[s] = a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx;
+  }
+  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
+
+  // staging registers of the next chunk (kept as plain scalars/arrays indexed by constants so they stay in VGPRs)
+  float pv[CK][NSLOT];
+  float4 wv0 = make_float4(0.f, 0.f, 0.f, 0.f), wv1 = wv0, wv2 = wv0, wv3 = wv0, wv4 = wv0, wv5 = wv0, wv6 = wv0, wv7 = wv0, wv8 = wv0;
+  static_assert(NWF + (WREM > 0) <= 9, "weight staging registers");
+#define GR_WLOAD(i, reg)                                                                         \
+  if ((i) < NWF || ((i) == NWF && WREM > 0 && tid < WREM)) {                                      \
+    const int f_ = tid + 256 * (i), row_ = f_ / (CT / 4), c4_ = f_ - row_ * (CT / 4);            \
+    reg = *reinterpret_cast<const float4*>(wp_ + (size_t)row_ * a.cout_pad + c4_ * 4);           \
+  }
+#define GR_WSTORE(i, reg)                                                                        \
+  if ((i) < NWF || ((i) == NWF && WREM > 0 && tid < WREM)) *reinterpret_cast<float4*>(wd_ + (tid + 256 * (i)) * 4) = reg;
+#define GR_LOAD_CHUNK(ch_)                                                                       \
+  {                                                                                              \
+    _Pragma("unroll") for (int cil = 0; cil < CK; ++cil) {                                       \
+      const int ci = (ch_) * CK + cil;                                                           \
+      const float* p_ = in_base + (size_t)ci * HWs;                                              \
+      _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) pv[cil][s] = (inb[s] && ci < a.Cin) ? p_[src_off[s]] : 0.f; \
+    }                                                                                            \
+    const float* wp_ = a.wt + (size_t)(ch_) * WROWS * a.cout_pad + o0;                           \
+    GR_WLOAD(0, wv0) GR_WLOAD(1, wv1) GR_WLOAD(2, wv2) GR_WLOAD(3, wv3) GR_WLOAD(4, wv4)         \
+    GR_WLOAD(5, wv5) GR_WLOAD(6, wv6) GR_WLOAD(7, wv7) GR_WLOAD(8, wv8)                          \
+  }
+#define GR_STORE_CHUNK(buf_)                                                                     \
+  {                                                                                              \
+    float* pd_ = patch + (buf_) * CK * PS;                                                       \
+    _Pragma("unroll") for (int cil = 0; cil < CK; ++cil)                                         \
+      _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                        \
+        const int e_ = tid + 256 * s;                                                            \
+        if (e_ < PS) pd_[cil * PS + e_] = pv[cil][s];                                            \
+      }                                                                                          \
+    float* wd_ = wts + (buf_) * WROWS * CT;                                                      \
+    GR_WSTORE(0, wv0) GR_WSTORE(1, wv1) GR_WSTORE(2, wv2) GR_WSTORE(3, wv3) GR_WSTORE(4, wv4)    \
+    GR_WSTORE(5, wv5) GR_WSTORE(6, wv6) GR_WSTORE(7, wv7) GR_WSTORE(8, wv8)                      \
+  }
+
+  f32x16 acc[MT][NG];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][ng][r] = 0.f;
+
+  int pixoff[NG];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
+    pixoff[ng] = pr * PC + pc + h * PS;
+  }
+  const int aoff = h * CT + l31;
+
+  GR_LOAD_CHUNK(0)
+  GR_STORE_CHUNK(0)
+  __syncthreads();
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+    if (ch + 1 < a.nchunks) GR_LOAD_CHUNK(ch + 1)
+    const float* pb = patch + (ch & 1) * CK * PS;
+    const float* wb = wts + (ch & 1) * WROWS * CT;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int cp = 0; cp < CK / 2; ++cp) {
+        float av[MT], bv[NG];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = wb[(tap * CK + 2 * cp) * CT + aoff + mt * 32];
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng) bv[ng] = pb[(2 * cp) * PS + ky * PC + kx + pixoff[ng]];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int ng = 0; ng < NG; ++ng)
+            acc[mt][ng] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[ng], acc[mt][ng], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < a.nchunks) GR_STORE_CHUNK((ch + 1) & 1)
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: column (pixel) = lane&31, row (channel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
+    const int y = y0 + pr, x = x0 + pc;
+    if (y < H && x < W) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (o < a.Cout) {
+            const float bv = a.bias ? a.bias[o] : 0.f;
+            a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = acc[mt][ng][r] + bv;
+          }
+        }
+    }
+  }
+}
+
+template <int MT, int TW>
+static void launch_conv_t(const ConvArgs& a0, hipStream_t s) {
+  ConvArgs a = a0;
+  constexpr int TR = 256 / TW, PS = (TR + 2) * (TW + 2), CT = MT * 32;
+  a.tiles_x = (a.W + TW - 1) / TW;
+  a.tiles_y = (a.H + TR - 1) / TR;
+  a.n_otiles = a.cout_pad / CT;
+  const size_t lds = sizeof(float) * (2 * CONV_CK * PS + 2 * 9 * CONV_CK * CT);
+  const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<MT, TW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<MT, TW>), dim3(grid), dim3(256), lds, s, a);
+}
+
+template <int MT>
+static void launch_conv_mt(const ConvArgs& a, hipStream_t s) {
+  if (a.W <= 8) launch_conv_t<MT, 8>(a, s);
+  else if (a.W <= 16) launch_conv_t<MT, 16>(a, s);
+  else launch_conv_t<MT, 32>(a, s);
+}
+
+void launch_conv3x3(const float* in, const float* wt, const float* bias, float* out,
+                    int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s) {
+  const ConvWeightLayout L = conv_weight_layout(Cin, Cout);
+  ConvArgs a{};
+  a.in = in; a.wt = wt; a.bias = bias; a.out = out;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
+  a.nchunks = L.cin_pad / CONV_CK; a.cout_pad = L.cout_pad;
+  if (L.cout_pad % 64 == 0) launch_conv_mt<2>(a, s);
+  else launch_conv_mt<1>(a, s);
+}
+
+// ---------------------------------------------------------------- weight layout preparation
+// dst[((ch*9 + tap)*8 + cil)*cout_pad + oo]
+//   forward:        = W[oo][ci][tap]                (ci = ch*8+cil over Cin, oo over Cout)
+//   backward-data:  = W[ci][oo][8-tap]              (ci over Cout, oo over Cin; spatial flip = 8-tap)
+__global__ void conv_weight_prep_kernel(const float* __restrict__ w, float* __restrict__ dst,
+                                        int cin, int cout, int CI, int CO, int cin_pad, int cout_pad, int bwd) {
+  const long n = (long)cin_pad * 9 * cout_pad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int oo = (int)(i % cout_pad); long r = i / cout_pad;
+    const int cil = (int)(r % CONV_CK); r /= CONV_CK;
+    const int tap = (int)(r % 9); const int ch = (int)(r / 9);
+    const int ci = ch * CONV_CK + cil;
+    float v = 0.f;
+    if (ci < CI && oo < CO)
+      v = bwd ? w[((long)ci * cin + oo) * 9 + (8 - tap)] : w[((long)oo * cin + ci) * 9 + tap];
+    dst[i] = v;
+  }
+}
+
+void launch_conv_weight_prep(const float* w_native, float* wt, int cin, int cout, bool bwd, hipStream_t s) {
+  // forward: reduce over CI=cin, produce CO=cout ; backward-data: reduce over CI=cout, produce CO=cin
+  const int CI = bwd ? cout : cin, CO = bwd ? cin : cout;
+  const ConvWeightLayout L = conv_weight_layout(CI, CO);
+  const long n = (long)L.elems();
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  hipLaunchKernelGGL(conv_weight_prep_kernel, dim3(grid), dim3(256), 0, s, w_native, wt, cin, cout, CI, CO,
+                     L.cin_pad, L.cout_pad, bwd ? 1 : 0);
+}
+
+// ---------------------------------------------------------------- backward-weight
+// gw[o][ci][tap] += sum_{b,y,x} dy[b,o,y,x] * x[b,ci,y+ky-1,x+kx-1]
+// GEMM view: M = Cout, N = (tap, ci), K = B*H*W.  A workgroup owns a 64(o) x 64(ci) x 9(tap) block and a
+// strided subset of 64-pixel tiles; wave (mt, cg) keeps 9 accumulators (one per tap) of 32(o) x 32(ci).
+// Partial blocks go to a slab [split][tap][o][ci]; a second kernel sums the slabs into the native layout.
+struct WgradArgs {
+  const float* x; const float* dy; float* slab;
+  int B, Cin, Cout, H, W;
+  int tiles_x, tiles_y, n_ob, n_cb, nsplit, cinp, coutp;
+  long tiles_total;
+};
+
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr int PT = 64, TR = PT / TW, PR = TR + 2, PC = TW + 2, PSR = PR * PC, PSW = PSR | 1, DYS = PT + 1;
+  constexpr int NX = (64 * PSR + 255) / 256;
+  __shared__ float dyT[64 * DYS];
+  __shared__ float xp[64 * PSW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int mt = wave >> 1, cg = wave & 1;
+  int bid = blockIdx.x;
+  const int cb = bid % a.n_cb; bid /= a.n_cb;
+  const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
+  const int o0 = ob * 64, c0 = cb * 64;
+  const int H = a.H, W = a.W;
+  const size_t HW = (size_t)H * W;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int dpix = tid & 63, dpr = dpix / TW, dpc = dpix - dpr * TW;
+  for (long tile = split; tile < a.tiles_total; tile += a.nsplit) {
+    long t = tile;
+    const int tx = (int)(t % a.tiles_x); t /= a.tiles_x;
+    const int ty = (int)(t % a.tiles_y); const int b = (int)(t / a.tiles_y);
+    const int y0 = ty * TR, x0 = tx * TW;
+    // dy tile: [64 o][64 pixels]
+    {
+      const int y = y0 + dpr, x = x0 + dpc;
+      const bool pin = y < H && x < W;
+      const float* dbase = a.dy + ((size_t)b * a.Cout) * HW + (size_t)y * W + x;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int o = (tid >> 6) + 4 * i;
+        float v = 0.f;
+        if (pin && o0 + o < a.Cout) v = dbase[(size_t)(o0 + o) * HW];
+        dyT[o * DYS + dpix] = v;
+      }
+    }
+    // x patch: [64 ci][PR][PC] zero padded
+    {
+      const float* xbase = a.x + ((size_t)b * a.Cin) * HW;
+#pragma unroll 4
+      for (int i = 0; i < NX; ++i) {
+        const int e = tid + 256 * i;
+        if (e < 64 * PSR) {
+          const int ci = e / PSR, rem = e - ci * PSR, r = rem / PC, c = rem - r * PC;
+          const int yy = y0 + r - 1, xx = x0 + c - 1;
+          float v = 0.f;
+          if (c0 + ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W) v = xbase[(size_t)(c0 + ci) * HW + (size_t)yy * W + xx];
+          xp[ci * PSW + rem] = v;
+        }
+      }
+    }
+    __syncthreads();
+    const float* ap = dyT + (mt * 32 + l31) * DYS + h;
+    const float* bp = xp + (cg * 32 + l31) * PSW + h;
+#pragma unroll
+    for (int s = 0; s < PT / 2; ++s) {
+      const int p0 = 2 * s, pr = p0 / TW, pc = p0 - pr * TW;
+      const float av = ap[p0];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const float bv = bp[(pr + ky) * PC + pc + kx];
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  float* sl = a.slab + (size_t)split * 9 * a.coutp * a.cinp;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int ci = c0 + cg * 32 + l31;
+      sl[((size_t)tap * a.coutp + o) * a.cinp + ci] = acc[tap][r];
+    }
+}
+
+__global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gw,
+                                            int Cin, int Cout, int cinp, int coutp, int nsplit) {
+  const long n = (long)9 * Cout * cinp;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ci = (int)(i % cinp); long r = i / cinp;
+  const int o = (int)(r % Cout); const int tap = (int)(r / Cout);
+  if (ci >= Cin) return;
+  const size_t stride = (size_t)9 * coutp * cinp;
+  const float* p = slab + ((size_t)tap * coutp + o) * cinp + ci;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += p[(size_t)k * stride];
+  gw[((size_t)o * Cin + ci) * 9 + tap] += s;
+}
+
+static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a, int& TW) {
+  TW = W <= 8 ? 8 : (W <= 16 ? 16 : 32);
+  const int TR = 64 / TW;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TR - 1) / TR;
+  a.tiles_total = (long)B * a.tiles_x * a.tiles_y;
+  a.cinp = round_up(Cin, 64); a.coutp = round_up(Cout, 64);
+  a.n_ob = a.coutp / 64; a.n_cb = a.cinp / 64;
+  long want = 512 / (a.n_ob * a.n_cb);
+  if (want < 1) want = 1;
+  if (want > a.tiles_total) want = a.tiles_total;
+  a.nsplit = (int)want;
+}
+
+size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W) {
+  WgradArgs a{}; int TW;
+  wgrad_geometry(B, Cin, Cout, H, W, a, TW);
+  return sizeof(float) * (size_t)a.nsplit * 9 * a.coutp * a.cinp;
+}
+
+void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,
+                          int B, int Cin, int Cout, int H, int W, hipStream_t s) {
+  WgradArgs a{}; int TW;
+  wgrad_geometry(B, Cin, Cout, H, W, a, TW);
+  a.x = x; a.dy = dy; a.slab = reinterpret_cast<float*>(workspace);
+  const int grid = a.nsplit * a.n_ob * a.n_cb;
+  if (TW == 8) hipLaunchKernelGGL(conv3x3_wgrad_kernel<8>, dim3(grid), dim3(256), 0, s, a);
+  else if (TW == 16) hipLaunchKernelGGL(conv3x3_wgrad_kernel<16>, dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, a);
+  const long n = (long)9 * Cout * a.cinp;
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                     a.slab, gw, Cin, Cout, a.cinp, a.coutp, a.nsplit);
+}
+
+}  // namespace gr

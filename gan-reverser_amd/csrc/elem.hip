@@ -1,0 +1,386 @@
+// elem.hip — HBM-bound per-channel pipelines around the convolutions, the criterion and the optimiser.
+// Compiled with -ffp-contract=off: every fp32 operation rounds where the Torch7 tensor op it replaces rounds,
+// so given identical inputs these kernels match the oracle bit for bit except through expf/tanhf.
+//
+// Replaces (reference file:line):
+//   nn.SpatialBatchNormalization / nn.BatchNormalization   models.lua:116,123,129,410..437,448
+//   nn.ELU / cudnn.ReLU / nn.Sigmoid / nn.Tanh / nn.LeakyReLU  models.lua:411,117,133,453,18
+//   nn.Dropout / nn.SpatialDropout / nn.SpatialMaxPooling  models.lua:402-405,412,439,422,440
+//   nn.MSECriterion                                        train_r.lua:119,147,150
+//   fevalR penalty+clamp and optim.adam                    train_r.lua:153-165,170
+#include "kernels.h"
+
+namespace gr {
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ double block_reduce_sum(double v, double* sh) {
+  // deterministic tree: wave shuffle then fixed-order sum over waves
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) for (int w = 0; w < nw; ++w) r += sh[w];
+  return r;  // valid on thread 0
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
+  switch (act) {
+    case ACT_ELU: return z <= 0.f ? (expf(z) - 1.f) * 1.f : z;
+    case ACT_RELU: return z > 0.f ? z : 0.f;
+    case ACT_LEAKYRELU: return z > 0.f ? z : z * slope;
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-z));
+    case ACT_TANH: return tanhf(z);
+    default: return z;
+  }
+}
+__device__ __forceinline__ float act_bwd(float g, float z, float a, int act, float slope) {
+  switch (act) {
+    case ACT_ELU: return a <= 0.f ? g * (a + 1.f) : g;
+    case ACT_RELU: return a > 0.f ? g : 0.f;
+    case ACT_LEAKYRELU: return z > 0.f ? g : g * slope;
+    case ACT_SIGMOID: return g * (1.f - a) * a;
+    case ACT_TANH: return g * (1.f - a * a);
+    default: return g;
+  }
+}
+__device__ __forceinline__ float mask_mul(const MaskRef& m, long e, long bc) {
+  switch (m.kind) {
+    case MASK_ELEM: return ((m.bits[e >> 5] >> (e & 31)) & 1u) ? m.scale : 0.f;
+    case MASK_SPATIAL: return ((m.bits[bc >> 5] >> (bc & 31)) & 1u) ? m.scale : 0.f;
+    case MASK_SCALE: return m.scale;
+    default: return 1.f;
+  }
+}
+__device__ __forceinline__ float bn_apply(const PostArgs& a, float y, int c) {
+  return a.has_bn ? ((y - a.mean[c]) * a.invstd[c]) * a.gamma[c] + a.beta[c] : y;
+}
+
+// ------------------------------------------------------------------ forward pipeline: BN -> act -> mask1 -> [pool] -> mask2
+__global__ __launch_bounds__(256) void post_forward_kernel(PostArgs a) {
+  const int H = a.H, W = a.W, Ho = a.pool ? H >> 1 : H, Wo = a.pool ? W >> 1 : W;
+  const long HW = (long)H * W, HWo = (long)Ho * Wo;
+  const long n = (long)a.B * a.C * HWo;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long bc = i / HWo; const int po = (int)(i - bc * HWo);
+    const int c = (int)(bc % a.C);
+    float r;
+    if (a.pool) {
+      const int yo = po / Wo, xo = po - yo * Wo;
+      float best = -INFINITY; int bi = 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const long e = bc * HW + (long)(2 * yo + (t >> 1)) * W + 2 * xo + (t & 1);
+        const float v = act_fwd(bn_apply(a, a.y[e], c), a.act, a.slope) * mask_mul(a.m1, e, bc);
+        if (v > best) { best = v; bi = t; }
+      }
+      a.pool_idx[i] = (uint8_t)bi;
+      r = best;
+    } else {
+      r = act_fwd(bn_apply(a, a.y[i], c), a.act, a.slope) * mask_mul(a.m1, i, bc);
+    }
+    a.out[i] = r * mask_mul(a.m2, i, bc);
+  }
+}
+
+void launch_post_forward(const PostArgs& a, hipStream_t s) {
+  const long n = (long)a.B * a.C * (a.pool ? (a.H >> 1) * (a.W >> 1) : a.H * a.W);
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(post_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------ BN statistics
+static inline int stat_splits(long n) {
+  long s = n / 4096;
+  if (s < 1) s = 1;
+  if (s > STAT_SPLITS) s = STAT_SPLITS;
+  return (int)s;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, int B, int C, int HW, int splits,
+                                                               double* __restrict__ partials) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const long n = (long)B * HW, chunk = (n + splits - 1) / splits;
+  const long j0 = sp * chunk, j1 = min(n, j0 + chunk);
+  double s = 0, q = 0;
+  for (long j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+    const long b = j / HW; const int p = (int)(j - b * HW);
+    const double v = y[(b * C + c) * HW + p];
+    s += v; q += v * v;
+  }
+  s = block_reduce_sum(s, sh);
+  q = block_reduce_sum(q, sh);
+  if (threadIdx.x == 0) { partials[((long)c * STAT_SPLITS + sp) * 2] = s; partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partials, int C, int splits, double n,
+                                         float* mean, float* invstd, float* run_mean, float* run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, q = 0;
+  for (int k = 0; k < splits; ++k) { s += partials[((long)c * STAT_SPLITS + k) * 2]; q += partials[((long)c * STAT_SPLITS + k) * 2 + 1]; }
+  const double m = s / n;
+  double vs = q - s * m;               // sum (x-mean)^2
+  if (vs < 0) vs = 0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(vs / n + 1e-5));
+  if (run_mean) {
+    run_mean[c] = (float)(0.1 * m + 0.9 * (double)run_mean[c]);
+    run_var[c] = (float)(0.1 * (vs / (n - 1)) + 0.9 * (double)run_var[c]);
+  }
+}
+
+__global__ void bn_eval_prepare_kernel(const float* rm, const float* rv, float* mean, float* invstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  invstd[c] = (float)(1.0 / sqrt((double)rv[c] + 1e-5));
+}
+
+void launch_bn_stats(const float* y, int B, int C, int HW, double* partials, float* mean, float* invstd,
+                     float* run_mean, float* run_var, int training, hipStream_t s) {
+  (void)training;
+  const long n = (long)B * HW;
+  const int splits = stat_splits(n);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, splits), dim3(256), 0, s, y, B, C, HW, splits, partials);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partials, C, splits, (double)n,
+                     mean, invstd, run_mean, run_var);
+}
+void launch_bn_eval_prepare(const float* rm, const float* rv, float* mean, float* invstd, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, s, rm, rv, mean, invstd, C);
+}
+
+// ------------------------------------------------------------------ backward pipeline
+// pass A: dz = grad wrt the BN output (or wrt y when there is no BN); per-channel partial sums of dz and (y-mean)*dz
+__global__ __launch_bounds__(256) void post_backward_a_kernel(PostBwdArgs a, int splits) {
+  __shared__ double sh[8];
+  const PostArgs& f = a.f;
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int H = f.H, W = f.W, Ho = f.pool ? H >> 1 : H, Wo = f.pool ? W >> 1 : W;
+  const long HW = (long)H * W, HWo = (long)Ho * Wo;
+  const long n = (long)f.B * HW, chunk = (n + splits - 1) / splits;
+  const long j0 = sp * chunk, j1 = min(n, j0 + chunk);
+  const float mean = f.has_bn ? f.mean[c] : 0.f;
+  double s = 0, q = 0;
+  for (long j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+    const long b = j / HW; const int p = (int)(j - b * HW);
+    const long bc = b * f.C + c, e = bc * HW + p;
+    float g;
+    if (f.pool) {
+      const int yy = p / W, xx = p - yy * W, yo = yy >> 1, xo = xx >> 1;
+      g = 0.f;
+      if (yo < Ho && xo < Wo) {
+        const long eo = bc * HWo + (long)yo * Wo + xo;
+        const int t = ((yy & 1) << 1) | (xx & 1);
+        if (f.pool_idx[eo] == t) g = a.gout[eo] * mask_mul(f.m2, eo, bc);
+      }
+    } else {
+      g = a.gout[e] * mask_mul(f.m2, e, bc);
+    }
+    g = g * mask_mul(f.m1, e, bc);
+    const float yv = f.y[e];
+    const float z = bn_apply(f, yv, c);
+    const float av = act_fwd(z, f.act, f.slope);
+    const float dz = act_bwd(g, z, av, f.act, f.slope);
+    a.dy[e] = dz;
+    s += (double)dz;
+    q += (double)(yv - mean) * (double)dz;
+  }
+  s = block_reduce_sum(s, sh);
+  q = block_reduce_sum(q, sh);
+  if (threadIdx.x == 0) { a.partials[((long)c * STAT_SPLITS + sp) * 2] = s; a.partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
+}
+
+__global__ void post_backward_finalize_kernel(PostBwdArgs a, int splits, double n) {
+  const PostArgs& f = a.f;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= f.C) return;
+  double s = 0, q = 0;
+  for (int k = 0; k < splits; ++k) { s += a.partials[((long)c * STAT_SPLITS + k) * 2]; q += a.partials[((long)c * STAT_SPLITS + k) * 2 + 1]; }
+  if (f.has_bn) {
+    const double invstd = f.invstd[c];
+    a.ggamma[c] += (float)(q * invstd);
+    a.gbeta[c] += (float)s;
+    a.coef[2 * c] = (float)(s / n);
+    a.coef[2 * c + 1] = (float)(q * invstd * invstd / n);
+  } else if (a.gbias) {
+    a.gbias[c] += (float)s;
+  }
+}
+
+// pass B (BN only): dy = ((dz - gm) - (y-mean)*k) * invstd * gamma ; per-channel sum of dy for the bias gradient
+__global__ __launch_bounds__(256) void post_backward_b_kernel(PostBwdArgs a, int splits) {
+  __shared__ double sh[8];
+  const PostArgs& f = a.f;
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const long HW = (long)f.H * f.W;
+  const long n = (long)f.B * HW, chunk = (n + splits - 1) / splits;
+  const long j0 = sp * chunk, j1 = min(n, j0 + chunk);
+  const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], gm = a.coef[2 * c], k = a.coef[2 * c + 1];
+  double s = 0;
+  for (long j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+    const long b = j / HW; const int p = (int)(j - b * HW);
+    const long e = (b * f.C + c) * HW + p;
+    const float d = ((a.dy[e] - gm) - (f.y[e] - mean) * k) * invstd * w;
+    a.dy[e] = d;
+    s += (double)d;
+  }
+  s = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) a.partials[((long)c * STAT_SPLITS + sp) * 2] = s;
+}
+
+__global__ void bias_grad_finalize_kernel(const double* __restrict__ partials, float* gbias, int C, int splits) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0;
+  for (int k = 0; k < splits; ++k) s += partials[((long)c * STAT_SPLITS + k) * 2];
+  gbias[c] += (float)s;
+}
+
+void launch_post_backward(const PostBwdArgs& a, hipStream_t s) {
+  const PostArgs& f = a.f;
+  const long n = (long)f.B * f.H * f.W;
+  const int splits = stat_splits(n);
+  hipLaunchKernelGGL(post_backward_a_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+  hipLaunchKernelGGL(post_backward_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a, splits, (double)n);
+  if (f.has_bn) {
+    hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+    if (a.gbias)
+      hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a.partials, a.gbias, f.C, splits);
+  }
+}
+
+// ------------------------------------------------------------------ nn.MSECriterion
+__global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ x, const float* __restrict__ t, long n, double inv_n,
+                                                   float norm, double* loss, float* grad) {
+  __shared__ double sh[16];
+  double s = 0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float z = x[i] - t[i];
+    s += (double)(z * z);
+    if (grad) grad[i] = norm * z;
+  }
+  s = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0 && loss) *loss = s * inv_n;
+}
+void launch_mse(const float* x, const float* t, long n, long n_global, double* loss_dev, float* grad, hipStream_t s) {
+  hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, x, t, n, 1.0 / (double)n_global, (float)(2.0 / (double)n_global), loss_dev, grad);
+}
+
+// ------------------------------------------------------------------ penalty + clamp + Adam, one pass over (theta, g, m, v)
+__global__ __launch_bounds__(256) void penalty_clamp_adam_kernel(float* __restrict__ theta, float* __restrict__ g, float* __restrict__ m,
+                                                                 float* __restrict__ v, long n, AdamConsts c) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float th = theta[i], gv = g[i], mv = m[i], vv = v[i];
+    if (c.use_penalty) {
+      const float sg = th > 0.f ? 1.f : (th < 0.f ? -1.f : 0.f);
+      const float pen = sg * c.l1 + th * c.l2;
+      gv = gv + pen;
+    }
+    if (c.use_clamp) gv = gv < -c.clamp ? -c.clamp : (gv > c.clamp ? c.clamp : gv);
+    mv = mv * c.b1 + c.c1 * gv;
+    vv = vv * c.b2 + (c.c2 * gv) * gv;
+    const float denom = sqrtf(vv) + c.eps;
+    th = th + (c.step * mv) / denom;
+    theta[i] = th; g[i] = gv; m[i] = mv; v[i] = vv;
+  }
+}
+void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long n, const AdamConsts& c, hipStream_t s) {
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(penalty_clamp_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, theta, g, m, v, n, c);
+}
+
+// ------------------------------------------------------------------ counter-based RNG (Philox4x32-10)
+struct u4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ u4 philox4x32(u4 ctr, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * ctr.x, p1 = (uint64_t)0xCD9E8D57u * ctr.z;
+    u4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ ctr.y ^ k0; n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ ctr.w ^ k1; n.w = (uint32_t)p0;
+    ctr = n; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return ctr;
+}
+
+// keep-bit = Bernoulli(1-p).  p == 0.5: one Philox call yields 128 keep bits; otherwise one 32-bit uniform per element.
+__global__ void gen_mask_kernel(uint32_t* words, long nwords, uint32_t thresh, int half, uint32_t s0, uint32_t s1,
+                                uint32_t c0, uint32_t c1, uint32_t layer) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (half) {
+    if (i * 4 >= nwords) return;
+    const u4 r = philox4x32(u4{(uint32_t)i, layer, c0, c1}, s0, s1);
+    const uint32_t o[4] = {r.x, r.y, r.z, r.w};
+    for (int k = 0; k < 4; ++k) if (i * 4 + k < nwords) words[i * 4 + k] = o[k];
+  } else {
+    if (i >= nwords) return;
+    uint32_t w = 0;
+    for (int j = 0; j < 8; ++j) {
+      const u4 r = philox4x32(u4{(uint32_t)i, (uint32_t)j | (layer << 8), c0, c1}, s0, s1);
+      const uint32_t o[4] = {r.x, r.y, r.z, r.w};
+      for (int k = 0; k < 4; ++k) w |= (o[k] >= thresh ? 1u : 0u) << (j * 4 + k);
+    }
+    words[i] = w;
+  }
+}
+void launch_gen_mask(uint32_t* words, long n_elems, float p_drop, uint64_t seed, uint64_t counter, uint32_t layer, hipStream_t s) {
+  const long nwords = (n_elems + 31) / 32;
+  const int half = p_drop == 0.5f;
+  const long threads = half ? (nwords + 3) / 4 : nwords;
+  const uint32_t thresh = (uint32_t)fmin(4294967295.0, (double)p_drop * 4294967296.0);
+  hipLaunchKernelGGL(gen_mask_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, words, nwords, thresh, half,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)counter, (uint32_t)(counter >> 32), layer);
+}
+
+__global__ void pack_mask_kernel(const uint8_t* keep, uint32_t* words, long n) {
+  const long wi = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (wi * 32 >= n) return;
+  uint32_t w = 0;
+  for (int k = 0; k < 32; ++k) { const long e = wi * 32 + k; if (e < n && keep[e]) w |= 1u << k; }
+  words[wi] = w;
+}
+__global__ void unpack_mask_kernel(const uint32_t* words, uint8_t* keep, long n) {
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e < n) keep[e] = (words[e >> 5] >> (e & 31)) & 1u;
+}
+void launch_pack_mask(const uint8_t* keep, uint32_t* words, long n, hipStream_t s) {
+  const long nw = (n + 31) / 32;
+  hipLaunchKernelGGL(pack_mask_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, keep, words, n);
+}
+void launch_unpack_mask(const uint32_t* words, uint8_t* keep, long n, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, words, keep, n);
+}
+
+__global__ void fill_normal_kernel(float* dst, long n, uint32_t s0, uint32_t s1) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i * 4 >= n) return;
+  const u4 r = philox4x32(u4{(uint32_t)i, (uint32_t)(i >> 32), 0x6e6f6973u, 0u}, s0, s1);
+  const float u1 = ((float)(r.x >> 8) + 1.f) * (1.f / 16777216.f), u2 = (float)(r.y >> 8) * (1.f / 16777216.f);
+  const float u3 = ((float)(r.z >> 8) + 1.f) * (1.f / 16777216.f), u4_ = (float)(r.w >> 8) * (1.f / 16777216.f);
+  const float ra = sqrtf(-2.f * logf(u1)), rb = sqrtf(-2.f * logf(u3));
+  const float o[4] = {ra * cosf(6.2831853071795864f * u2), ra * sinf(6.2831853071795864f * u2),
+                      rb * cosf(6.2831853071795864f * u4_), rb * sinf(6.2831853071795864f * u4_)};
+  for (int k = 0; k < 4; ++k) if (i * 4 + k < n) dst[i * 4 + k] = o[k];
+}
+void launch_fill_normal(float* dst, long n, uint64_t seed, hipStream_t s) {
+  const long t = (n + 3) / 4;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, dst, n, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+__global__ void scale_copy_kernel(const float* src, float* dst, long n, float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
+}
+void launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s) {
+  long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n, scale);
+}
+
+}  // namespace gr

@@ -1,0 +1,129 @@
+// gemm.hip — fp32 MFMA GEMM for nn.Linear (reference models.lua:115 G.fc, models.lua:447,451 R.fc1/fc2):
+//   C[m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]),   A(m,k) = A[m*rsA + k*ksA],  B(n,k) = Bm[n*rsB + k*ksB]
+// forward  y = x W^T + b : A = x   (K-contiguous), B = W        (K-contiguous)
+// bwd-data gx = gy W     : A = gy  (K-contiguous), B(n=i,k=o)=W (N-contiguous)
+// bwd-wt   gW += gy^T x  : A(m=o,k=b)=gy (M-contiguous), B(n=i,k=b)=x (N-contiguous)
+// Workgroup tile 64x64 (4 waves, one 32x32 MFMA accumulator each), K chunks of 32 through LDS; split-K over
+// blockIdx.z into fp32 slabs that a reduce kernel sums in a fixed order (deterministic, no atomics).
+#include "kernels.h"
+
+namespace gr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float* A; const float* Bm; float* C; float* slab; const float* bias;
+  long rsA, ksA, rsB, ksB, ldc;
+  int M, N, K, klen, nsplit, accumulate;
+};
+
+// stage a 64(rows) x 32(k) operand tile into LDS as T[k][row] (row stride 65)
+template <bool KCONTIG>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ P, long rs, long ks, int row0, int nrows,
+                                           int k0, int kend, float* T, int tid) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int r, k;
+    if (KCONTIG) { k = tid & 31; r = (tid >> 5) + 8 * i; }
+    else { r = tid & 63; k = (tid >> 6) + 4 * i; }
+    float v = 0.f;
+    if (row0 + r < nrows && k0 + k < kend) v = P[(long)(row0 + r) * rs + (long)(k0 + k) * ks];
+    T[k * 65 + r] = v;
+  }
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
+  __shared__ float As[32 * 65];
+  __shared__ float Bs[32 * 65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kbeg = blockIdx.z * a.klen;
+  const int kend = min(a.K, kbeg + a.klen);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    stage_tile<AK>(a.A, a.rsA, a.ksA, m0, a.M, k0, kend, As, tid);
+    stage_tile<BK>(a.Bm, a.rsB, a.ksB, n0, a.N, k0, kend, Bs, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float av = As[(kk + h) * 65 + wm * 32 + l31];
+      const float bv = Bs[(kk + h) * 65 + wn * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + l31;
+  if (n < a.N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < a.M) {
+        if (a.nsplit > 1) {
+          a.slab[((size_t)blockIdx.z * a.M + m) * a.N + n] = acc[r];
+        } else {
+          float v = acc[r] + (a.bias ? a.bias[n] : 0.f);
+          float* c = a.C + (long)m * a.ldc + n;
+          *c = a.accumulate ? *c + v : v;
+        }
+      }
+    }
+  }
+}
+
+__global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, const float* __restrict__ bias,
+                                          long ldc, int M, int N, int nsplit, int accumulate) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)M * N) return;
+  const int n = (int)(i % N); const int m = (int)(i / N);
+  float s = 0.f;
+  for (int z = 0; z < nsplit; ++z) s += slab[(size_t)z * M * N + i];
+  s += bias ? bias[n] : 0.f;
+  float* c = C + (long)m * ldc + n;
+  *c = accumulate ? *c + s : s;
+}
+
+static void gemm_plan(int M, int N, int K, int& nsplit, int& klen) {
+  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+  nsplit = 1;
+  if (tiles < 256 && K >= 256) {
+    long want = (512 + tiles - 1) / tiles;
+    const long maxs = K / 128;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    nsplit = (int)want;
+  }
+  klen = round_up((K + nsplit - 1) / nsplit, 32);
+  nsplit = (K + klen - 1) / klen;
+}
+
+size_t gemm_workspace_bytes(int M, int N, int K) {
+  int ns, kl; gemm_plan(M, N, K, ns, kl);
+  return ns > 1 ? sizeof(float) * (size_t)ns * M * N : 0;
+}
+
+void launch_gemm(const float* A, long rsA, long ksA, const float* Bm, long rsB, long ksB,
+                 float* C, long ldc, const float* bias, bool accumulate, int M, int N, int K,
+                 void* workspace, hipStream_t s) {
+  GemmArgs a{};
+  a.A = A; a.Bm = Bm; a.C = C; a.slab = reinterpret_cast<float*>(workspace); a.bias = bias;
+  a.rsA = rsA; a.ksA = ksA; a.rsB = rsB; a.ksB = ksB; a.ldc = ldc;
+  a.M = M; a.N = N; a.K = K; a.accumulate = accumulate ? 1 : 0;
+  gemm_plan(M, N, K, a.nsplit, a.klen);
+  dim3 grid((N + 63) / 64, (M + 63) / 64, a.nsplit);
+  const bool ak = ksA == 1, bk = ksB == 1;
+  if (ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), 0, s, a);
+  else if (ak && !bk) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), 0, s, a);
+  else if (!ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), 0, s, a);
+  if (a.nsplit > 1) {
+    const long n = (long)M * N;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       a.slab, C, bias, ldc, M, N, a.nsplit, a.accumulate);
+  }
+}
+
+}  // namespace gr

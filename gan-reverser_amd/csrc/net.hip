@@ -1,0 +1,839 @@
+// net.hip — the C ABI (include/ganrev.h) and the nn.Sequential runtime behind it.
+//
+// A gr_net is the reference's nn.Sequential (models.lua:104-143 G3, models.lua:389-464 R) compiled into
+// STAGES:  [UpSample2] (Conv3x3 | Linear) [BN] [act] [Dropout|SpatialDropout] [MaxPool2] [Dropout]
+// Each stage runs as: main MFMA kernel -> (training) BN statistics -> one fused per-channel pipeline kernel.
+// Backward mirrors it (train_r.lua:151): pipeline backward (two passes around the BN reduction) ->
+// weight-gradient kernel -> data-gradient kernel.  All device memory is owned by the net / ctx; there is
+// no CPU fallback anywhere in this file.
+#include "../../include/ganrev.h"
+#include "kernels.h"
+#include <rccl/rccl.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gr;
+
+// ------------------------------------------------------------------ context
+struct gr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  void* ws = nullptr; size_t ws_bytes = 0;
+  double* d_loss = nullptr;     // device scalar
+  double* h_loss = nullptr;     // pinned host scalar
+  bool timing = false;
+  hipEvent_t ev[7] = {};
+  float times[6] = {0, 0, 0, 0, 0, 0};
+};
+
+static int fail(gr_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+#define HIPCHK(ctx, call)                                                                             \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess)                                                  \
+      return fail(ctx, GR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define NCCLCHK(ctx, call)                                                                            \
+  do { ncclResult_t r_ = (call); if (r_ != ncclSuccess)                                               \
+      return fail(ctx, GR_ERR_COMM, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); } while (0)
+#define LAUNCHCHK(ctx)                                                                                \
+  do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess)                                       \
+      return fail(ctx, GR_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static int ensure_ws(gr_ctx* c, size_t bytes) {
+  if (bytes <= c->ws_bytes) return GR_OK;
+  if (c->ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+  bytes = (bytes + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+  HIPCHK(c, hipMalloc(&c->ws, bytes));
+  c->ws_bytes = bytes;
+  return GR_OK;
+}
+
+extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.1 (round 1)"; }
+
+extern "C" int gr_init(int device, gr_ctx** out) {
+  if (!out) return GR_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GR_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return GR_ERR_INVALID;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) return GR_ERR_HIP;
+  if (strncmp(p.gcnArchName, "gfx950", 6) != 0) return GR_ERR_NO_DEVICE;  // kernels are built for gfx950 only
+  gr_ctx* c = new gr_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&c->d_loss, 64) != hipSuccess || hipHostMalloc((void**)&c->h_loss, 64) != hipSuccess) {
+    delete c; return GR_ERR_HIP;
+  }
+  for (auto& e : c->ev) (void)hipEventCreate(&e);
+  *out = c;
+  return GR_OK;
+}
+
+extern "C" int gr_shutdown(gr_ctx* c) {
+  if (!c) return GR_ERR_INVALID;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  if (c->ws) (void)hipFree(c->ws);
+  (void)hipFree(c->d_loss); (void)hipHostFree(c->h_loss);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return GR_OK;
+}
+extern "C" const char* gr_last_error(gr_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+extern "C" void* gr_stream(gr_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int gr_synchronize(gr_ctx* c) { if (!c) return GR_ERR_INVALID; HIPCHK(c, hipStreamSynchronize(c->stream)); return GR_OK; }
+extern "C" int gr_device_info(gr_ctx* c, char* buf, int n) {
+  if (!c || !buf) return GR_ERR_INVALID;
+  hipDeviceProp_t p; HIPCHK(c, hipGetDeviceProperties(&p, c->device));
+  int rv = 0; (void)hipRuntimeGetVersion(&rv);
+  snprintf(buf, n, "arch=%s CUs=%d clock_khz=%d mem_mb=%zu hip_runtime=%d", p.gcnArchName, p.multiProcessorCount, p.clockRate,
+           p.totalGlobalMem >> 20, rv);
+  return GR_OK;
+}
+extern "C" int gr_set_timing(gr_ctx* c, int en) { if (!c) return GR_ERR_INVALID; c->timing = en != 0; return GR_OK; }
+extern "C" int gr_last_step_times(gr_ctx* c, float* ms6) { if (!c || !ms6) return GR_ERR_INVALID; memcpy(ms6, c->times, sizeof c->times); return GR_OK; }
+
+extern "C" int gr_malloc(gr_ctx* c, int64_t bytes, void** out) { if (!c || !out) return GR_ERR_INVALID; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMalloc(out, bytes > 0 ? bytes : 1)); return GR_OK; }
+extern "C" int gr_free(gr_ctx* c, void* p) { if (!c) return GR_ERR_INVALID; HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); return GR_OK; }
+extern "C" int gr_memcpy_h2d(gr_ctx* c, void* d, const void* h, int64_t b) { if (!c) return GR_ERR_INVALID; HIPCHK(c, hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return GR_OK; }
+extern "C" int gr_memcpy_d2h(gr_ctx* c, void* h, const void* d, int64_t b) { if (!c) return GR_ERR_INVALID; HIPCHK(c, hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return GR_OK; }
+extern "C" int gr_fill_normal_dev(gr_ctx* c, float* d, int64_t n, uint64_t seed) { if (!c || !d) return GR_ERR_INVALID; launch_fill_normal(d, n, seed, c->stream); LAUNCHCHK(c); return GR_OK; }
+
+// ------------------------------------------------------------------ net
+enum { ST_CONV = 1, ST_LINEAR = 2, ST_ELEM = 3 };
+
+struct MaskSlot {
+  int layer = -1, kind = MASK_NONE; float p = 0; int flags = 0;
+  int C = 0, H = 0, W = 0;           // tensor the noise is drawn for (per sample)
+  uint32_t* bits = nullptr; size_t words_cap = 0;
+  bool injected = false; int64_t n_last = 0;
+};
+
+struct Stage {
+  int kind = 0, first = 0, last = 0, main_layer = -1;
+  int inC = 0, inH = 0, inW = 0;
+  bool up = false, fullconv = false;
+  int Cin = 0, Cout = 0, H = 0, W = 0;       // main-op output channels / spatial dims (ELEM: the input dims)
+  int64_t w_off = -1, b_off = -1;
+  bool has_bn = false; int64_t g_off = -1, be_off = -1; int bn_idx = -1;
+  int act = ACT_NONE; float slope = 0;
+  int m1 = -1, m2 = -1; bool pool = false;
+  bool has_post = false;
+  int outC = 0, outH = 0, outW = 0;
+  float *y = nullptr, *out = nullptr; uint8_t* pool_idx = nullptr;
+  float *wt_fwd = nullptr, *wt_bwd = nullptr; uint64_t wt_version = 0;
+  float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr;
+  float *run_mean = nullptr, *run_var = nullptr;
+  const float* x_in = nullptr;              // input of the last forward
+};
+
+struct gr_net {
+  gr_ctx* ctx = nullptr;
+  std::vector<gr_layer_desc> layers;
+  std::vector<Stage> st;
+  std::vector<MaskSlot> masks;
+  std::vector<int> bn_stage;
+  int inC = 0, inH = 0, inW = 0, outC = 0, outH = 0, outW = 0;
+  int64_t n_params = 0;
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  uint64_t params_version = 1;
+  bool training = true;
+  uint64_t seed = 1, fwd_counter = 0;
+  int capB = 0, lastB = 0;
+  float *in_buf = nullptr, *gout_buf = nullptr, *dy_buf = nullptr, *g_buf[2] = {nullptr, nullptr};
+  size_t max_y = 0, max_in = 0;      // per-sample element counts
+  uint8_t* mask_stage = nullptr; size_t mask_stage_cap = 0;
+};
+
+static int64_t vol3(int c, int h, int w) { return (int64_t)c * h * w; }
+static bool is_act(int k) { return k == GR_ELU || k == GR_RELU || k == GR_LEAKYRELU || k == GR_SIGMOID || k == GR_TANH; }
+
+extern "C" int gr_net_destroy(gr_net* n) {
+  if (!n) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& s : n->st) {
+    if (s.kind != ST_ELEM) (void)hipFree(s.y);
+    if (s.has_post) (void)hipFree(s.out);
+    (void)hipFree(s.pool_idx); (void)hipFree(s.wt_fwd); (void)hipFree(s.wt_bwd);
+    (void)hipFree(s.mean); (void)hipFree(s.invstd); (void)hipFree(s.coef); (void)hipFree(s.partials);
+    (void)hipFree(s.run_mean); (void)hipFree(s.run_var);
+  }
+  for (auto& m : n->masks) (void)hipFree(m.bits);
+  (void)hipFree(n->params); (void)hipFree(n->grads); (void)hipFree(n->adam_m); (void)hipFree(n->adam_v);
+  (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
+  (void)hipFree(n->mask_stage);
+  delete n;
+  return GR_OK;
+}
+
+extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c, int in_h, int in_w, gr_net** out) {
+  if (!c || !L || nl <= 0 || !out || in_c <= 0 || in_h <= 0 || in_w <= 0) return fail(c, GR_ERR_INVALID, "gr_net_create: bad arguments");
+  *out = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  gr_net* n = new gr_net();
+  n->ctx = c; n->layers.assign(L, L + nl); n->inC = in_c; n->inH = in_h; n->inW = in_w;
+  // pass 1: per-layer parameter offsets in getParameters() order + shape check
+  std::vector<int64_t> woff(nl, -1), boff(nl, -1);
+  {
+    int cc = in_c, h = in_h, w = in_w; int64_t off = 0;
+    for (int i = 0; i < nl; ++i) {
+      const gr_layer_desc& d = L[i];
+      switch (d.kind) {
+        case GR_CONV3: case GR_FULLCONV3:
+          if (d.a != cc) { delete n; return fail(c, GR_ERR_INVALID, "layer %d: conv expects %d input planes, got %d", i, d.a, cc); }
+          woff[i] = off; off += (int64_t)d.a * d.b * 9; boff[i] = off; off += d.b; cc = d.b; break;
+        case GR_LINEAR:
+          if (d.a != vol3(cc, h, w)) { delete n; return fail(c, GR_ERR_INVALID, "layer %d: linear expects %d inputs, got %lld", i, d.a, (long long)vol3(cc, h, w)); }
+          woff[i] = off; off += (int64_t)d.a * d.b; boff[i] = off; off += d.b; cc = d.b; h = 1; w = 1; break;
+        case GR_BN:
+          if (d.a != cc) { delete n; return fail(c, GR_ERR_INVALID, "layer %d: BN expects %d features, got %d", i, d.a, cc); }
+          woff[i] = off; off += cc; boff[i] = off; off += cc; break;
+        case GR_MAXPOOL2: h /= 2; w /= 2; break;
+        case GR_UPSAMPLE2: h *= 2; w *= 2; break;
+        case GR_VIEW: {
+          const int vb = d.b > 0 ? d.b : 1, vc = d.c > 0 ? d.c : 1;
+          if (vol3(d.a, vb, vc) != vol3(cc, h, w)) { delete n; return fail(c, GR_ERR_INVALID, "layer %d: view size mismatch", i); }
+          cc = d.a; h = vb; w = vc; break; }
+        case GR_ELU: case GR_RELU: case GR_LEAKYRELU: case GR_SIGMOID: case GR_TANH: case GR_DROPOUT: case GR_SPATIAL_DROPOUT: break;
+        default: delete n; return fail(c, GR_ERR_INVALID, "layer %d: unknown kind %d", i, d.kind);
+      }
+      if (h <= 0 || w <= 0) { delete n; return fail(c, GR_ERR_INVALID, "layer %d: empty spatial extent", i); }
+    }
+    n->n_params = off; n->outC = cc; n->outH = h; n->outW = w;
+  }
+  // pass 2: stages
+  {
+    int cc = in_c, h = in_h, w = in_w, i = 0;
+    while (i < nl) {
+      Stage s; s.first = i;
+      while (i < nl && L[i].kind == GR_VIEW) { cc = L[i].a; h = L[i].b > 0 ? L[i].b : 1; w = L[i].c > 0 ? L[i].c : 1; ++i; }
+      if (i >= nl) { if (!n->st.empty()) n->st.back().last = nl - 1; break; }
+      s.inC = cc; s.inH = h; s.inW = w;
+      if (L[i].kind == GR_UPSAMPLE2) {
+        if (i + 1 >= nl || L[i + 1].kind != GR_CONV3) { gr_net_destroy(n); return fail(c, GR_ERR_UNSUPPORTED, "layer %d: UpSamplingNearest(2) is only fused in front of a 3x3 convolution", i); }
+        s.up = true; h *= 2; w *= 2; ++i;
+      }
+      const int k = L[i].kind;
+      if (k == GR_CONV3 || k == GR_FULLCONV3) {
+        s.kind = ST_CONV; s.fullconv = k == GR_FULLCONV3; s.main_layer = i; s.Cin = L[i].a; s.Cout = L[i].b; s.H = h; s.W = w;
+        s.w_off = woff[i]; s.b_off = boff[i]; cc = s.Cout; ++i;
+      } else if (k == GR_LINEAR) {
+        s.kind = ST_LINEAR; s.main_layer = i; s.Cin = L[i].a; s.Cout = L[i].b; s.H = 1; s.W = 1;
+        s.w_off = woff[i]; s.b_off = boff[i]; cc = s.Cout; h = 1; w = 1; ++i;
+      } else {
+        s.kind = ST_ELEM; s.Cin = s.Cout = cc; s.H = h; s.W = w;
+      }
+      int phase = -1;
+      while (i < nl) {
+        const gr_layer_desc& d = L[i];
+        int ph;
+        if (d.kind == GR_BN) ph = 0;
+        else if (is_act(d.kind)) ph = 1;
+        else if (d.kind == GR_DROPOUT || d.kind == GR_SPATIAL_DROPOUT) ph = s.pool ? 4 : 2;
+        else if (d.kind == GR_MAXPOOL2) ph = 3;
+        else break;
+        if (ph <= phase) break;
+        phase = ph; s.has_post = true;
+        if (ph == 0) { s.has_bn = true; s.g_off = woff[i]; s.be_off = boff[i]; s.bn_idx = (int)n->bn_stage.size(); n->bn_stage.push_back((int)n->st.size()); }
+        else if (ph == 1) { s.act = d.kind; s.slope = d.p; }
+        else if (ph == 3) { s.pool = true; h /= 2; w /= 2; }
+        else {
+          MaskSlot m; m.layer = i; m.kind = d.kind == GR_DROPOUT ? MASK_ELEM : MASK_SPATIAL; m.p = d.p; m.flags = d.flags;
+          m.C = cc; m.H = h; m.W = w;
+          if (ph == 2) s.m1 = (int)n->masks.size(); else s.m2 = (int)n->masks.size();
+          n->masks.push_back(m);
+        }
+        ++i;
+      }
+      s.last = i - 1;
+      s.outC = cc; s.outH = h; s.outW = w;
+      if (s.kind == ST_ELEM && !s.has_post) { gr_net_destroy(n); return fail(c, GR_ERR_UNSUPPORTED, "layer %d: kind %d cannot start a stage", i, L[i].kind); }
+      n->st.push_back(s);
+    }
+  }
+  // allocate parameters, optimiser state, per-stage constant-size buffers
+  const size_t pb = sizeof(float) * (size_t)(n->n_params > 0 ? n->n_params : 1);
+  if (hipMalloc((void**)&n->params, pb) || hipMalloc((void**)&n->grads, pb) || hipMalloc((void**)&n->adam_m, pb) || hipMalloc((void**)&n->adam_v, pb)) {
+    gr_net_destroy(n); return fail(c, GR_ERR_HIP, "parameter allocation failed");
+  }
+  (void)hipMemsetAsync(n->params, 0, pb, c->stream); (void)hipMemsetAsync(n->grads, 0, pb, c->stream);
+  (void)hipMemsetAsync(n->adam_m, 0, pb, c->stream); (void)hipMemsetAsync(n->adam_v, 0, pb, c->stream);
+  for (auto& s : n->st) {
+    const int C = s.Cout;
+    if (s.has_bn) {
+      if (hipMalloc((void**)&s.run_mean, sizeof(float) * C) || hipMalloc((void**)&s.run_var, sizeof(float) * C)) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
+      std::vector<float> ones(C, 1.f);
+      (void)hipMemsetAsync(s.run_mean, 0, sizeof(float) * C, c->stream);
+      (void)hipMemcpy(s.run_var, ones.data(), sizeof(float) * C, hipMemcpyHostToDevice);
+    }
+    if (hipMalloc((void**)&s.mean, sizeof(float) * C) || hipMalloc((void**)&s.invstd, sizeof(float) * C) ||
+        hipMalloc((void**)&s.coef, sizeof(float) * 2 * C) || hipMalloc((void**)&s.partials, sizeof(double) * 2 * STAT_SPLITS * C)) {
+      gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed");
+    }
+    if (s.kind == ST_CONV) {
+      // forward reduces over Cin; backward-data reduces over Cout.  (FullConvolution swaps the two roles.)
+      const ConvWeightLayout lf = s.fullconv ? conv_weight_layout(s.Cin, s.Cout) : conv_weight_layout(s.Cin, s.Cout);
+      const ConvWeightLayout lb = conv_weight_layout(s.Cout, s.Cin);
+      if (hipMalloc((void**)&s.wt_fwd, sizeof(float) * lf.elems()) || hipMalloc((void**)&s.wt_bwd, sizeof(float) * lb.elems())) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
+    }
+    const size_t ye = (size_t)vol3(s.Cout, s.H, s.W), ie = (size_t)vol3(s.inC, s.inH, s.inW);
+    if (ye > n->max_y) n->max_y = ye;
+    if (ie > n->max_in) n->max_in = ie;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = n;
+  return GR_OK;
+}
+
+extern "C" int gr_net_out_dim(gr_net* n, int* c, int* h, int* w) { if (!n) return GR_ERR_INVALID; if (c) *c = n->outC; if (h) *h = n->outH; if (w) *w = n->outW; return GR_OK; }
+extern "C" int64_t gr_net_param_count(gr_net* n) { return n ? n->n_params : -1; }
+extern "C" float* gr_net_params_dev(gr_net* n) { return n ? n->params : nullptr; }
+extern "C" float* gr_net_grads_dev(gr_net* n) { return n ? n->grads : nullptr; }
+
+static int copy_flat(gr_net* n, float* dev, float* host_out, const float* host_in) {
+  gr_ctx* c = n->ctx;
+  const size_t b = sizeof(float) * (size_t)n->n_params;
+  if (host_out) HIPCHK(c, hipMemcpyAsync(host_out, dev, b, hipMemcpyDeviceToHost, c->stream));
+  if (host_in) HIPCHK(c, hipMemcpyAsync(dev, host_in, b, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+extern "C" int gr_net_get_params(gr_net* n, float* h) { if (!n || !h) return GR_ERR_INVALID; return copy_flat(n, n->params, h, nullptr); }
+extern "C" int gr_net_set_params(gr_net* n, const float* h) { if (!n || !h) return GR_ERR_INVALID; n->params_version++; return copy_flat(n, n->params, nullptr, h); }
+extern "C" int gr_net_get_grads(gr_net* n, float* h) { if (!n || !h) return GR_ERR_INVALID; return copy_flat(n, n->grads, h, nullptr); }
+extern "C" int gr_net_set_grads(gr_net* n, const float* h) { if (!n || !h) return GR_ERR_INVALID; return copy_flat(n, n->grads, nullptr, h); }
+extern "C" int gr_net_zero_grads(gr_net* n) { if (!n) return GR_ERR_INVALID; HIPCHK(n->ctx, hipMemsetAsync(n->grads, 0, sizeof(float) * (size_t)n->n_params, n->ctx->stream)); return GR_OK; }
+extern "C" int gr_adam_reset(gr_net* n) {
+  if (!n) return GR_ERR_INVALID;
+  HIPCHK(n->ctx, hipMemsetAsync(n->adam_m, 0, sizeof(float) * (size_t)n->n_params, n->ctx->stream));
+  HIPCHK(n->ctx, hipMemsetAsync(n->adam_v, 0, sizeof(float) * (size_t)n->n_params, n->ctx->stream));
+  return GR_OK;
+}
+extern "C" int gr_adam_get_state(gr_net* n, float* m, float* v) { if (!n) return GR_ERR_INVALID; int r = m ? copy_flat(n, n->adam_m, m, nullptr) : 0; if (r) return r; return v ? copy_flat(n, n->adam_v, v, nullptr) : GR_OK; }
+extern "C" int gr_adam_set_state(gr_net* n, const float* m, const float* v) { if (!n) return GR_ERR_INVALID; int r = m ? copy_flat(n, n->adam_m, nullptr, m) : 0; if (r) return r; return v ? copy_flat(n, n->adam_v, nullptr, v) : GR_OK; }
+
+extern "C" int gr_net_n_bn(gr_net* n) { return n ? (int)n->bn_stage.size() : -1; }
+extern "C" int gr_net_bn_features(gr_net* n, int i) { if (!n || i < 0 || i >= (int)n->bn_stage.size()) return -1; return n->st[n->bn_stage[i]].Cout; }
+extern "C" int gr_net_get_bn_running(gr_net* n, int i, float* m, float* v) {
+  if (!n || i < 0 || i >= (int)n->bn_stage.size()) return GR_ERR_INVALID;
+  Stage& s = n->st[n->bn_stage[i]]; gr_ctx* c = n->ctx;
+  if (m) HIPCHK(c, hipMemcpyAsync(m, s.run_mean, sizeof(float) * s.Cout, hipMemcpyDeviceToHost, c->stream));
+  if (v) HIPCHK(c, hipMemcpyAsync(v, s.run_var, sizeof(float) * s.Cout, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+extern "C" int gr_net_set_bn_running(gr_net* n, int i, const float* m, const float* v) {
+  if (!n || i < 0 || i >= (int)n->bn_stage.size()) return GR_ERR_INVALID;
+  Stage& s = n->st[n->bn_stage[i]]; gr_ctx* c = n->ctx;
+  if (m) HIPCHK(c, hipMemcpyAsync(s.run_mean, m, sizeof(float) * s.Cout, hipMemcpyHostToDevice, c->stream));
+  if (v) HIPCHK(c, hipMemcpyAsync(s.run_var, v, sizeof(float) * s.Cout, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+extern "C" int gr_net_set_training(gr_net* n, int t) { if (!n) return GR_ERR_INVALID; n->training = t != 0; return GR_OK; }
+extern "C" int gr_net_set_seed(gr_net* n, uint64_t seed) { if (!n) return GR_ERR_INVALID; n->seed = seed; n->fwd_counter = 0; return GR_OK; }
+
+static MaskSlot* find_mask(gr_net* n, int layer) { for (auto& m : n->masks) if (m.layer == layer) return &m; return nullptr; }
+static int64_t mask_elems(const MaskSlot& m, int B) { return m.kind == MASK_ELEM ? (int64_t)B * vol3(m.C, m.H, m.W) : (int64_t)B * m.C; }
+extern "C" int64_t gr_net_mask_size(gr_net* n, int layer, int B) { if (!n) return -1; MaskSlot* m = find_mask(n, layer); return m ? mask_elems(*m, B) : -1; }
+
+static int ensure_mask_bits(gr_net* n, MaskSlot& m, int64_t elems) {
+  const size_t words = (size_t)((elems + 31) / 32) + 4;
+  if (words > m.words_cap) {
+    gr_ctx* c = n->ctx;
+    if (m.bits) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(m.bits)); m.bits = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&m.bits, sizeof(uint32_t) * words));
+    m.words_cap = words;
+  }
+  return GR_OK;
+}
+extern "C" int gr_net_set_mask(gr_net* n, int layer, const uint8_t* keep, int64_t cnt) {
+  if (!n || !keep || cnt <= 0) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx; MaskSlot* m = find_mask(n, layer);
+  if (!m) return fail(c, GR_ERR_INVALID, "layer %d is not a Dropout / SpatialDropout", layer);
+  if ((size_t)cnt > n->mask_stage_cap) {
+    if (n->mask_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(n->mask_stage)); n->mask_stage = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&n->mask_stage, (size_t)cnt)); n->mask_stage_cap = (size_t)cnt;
+  }
+  int r = ensure_mask_bits(n, *m, cnt); if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(n->mask_stage, keep, (size_t)cnt, hipMemcpyHostToDevice, c->stream));
+  launch_pack_mask(n->mask_stage, m->bits, cnt, c->stream); LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  m->injected = true; m->n_last = cnt;
+  return GR_OK;
+}
+extern "C" int gr_net_get_mask(gr_net* n, int layer, uint8_t* keep, int64_t cnt) {
+  if (!n || !keep || cnt <= 0) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx; MaskSlot* m = find_mask(n, layer);
+  if (!m || !m->bits || cnt > m->n_last) return fail(c, GR_ERR_STATE, "no noise recorded for layer %d", layer);
+  if ((size_t)cnt > n->mask_stage_cap) {
+    if (n->mask_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(n->mask_stage)); n->mask_stage = nullptr; }
+    HIPCHK(c, hipMalloc((void**)&n->mask_stage, (size_t)cnt)); n->mask_stage_cap = (size_t)cnt;
+  }
+  launch_unpack_mask(m->bits, n->mask_stage, cnt, c->stream); LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(keep, n->mask_stage, (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+
+static int ensure_batch(gr_net* n, int B) {
+  if (B <= n->capB) return GR_OK;
+  gr_ctx* c = n->ctx;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& s : n->st) {
+    if (s.kind != ST_ELEM) { (void)hipFree(s.y); s.y = nullptr; HIPCHK(c, hipMalloc((void**)&s.y, sizeof(float) * (size_t)B * vol3(s.Cout, s.H, s.W))); }
+    if (s.has_post) { (void)hipFree(s.out); s.out = nullptr; HIPCHK(c, hipMalloc((void**)&s.out, sizeof(float) * (size_t)B * vol3(s.outC, s.outH, s.outW))); }
+    if (s.pool) { (void)hipFree(s.pool_idx); s.pool_idx = nullptr; HIPCHK(c, hipMalloc((void**)&s.pool_idx, (size_t)B * vol3(s.outC, s.outH, s.outW))); }
+  }
+  (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
+  n->in_buf = n->gout_buf = n->dy_buf = n->g_buf[0] = n->g_buf[1] = nullptr;
+  HIPCHK(c, hipMalloc((void**)&n->in_buf, sizeof(float) * (size_t)B * vol3(n->inC, n->inH, n->inW)));
+  HIPCHK(c, hipMalloc((void**)&n->gout_buf, sizeof(float) * (size_t)B * vol3(n->outC, n->outH, n->outW)));
+  HIPCHK(c, hipMalloc((void**)&n->dy_buf, sizeof(float) * (size_t)B * n->max_y));
+  HIPCHK(c, hipMalloc((void**)&n->g_buf[0], sizeof(float) * (size_t)B * n->max_in));
+  HIPCHK(c, hipMalloc((void**)&n->g_buf[1], sizeof(float) * (size_t)B * n->max_in));
+  n->capB = B;
+  return GR_OK;
+}
+
+static int prep_weights(gr_net* n, Stage& s) {
+  if (s.kind != ST_CONV || s.wt_version == n->params_version) return GR_OK;
+  gr_ctx* c = n->ctx;
+  const float* w = n->params + s.w_off;
+  if (!s.fullconv) {
+    launch_conv_weight_prep(w, s.wt_fwd, s.Cin, s.Cout, false, c->stream);
+    launch_conv_weight_prep(w, s.wt_bwd, s.Cin, s.Cout, true, c->stream);
+  } else {
+    // SpatialFullConvolution weight is [Cin][Cout][3][3]: its forward is the backward-data of a (Cout -> Cin) conv
+    launch_conv_weight_prep(w, s.wt_fwd, s.Cout, s.Cin, true, c->stream);
+    launch_conv_weight_prep(w, s.wt_bwd, s.Cout, s.Cin, false, c->stream);
+  }
+  LAUNCHCHK(c);
+  s.wt_version = n->params_version;
+  return GR_OK;
+}
+
+static MaskRef mask_ref(gr_net* n, int slot, bool& need_bits) {
+  need_bits = false;
+  MaskRef r{MASK_NONE, nullptr, 1.f};
+  if (slot < 0) return r;
+  MaskSlot& m = n->masks[slot];
+  const bool v2 = (m.flags & GR_DROPOUT_V2) != 0;
+  const bool active = m.kind == MASK_ELEM ? (n->training || (m.flags & GR_DROPOUT_ALWAYS_ON)) : n->training;
+  if (active) {
+    need_bits = true;
+    r.kind = m.kind; r.bits = m.bits;
+    r.scale = (m.kind == MASK_ELEM && v2) ? 1.f / (1.f - m.p) : 1.f;
+  } else if (m.kind == MASK_SPATIAL || !v2) {
+    r.kind = MASK_SCALE; r.scale = 1.f - m.p;
+  }
+  return r;
+}
+
+static PostArgs post_args(gr_net* n, Stage& s, int B) {
+  PostArgs a{};
+  a.y = s.kind == ST_ELEM ? s.x_in : s.y; a.out = s.out;
+  a.B = B; a.C = s.Cout; a.H = s.H; a.W = s.W;
+  a.has_bn = s.has_bn ? 1 : 0;
+  a.mean = s.mean; a.invstd = s.invstd;
+  a.gamma = s.has_bn ? n->params + s.g_off : nullptr; a.beta = s.has_bn ? n->params + s.be_off : nullptr;
+  a.act = s.act; a.slope = s.slope;
+  bool nb;
+  a.m1 = mask_ref(n, s.m1, nb); a.m2 = mask_ref(n, s.m2, nb);
+  a.pool = s.pool ? 1 : 0; a.pool_idx = s.pool_idx;
+  return a;
+}
+
+static int forward_impl(gr_net* n, const float* in_dev, int B) {
+  gr_ctx* c = n->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = ensure_batch(n, B); if (r) return r;
+  const float* x = in_dev;
+  n->fwd_counter++;
+  for (auto& s : n->st) {
+    s.x_in = x;
+    if (s.kind == ST_CONV) {
+      r = prep_weights(n, s); if (r) return r;
+      launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream);
+    } else if (s.kind == ST_LINEAR) {
+      const size_t wsb = gemm_workspace_bytes(B, s.Cout, s.Cin);
+      r = ensure_ws(c, wsb); if (r) return r;
+      launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.y, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream);
+    }
+    LAUNCHCHK(c);
+    if (!s.has_post) { s.out = s.y; x = s.out; continue; }
+    const float* yv = s.kind == ST_ELEM ? x : s.y;
+    if (s.has_bn) {
+      if (n->training) launch_bn_stats(yv, B, s.Cout, s.H * s.W, s.partials, s.mean, s.invstd, s.run_mean, s.run_var, 1, c->stream);
+      else launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream);
+    }
+    for (int slot : {s.m1, s.m2}) {
+      if (slot < 0) continue;
+      bool need; (void)mask_ref(n, slot, need);
+      if (!need) continue;
+      MaskSlot& m = n->masks[slot];
+      const int64_t elems = mask_elems(m, B);
+      if (m.injected) {
+        if (m.n_last != elems) return fail(c, GR_ERR_INVALID, "injected noise for layer %d has %lld elements, forward needs %lld", m.layer, (long long)m.n_last, (long long)elems);
+        m.injected = false;
+      } else {
+        r = ensure_mask_bits(n, m, elems); if (r) return r;
+        launch_gen_mask(m.bits, elems, m.p, n->seed, n->fwd_counter, (uint32_t)m.layer, c->stream);
+        m.n_last = elems;
+      }
+    }
+    launch_post_forward(post_args(n, s, B), c->stream);
+    LAUNCHCHK(c);
+    x = s.out;
+  }
+  n->lastB = B;
+  return GR_OK;
+}
+
+extern "C" float* gr_net_output_dev(gr_net* n) { return (n && !n->st.empty()) ? n->st.back().out : nullptr; }
+
+extern "C" int gr_net_forward_dev(gr_net* n, const float* in_dev, int B, float* out_dev) {
+  if (!n || !in_dev || B <= 0) return GR_ERR_INVALID;
+  int r = forward_impl(n, in_dev, B); if (r) return r;
+  if (out_dev) HIPCHK(n->ctx, hipMemcpyAsync(out_dev, n->st.back().out, sizeof(float) * (size_t)B * vol3(n->outC, n->outH, n->outW), hipMemcpyDeviceToDevice, n->ctx->stream));
+  return GR_OK;
+}
+
+extern "C" int gr_net_forward_host(gr_net* n, const float* in_host, int B, float* out_host) {
+  if (!n || !in_host || B <= 0) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = ensure_batch(n, B); if (r) return r;
+  HIPCHK(c, hipMemcpyAsync(n->in_buf, in_host, sizeof(float) * (size_t)B * vol3(n->inC, n->inH, n->inW), hipMemcpyHostToDevice, c->stream));
+  r = forward_impl(n, n->in_buf, B); if (r) return r;
+  if (out_host) HIPCHK(c, hipMemcpyAsync(out_host, n->st.back().out, sizeof(float) * (size_t)B * vol3(n->outC, n->outH, n->outW), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+
+extern "C" int gr_net_layer_output(gr_net* n, int layer, float* host, int64_t cnt) {
+  if (!n || !host || n->lastB <= 0) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx;
+  for (auto& s : n->st) {
+    const float* p = nullptr; int64_t e = 0;
+    if (layer == s.main_layer) { p = s.y; e = (int64_t)n->lastB * vol3(s.Cout, s.H, s.W); }
+    else if (layer == s.last && s.has_post) { p = s.out; e = (int64_t)n->lastB * vol3(s.outC, s.outH, s.outW); }
+    if (p) {
+      if (cnt != e) return fail(c, GR_ERR_INVALID, "layer %d output has %lld elements", layer, (long long)e);
+      HIPCHK(c, hipMemcpyAsync(host, p, sizeof(float) * (size_t)e, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      return GR_OK;
+    }
+  }
+  return fail(c, GR_ERR_UNSUPPORTED, "layer %d is fused into its stage; its output is never materialised", layer);
+}
+
+static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, int B, float* gin_dev) {
+  gr_ctx* c = n->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (B != n->lastB) return fail(c, GR_ERR_STATE, "backward batch %d does not match the last forward (%d)", B, n->lastB);
+  const float* g = gout_dev;
+  for (int si = (int)n->st.size() - 1; si >= 0; --si) {
+    Stage& s = n->st[si];
+    if (s.has_bn && !n->training) return fail(c, GR_ERR_STATE, "backward through BatchNormalization requires training mode");
+    const float* x = si == 0 ? in_dev : s.x_in;
+    const bool need_gin = si > 0 || gin_dev != nullptr;
+    float* gin = (si == 0 && gin_dev) ? gin_dev : n->g_buf[si & 1];
+    // pipeline backward: g (wrt stage output) -> dy (wrt raw main-op output / ELEM input)
+    PostBwdArgs pb{};
+    pb.f = post_args(n, s, B);
+    if (!s.has_post) { pb.f.out = nullptr; }
+    pb.gout = g;
+    pb.dy = s.kind == ST_ELEM ? gin : n->dy_buf;
+    pb.partials = s.partials; pb.coef = s.coef;
+    pb.ggamma = s.has_bn ? n->grads + s.g_off : nullptr; pb.gbeta = s.has_bn ? n->grads + s.be_off : nullptr;
+    pb.gbias = s.kind == ST_ELEM ? nullptr : n->grads + s.b_off;
+    launch_post_backward(pb, c->stream);
+    LAUNCHCHK(c);
+    if (s.kind == ST_CONV) {
+      if (s.up) return fail(c, GR_ERR_UNSUPPORTED, "backward through the fused UpSamplingNearest is not implemented (G is forward-only on this path)");
+      if (s.fullconv) return fail(c, GR_ERR_UNSUPPORTED, "SpatialFullConvolution backward is not implemented");
+      int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W)); if (r) return r;
+      launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream);
+      if (need_gin) launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+      LAUNCHCHK(c);
+    } else if (s.kind == ST_LINEAR) {
+      size_t wsb = gemm_workspace_bytes(s.Cout, s.Cin, B);
+      const size_t wsb2 = gemm_workspace_bytes(B, s.Cin, s.Cout);
+      if (wsb2 > wsb) wsb = wsb2;
+      int r = ensure_ws(c, wsb); if (r) return r;
+      // gW[o][i] += sum_b dy[b][o] x[b][i]
+      launch_gemm(n->dy_buf, 1, s.Cout, x, 1, s.Cin, n->grads + s.w_off, s.Cin, nullptr, true, s.Cout, s.Cin, B, c->ws, c->stream);
+      // gx[b][i] = sum_o dy[b][o] W[o][i]
+      if (need_gin) launch_gemm(n->dy_buf, s.Cout, 1, n->params + s.w_off, 1, s.Cin, gin, s.Cin, nullptr, false, B, s.Cin, s.Cout, c->ws, c->stream);
+      LAUNCHCHK(c);
+    }
+    g = gin;
+  }
+  return GR_OK;
+}
+
+extern "C" int gr_net_backward_dev(gr_net* n, const float* in_dev, const float* gout_dev, int B, float* gin_dev) {
+  if (!n || !in_dev || !gout_dev || B <= 0) return GR_ERR_INVALID;
+  return backward_impl(n, in_dev, gout_dev, B, gin_dev);
+}
+
+extern "C" int gr_net_backward_host(gr_net* n, const float* in_host, const float* gout_host, int B, float* gin_host) {
+  if (!n || !in_host || !gout_host || B <= 0) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (B > n->capB) return fail(c, GR_ERR_STATE, "backward before forward");
+  // the module caches state from forward; `input` must hold the same values (Torch7 contract), re-upload it
+  HIPCHK(c, hipMemcpyAsync(n->in_buf, in_host, sizeof(float) * (size_t)B * vol3(n->inC, n->inH, n->inW), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(n->gout_buf, gout_host, sizeof(float) * (size_t)B * vol3(n->outC, n->outH, n->outW), hipMemcpyHostToDevice, c->stream));
+  float* gin_dev = nullptr;
+  if (gin_host) gin_dev = n->g_buf[0];   // stage 0 writes g_buf[0] anyway
+  int r = backward_impl(n, n->in_buf, n->gout_buf, B, gin_dev); if (r) return r;
+  if (gin_host) HIPCHK(c, hipMemcpyAsync(gin_host, gin_dev, sizeof(float) * (size_t)B * vol3(n->inC, n->inH, n->inW), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+
+// ------------------------------------------------------------------ criterion
+extern "C" int gr_mse_dev(gr_ctx* c, const float* x, const float* t, int64_t n, int64_t ng, double* loss_dev, float* grad) {
+  if (!c || !x || !t || n <= 0 || ng <= 0) return GR_ERR_INVALID;
+  launch_mse(x, t, n, ng, loss_dev, grad, c->stream); LAUNCHCHK(c);
+  return GR_OK;
+}
+extern "C" int gr_mse_host(gr_ctx* c, const float* x, const float* t, int64_t n, int64_t ng, double* loss, float* grad) {
+  if (!c || !x || !t || n <= 0 || ng <= 0) return GR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = ensure_ws(c, sizeof(float) * 3 * (size_t)n); if (r) return r;
+  float* dx = (float*)c->ws; float* dt = dx + n; float* dg = dt + n;
+  HIPCHK(c, hipMemcpyAsync(dx, x, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dt, t, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  launch_mse(dx, dt, n, ng, c->d_loss, grad ? dg : nullptr, c->stream); LAUNCHCHK(c);
+  if (grad) HIPCHK(c, hipMemcpyAsync(grad, dg, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (loss) *loss = *c->h_loss;
+  return GR_OK;
+}
+
+// ------------------------------------------------------------------ optimiser
+static AdamConsts adam_consts(const gr_hyper* h, int t) {
+  AdamConsts k{};
+  k.b1 = (float)h->beta1; k.b2 = (float)h->beta2; k.eps = (float)h->eps;
+  k.c1 = (float)(1.0 - h->beta1); k.c2 = (float)(1.0 - h->beta2);
+  const double bc1 = 1.0 - std::pow(h->beta1, t), bc2 = 1.0 - std::pow(h->beta2, t);
+  k.step = (float)(-(h->lr * std::sqrt(bc2) / bc1));
+  k.l1 = (float)h->l1; k.l2 = (float)h->l2; k.clamp = (float)h->clamp;
+  k.use_penalty = (h->l1 != 0 || h->l2 != 0) ? 1 : 0;
+  k.use_clamp = h->clamp != 0 ? 1 : 0;
+  return k;
+}
+extern "C" int gr_adam_step(gr_net* n, const gr_hyper* h, int t) {
+  if (!n || !h || t < 1) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx;
+  launch_penalty_clamp_adam(n->params, n->grads, n->adam_m, n->adam_v, n->n_params, adam_consts(h, t), c->stream);
+  LAUNCHCHK(c);
+  n->params_version++;
+  return GR_OK;
+}
+
+// ------------------------------------------------------------------ data parallelism (RCCL over xGMI)
+static_assert(sizeof(ncclUniqueId) <= GR_COMM_ID_BYTES, "unique id does not fit");
+extern "C" int gr_comm_unique_id(gr_ctx* c, void* id_out) {
+  if (!c || !id_out) return GR_ERR_INVALID;
+  ncclUniqueId id; NCCLCHK(c, ncclGetUniqueId(&id));
+  memset(id_out, 0, GR_COMM_ID_BYTES); memcpy(id_out, &id, sizeof id);
+  return GR_OK;
+}
+extern "C" int gr_comm_init(gr_ctx* c, const void* idb, int nranks, int rank) {
+  if (!c || !idb || nranks < 1 || rank < 0 || rank >= nranks) return GR_ERR_INVALID;
+  if (c->comm) return fail(c, GR_ERR_STATE, "communicator already initialised");
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId id; memcpy(&id, idb, sizeof id);
+  NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+  c->nranks = nranks; c->rank = rank;
+  return GR_OK;
+}
+extern "C" int gr_comm_destroy(gr_ctx* c) {
+  if (!c) return GR_ERR_INVALID;
+  if (c->comm) { HIPCHK(c, hipStreamSynchronize(c->stream)); NCCLCHK(c, ncclCommDestroy(c->comm)); c->comm = nullptr; }
+  c->nranks = 1; c->rank = 0;
+  return GR_OK;
+}
+extern "C" int gr_comm_ranks(gr_ctx* c, int* nr, int* r) { if (!c) return GR_ERR_INVALID; if (nr) *nr = c->nranks; if (r) *r = c->rank; return GR_OK; }
+extern "C" int gr_allreduce_dev(gr_ctx* c, float* buf, int64_t n) {
+  if (!c || !buf || n <= 0) return GR_ERR_INVALID;
+  if (c->nranks <= 1 || !c->comm) return GR_OK;
+  NCCLCHK(c, ncclAllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
+  return GR_OK;
+}
+extern "C" int gr_allreduce_grads(gr_net* n) { if (!n) return GR_ERR_INVALID; return gr_allreduce_dev(n->ctx, n->grads, n->n_params); }
+extern "C" int gr_broadcast_params(gr_net* n, int root) {
+  if (!n) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx;
+  if (c->nranks <= 1 || !c->comm) return GR_OK;
+  NCCLCHK(c, ncclBroadcast(n->params, n->params, (size_t)n->n_params, ncclFloat, root, c->comm, c->stream));
+  for (auto& s : n->st) if (s.has_bn) {
+    NCCLCHK(c, ncclBroadcast(s.run_mean, s.run_mean, (size_t)s.Cout, ncclFloat, root, c->comm, c->stream));
+    NCCLCHK(c, ncclBroadcast(s.run_var, s.run_var, (size_t)s.Cout, ncclFloat, root, c->comm, c->stream));
+  }
+  n->params_version++;
+  return GR_OK;
+}
+
+// ------------------------------------------------------------------ the whole train_r.lua:138-170 iteration
+extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, int B, int GB, const gr_hyper* h, int t, double* loss_out) {
+  if (!g || !rn || !noise_dev || !h || B <= 0 || GB < B || t < 1) return GR_ERR_INVALID;
+  gr_ctx* c = rn->ctx;
+  if (g->ctx != c) return fail(c, GR_ERR_INVALID, "G and R live on different contexts");
+  const int64_t nd = vol3(rn->outC, rn->outH, rn->outW);
+  if (vol3(g->inC, g->inH, g->inW) != nd) return fail(c, GR_ERR_INVALID, "noise dim mismatch: G takes %lld, R emits %lld", (long long)vol3(g->inC, g->inH, g->inW), (long long)nd);
+  if (vol3(g->outC, g->outH, g->outW) != vol3(rn->inC, rn->inH, rn->inW)) return fail(c, GR_ERR_INVALID, "image dim mismatch between G and R");
+  const bool tm = c->timing;
+  int r;
+  if (tm) (void)hipEventRecord(c->ev[0], c->stream);
+  g->training = false;                                         // train_r.lua:70  MODEL_G:evaluate()
+  r = forward_impl(g, noise_dev, B); if (r) return r;          // train_r.lua:139
+  const float* images = g->st.back().out;
+  if (tm) (void)hipEventRecord(c->ev[1], c->stream);
+  rn->training = true;
+  r = gr_net_zero_grads(rn); if (r) return r;                  // :143
+  r = forward_impl(rn, images, B); if (r) return r;            // :146
+  if (tm) (void)hipEventRecord(c->ev[2], c->stream);
+  launch_mse(rn->st.back().out, noise_dev, (long)B * nd, (long)GB * nd, c->d_loss, rn->gout_buf, c->stream);  // :147,150
+  LAUNCHCHK(c);
+  if (tm) (void)hipEventRecord(c->ev[3], c->stream);
+  r = backward_impl(rn, images, rn->gout_buf, B, nullptr); if (r) return r;   // :151
+  if (tm) (void)hipEventRecord(c->ev[4], c->stream);
+  if (c->nranks > 1 && c->comm) {
+    // the penalty and the clamp are non-linear in g (train_r.lua:154-165): reduce first
+    NCCLCHK(c, ncclAllReduce(rn->grads, rn->grads, (size_t)rn->n_params, ncclFloat, ncclSum, c->comm, c->stream));
+    NCCLCHK(c, ncclAllReduce(c->d_loss, c->d_loss, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  }
+  if (tm) (void)hipEventRecord(c->ev[5], c->stream);
+  r = gr_adam_step(rn, h, t); if (r) return r;                 // :153-170
+  if (tm) (void)hipEventRecord(c->ev[6], c->stream);
+  if (loss_out || tm) {
+    HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (loss_out) *loss_out = *c->h_loss;
+    if (tm) for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]);
+  }
+  return GR_OK;
+}
+
+// ------------------------------------------------------------------ search
+extern "C" int gr_cosine_topk_dev(gr_ctx* c, const float* emb, int64_t N, int d, const int64_t* qrows, int Q, int k,
+                                  int64_t* idx_out, float* score_out, int accf) {
+  if (!c || !emb || !qrows || !idx_out || N <= 0 || d <= 0 || Q <= 0 || k <= 0) return GR_ERR_INVALID;
+  if (k > N) k = (int)N;
+  for (int q = 0; q < Q; ++q) if (qrows[q] < 0 || qrows[q] >= N) return fail(c, GR_ERR_INVALID, "query row %lld out of range", (long long)qrows[q]);
+  if (k > 1024) return fail(c, GR_ERR_UNSUPPORTED, "k > 1024");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t tail = sizeof(long) * (size_t)Q * (k + 1) + sizeof(float) * (size_t)Q * k + 256;
+  const size_t wsb = cosine_topk_workspace_bytes(N, d, Q, k);
+  int r = ensure_ws(c, wsb + tail); if (r) return r;
+  char* base = (char*)c->ws + ((wsb + 255) & ~(size_t)255);
+  long* d_q = (long*)base; long* d_idx = d_q + Q; float* d_sc = (float*)(d_idx + (size_t)Q * k);
+  HIPCHK(c, hipMemcpyAsync(d_q, qrows, sizeof(long) * Q, hipMemcpyHostToDevice, c->stream));
+  if (launch_cosine_topk(emb, N, d, d_q, Q, k, d_idx, d_sc, accf, c->ws, c->stream)) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(idx_out, d_idx, sizeof(long) * (size_t)Q * k, hipMemcpyDeviceToHost, c->stream));
+  if (score_out) HIPCHK(c, hipMemcpyAsync(score_out, d_sc, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+extern "C" int gr_cosine_topk_host(gr_ctx* c, const float* emb, int64_t N, int d, const int64_t* qrows, int Q, int k,
+                                   int64_t* idx_out, float* score_out, int accf) {
+  if (!c || !emb || N <= 0 || d <= 0) return GR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  float* dev = nullptr;
+  HIPCHK(c, hipMalloc((void**)&dev, sizeof(float) * (size_t)N * d));
+  hipError_t e = hipMemcpyAsync(dev, emb, sizeof(float) * (size_t)N * d, hipMemcpyHostToDevice, c->stream);
+  int r = e == hipSuccess ? gr_cosine_topk_dev(c, dev, N, d, qrows, Q, k, idx_out, score_out, accf) : fail(c, GR_ERR_HIP, "upload failed");
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(dev);
+  return r;
+}
+extern "C" int gr_cosine_similarity_host(gr_ctx* c, const float* a, const float* b, int d, float* out) {
+  if (!c || !a || !b || !out || d <= 0) return GR_ERR_INVALID;
+  std::vector<float> two((size_t)2 * d);
+  memcpy(two.data(), a, sizeof(float) * d); memcpy(two.data() + d, b, sizeof(float) * d);
+  int64_t q = 0, idx[2]; float sc[2];
+  int r = gr_cosine_topk_host(c, two.data(), 2, d, &q, 1, 2, idx, sc, 0); if (r) return r;
+  *out = idx[0] == 1 ? sc[0] : sc[1];   // score of row 1 against needle row 0
+  return GR_OK;
+}
+
+// ------------------------------------------------------------------ single-kernel entry points
+static int with_prepped(gr_ctx* c, const float* w, int cin, int cout, bool bwd, float** wt) {
+  const ConvWeightLayout L = bwd ? conv_weight_layout(cout, cin) : conv_weight_layout(cin, cout);
+  HIPCHK(c, hipMalloc((void**)wt, sizeof(float) * L.elems()));
+  launch_conv_weight_prep(w, *wt, cin, cout, bwd, c->stream);
+  LAUNCHCHK(c);
+  return GR_OK;
+}
+extern "C" int gr_conv3_forward_dev(gr_ctx* c, const float* in, const float* w, const float* bias, float* out, int B, int cin, int cout, int h, int wd, int up) {
+  if (!c || !in || !w || !out) return GR_ERR_INVALID;
+  float* wt = nullptr; int r = with_prepped(c, w, cin, cout, false, &wt); if (r) return r;
+  launch_conv3x3(in, wt, bias, out, B, cin, cout, h, wd, up != 0, c->stream);
+  hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(wt);
+  return e == hipSuccess ? GR_OK : fail(c, GR_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
+}
+extern "C" int gr_conv3_backward_data_dev(gr_ctx* c, const float* gout, const float* w, float* gin, int B, int cin, int cout, int h, int wd) {
+  if (!c || !gout || !w || !gin) return GR_ERR_INVALID;
+  float* wt = nullptr; int r = with_prepped(c, w, cin, cout, true, &wt); if (r) return r;
+  launch_conv3x3(gout, wt, nullptr, gin, B, cout, cin, h, wd, false, c->stream);
+  hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(wt);
+  return e == hipSuccess ? GR_OK : fail(c, GR_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
+}
+extern "C" int gr_conv3_backward_weight_dev(gr_ctx* c, const float* in, const float* gout, float* gw, int B, int cin, int cout, int h, int wd) {
+  if (!c || !in || !gout || !gw) return GR_ERR_INVALID;
+  int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd)); if (r) return r;
+  launch_conv3x3_wgrad(in, gout, gw, c->ws, B, cin, cout, h, wd, c->stream);
+  LAUNCHCHK(c);
+  return GR_OK;
+}
+extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, int h, int wd, int iters, float* avg_ms) {
+  if (!c || iters < 1 || !avg_ms) return GR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nin = (size_t)B * cin * h * wd, nout = (size_t)B * cout * h * wd, nw = (size_t)cin * cout * 9;
+  float *x = nullptr, *y = nullptr, *w = nullptr, *wt = nullptr, *gw = nullptr;
+  HIPCHK(c, hipMalloc((void**)&x, sizeof(float) * nin)); HIPCHK(c, hipMalloc((void**)&y, sizeof(float) * nout));
+  HIPCHK(c, hipMalloc((void**)&w, sizeof(float) * nw)); HIPCHK(c, hipMalloc((void**)&gw, sizeof(float) * nw));
+  launch_fill_normal(x, (long)nin, 11, c->stream); launch_fill_normal(y, (long)nout, 12, c->stream); launch_fill_normal(w, (long)nw, 13, c->stream);
+  (void)hipMemsetAsync(gw, 0, sizeof(float) * nw, c->stream);
+  int r = with_prepped(c, w, cin, cout, which == 1, &wt); if (r) return r;
+  r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd)); if (r) return r;
+  auto run = [&]() {
+    if (which == 0) launch_conv3x3(x, wt, nullptr, y, B, cin, cout, h, wd, false, c->stream);
+    else if (which == 1) launch_conv3x3(y, wt, nullptr, x, B, cout, cin, h, wd, false, c->stream);
+    else launch_conv3x3_wgrad(x, y, gw, c->ws, B, cin, cout, h, wd, c->stream);
+  };
+  for (int i = 0; i < 3; ++i) run();
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, c->stream);
+  for (int i = 0; i < iters; ++i) run();
+  (void)hipEventRecord(e1, c->stream);
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+  *avg_ms = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(wt); (void)hipFree(gw);
+  LAUNCHCHK(c);
+  return GR_OK;
+}

