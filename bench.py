@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the gan-reverser hot path step on MI355X:
+   noise -> G forward (evaluate) -> R forward/backward (training) -> [RCCL all-reduce] -> L2+clamp+Adam
+   (reference train_r.lua:138-170) at BASELINE.json configs[1]: 32x32 grayscale, noise=32, batch=256 per GPU.
+
+python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run, one rank per GPU)
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "gan-reverser_amd"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # BASELINE.json configs[1] / configs[2]
+    "cfg2": dict(dims=(1, 32, 32), nd=32, batch=256, name="32x32 grayscale, noise=32, batch=256/GPU: G fwd + R fwd/bwd + Adam"),
+    "cfg3": dict(dims=(3, 64, 64), nd=100, batch=512, name="64x64 RGB, noise=100, batch=512/GPU: G fwd + R fwd/bwd + Adam"),
+}
+
+
+def step_flops_per_image(dims, nd):
+    """Algorithmic FLOPs (multiply-add = 2) of one image through the step: G fwd + 3 x R fwd."""
+    c, h, w = dims
+    h4, w4 = h // 4, w // 4
+    conv = lambda ci, co, hh, ww: 2.0 * 9 * ci * co * hh * ww
+    g = 2.0 * nd * 512 * h4 * w4 + conv(512, 256, h // 2, w // 2) + conv(256, 128, h, w) + conv(128, c, h, w)
+    r = (conv(c, 64, h, w) + 2 * conv(64, 64, h, w) + conv(64, 128, h // 2, w // 2) + 2 * conv(128, 128, h // 2, w // 2)
+         + 2.0 * 128 * h4 * w4 * 512 + 2.0 * 512 * nd)
+    return g + 3 * r, g, r
+
+
+def cpu_baseline(dims, nd, sample_batch, threads):
+    """The oracle (CPU restatement of the Torch7 nn path) timed on this box's host cores on a bounded sample."""
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    import numpy as np
+    from ganrev import models, synth
+    from oracle import oracle
+    G = models.create_G(dims, nd); synth.init_params(G, 1)
+    R = models.create_R(dims, nd); synth.init_params(R, 2)
+    oG, oR = oracle.from_model(G, (nd, 1, 1)), oracle.from_model(R, dims)
+    for m in R.leaves():
+        if m.typename in ("nn.Dropout", "nn.SpatialDropout"):
+            li = oR.layer_index[id(m)]
+            oR.set_mask(li, synth.bernoulli_keep((oR.mask_size(li, sample_batch),), 7 + li, m.p))
+    mm = np.zeros(oR.n_params, np.float32); vv = np.zeros_like(mm)
+    noise = synth.normal((sample_batch, nd), 9)
+    oracle.train_r_step(oG, oR, noise, oracle.GoHyper(), mm, vv, 1)          # warm-up (page-in, thread pool)
+    t0 = time.perf_counter(); n = 0
+    while True:
+        oracle.train_r_step(oG, oR, noise, oracle.GoHyper(), mm, vv, 2 + n)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 8.0 or n >= 20:
+            break
+    return dict(value=round(sample_batch * n / dt, 2), unit="images/sec", cores=threads, kind="port",
+                sample=f"{n} steps of the same step at batch {sample_batch} ({dt:.1f} s); oracle = C restatement of the Torch7 nn CPU path, OpenMP")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=32)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    import ganrev._lib as L
+    from ganrev import models, synth
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only; gradients go over RCCL
+
+    wl = WORKLOADS[args.workload]
+    dims, nd, B = wl["dims"], wl["nd"], wl["batch"]
+    ctx = L.Context(local_rank)
+    G = models.create_G(dims, nd); synth.init_params(G, 1)               # random-init weights of the named architecture
+    R = models.create_R(dims, nd); synth.init_params(R, 2)
+    dnoise = ctx.malloc(4 * B * nd)
+    G._ctx = R._ctx = ctx
+    # compile the nets with one small forward each (allocation happens at the first full-size step, in warm-up)
+    import numpy as np
+    G.evaluate(); G.forward(synth.normal((2, nd), 1))
+    R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
+    gnet, rnet = G._net, R._net
+    rnet.set_seed(1 + rank)                                              # independent dropout noise per rank
+    rnet.adam_reset()
+    if world > 1:
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], world, rank)
+        rnet.broadcast_params(0)
+    hyper = L.Hyper()
+    GB = B * world
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_adam = 0
+
+    def step(want_loss=False):
+        nonlocal t_adam
+        t_adam += 1
+        ctx.fill_normal(dnoise, B * nd, (t_adam << 8) + rank)            # createNoiseInputs (utils/nn_utils.lua:39-51), on device
+        return L.train_r_step(gnet, rnet, dnoise, B, GB, hyper, t_adam, want_loss=want_loss)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = step(want_loss=True)
+
+    out = None
+    if rank == 0:
+        # ---- roofline leg: per-kernel HIP events (on the launch stream) over extra steps of the same workload
+        ctx.set_timing(2)
+        nprof = 3
+        for _ in range(nprof):
+            step()
+        kt = ctx.kernel_times()
+        ctx.set_timing(0)
+        fl_img, g_fl, r_fl = step_flops_per_image(dims, nd)
+        mfma = [k for k in kt if k["kernel"].startswith(("conv3x3_mfma", "conv3x3_wgrad_kernel"))]
+        dom = max(mfma, key=lambda k: k["total_ms"])
+        avg_ms = dom["total_ms"] / dom["launches"]
+        achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload, {}).get(dom["kernel"])
+            except Exception:
+                traffic = None
+        roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                        avg_launch_ms=round(avg_ms, 4), launches_per_step=dom["launches"] / nprof,
+                        algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3))
+        conv_ms = sum(k["total_ms"] for k in mfma) / nprof
+        conv_fl = sum(k["flops"] for k in mfma) / nprof
+        kernels = {k["kernel"]: dict(ms_per_step=round(k["total_ms"] / nprof, 4), launches_per_step=round(k["launches"] / nprof, 2),
+                                     tflops=round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 2) if k["flops"] else None,
+                                     gbs=round(k["bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1) if k["bytes"] else None)
+                   for k in sorted(kt, key=lambda k: -k["total_ms"])}
+        ms_step = dt / args.steps * 1e3
+        out = {
+            "metric": "images/sec G+R fwd/bwd", "value": round(GB * args.steps / dt, 1), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "global_batch": GB, "per_gpu_batch": B,
+                       "parallelism": f"dp{world}" + (" (RCCL all-reduce of R's flat gradient)" if world > 1 else ""),
+                       "bn": "per-rank batch statistics"},
+            "step_tflops": round(fl_img * GB * args.steps / dt / 1e12 / world, 2),
+            "step_frac_of_fp32_mfma_peak": round(fl_img * GB * args.steps / dt / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
+            "conv_kernels_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+            "last_loss": loss,
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(dims, nd, args.cpu_sample_batch, threads)
+        else:
+            out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        ctx.comm_destroy()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@
 //     adjacent input channels at the same tap, so the B operand read is patch[ci+h][pix + tap offset]
 //     (consecutive lanes -> consecutive LDS words) and the A operand read is wts[k+h][o] (same).
 #include "kernels.h"
+#include <string>
 
 namespace gr {
 
@@ -179,6 +180,10 @@ static void launch_conv_t(const ConvArgs& a0, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  static const std::string name = "conv3x3_mfma_kernel<" + std::to_string(MT) + ", " + std::to_string(TW) + ">";
+  const double px = (double)a.B * a.H * a.W;
+  KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0,
+             4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_mfma_kernel<MT, TW>), dim3(grid), dim3(256), lds, s, a);
 }
 
@@ -225,6 +230,7 @@ void launch_conv_weight_prep(const float* w_native, float* wt, int cin, int cout
   const ConvWeightLayout L = conv_weight_layout(CI, CO);
   const long n = (long)L.elems();
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  KtScope kt("conv_weight_prep_kernel", 0.0, 4.0 * (9.0 * cin * cout + (double)n), s);
   hipLaunchKernelGGL(conv_weight_prep_kernel, dim3(grid), dim3(256), 0, s, w_native, wt, cin, cout, CI, CO,
                      L.cin_pad, L.cout_pad, bwd ? 1 : 0);
 }
@@ -364,10 +370,16 @@ void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* work
   wgrad_geometry(B, Cin, Cout, H, W, a, TW);
   a.x = x; a.dy = dy; a.slab = reinterpret_cast<float*>(workspace);
   const int grid = a.nsplit * a.n_ob * a.n_cb;
-  if (TW == 8) hipLaunchKernelGGL(conv3x3_wgrad_kernel<8>, dim3(grid), dim3(256), 0, s, a);
-  else if (TW == 16) hipLaunchKernelGGL(conv3x3_wgrad_kernel<16>, dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, a);
+  const double px = (double)B * H * W;
+  {
+    const char* name = TW == 8 ? "conv3x3_wgrad_kernel<8>" : (TW == 16 ? "conv3x3_wgrad_kernel<16>" : "conv3x3_wgrad_kernel<32>");
+    KtScope kt(name, 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
+    if (TW == 8) hipLaunchKernelGGL(conv3x3_wgrad_kernel<8>, dim3(grid), dim3(256), 0, s, a);
+    else if (TW == 16) hipLaunchKernelGGL(conv3x3_wgrad_kernel<16>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, a);
+  }
   const long n = (long)9 * Cout * a.cinp;
+  KtScope kt("conv3x3_wgrad_reduce_kernel", (double)n * a.nsplit, 4.0 * n * (a.nsplit + 2.0), s);
   hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                      a.slab, gw, Cin, Cout, a.cinp, a.coutp, a.nsplit);
 }

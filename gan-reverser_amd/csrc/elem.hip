@@ -90,6 +90,7 @@ void launch_post_forward(const PostArgs& a, hipStream_t s) {
   long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
+  KtScope kt("post_forward_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + (double)n), s);
   hipLaunchKernelGGL(post_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
@@ -147,7 +148,11 @@ void launch_bn_stats(const float* y, int B, int C, int HW, double* partials, flo
   (void)training;
   const long n = (long)B * HW;
   const int splits = stat_splits(n);
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, splits), dim3(256), 0, s, y, B, C, HW, splits, partials);
+  {
+    KtScope kt("bn_stats_partial_kernel", 0.0, 4.0 * (double)n * C, s);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, splits), dim3(256), 0, s, y, B, C, HW, splits, partials);
+  }
+  KtScope kt("bn_stats_finalize_kernel", 0.0, 0.0, s);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partials, C, splits, (double)n,
                      mean, invstd, run_mean, run_var);
 }
@@ -246,10 +251,17 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s) {
   const PostArgs& f = a.f;
   const long n = (long)f.B * f.H * f.W;
   const int splits = stat_splits(n);
-  hipLaunchKernelGGL(post_backward_a_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+  const double pre = (double)n * f.C, post = f.pool ? pre / 4 : pre;
+  {
+    KtScope kt("post_backward_a_kernel", 0.0, 4.0 * (2.0 * pre + post), s);
+    hipLaunchKernelGGL(post_backward_a_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+  }
   hipLaunchKernelGGL(post_backward_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a, splits, (double)n);
   if (f.has_bn) {
-    hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+    {
+      KtScope kt("post_backward_b_kernel", 0.0, 4.0 * 3.0 * pre, s);
+      hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+    }
     if (a.gbias)
       hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a.partials, a.gbias, f.C, splits);
   }
@@ -294,6 +306,7 @@ void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long 
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
+  KtScope kt("penalty_clamp_adam_kernel", 0.0, 32.0 * (double)n, s);   // read theta,g,m,v + write theta,g,m,v
   hipLaunchKernelGGL(penalty_clamp_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, theta, g, m, v, n, c);
 }
 

@@ -115,12 +115,16 @@ void launch_gemm(const float* A, long rsA, long ksA, const float* Bm, long rsB, 
   gemm_plan(M, N, K, a.nsplit, a.klen);
   dim3 grid((N + 63) / 64, (M + 63) / 64, a.nsplit);
   const bool ak = ksA == 1, bk = ksB == 1;
+  {
+  KtScope kt("gemm_mfma_kernel", 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), s);
   if (ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), 0, s, a);
   else if (ak && !bk) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), 0, s, a);
   else if (!ak && bk) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), 0, s, a);
+  }
   if (a.nsplit > 1) {
     const long n = (long)M * N;
+    KtScope kt("gemm_splitk_reduce_kernel", (double)n * a.nsplit, 4.0 * n * (a.nsplit + 1.0), s);
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        a.slab, C, bias, ldc, M, N, a.nsplit, a.accumulate);
   }

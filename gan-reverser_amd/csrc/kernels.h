@@ -11,6 +11,21 @@ constexpr int CONV_CK = 8;  // input channels per LDS chunk (k = tap*8 + ci_loca
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// ---------------------------------------------------------------- optional per-kernel HIP-event timing (bench / roofline leg)
+// When a timer is installed every launch_* brackets its kernel with two events ON THE LAUNCH STREAM and reports the
+// kernel's name plus its ALGORITHMIC flops and bytes; with no timer installed these are two null checks.
+struct KernelTimer {
+  virtual void begin(const char* name, double flops, double bytes, hipStream_t s) = 0;
+  virtual void end(hipStream_t s) = 0;
+  virtual ~KernelTimer() {}
+};
+extern KernelTimer* g_ktimer;
+struct KtScope {
+  hipStream_t s;
+  KtScope(const char* name, double flops, double bytes, hipStream_t st) : s(st) { if (g_ktimer) g_ktimer->begin(name, flops, bytes, s); }
+  ~KtScope() { if (g_ktimer) g_ktimer->end(s); }
+};
+
 // Weights in "k-major" layout consumed by conv3x3_mfma: [Cin_pad/8][9 taps][8 ci][cout_pad]
 struct ConvWeightLayout {
   int cin_pad, cout_pad;

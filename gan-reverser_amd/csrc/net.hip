@@ -33,6 +33,34 @@ struct gr_ctx {
   float times[6] = {0, 0, 0, 0, 0, 0};
 };
 
+// ---- per-kernel event timer (gr_set_timing(ctx, 2)) -------------------------------------------------------------
+namespace gr { KernelTimer* g_ktimer = nullptr; }
+struct EventTimer : gr::KernelTimer {
+  struct Rec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
+  std::vector<hipEvent_t> pool; size_t next = 0;
+  std::vector<Rec> open_, recs;
+  struct Agg { long launches = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::vector<std::pair<std::string, Agg>> agg;
+  hipEvent_t get() { if (next == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); } return pool[next++]; }
+  void begin(const char* name, double flops, double bytes, hipStream_t s) override {
+    Rec r{name, flops, bytes, get(), get()}; (void)hipEventRecord(r.e0, s); open_.push_back(r);
+  }
+  void end(hipStream_t s) override { Rec r = open_.back(); open_.pop_back(); (void)hipEventRecord(r.e1, s); recs.push_back(r); }
+  void collect() {   // caller has synchronised the stream
+    for (auto& r : recs) {
+      float ms = 0; (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+      Agg* a = nullptr;
+      for (auto& kv : agg) if (kv.first == r.name) a = &kv.second;
+      if (!a) { agg.push_back({r.name, Agg()}); a = &agg.back().second; }
+      a->launches++; a->ms += ms; a->flops += r.flops; a->bytes += r.bytes;
+    }
+    recs.clear(); next = 0;
+  }
+  void reset() { recs.clear(); open_.clear(); agg.clear(); next = 0; }
+  ~EventTimer() override { for (auto e : pool) (void)hipEventDestroy(e); }
+};
+static EventTimer* g_evtimer = nullptr;
+
 static int fail(gr_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -103,7 +131,36 @@ extern "C" int gr_device_info(gr_ctx* c, char* buf, int n) {
            p.totalGlobalMem >> 20, rv);
   return GR_OK;
 }
-extern "C" int gr_set_timing(gr_ctx* c, int en) { if (!c) return GR_ERR_INVALID; c->timing = en != 0; return GR_OK; }
+extern "C" int gr_set_timing(gr_ctx* c, int en) {
+  if (!c) return GR_ERR_INVALID;
+  c->timing = en == 1;
+  if (en == 2) {
+    if (!g_evtimer) g_evtimer = new EventTimer();
+    g_evtimer->reset();
+    gr::g_ktimer = g_evtimer;
+  } else {
+    gr::g_ktimer = nullptr;
+  }
+  return GR_OK;
+}
+extern "C" int gr_kernel_times(gr_ctx* c, char* buf, int buflen) {
+  if (!c || !buf || buflen < 64) return GR_ERR_INVALID;
+  if (!g_evtimer) { snprintf(buf, buflen, "[]"); return GR_OK; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  g_evtimer->collect();
+  std::string out = "[";
+  for (size_t i = 0; i < g_evtimer->agg.size(); ++i) {
+    const auto& kv = g_evtimer->agg[i];
+    char line[512];
+    snprintf(line, sizeof line, "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+             i ? ", " : "", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes);
+    out += line;
+  }
+  out += "]";
+  if ((int)out.size() + 1 > buflen) return fail(c, GR_ERR_INVALID, "gr_kernel_times: buffer too small (%zu needed)", out.size() + 1);
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return GR_OK;
+}
 extern "C" int gr_last_step_times(gr_ctx* c, float* ms6) { if (!c || !ms6) return GR_ERR_INVALID; memcpy(ms6, c->times, sizeof c->times); return GR_OK; }
 
 extern "C" int gr_malloc(gr_ctx* c, int64_t bytes, void** out) { if (!c || !out) return GR_ERR_INVALID; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMalloc(out, bytes > 0 ? bytes : 1)); return GR_OK; }

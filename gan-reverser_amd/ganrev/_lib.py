@@ -99,6 +99,7 @@ _SIGS = {
     "gr_train_r_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(Hyper), C.c_int, C.POINTER(C.c_double)]),
     "gr_set_timing": (C.c_int, [_P, C.c_int]),
     "gr_last_step_times": (C.c_int, [_P, _P]),
+    "gr_kernel_times": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "gr_cosine_topk_host": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "gr_cosine_topk_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "gr_cosine_similarity_host": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float)]),
@@ -248,8 +249,14 @@ class Context:
     def allreduce(self, dptr, n):
         self.check(self.lib.gr_allreduce_dev(self.h, _ptr(dptr), int(n)), "gr_allreduce_dev")
 
-    def set_timing(self, on):
-        self.check(self.lib.gr_set_timing(self.h, int(bool(on))), "gr_set_timing")
+    def set_timing(self, mode):
+        self.check(self.lib.gr_set_timing(self.h, int(mode)), "gr_set_timing")
+
+    def kernel_times(self):
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        self.check(self.lib.gr_kernel_times(self.h, buf, 1 << 16), "gr_kernel_times")
+        return json.loads(buf.value.decode())
 
     def last_step_times(self):
         t = np.zeros(6, dtype=np.float32)

@@ -133,7 +133,9 @@ int gr_broadcast_params(gr_net* net, int root);             /* make replicas ide
 int gr_train_r_step(gr_net* gnet, gr_net* rnet, const float* noise_dev, int batch, int global_batch,
                     const gr_hyper* h, int t, double* loss_out /*nullable: skipping it avoids a host sync*/);
 /* per-phase device times (ms) of the last gr_train_r_step when timing is enabled: [G fwd, R fwd, loss, R bwd, allreduce, adam] */
-int gr_set_timing(gr_ctx* ctx, int enabled);
+int gr_set_timing(gr_ctx* ctx, int mode /*0 off, 1 per-phase events in gr_train_r_step, 2 per-kernel events*/);
+/* mode 2: JSON array of {kernel, launches, total_ms, flops, bytes} (algorithmic flops/bytes) accumulated since it was enabled */
+int gr_kernel_times(gr_ctx* ctx, char* buf, int buflen);
 int gr_last_step_times(gr_ctx* ctx, float* ms6);
 
 /* ---- apply_r.lua:265-282 search loop + apply_r.lua:396-400 cosineSimilarity (nn.CosineDistance) ----
