@@ -61,7 +61,8 @@ class Module:
 
     def evaluate(self):
         for m in self.listModules():
-            m.train = False
+            if not getattr(m, "always_on", False):     # models.lua:404  drop.evaluate = function() end
+                m.train = False
         return self
 
     def float(self):   # train_r.lua:78,104 — tensors are already float
@@ -462,11 +463,6 @@ class Dropout(Module):
         """models.lua:402-405:  drop:training(); drop.evaluate = function() end"""
         self.always_on = True
         self.train = True
-        return self
-
-    def evaluate(self):
-        if not self.always_on:
-            self.train = False
         return self
 
     def desc(self, dims):

@@ -279,3 +279,78 @@ def test_rccl_single_rank_allreduce(ctx):
         assert np.array_equal(ctx.download(d, a.shape), a)
     finally:
         ctx.comm_destroy()
+
+
+# ------------------------------------------------------------------ committed golden vectors (tests/golden/golden_v1.npz)
+import os as _os
+
+from golden_cases import CASES as _CASES, build_case as _build_case, step_inputs as _step_inputs, STRIDE as _STRIDE
+
+_GOLD = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "golden_v1.npz"))
+
+
+@pytest.mark.parametrize("name", [n for n, c in sorted(_CASES.items()) if c["kind"] in ("R", "G")])
+def test_nets_vs_golden(name):
+    from ganrev import synth
+    case = _CASES[name]
+    model, in_dims, x, masks = _build_case(case)
+    index = model._descs(tuple(in_dims))[1]
+    by_layer = {index[id(m)]: m for m in model.leaves()}
+    if case["training"]:
+        model.training()
+    else:
+        model.evaluate()
+    flat, grads = model.getParameters()
+    for li, keep in masks.items():
+        model.setNoise(by_layer[li], keep)
+    out = model.forward(x)
+    assert_close(out, _GOLD[f"{name}/out"], TOL, f"{name} forward")
+    if case["kind"] == "R" and case["training"]:
+        gy = synth.normal(out.shape, case["seed"] + 9) * np.float32(0.1)
+        grads[...] = 0
+        gin = model.backward(x, gy)
+        assert_close(gin, _GOLD[f"{name}/gin"], TOL * max(1.0, float(np.abs(_GOLD[f'{name}/gin']).max())), f"{name} gradInput")
+        gs = _GOLD[f"{name}/grads_sample"]
+        assert_close(grads[::_STRIDE], gs, 2 * TOL * max(1.0, float(np.abs(gs).max())), f"{name} gradient sample")
+        rel = abs(float(np.abs(grads.astype(np.float64)).sum()) - float(_GOLD[f"{name}/grads_abs"])) / float(_GOLD[f"{name}/grads_abs"])
+        assert rel < 1e-4, f"{name} |grad| checksum off by {rel:.2e}"
+        model.pull_params()
+        bn0 = [m for m in model.leaves() if hasattr(m, "running_mean")][0]
+        assert_close(bn0.running_mean, _GOLD[f"{name}/running_mean0"], 1e-5); assert_close(bn0.running_var, _GOLD[f"{name}/running_var0"], 1e-5)
+
+
+def test_search_vs_golden(ctx):
+    from ganrev import synth
+    for name in ("search_10k_32", "search_pixel"):
+        case = _CASES[name]
+        emb = synth.normal((case["N"], case["d"]), case["seed"])
+        emb[case["needles"][0] + 7] = emb[case["needles"][0]]
+        idx, sc = ctx.cosine_topk(emb, case["needles"], case["k"])
+        assert np.array_equal(idx, _GOLD[f"{name}/idx"]), f"{name}: top-k indices must be bit-exact"
+        assert np.array_equal(sc, _GOLD[f"{name}/scores"]), f"{name}: scores must be bit-exact"
+        assert np.array_equal(idx[:, :50], _GOLD[f"{name}/idx"][:, :50])      # BASELINE.json: top-50 exact match
+
+
+def test_train_step_vs_golden(ctx, oracle):
+    """First iteration of the golden 3-step trajectory (identical initial state): images, loss, clamped gradient."""
+    import ganrev._lib as L
+    from ganrev import models, synth
+    case = _CASES["step_gray32"]
+    dims, nd, B = case["dims"], case["nd"], case["B"]
+    G = models.create_G(dims, nd); synth.init_params(G, case["seed"])
+    R = models.create_R(dims, nd); synth.init_params(R, case["seed"] + 1)
+    oR = oracle.from_model(R, dims)      # only used for mask sizes / layer indices
+    G.evaluate(); G.forward(synth.normal((B, nd), 1))
+    R.training(); inject_noise(R, oR, B, 0); R.forward(synth.uniform((B,) + dims, 2, 0, 1)); R.push_params()
+    R._net.adam_reset()
+    inject_noise(R, oR, B, case["seed"] + 1)
+    for module, keep in R._pending_masks.values():
+        R._net.set_mask(R._leaf_layer(module), keep)
+    R._pending_masks = {}
+    dn = ctx.upload(_step_inputs(case, 1))
+    loss = L.train_r_step(G._net, R._net, dn, B, B, L.Hyper(), 1)
+    img = ctx.download(G._net.lib.gr_net_output_dev(G._net.h), (B,) + dims)
+    assert_close(img, _GOLD["step_gray32/images1"], TOL, "G images")
+    assert abs(loss - float(_GOLD["step_gray32/losses"][0])) < 1e-5 * max(1.0, abs(loss))
+    g = R._net.get_grads()
+    assert_close(g[::_STRIDE], _GOLD["step_gray32/grads_sample1"], 2e-5, "clamped gradient sample")

@@ -1,0 +1,118 @@
+"""not-gpu: the host-side mirror of the reference interface (models.lua / weight-init.lua / utils/nn_utils.lua)."""
+import numpy as np
+import pytest
+
+import ganrev._lib as L
+from ganrev import models, nn, nn_utils, synth, weight_init
+from ganrev.parallel import shard_bounds
+
+
+def test_parameter_counts_match_the_reference_architectures():
+    # R = 4 656 928 / 17 275 876 ; G = 2 623 745 / 14 979 587
+    def count(m):
+        return sum(a.size for x in m.leaves() for a in x.param_arrays())
+    assert count(models.create_R((1, 32, 32), 32)) == 4656928
+    assert count(models.create_G((1, 32, 32), 32)) == 2623745
+    assert count(models.create_R((3, 64, 64), 100)) == 17275876
+    assert count(models.create_G((3, 64, 64), 100)) == 14979587
+
+
+def test_R_layer_list_is_models_lua_389_464():
+    R = models.create_R((1, 32, 32), 32)
+    names = [m.typename for m in R.modules]
+    assert names[0] == "nn.Copy" and names[-1] == "nn.Copy"
+    body = names[1:-1]
+    blk = ["nn.SpatialConvolution", "nn.SpatialBatchNormalization", "nn.ELU"]
+    assert body[:4] == blk + ["nn.Dropout"]
+    assert body[8:13] == blk + ["nn.SpatialMaxPooling", "nn.Dropout"]                 # models.lua:419-423
+    assert body[21:26] == blk + ["nn.SpatialDropout", "nn.SpatialMaxPooling"]         # models.lua:436-440
+    assert body[26:] == ["nn.View", "nn.Linear", "nn.BatchNormalization", "nn.ELU", "nn.Dropout", "nn.Linear"]
+    Ru = models.create_R((3, 16, 16), 10, "uniform", fixer=True)
+    names = [m.typename for m in Ru.modules]
+    assert names[1] == "nn.Dropout" and Ru.modules[1].always_on and not Ru.modules[1].v2   # models.lua:399-406
+    assert names[-2] == "nn.Tanh"                                                           # models.lua:452-454
+    Ru.evaluate()
+    assert Ru.modules[1].train is True          # drop.evaluate = function() end
+    with pytest.raises(AssertionError):
+        models.create_R((1, 8, 8), 4, "gaussian")                                           # models.lua:390
+
+
+def test_descriptor_lists_and_stage_grammar():
+    R = models.create_R((1, 32, 32), 32)
+    descs, index = R._descs((1, 32, 32))
+    kinds = [d[0] for d in descs]
+    assert len(descs) == 32 and kinds.count(L.CONV3) == 6 and kinds.count(L.BN) == 7 and kinds.count(L.DROPOUT) == 6
+    assert descs[0][:3] == (L.CONV3, 1, 64) and descs[-1][:3] == (L.LINEAR, 512, 32)
+    view = [d for d in descs if d[0] == L.VIEW][0]
+    assert view[1:4] == (8192, 1, 1)
+    G = models.create_G((3, 64, 64), 100)
+    gd, _ = G._descs((100, 1, 1))
+    assert [d[0] for d in gd] == [L.LINEAR, L.BN, L.RELU, L.VIEW, L.UPSAMPLE2, L.CONV3, L.BN, L.RELU, L.UPSAMPLE2, L.CONV3, L.BN,
+                                   L.RELU, L.CONV3, L.SIGMOID]
+    assert gd[0][1:3] == (100, 512 * 16 * 16) and gd[3][1:4] == (512, 16, 16)
+
+
+def test_weight_init_semantics():
+    # weight-init.lua:52-72: nn.SpatialConvolution / nn.Linear re-initialised with U(+-stdv*sqrt(3)), every bias zeroed;
+    # cudnn.SpatialConvolution (G) is NOT matched by the typename test, only its bias is zeroed
+    R = models.create_R((1, 32, 32), 32)
+    conv = R.modules[1]
+    stdv = weight_init.w_init_heuristic(1 * 9, 64 * 9) * np.sqrt(3)
+    assert np.all(conv.bias == 0) and np.abs(conv.weight).max() <= stdv + 1e-7 and np.abs(conv.weight).max() > 0.8 * stdv
+    G = models.create_G((1, 32, 32), 32)
+    gconv = [m for m in G.modules if m.typename == "cudnn.SpatialConvolution"][0]
+    assert np.all(gconv.bias == 0)
+    assert np.abs(gconv.weight).max() <= 1.0 / np.sqrt(512 * 9) + 1e-7     # constructor default, untouched
+    bn = [m for m in G.modules if "BatchNormalization" in m.typename][0]
+    assert np.all(bn.bias == 0) and bn.weight.min() >= 0 and bn.weight.max() <= 1
+
+
+def test_getParameters_makes_views():
+    R = models.create_R((1, 8, 8), 4)
+    flat, grads = R.getParameters()
+    conv = R.modules[1]
+    conv.weight[0, 0, 0, 0] = 123.0
+    assert flat[0] == 123.0 and flat.size == grads.size
+    flat[1] = -7.0
+    assert conv.weight[0, 0, 0, 1] == -7.0
+    assert R.getParameters()[0] is flat
+
+
+def test_forwardBatched_chunks_like_nn_utils_lua():
+    class Fake:
+        calls = []
+
+        def forward(self, x):
+            self.calls.append(len(x))
+            return np.asarray(x, np.float32) * 2
+    m = Fake()
+    x = synth.normal((70, 3), 1)
+    out = nn_utils.forwardBatched(m, x, 32)
+    assert m.calls == [32, 32, 6] and np.array_equal(out, x * 2)           # ceil(70/32) batches, last one ragged
+    assert nn_utils.createNoiseInputs(5, 7, "uniform").shape == (5, 7)
+    assert np.abs(nn_utils.createNoiseInputs(1000, 8, "uniform")).max() <= 1
+    with pytest.raises(ValueError):
+        nn_utils.createNoiseInputs(1, 1, "laplace")
+
+
+def test_synth_is_deterministic_and_sane():
+    a, b = synth.normal((1000, 8), 3), synth.normal((1000, 8), 3)
+    assert np.array_equal(a, b) and abs(float(a.mean())) < 0.05 and abs(float(a.std()) - 1) < 0.05
+    assert not np.array_equal(a, synth.normal((1000, 8), 4))
+    k = synth.bernoulli_keep((100000,), 1, 0.25)
+    assert abs(k.mean() - 0.75) < 0.01
+
+
+def test_unsupported_geometries_raise():
+    with pytest.raises(L.GanrevError):
+        nn.SpatialConvolution(3, 8, 5, 5, 1, 1, 2, 2)
+    with pytest.raises(L.GanrevError):
+        nn.SpatialMaxPooling(3, 3)
+    with pytest.raises(L.GanrevError):
+        nn.SpatialUpSamplingNearest(3)
+
+
+def test_shard_bounds():
+    assert [shard_bounds(4096, 8, r) for r in (0, 7)] == [(0, 512), (3584, 4096)]
+    with pytest.raises(ValueError):
+        shard_bounds(10, 4, 0)

@@ -1,0 +1,182 @@
+"""not-gpu: pin the CPU oracle.  The reference holds no golden vectors for this path (parity
+unpinned vs Torch7), so the oracle is cross-checked operator by operator and net by net against an independent
+float64 PyTorch-CPU evaluation of the same definitions, and by the known-answer checks below."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ganrev import models, synth
+from helpers import assert_close, dropout_modules, maxdiff
+from torch_twin import Twin
+
+T = lambda a: torch.tensor(np.asarray(a, np.float64))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 3, 5, 6, 7), (3, 16, 8, 8, 8), (1, 1, 64, 32, 32), (2, 64, 3, 16, 16)])
+def test_conv3_ops(oracle, B, Cin, Cout, H, W):
+    x, w, b = synth.normal((B, Cin, H, W), 1), synth.uniform((Cout, Cin, 3, 3), 2, -0.3, 0.3), synth.uniform((Cout,), 3)
+    gy = synth.normal((B, Cout, H, W), 4)
+    xt, wt, bt = T(x).requires_grad_(True), T(w).requires_grad_(True), T(b).requires_grad_(True)
+    y = F.conv2d(xt, wt, bt, padding=1)
+    gx, gw, gb = torch.autograd.grad(y, (xt, wt, bt), T(gy))
+    assert_close(oracle.conv3_forward(x, w, b), y.detach().numpy(), 2e-5, "conv forward")
+    assert_close(oracle.conv3_backward_data(gy, w), gx.numpy(), 2e-5, "conv backward-data")
+    ogw, ogb = oracle.conv3_backward_weight(x, gy)
+    assert_close(ogw, gw.numpy(), 1e-4 * max(1, np.abs(gw.numpy()).max()), "conv backward-weight")
+    assert_close(ogb, gb.numpy(), 1e-4 * max(1, np.abs(gb.numpy()).max()), "conv backward-bias")
+
+
+def test_conv3_known_answer(oracle):
+    # identity kernel (centre tap = 1) reproduces the input; a shifted delta reproduces a zero-padded shift
+    x = synth.normal((1, 1, 5, 5), 7)
+    w = np.zeros((1, 1, 3, 3), np.float32); w[0, 0, 1, 1] = 1
+    assert np.array_equal(oracle.conv3_forward(x, w, np.zeros(1, np.float32)), x)
+    w[...] = 0; w[0, 0, 0, 2] = 1           # out[y,x] = in[y-1, x+1]  (cross-correlation, no flip)
+    y = oracle.conv3_forward(x, w, np.zeros(1, np.float32))
+    ref = np.zeros_like(x); ref[0, 0, 1:, :-1] = x[0, 0, :-1, 1:]
+    assert np.array_equal(y, ref)
+
+
+def test_linear_ops(oracle):
+    x, w, b, gy = synth.normal((5, 37), 1), synth.uniform((11, 37), 2), synth.uniform((11,), 3), synth.normal((5, 11), 4)
+    xt, wt, bt = T(x).requires_grad_(True), T(w).requires_grad_(True), T(b).requires_grad_(True)
+    y = F.linear(xt, wt, bt)
+    gx, gw, gb = torch.autograd.grad(y, (xt, wt, bt), T(gy))
+    assert_close(oracle.linear_forward(x, w, b), y.detach().numpy(), 1e-5)
+    ogx, ogw, ogb = oracle.linear_backward(x, gy, w)
+    assert_close(ogx, gx.numpy(), 1e-5); assert_close(ogw, gw.numpy(), 1e-5); assert_close(ogb, gb.numpy(), 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(6, 5, 4, 4), (8, 12)])
+def test_batchnorm_ops(oracle, shape):
+    x = synth.normal(shape, 1) * np.float32(1.7) + np.float32(0.3)
+    C = shape[1]
+    gamma, beta, gy = synth.uniform((C,), 2, 0.5, 1.5), synth.uniform((C,), 3), synth.normal(shape, 4)
+    rm, rv = synth.uniform((C,), 5, -0.2, 0.2), synth.uniform((C,), 6, 0.5, 1.5)
+    rm_t, rv_t = T(rm).clone(), T(rv).clone()
+    xt, gt, bt = T(x).requires_grad_(True), T(gamma).requires_grad_(True), T(beta).requires_grad_(True)
+    y = F.batch_norm(xt, rm_t, rv_t, gt, bt, True, 0.1, 1e-5)
+    gx, gg, gb = torch.autograd.grad(y, (xt, gt, bt), T(gy))
+    orm, orv = rm.copy(), rv.copy()
+    oy, sm, si = oracle.bn_forward_train(x, gamma, beta, orm, orv)
+    assert_close(oy, y.detach().numpy(), 1e-5, "BN train forward")
+    assert_close(orm, rm_t.numpy(), 1e-6, "running_mean"); assert_close(orv, rv_t.numpy(), 1e-6, "running_var (unbiased)")
+    ogx, ogg, ogb = oracle.bn_backward_train(x, gy, gamma, sm, si)
+    assert_close(ogx, gx.numpy(), 1e-5); assert_close(ogg, gg.numpy(), 1e-4); assert_close(ogb, gb.numpy(), 1e-4)
+    ye = F.batch_norm(T(x), T(rm), T(rv), T(gamma), T(beta), False, 0.1, 1e-5)
+    assert_close(oracle.bn_forward_eval(x, gamma, beta, rm, rv), ye.numpy(), 1e-5, "BN eval forward")
+
+
+def _twin_and_oracle(oracle, model, in_dims, B, training, seed):
+    descs, index = model._descs(tuple(in_dims))
+    onet = oracle.from_model(model, in_dims)
+    onet.set_training(training)
+    masks = {}
+    for m in dropout_modules(model):
+        if training or getattr(m, "always_on", False):
+            li = index[id(m)]
+            keep = synth.bernoulli_keep((onet.mask_size(li, B),), seed * 131 + li, m.p)
+            onet.set_mask(li, keep); masks[li] = keep
+    running = [(m.running_mean.copy(), m.running_var.copy()) for m in model.leaves() if hasattr(m, "running_mean")]
+    twin = Twin(descs, in_dims, model._flat_host(), running, training, masks)
+    return onet, twin
+
+
+@pytest.mark.parametrize("dims,nd,B,method,fixer", [((1, 8, 8), 6, 6, "normal", False), ((3, 16, 16), 10, 4, "uniform", True),
+                                                    ((1, 32, 32), 32, 3, "normal", False)])
+def test_R_net_forward_backward(oracle, dims, nd, B, method, fixer):
+    R = models.create_R(dims, nd, method, fixer); synth.init_params(R, 3)
+    onet, twin = _twin_and_oracle(oracle, R, dims, B, True, 7)
+    x = synth.uniform((B,) + dims, 5, 0, 1)
+    out = onet.forward(x)
+    assert_close(out, twin.forward(x), 2e-5, "R forward (training)")
+    gy = synth.normal(out.shape, 9) * np.float32(0.1)
+    onet.zero_grads(); onet.backward(x, gy)
+    ref = twin.backward(gy)
+    assert_close(onet.grads, ref, 2e-4 * max(1.0, np.abs(ref).max()), "R flat gradient vs float64 autograd")
+    # evaluate mode (apply_r.lua path)
+    onet2, twin2 = _twin_and_oracle(oracle, R, dims, B, False, 7)
+    assert_close(onet2.forward(x), twin2.forward(x), 2e-5, "R forward (evaluate)")
+
+
+@pytest.mark.parametrize("dims,nd,B", [((1, 32, 32), 32, 3), ((3, 16, 16), 10, 2)])
+def test_G_net_forward(oracle, dims, nd, B):
+    G = models.create_G(dims, nd); synth.init_params(G, 2)
+    onet, twin = _twin_and_oracle(oracle, G, (nd, 1, 1), B, False, 1)
+    z = synth.normal((B, nd), 8)
+    img = onet.forward(z)
+    assert img.shape == (B,) + dims and img.min() >= 0 and img.max() <= 1
+    assert_close(img, twin.forward(z), 1e-5, "G images")
+
+
+def test_fullconv_and_leakyrelu_extras(oracle):
+    from ganrev import nn
+    m = nn.Sequential().add(nn.SpatialFullConvolution(4, 6)).add(nn.LeakyReLU(0.333))
+    synth.init_params(m, 4)
+    onet, twin = _twin_and_oracle(oracle, m, (4, 8, 8), 2, True, 1)
+    x = synth.normal((2, 4, 8, 8), 3)
+    out = onet.forward(x)
+    assert_close(out, twin.forward(x), 1e-5, "SpatialFullConvolution + LeakyReLU forward")
+    gy = synth.normal(out.shape, 5)
+    onet.zero_grads(); onet.backward(x, gy)
+    assert_close(onet.grads, twin.backward(gy), 1e-4, "SpatialFullConvolution gradients")
+
+
+def test_mse_and_adam(oracle):
+    x, t = synth.normal((16, 32), 1), synth.normal((16, 32), 2)
+    loss, g = oracle.mse(x, t)
+    xt = T(x).requires_grad_(True)
+    l = F.mse_loss(xt, T(t)); l.backward()
+    assert abs(loss - l.item()) < 1e-7 and maxdiff(g, xt.grad.numpy()) < 1e-7
+    # Adam: three steps against torch.optim.Adam (eps outside the bias correction in both 2016 optim.adam and PyTorch<=1.x
+    # differs by the sqrt(bc2) placement of eps: compare against a float64 transcription of optim/adam.lua instead)
+    n = 1000
+    th = synth.normal((n,), 3).astype(np.float32); m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    th64, m64, v64 = th.astype(np.float64), np.zeros(n), np.zeros(n)
+    h = oracle.GoHyper()
+    for t_ in (1, 2, 3):
+        g = synth.normal((n,), 10 + t_) * np.float32(3.0)
+        g64 = g.astype(np.float64) + 1e-4 * th64                     # L2 (train_r.lua:158-159), L1 = 0
+        g64 = np.clip(g64, -1, 1)                                    # train_r.lua:163-165
+        m64 = 0.9 * m64 + 0.1 * g64; v64 = 0.999 * v64 + 0.001 * g64 * g64
+        step = 1e-3 * np.sqrt(1 - 0.999 ** t_) / (1 - 0.9 ** t_)
+        th64 = th64 - step * m64 / (np.sqrt(v64) + 1e-8)
+        gg = g.copy()
+        oracle.penalty_clamp_adam(th, gg, m, v, h, t_)
+        assert maxdiff(gg, g64) < 1e-6 and maxdiff(th, th64) < 1e-6 and maxdiff(m, m64) < 1e-6 and maxdiff(v, v64) < 1e-6
+
+
+def test_cosine_known_answers(oracle):
+    a = np.array([1, 2, 3, 4], np.float32)
+    assert abs(oracle.cosine_similarity(a, a) - 1) < 1e-6 and abs(oracle.cosine_similarity(a, -a) + 1) < 1e-6
+    assert oracle.cosine_similarity(a, np.zeros(4, np.float32)) == 0.0          # eps keeps the zero vector finite
+    e = np.eye(4, dtype=np.float32)
+    assert oracle.cosine_similarity(e[0], e[1]) == 0.0
+    emb = synth.normal((500, 16), 1); emb[77] = emb[10]
+    idx, sc = oracle.cosine_topk(emb, [10], 5)
+    assert list(idx[0][:2]) == [10, 77] and sc[0][0] == sc[0][1]                # tie -> index ascending
+    full = np.array([oracle.cosine_similarity(emb[10], emb[j]) for j in range(500)])
+    order = np.lexsort((np.arange(500), -full.astype(np.float64)))
+    assert np.array_equal(idx[0], order[:5])
+    ref = (emb @ emb[10]) / (np.linalg.norm(emb, axis=1) * np.linalg.norm(emb[10]))
+    assert maxdiff(full, ref) < 1e-6
+
+
+def test_bn_groups_model_per_rank_statistics(oracle):
+    """BN evaluated in P groups == P independent nets each fed one shard (what P data-parallel ranks compute)."""
+    dims, nd, B, P = (1, 8, 8), 4, 8, 2
+    R = models.create_R(dims, nd); synth.init_params(R, 5)
+    x = synth.uniform((B,) + dims, 1, 0, 1)
+    big = oracle.from_model(R, dims); big.set_bn_groups(P)
+    keeps = {}
+    for m in dropout_modules(R):
+        li = big.layer_index[id(m)]
+        keeps[li] = synth.bernoulli_keep((big.mask_size(li, B),), li, m.p); big.set_mask(li, keeps[li])
+    out = big.forward(x)
+    for r in range(P):
+        small = oracle.from_model(R, dims)
+        for li, k in keeps.items():
+            per = k.size // B
+            small.set_mask(li, k[r * (B // P) * per:(r + 1) * (B // P) * per])
+        assert np.array_equal(small.forward(x[r * (B // P):(r + 1) * (B // P)]), out[r * (B // P):(r + 1) * (B // P)])
