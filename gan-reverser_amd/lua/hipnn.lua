@@ -1,0 +1,176 @@
+--[[ hipnn.lua — LuaJIT FFI binding of libganrev.so for a box that has Torch7 (th / luajit).
+
+  UNTESTED: neither the build container nor the GPU box of this project has luajit or Torch7, so this file has
+  never been executed.  It shows the reference-side binding a maintainer would add (see INTEGRATION.md); the Python
+  package gan-reverser_amd/ganrev is the tested host mirror of the same ABI.
+
+  Usage inside train_r.lua / apply_r.lua (unchanged otherwise):
+      local hipnn = require 'hipnn'
+      MODEL_R = hipnn.wrap(MODELS.create_R(IMG_DIMENSIONS, OPT.noiseDim, OPT.noiseMethod, OPT.fixer, false))
+      MODEL_G = hipnn.wrap(MODEL_G)          -- after cudnn.convert(MODEL_G, nn)
+  The wrapper keeps the nn.Module protocol the scripts use: :forward, :backward, :training, :evaluate,
+  :getParameters (host FloatTensors, flat order identical to nn's), :float, :listModules.
+]]
+local ffi = require 'ffi'
+require 'torch'
+require 'nn'
+
+ffi.cdef[[
+typedef struct { int32_t kind, a, b, c; float p; int32_t flags; } gr_layer_desc;
+typedef struct gr_ctx gr_ctx; typedef struct gr_net gr_net;
+typedef struct { double lr, beta1, beta2, eps, l1, l2, clamp; } gr_hyper;
+int gr_init(int device, gr_ctx** out);
+int gr_shutdown(gr_ctx* ctx);
+const char* gr_last_error(gr_ctx* ctx);
+int gr_net_create(gr_ctx*, const gr_layer_desc*, int n, int c, int h, int w, gr_net** out);
+int gr_net_destroy(gr_net*);
+int64_t gr_net_param_count(gr_net*);
+int gr_net_get_params(gr_net*, float*);  int gr_net_set_params(gr_net*, const float*);
+int gr_net_get_grads(gr_net*, float*);   int gr_net_zero_grads(gr_net*);
+int gr_net_n_bn(gr_net*);
+int gr_net_get_bn_running(gr_net*, int, float*, float*); int gr_net_set_bn_running(gr_net*, int, const float*, const float*);
+int gr_net_set_training(gr_net*, int);   int gr_net_set_seed(gr_net*, uint64_t);
+int gr_net_forward_host(gr_net*, const float* in_host, int batch, float* out_host);
+int gr_net_backward_host(gr_net*, const float* in_host, const float* gout_host, int batch, float* gin_host);
+int gr_mse_host(gr_ctx*, const float*, const float*, int64_t n, int64_t n_global, double* loss, float* grad);
+int gr_adam_step(gr_net*, const gr_hyper*, int t);
+int gr_cosine_topk_host(gr_ctx*, const float* emb, int64_t n, int d, const int64_t* rows, int q, int k,
+                        int64_t* idx, float* score, int accumulate_in_float);
+int gr_cosine_similarity_host(gr_ctx*, const float* a, const float* b, int d, float* out);
+]]
+local C = ffi.load('ganrev')          -- libganrev.so on LD_LIBRARY_PATH
+local hipnn = {}
+local ctx
+
+local function context()
+   if not ctx then
+      local p = ffi.new('gr_ctx*[1]')
+      assert(C.gr_init((OPT and OPT.gpu and OPT.gpu >= 0) and OPT.gpu or 0, p) == 0, 'gr_init failed: no gfx950 GPU')
+      ctx = p[0]
+   end
+   return ctx
+end
+local function check(rc, what) if rc ~= 0 then error(what .. ': ' .. ffi.string(C.gr_last_error(context()))) end end
+
+-- kind numbers of include/ganrev.h
+local K = {CONV3=1, BN=2, ELU=3, RELU=4, LEAKYRELU=5, SIGMOID=6, TANH=7, DROPOUT=8, SPATIAL_DROPOUT=9,
+           MAXPOOL2=10, UPSAMPLE2=11, VIEW=12, LINEAR=13, FULLCONV3=14}
+
+-- nn module -> descriptor rows, in nn.Sequential order (models.lua:104-143, 389-464)
+local function describe(m, out, leaves)
+   local t = torch.type(m)
+   if t == 'nn.Sequential' then for _, c in ipairs(m.modules) do describe(c, out, leaves) end; return end
+   if t == 'nn.Copy' then return end
+   local d = {kind=0, a=0, b=0, c=0, p=0, flags=0}
+   if t == 'nn.SpatialConvolution' or t == 'cudnn.SpatialConvolution' or t == 'nn.SpatialConvolutionMM' then
+      assert(m.kW == 3 and m.kH == 3 and m.dW == 1 and m.dH == 1 and m.padW == 1, 'hipnn: only 3x3 s1 p1')
+      d.kind, d.a, d.b = K.CONV3, m.nInputPlane, m.nOutputPlane
+   elseif t == 'nn.SpatialFullConvolution' then d.kind, d.a, d.b = K.FULLCONV3, m.nInputPlane, m.nOutputPlane
+   elseif t == 'nn.SpatialBatchNormalization' or t == 'nn.BatchNormalization' then d.kind, d.a = K.BN, m.running_mean:size(1)
+   elseif t == 'nn.ELU' then d.kind = K.ELU
+   elseif t == 'nn.ReLU' or t == 'cudnn.ReLU' then d.kind = K.RELU
+   elseif t == 'nn.LeakyReLU' then d.kind, d.p = K.LEAKYRELU, m.negval
+   elseif t == 'nn.Sigmoid' or t == 'cudnn.Sigmoid' then d.kind = K.SIGMOID
+   elseif t == 'nn.Tanh' or t == 'cudnn.Tanh' then d.kind = K.TANH
+   elseif t == 'nn.Dropout' then
+      d.kind, d.p = K.DROPOUT, m.p
+      d.flags = (m.v2 and 1 or 0) + ((rawget(m, 'evaluate') ~= nil) and 2 or 0)   -- models.lua:404 overrides evaluate
+   elseif t == 'nn.SpatialDropout' then d.kind, d.p = K.SPATIAL_DROPOUT, m.p
+   elseif t == 'nn.SpatialMaxPooling' then assert(m.kW == 2 and m.kH == 2 and m.dW == 2); d.kind = K.MAXPOOL2
+   elseif t == 'nn.SpatialUpSamplingNearest' then assert(m.scale_factor == 2); d.kind = K.UPSAMPLE2
+   elseif t == 'nn.View' then
+      d.kind = K.VIEW; d.a = m.size[1]; d.b = m.size:size() > 1 and m.size[2] or 1; d.c = m.size:size() > 2 and m.size[3] or 1
+   elseif t == 'nn.Linear' then d.kind, d.a, d.b = K.LINEAR, m.weight:size(2), m.weight:size(1)
+   else error('hipnn: no gfx950 kernel for ' .. t) end
+   out[#out + 1] = d; leaves[#leaves + 1] = m
+end
+
+local Wrapped = torch.class('hipnn.Sequential', 'nn.Module')
+
+function Wrapped:__init(inner)
+   nn.Module.__init(self)
+   self.inner = inner; self.modules = inner.modules
+   self.output = torch.FloatTensor(); self.gradInput = torch.FloatTensor()
+   self.train = true
+end
+
+function Wrapped:compile(input)
+   local c, h, w
+   if input:dim() == 4 then c, h, w = input:size(2), input:size(3), input:size(4) else c, h, w = input:size(2), 1, 1 end
+   if self.net and self.key == c .. 'x' .. h .. 'x' .. w then return end
+   local rows, leaves = {}, {}
+   describe(self.inner, rows, leaves)
+   local arr = ffi.new('gr_layer_desc[?]', #rows)
+   for i, d in ipairs(rows) do arr[i-1].kind, arr[i-1].a, arr[i-1].b, arr[i-1].c, arr[i-1].p, arr[i-1].flags = d.kind, d.a, d.b, d.c, d.p, d.flags end
+   local p = ffi.new('gr_net*[1]')
+   check(C.gr_net_create(context(), arr, #rows, c, h, w, p), 'gr_net_create')
+   self.net, self.key, self.leaves = p[0], c .. 'x' .. h .. 'x' .. w, leaves
+   self:pushParams()
+end
+
+function Wrapped:getParameters()          -- train_r.lua:122: same flat order as nn (weight, bias per module)
+   if not self.flat then self.flat, self.flatGrad = self.inner:getParameters() end
+   return self.flat, self.flatGrad
+end
+
+function Wrapped:pushParams()
+   local flat = self:getParameters()
+   check(C.gr_net_set_params(self.net, flat:data()), 'gr_net_set_params')
+   local bi = 0
+   for _, m in ipairs(self.leaves) do
+      if m.running_mean then C.gr_net_set_bn_running(self.net, bi, m.running_mean:float():data(), m.running_var:float():data()); bi = bi + 1 end
+   end
+end
+
+function Wrapped:updateOutput(input)
+   input = input:contiguous()
+   self:compile(input)
+   check(C.gr_net_set_params(self.net, self.flat:data()), 'gr_net_set_params')   -- host storage is authoritative (compat mode)
+   C.gr_net_set_training(self.net, self.train and 1 or 0)
+   local B = input:size(1)
+   local out = ffi.new('int[3]')
+   self.output:resize(B, self.inner:forward and 1 or 1)                            -- resized for real below
+   -- output dims come from the last module's shape; ask the library
+   ffi.cdef[[int gr_net_out_dim(gr_net*, int*, int*, int*);]]
+   C.gr_net_out_dim(self.net, out, out + 1, out + 2)
+   if out[1] == 1 and out[2] == 1 then self.output:resize(B, out[0]) else self.output:resize(B, out[0], out[1], out[2]) end
+   check(C.gr_net_forward_host(self.net, input:data(), B, self.output:data()), 'gr_net_forward_host')
+   return self.output
+end
+
+function Wrapped:backward(input, gradOutput)   -- updateGradInput + accGradParameters(scale = 1), train_r.lua:151
+   input = input:contiguous(); gradOutput = gradOutput:contiguous()
+   self.gradInput:resizeAs(input)
+   check(C.gr_net_zero_grads(self.net), 'gr_net_zero_grads')
+   check(C.gr_net_backward_host(self.net, input:data(), gradOutput:data(), input:size(1), self.gradInput:data()), 'gr_net_backward_host')
+   self.tmpGrad = self.tmpGrad or self.flatGrad:clone()
+   check(C.gr_net_get_grads(self.net, self.tmpGrad:data()), 'gr_net_get_grads')
+   self.flatGrad:add(self.tmpGrad)              -- accumulate, as nn does into GRAD_PARAMETERS_R
+   return self.gradInput
+end
+
+function Wrapped:training() self.train = true; self.inner:training(); return self end
+function Wrapped:evaluate() self.train = false; self.inner:evaluate(); return self end
+function Wrapped:float() return self end
+function Wrapped:listModules() return self.inner:listModules() end
+
+function hipnn.wrap(model) return hipnn.Sequential(model) end
+
+-- apply_r.lua:396-400 replacement
+function hipnn.cosineSimilarity(v1, v2)
+   local out = ffi.new('float[1]')
+   check(C.gr_cosine_similarity_host(context(), v1:contiguous():data(), v2:contiguous():data(), v1:nElement(), out), 'cosine')
+   return out[0]
+end
+
+-- apply_r.lua:266-282 replacement: returns a LongTensor [#needles x k] of 1-based row indices, best first
+function hipnn.cosineTopK(attributes, needles, k)
+   local N, d, Q = attributes:size(1), attributes:size(2), #needles
+   local rows = ffi.new('int64_t[?]', Q); for i = 1, Q do rows[i-1] = needles[i] - 1 end
+   local idx = torch.LongTensor(Q, k); local sc = torch.FloatTensor(Q, k)
+   check(C.gr_cosine_topk_host(context(), attributes:contiguous():data(), N, d, rows, Q, k,
+                               ffi.cast('int64_t*', idx:data()), sc:data(), 0), 'gr_cosine_topk_host')
+   return idx:add(1), sc
+end
+
+return hipnn
