@@ -24,6 +24,7 @@ int gr_shutdown(gr_ctx* ctx);
 const char* gr_last_error(gr_ctx* ctx);
 int gr_net_create(gr_ctx*, const gr_layer_desc*, int n, int c, int h, int w, gr_net** out);
 int gr_net_destroy(gr_net*);
+int gr_net_out_dim(gr_net*, int*, int*, int*);
 int64_t gr_net_param_count(gr_net*);
 int gr_net_get_params(gr_net*, float*);  int gr_net_set_params(gr_net*, const float*);
 int gr_net_get_grads(gr_net*, float*);   int gr_net_zero_grads(gr_net*);
@@ -129,9 +130,7 @@ function Wrapped:updateOutput(input)
    C.gr_net_set_training(self.net, self.train and 1 or 0)
    local B = input:size(1)
    local out = ffi.new('int[3]')
-   self.output:resize(B, self.inner:forward and 1 or 1)                            -- resized for real below
-   -- output dims come from the last module's shape; ask the library
-   ffi.cdef[[int gr_net_out_dim(gr_net*, int*, int*, int*);]]
+   -- output dims come from the library's shape inference
    C.gr_net_out_dim(self.net, out, out + 1, out + 2)
    if out[1] == 1 and out[2] == 1 then self.output:resize(B, out[0]) else self.output:resize(B, out[0], out[1], out[2]) end
    check(C.gr_net_forward_host(self.net, input:data(), B, self.output:data()), 'gr_net_forward_host')
