@@ -329,6 +329,261 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     }
 }
 
+// Vectorised, software-pipelined variant (W % 4 == 0, tile = 64/TW rows x TW cols): every thread fetches its share of
+// the NEXT tile (float4 interior columns + scalar halo columns + float4 dy) into registers before the MFMA phase of the
+// current tile, so HBM/L2 latency hides behind 288 MFMAs and one workgroup per CU keeps the matrix pipe busy.
+template <int TW>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_vec_kernel(WgradArgs a) {
+  constexpr int PT = 64, TR = PT / TW, PR = TR + 2, PC = TW + 2, PSR = PR * PC, PSW = PSR | 1, DYS = PT + 1;
+  constexpr int Q4 = TW / 4;
+  constexpr int NXV = 64 * PR * Q4 / 256;            // float4 loads per thread: x interior
+  constexpr int NH = (64 * PR * 2 + 255) / 256;      // scalar loads per thread: x halo columns
+  constexpr int NDV = 64 * PT / 4 / 256;             // float4 loads per thread: dy
+  static_assert((64 * PR * Q4) % 256 == 0, "interior float4 count must divide evenly");
+  __shared__ float dyT[64 * DYS];
+  __shared__ float xp[64 * PSW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int mt = wave >> 1, cg = wave & 1;
+  int bid = blockIdx.x;
+  const int cb = bid % a.n_cb; bid /= a.n_cb;
+  const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
+  const int o0 = ob * 64, c0 = cb * 64;
+  const int H = a.H, W = a.W;
+  const size_t HW = (size_t)H * W;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  float4 xv[NXV]; float hv[NH]; float4 dv[NDV];
+#define GR_WG_LOAD(tile_)                                                                                     \
+  {                                                                                                           \
+    long t_ = (tile_);                                                                                        \
+    const int tx_ = (int)(t_ % a.tiles_x); t_ /= a.tiles_x;                                                   \
+    const int ty_ = (int)(t_ % a.tiles_y); const int b_ = (int)(t_ / a.tiles_y);                              \
+    const int y0_ = ty_ * TR, x0_ = tx_ * TW;                                                                 \
+    const float* xb_ = a.x + ((size_t)b_ * a.Cin) * HW;                                                       \
+    _Pragma("unroll") for (int i = 0; i < NXV; ++i) {                                                         \
+      const int f = tid + 256 * i, q = f % Q4, r = (f / Q4) % PR, ci = f / (Q4 * PR);                         \
+      const int yy = y0_ + r - 1, xx = x0_ + 4 * q;                                                           \
+      xv[i] = (c0 + ci < a.Cin && yy >= 0 && yy < H && xx < W)                                                \
+                  ? *reinterpret_cast<const float4*>(xb_ + (size_t)(c0 + ci) * HW + (size_t)yy * W + xx)      \
+                  : make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NH; ++i) {                                                          \
+      const int e = tid + 256 * i, side = e & 1, r = (e >> 1) % PR, ci = (e >> 1) / PR;                       \
+      const int yy = y0_ + r - 1, xx = side ? x0_ + TW : x0_ - 1;                                             \
+      hv[i] = (e < 64 * PR * 2 && c0 + ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)                  \
+                  ? xb_[(size_t)(c0 + ci) * HW + (size_t)yy * W + xx] : 0.f;                                  \
+    }                                                                                                         \
+    const float* db_ = a.dy + ((size_t)b_ * a.Cout) * HW;                                                     \
+    _Pragma("unroll") for (int i = 0; i < NDV; ++i) {                                                         \
+      const int f = tid + 256 * i, q = f % (PT / 4), o = f / (PT / 4);                                        \
+      const int px = 4 * q, pr = px / TW, pc = px - pr * TW, y = y0_ + pr, x = x0_ + pc;                      \
+      dv[i] = (o0 + o < a.Cout && y < H && x < W)                                                             \
+                  ? *reinterpret_cast<const float4*>(db_ + (size_t)(o0 + o) * HW + (size_t)y * W + x)         \
+                  : make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+    }                                                                                                         \
+  }
+
+  long tile = split;
+  bool have = tile < a.tiles_total;
+  if (have) GR_WG_LOAD(tile)
+  while (have) {
+    // registers -> LDS (the previous tile's MFMA phase ended at the barrier below)
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int f = tid + 256 * i, q = f % Q4, r = (f / Q4) % PR, ci = f / (Q4 * PR);
+      float* d = xp + ci * PSW + r * PC + 1 + 4 * q;
+      d[0] = xv[i].x; d[1] = xv[i].y; d[2] = xv[i].z; d[3] = xv[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int e = tid + 256 * i, side = e & 1, r = (e >> 1) % PR, ci = (e >> 1) / PR;
+      if (e < 64 * PR * 2) xp[ci * PSW + r * PC + (side ? TW + 1 : 0)] = hv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int f = tid + 256 * i, q = f % (PT / 4), o = f / (PT / 4);
+      float* d = dyT + o * DYS + 4 * q;
+      d[0] = dv[i].x; d[1] = dv[i].y; d[2] = dv[i].z; d[3] = dv[i].w;
+    }
+    __syncthreads();
+    const long next = tile + a.nsplit;
+    const bool have_next = next < a.tiles_total;
+    if (have_next) GR_WG_LOAD(next)
+    const float* ap = dyT + (mt * 32 + l31) * DYS + h;
+    const float* bp = xp + (cg * 32 + l31) * PSW + h;
+#pragma unroll
+    for (int s = 0; s < PT / 2; ++s) {
+      const int p0 = 2 * s, pr = p0 / TW, pc = p0 - pr * TW;
+      const float av = ap[p0];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const float bv = bp[(pr + ky) * PC + pc + kx];
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    tile = next; have = have_next;
+  }
+#undef GR_WG_LOAD
+  float* sl = a.slab + (size_t)split * 9 * a.coutp * a.cinp;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int ci = c0 + cg * 32 + l31;
+      sl[((size_t)tap * a.coutp + o) * a.cinp + ci] = acc[tap][r];
+    }
+}
+
+// Few input channels (9*Cin <= 32: R.conv1 on gray / RGB images, models.lua:409): the whole (ci, tap) axis fits ONE
+// 32-wide MFMA column block, so the GEMM is M = Cout, N = 32 (9*Cin used), K = pixels and the kernel is HBM-bound on dy.
+// Wave (mt, kh): output-channel block mt, pixel half kh of each 64-pixel tile; the two halves meet in LDS at the end.
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_small_kernel(WgradArgs a) {
+  constexpr int PT = 64, TR = PT / TW, PR = TR + 2, PC = TW + 2, PSR = PR * PC, DYS = PT + 1, MAXC = 3;
+  constexpr int NDV = 64 * PT / 4 / 256;
+  constexpr int NXS = (MAXC * PSR + 255) / 256;
+  __shared__ float dyT[64 * DYS];
+  __shared__ float xp[MAXC * PSR + 64];
+  __shared__ float red[2][32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int mt = wave & 1, kh = wave >> 1;
+  const int ob = blockIdx.x % a.n_ob, split = blockIdx.x / a.n_ob;
+  const int o0 = ob * 64;
+  const int H = a.H, W = a.W, Cin = a.Cin;
+  const size_t HW = (size_t)H * W;
+  // column j of the MFMA tile = (ci, tap); unused columns read offset 0 (their results are dropped by the reduce)
+  int boff = 0;
+  if (l31 < 9 * Cin) { const int ci = l31 / 9, tap = l31 - ci * 9, ky = tap / 3, kx = tap - ky * 3; boff = ci * PSR + ky * PC + kx; }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 dv[NDV]; float xs[NXS];
+#define GR_WS_LOAD(tile_)                                                                                     \
+  {                                                                                                           \
+    long t_ = (tile_);                                                                                        \
+    const int tx_ = (int)(t_ % a.tiles_x); t_ /= a.tiles_x;                                                   \
+    const int ty_ = (int)(t_ % a.tiles_y); const int b_ = (int)(t_ / a.tiles_y);                              \
+    const int y0_ = ty_ * TR, x0_ = tx_ * TW;                                                                 \
+    const float* xb_ = a.x + ((size_t)b_ * Cin) * HW;                                                         \
+    _Pragma("unroll") for (int i = 0; i < NXS; ++i) {                                                         \
+      const int e = tid + 256 * i, ci = e / PSR, rem = e - ci * PSR, r = rem / PC, c = rem - r * PC;          \
+      const int yy = y0_ + r - 1, xx = x0_ + c - 1;                                                           \
+      xs[i] = (ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb_[(size_t)ci * HW + (size_t)yy * W + xx] : 0.f; \
+    }                                                                                                         \
+    const float* db_ = a.dy + ((size_t)b_ * a.Cout) * HW;                                                     \
+    _Pragma("unroll") for (int i = 0; i < NDV; ++i) {                                                         \
+      const int f = tid + 256 * i, q = f % (PT / 4), o = f / (PT / 4);                                        \
+      const int px = 4 * q, pr = px / TW, pc = px - pr * TW, y = y0_ + pr, x = x0_ + pc;                      \
+      dv[i] = (o0 + o < a.Cout && y < H && x < W)                                                             \
+                  ? *reinterpret_cast<const float4*>(db_ + (size_t)(o0 + o) * HW + (size_t)y * W + x)         \
+                  : make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+    }                                                                                                         \
+  }
+  long tile = split;
+  bool have = tile < a.tiles_total;
+  if (have) GR_WS_LOAD(tile)
+  while (have) {
+#pragma unroll
+    for (int i = 0; i < NXS; ++i) { const int e = tid + 256 * i; if (e < MAXC * PSR) xp[e] = xs[i]; }
+#pragma unroll
+    for (int i = 0; i < NDV; ++i) {
+      const int f = tid + 256 * i, q = f % (PT / 4), o = f / (PT / 4);
+      float* d = dyT + o * DYS + 4 * q;
+      d[0] = dv[i].x; d[1] = dv[i].y; d[2] = dv[i].z; d[3] = dv[i].w;
+    }
+    __syncthreads();
+    const long next = tile + a.nsplit;
+    const bool have_next = next < a.tiles_total;
+    if (have_next) GR_WS_LOAD(next)
+    const float* ap = dyT + (mt * 32 + l31) * DYS + h + kh * (PT / 2);
+    const float* bp = xp + boff + h;
+#pragma unroll
+    for (int s = 0; s < PT / 4; ++s) {
+      const int p0 = kh * (PT / 2) + 2 * s;     // kh is wave-uniform; pr/pc below are computed at run time from it
+      const int pr = p0 / TW, pc = p0 - pr * TW;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[pr * PC + pc], acc, 0, 0, 0);
+    }
+    __syncthreads();
+    tile = next; have = have_next;
+  }
+#undef GR_WS_LOAD
+  // combine the two pixel halves, then one slab [split][32 cols][coutp]
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[mt][((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc[r];
+  }
+  __syncthreads();
+  if (kh == 0) {
+    float* sl = a.slab + (size_t)split * 32 * a.coutp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      sl[(size_t)l31 * a.coutp + o0 + mt * 32 + row] = acc[r] + red[mt][row * 33 + l31];
+    }
+  }
+}
+
+// slab [split][32][coutp] -> gw[o][ci][tap] += sum over splits (fixed order): 16 outputs x 16 split groups per block
+__global__ __launch_bounds__(256) void conv3x3_wgrad_small_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gw,
+                                                                         int Cin, int Cout, int coutp, int nsplit) {
+  __shared__ float part[16][17];
+  const int lo = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + lo, n = 9 * Cin * Cout;
+  float s = 0.f;
+  int o = 0, j = 0;
+  if (i < n) {
+    o = i % Cout; j = i / Cout;      // j = ci*9 + tap
+    const int per = (nsplit + 15) / 16, k0 = grp * per, k1 = min(nsplit, k0 + per);
+    const float* p = slab + (size_t)j * coutp + o;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) s += p[(size_t)k * 32 * coutp];
+  }
+  part[grp][lo] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][lo];
+    gw[(size_t)o * Cin * 9 + j] += t;
+  }
+}
+
+// slab [split][tap][o][ci] -> gw[o][ci][tap] += sum over splits, in a fixed order (deterministic).
+// 256 threads = 32 consecutive ci x 8 split groups; the 8 partial sums meet in LDS.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce8_kernel(const float* __restrict__ slab, float* __restrict__ gw,
+                                                                    int Cin, int Cout, int cinp, int coutp, int nsplit) {
+  __shared__ float part[8][33];
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long n = (long)9 * Cout * cinp;
+  const long i = (long)blockIdx.x * 32 + lane;
+  float s = 0.f;
+  int ci = 0, o = 0, tap = 0;
+  if (i < n) {
+    ci = (int)(i % cinp); long r = i / cinp;
+    o = (int)(r % Cout); tap = (int)(r / Cout);
+    const size_t stride = (size_t)9 * coutp * cinp;
+    const float* p = slab + ((size_t)tap * coutp + o) * cinp + ci;
+    const int per = (nsplit + 7) / 8, k0 = grp * per, k1 = min(nsplit, k0 + per);
+    for (int k = k0; k < k1; ++k) s += p[(size_t)k * stride];
+  }
+  part[grp][lane] = s;
+  __syncthreads();
+  if (grp == 0 && i < n && ci < Cin) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += part[g][lane];
+    gw[((size_t)o * Cin + ci) * 9 + tap] += t;
+  }
+}
+
 __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gw,
                                             int Cin, int Cout, int cinp, int coutp, int nsplit) {
   const long n = (long)9 * Cout * cinp;
@@ -344,6 +599,8 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, floa
   gw[((size_t)o * Cin + ci) * 9 + tap] += s;
 }
 
+static bool wgrad_use_vec(int W) { return W >= 16 && W % 4 == 0; }
+static bool wgrad_use_small(int Cin, int W) { return Cin <= 3 && W >= 16 && W % 4 == 0; }
 static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a, int& TW) {
   TW = W <= 8 ? 8 : (W <= 16 ? 16 : 32);
   const int TR = 64 / TW;
@@ -352,7 +609,8 @@ static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a,
   a.tiles_total = (long)B * a.tiles_x * a.tiles_y;
   a.cinp = round_up(Cin, 64); a.coutp = round_up(Cout, 64);
   a.n_ob = a.coutp / 64; a.n_cb = a.cinp / 64;
-  long want = 512 / (a.n_ob * a.n_cb);
+  long want = (wgrad_use_vec(W) ? 256 : 512) / (a.n_ob * a.n_cb);   // vec kernel: one software-pipelined workgroup per CU
+  if (wgrad_use_small(Cin, W)) want = 1024 / a.n_ob;
   if (want < 1) want = 1;
   if (want > a.tiles_total) want = a.tiles_total;
   a.nsplit = (int)want;
@@ -361,6 +619,7 @@ static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a,
 size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W) {
   WgradArgs a{}; int TW;
   wgrad_geometry(B, Cin, Cout, H, W, a, TW);
+  if (wgrad_use_small(Cin, W)) return sizeof(float) * (size_t)a.nsplit * 32 * a.coutp;
   return sizeof(float) * (size_t)a.nsplit * 9 * a.coutp * a.cinp;
 }
 
@@ -369,18 +628,36 @@ void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* work
   WgradArgs a{}; int TW;
   wgrad_geometry(B, Cin, Cout, H, W, a, TW);
   a.x = x; a.dy = dy; a.slab = reinterpret_cast<float*>(workspace);
+  if (wgrad_use_small(Cin, W)) {
+    const double px_ = (double)B * H * W;
+    {
+      KtScope kt(TW == 16 ? "conv3x3_wgrad_small_kernel<16>" : "conv3x3_wgrad_small_kernel<32>", 2.0 * px_ * Cout * Cin * 9.0,
+                 4.0 * (px_ * Cin + px_ * Cout + 9.0 * Cin * Cout), s);
+      const int grid_ = a.nsplit * a.n_ob;
+      if (TW == 16) hipLaunchKernelGGL(conv3x3_wgrad_small_kernel<16>, dim3(grid_), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(conv3x3_wgrad_small_kernel<32>, dim3(grid_), dim3(256), 0, s, a);
+    }
+    const int n_ = 9 * Cin * Cout;
+    KtScope kt("conv3x3_wgrad_small_reduce_kernel", (double)n_ * a.nsplit, 4.0 * n_ * (a.nsplit + 2.0), s);
+    hipLaunchKernelGGL(conv3x3_wgrad_small_reduce_kernel, dim3((n_ + 15) / 16), dim3(256), 0, s, a.slab, gw, Cin, Cout, a.coutp, a.nsplit);
+    return;
+  }
   const int grid = a.nsplit * a.n_ob * a.n_cb;
   const double px = (double)B * H * W;
   {
-    const char* name = TW == 8 ? "conv3x3_wgrad_kernel<8>" : (TW == 16 ? "conv3x3_wgrad_kernel<16>" : "conv3x3_wgrad_kernel<32>");
+    const char* name = wgrad_use_vec(W) ? (TW == 16 ? "conv3x3_wgrad_vec_kernel<16>" : "conv3x3_wgrad_vec_kernel<32>")
+                       : (TW == 8 ? "conv3x3_wgrad_kernel<8>" : (TW == 16 ? "conv3x3_wgrad_kernel<16>" : "conv3x3_wgrad_kernel<32>"));
     KtScope kt(name, 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
-    if (TW == 8) hipLaunchKernelGGL(conv3x3_wgrad_kernel<8>, dim3(grid), dim3(256), 0, s, a);
+    if (wgrad_use_vec(W)) {
+      if (TW == 16) hipLaunchKernelGGL(conv3x3_wgrad_vec_kernel<16>, dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(conv3x3_wgrad_vec_kernel<32>, dim3(grid), dim3(256), 0, s, a);
+    } else if (TW == 8) hipLaunchKernelGGL(conv3x3_wgrad_kernel<8>, dim3(grid), dim3(256), 0, s, a);
     else if (TW == 16) hipLaunchKernelGGL(conv3x3_wgrad_kernel<16>, dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, dim3(grid), dim3(256), 0, s, a);
   }
   const long n = (long)9 * Cout * a.cinp;
-  KtScope kt("conv3x3_wgrad_reduce_kernel", (double)n * a.nsplit, 4.0 * n * (a.nsplit + 2.0), s);
-  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+  KtScope kt("conv3x3_wgrad_reduce8_kernel", (double)n * a.nsplit, 4.0 * n * (a.nsplit + 2.0), s);
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce8_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s,
                      a.slab, gw, Cin, Cout, a.cinp, a.coutp, a.nsplit);
 }
 
