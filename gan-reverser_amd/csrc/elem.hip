@@ -85,11 +85,81 @@ __global__ __launch_bounds__(256) void post_forward_kernel(PostArgs a) {
   }
 }
 
+// float4 variant: W % 4 == 0 (W % 8 == 0 with the pool).  One thread per 4 consecutive OUTPUT elements of a row; plane /
+// channel come from 32-bit divisions once per thread (the scalar kernel above pays 64-bit divisions per element).
+__device__ __forceinline__ float4 mask4(const MaskRef& m, unsigned e, unsigned bc) {
+  float4 r = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (m.kind == MASK_ELEM) {
+    const uint32_t w = m.bits[e >> 5] >> (e & 31);     // e % 4 == 0: the 4 bits never straddle a word
+    r.x = (w & 1u) ? m.scale : 0.f; r.y = (w & 2u) ? m.scale : 0.f; r.z = (w & 4u) ? m.scale : 0.f; r.w = (w & 8u) ? m.scale : 0.f;
+  } else if (m.kind == MASK_SPATIAL) {
+    const float v = ((m.bits[bc >> 5] >> (bc & 31)) & 1u) ? m.scale : 0.f;
+    r = make_float4(v, v, v, v);
+  } else if (m.kind == MASK_SCALE) {
+    r = make_float4(m.scale, m.scale, m.scale, m.scale);
+  }
+  return r;
+}
+__device__ __forceinline__ float4 bn_act4(const PostArgs& a, float4 v, float mean, float invstd, float g, float bt) {
+  if (a.has_bn) {
+    v.x = ((v.x - mean) * invstd) * g + bt; v.y = ((v.y - mean) * invstd) * g + bt;
+    v.z = ((v.z - mean) * invstd) * g + bt; v.w = ((v.w - mean) * invstd) * g + bt;
+  }
+  v.x = act_fwd(v.x, a.act, a.slope); v.y = act_fwd(v.y, a.act, a.slope);
+  v.z = act_fwd(v.z, a.act, a.slope); v.w = act_fwd(v.w, a.act, a.slope);
+  return v;
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+__global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
+  const unsigned H = a.H, W = a.W, Ho = a.pool ? H >> 1 : H, Wo = a.pool ? W >> 1 : W;
+  const unsigned HW = H * W, HWo = Ho * Wo, q_per_plane = HWo >> 2, wq = Wo >> 2;
+  const unsigned n4 = (unsigned)a.B * a.C * q_per_plane;
+  for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
+    const unsigned bc = i4 / q_per_plane, within = i4 - bc * q_per_plane, c = bc % (unsigned)a.C;
+    float mean = 0.f, invstd = 1.f, g = 1.f, bt = 0.f;
+    if (a.has_bn) { mean = a.mean[c]; invstd = a.invstd[c]; g = a.gamma[c]; bt = a.beta[c]; }
+    const unsigned eo = bc * HWo + within * 4;
+    float4 r;
+    if (a.pool) {
+      const unsigned yo = within / wq, xo = (within - yo * wq) * 4;
+      const unsigned e0 = bc * HW + (2 * yo) * W + 2 * xo, e1 = e0 + W;
+      const float4 t0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0), mean, invstd, g, bt), mask4(a.m1, e0, bc));
+      const float4 t1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0 + 4), mean, invstd, g, bt), mask4(a.m1, e0 + 4, bc));
+      const float4 b0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1), mean, invstd, g, bt), mask4(a.m1, e1, bc));
+      const float4 b1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1 + 4), mean, invstd, g, bt), mask4(a.m1, e1 + 4, bc));
+      const float top[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+      const float bot[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      float o[4]; uint32_t idx = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float best = -INFINITY; uint32_t bi = 0;      // scan order (0,0) (0,1) (1,0) (1,1); first strictly greater wins
+        if (top[2 * k] > best) { best = top[2 * k]; bi = 0; }
+        if (top[2 * k + 1] > best) { best = top[2 * k + 1]; bi = 1; }
+        if (bot[2 * k] > best) { best = bot[2 * k]; bi = 2; }
+        if (bot[2 * k + 1] > best) { best = bot[2 * k + 1]; bi = 3; }
+        o[k] = best; idx |= bi << (8 * k);
+      }
+      *reinterpret_cast<uint32_t*>(a.pool_idx + eo) = idx;
+      r = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      r = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + eo), mean, invstd, g, bt), mask4(a.m1, eo, bc));
+    }
+    *reinterpret_cast<float4*>(a.out + eo) = mul4(r, mask4(a.m2, eo, bc));
+  }
+}
+
 void launch_post_forward(const PostArgs& a, hipStream_t s) {
   const long n = (long)a.B * a.C * (a.pool ? (a.H >> 1) * (a.W >> 1) : a.H * a.W);
-  long blocks = (n + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  const bool vec = (a.pool ? (a.W % 8 == 0 && a.H % 2 == 0) : (a.W % 4 == 0)) && (long)a.B * a.C * a.H * a.W < (1l << 32);
+  long blocks = ((vec ? n / 4 : n) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
+  if (vec) {
+    KtScope kt("post_forward_vec_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + (double)n), s);
+    hipLaunchKernelGGL(post_forward_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return;
+  }
   KtScope kt("post_forward_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + (double)n), s);
   hipLaunchKernelGGL(post_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
@@ -143,12 +213,35 @@ __global__ void bn_eval_prepare_kernel(const float* rm, const float* rv, float* 
   invstd[c] = (float)(1.0 / sqrt((double)rv[c] + 1e-5));
 }
 
+// float4 variant: block (c, split) walks its images; inside a plane 256 threads take consecutive float4s (no divisions)
+__global__ __launch_bounds__(256) void bn_stats_partial_vec_kernel(const float* __restrict__ y, int B, int C, int HW, int splits,
+                                                                   double* __restrict__ partials) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int per = (B + splits - 1) / splits, b0 = sp * per, b1 = min(B, b0 + per), q4 = HW >> 2;
+  double s = 0, q = 0;
+  const unsigned tot = (unsigned)(b1 - b0) * q4;
+  for (unsigned j = threadIdx.x; j < tot; j += 256) {
+    const unsigned bb = j / (unsigned)q4, i = j - bb * q4;
+    const float4 v = reinterpret_cast<const float4*>(y + ((size_t)(b0 + bb) * C + c) * HW)[i];
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  s = block_reduce_sum(s, sh);
+  q = block_reduce_sum(q, sh);
+  if (threadIdx.x == 0) { partials[((long)c * STAT_SPLITS + sp) * 2] = s; partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
+}
+
 void launch_bn_stats(const float* y, int B, int C, int HW, double* partials, float* mean, float* invstd,
                      float* run_mean, float* run_var, int training, hipStream_t s) {
   (void)training;
   const long n = (long)B * HW;
-  const int splits = stat_splits(n);
-  {
+  int splits = stat_splits(n);
+  if (HW % 4 == 0 && HW >= 64) {
+    if (splits > B) splits = B;
+    KtScope kt("bn_stats_partial_vec_kernel", 0.0, 4.0 * (double)n * C, s);
+    hipLaunchKernelGGL(bn_stats_partial_vec_kernel, dim3(C, splits), dim3(256), 0, s, y, B, C, HW, splits, partials);
+  } else {
     KtScope kt("bn_stats_partial_kernel", 0.0, 4.0 * (double)n * C, s);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, splits), dim3(256), 0, s, y, B, C, HW, splits, partials);
   }
@@ -201,6 +294,87 @@ __global__ __launch_bounds__(256) void post_backward_a_kernel(PostBwdArgs a, int
   if (threadIdx.x == 0) { a.partials[((long)c * STAT_SPLITS + sp) * 2] = s; a.partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
 }
 
+// float4 variants of pass A / pass B: block (c, split) walks its images, threads take consecutive pre-pool float4s.
+__global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a, int splits) {
+  __shared__ double sh[8];
+  const PostArgs& f = a.f;
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const unsigned H = f.H, W = f.W, Wo = f.pool ? W >> 1 : W, HW = H * W, HWo = f.pool ? (H >> 1) * Wo : HW;
+  const int per = (f.B + splits - 1) / splits, b0 = sp * per, b1 = min(f.B, b0 + per);
+  const unsigned q4 = HW >> 2, wq = W >> 2;
+  float mean = 0.f, invstd = 1.f, gm = 1.f, bt = 0.f;
+  if (f.has_bn) { mean = f.mean[c]; invstd = f.invstd[c]; gm = f.gamma[c]; bt = f.beta[c]; }
+  double s = 0, q = 0;
+  const unsigned tot = (unsigned)(b1 - b0) * q4;
+  {
+    for (unsigned j = threadIdx.x; j < tot; j += 256) {
+      const unsigned bb = j / q4, i = j - bb * q4;
+      const unsigned bc = (unsigned)(b0 + bb) * f.C + c, pbase = bc * HW, obase = bc * HWo;
+      const unsigned e = pbase + i * 4;
+      float4 g;
+      if (f.pool) {
+        const unsigned yy = i / wq, xx = (i - yy * wq) * 4, eo = obase + (yy >> 1) * Wo + (xx >> 1);
+        const float2 go = *reinterpret_cast<const float2*>(a.gout + eo);
+        const uint32_t id2 = *reinterpret_cast<const uint16_t*>(f.pool_idx + eo);
+        const float m20 = mask_mul(f.m2, eo, bc), m21 = mask_mul(f.m2, eo + 1, bc);
+        const uint32_t t0 = (yy & 1) << 1;
+        g.x = ((id2 & 0xff) == t0) ? go.x * m20 : 0.f;
+        g.y = ((id2 & 0xff) == (t0 | 1)) ? go.x * m20 : 0.f;
+        g.z = ((id2 >> 8) == t0) ? go.y * m21 : 0.f;
+        g.w = ((id2 >> 8) == (t0 | 1)) ? go.y * m21 : 0.f;
+      } else {
+        g = mul4(*reinterpret_cast<const float4*>(a.gout + e), mask4(f.m2, e, bc));
+      }
+      g = mul4(g, mask4(f.m1, e, bc));
+      const float4 yv = *reinterpret_cast<const float4*>(f.y + e);
+      float4 z = yv;
+      if (f.has_bn) {
+        z.x = ((yv.x - mean) * invstd) * gm + bt; z.y = ((yv.y - mean) * invstd) * gm + bt;
+        z.z = ((yv.z - mean) * invstd) * gm + bt; z.w = ((yv.w - mean) * invstd) * gm + bt;
+      }
+      float4 dz;
+      dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, f.slope), f.act, f.slope);
+      dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, f.slope), f.act, f.slope);
+      dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, f.slope), f.act, f.slope);
+      dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, f.slope), f.act, f.slope);
+      *reinterpret_cast<float4*>(a.dy + e) = dz;
+      s += (double)dz.x + (double)dz.y + (double)dz.z + (double)dz.w;
+      q += (double)(yv.x - mean) * (double)dz.x + (double)(yv.y - mean) * (double)dz.y +
+           (double)(yv.z - mean) * (double)dz.z + (double)(yv.w - mean) * (double)dz.w;
+    }
+  }
+  s = block_reduce_sum(s, sh);
+  q = block_reduce_sum(q, sh);
+  if (threadIdx.x == 0) { a.partials[((long)c * STAT_SPLITS + sp) * 2] = s; a.partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
+}
+
+__global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a, int splits) {
+  __shared__ double sh[8];
+  const PostArgs& f = a.f;
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const unsigned HW = (unsigned)f.H * f.W, q4 = HW >> 2;
+  const int per = (f.B + splits - 1) / splits, b0 = sp * per, b1 = min(f.B, b0 + per);
+  const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], gm = a.coef[2 * c], k = a.coef[2 * c + 1];
+  double s = 0;
+  const unsigned tot = (unsigned)(b1 - b0) * q4;
+  {
+    for (unsigned j = threadIdx.x; j < tot; j += 256) {
+      const unsigned bb = j / q4, i = j - bb * q4;
+      const size_t base = ((size_t)(b0 + bb) * f.C + c) * HW;
+      float4* dyp = reinterpret_cast<float4*>(a.dy + base);
+      const float4* yp = reinterpret_cast<const float4*>(f.y + base);
+      const float4 dz = dyp[i], yv = yp[i];
+      float4 d;
+      d.x = ((dz.x - gm) - (yv.x - mean) * k) * invstd * w; d.y = ((dz.y - gm) - (yv.y - mean) * k) * invstd * w;
+      d.z = ((dz.z - gm) - (yv.z - mean) * k) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * k) * invstd * w;
+      dyp[i] = d;
+      s += (double)d.x + (double)d.y + (double)d.z + (double)d.w;
+    }
+  }
+  s = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) a.partials[((long)c * STAT_SPLITS + sp) * 2] = s;
+}
+
 __global__ void post_backward_finalize_kernel(PostBwdArgs a, int splits, double n) {
   const PostArgs& f = a.f;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,15 +424,23 @@ __global__ void bias_grad_finalize_kernel(const double* __restrict__ partials, f
 void launch_post_backward(const PostBwdArgs& a, hipStream_t s) {
   const PostArgs& f = a.f;
   const long n = (long)f.B * f.H * f.W;
-  const int splits = stat_splits(n);
+  int splits = stat_splits(n);
   const double pre = (double)n * f.C, post = f.pool ? pre / 4 : pre;
-  {
+  const bool vec = (f.pool ? (f.W % 8 == 0 && f.H % 2 == 0) : (f.W % 4 == 0)) && f.H * f.W >= 64 && pre < 4.0e9;
+  if (vec) {
+    if (splits > f.B) splits = f.B;
+    KtScope kt("post_backward_a_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);
+    hipLaunchKernelGGL(post_backward_a_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+  } else {
     KtScope kt("post_backward_a_kernel", 0.0, 4.0 * (2.0 * pre + post), s);
     hipLaunchKernelGGL(post_backward_a_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
   }
   hipLaunchKernelGGL(post_backward_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a, splits, (double)n);
   if (f.has_bn) {
-    {
+    if (vec) {
+      KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * 3.0 * pre, s);
+      hipLaunchKernelGGL(post_backward_b_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+    } else {
       KtScope kt("post_backward_b_kernel", 0.0, 4.0 * 3.0 * pre, s);
       hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
     }
