@@ -17,6 +17,7 @@
 //     (consecutive lanes -> consecutive LDS words) and the A operand read is wts[k+h][o] (same).
 #include "kernels.h"
 #include <string>
+#include <cstdlib>
 
 namespace gr {
 
@@ -35,9 +36,12 @@ struct ConvArgs {
   int up, nchunks, cout_pad, tiles_x, tiles_y, n_otiles;
 };
 
-template <int MT, int TW>
+// NI > 1: the tile is NI whole images of IH = PT/(NI*TW) rows each (planes too small to fill a tile on their own, e.g. 16x16);
+// their zero-padded patches are stacked in LDS, so tap offsets never cross from one image into the next.
+template <int MT, int TW, int NG, int NI = 1>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
-  constexpr int NG = 2, PT = 256, TR = PT / TW, PR = TR + 2, PC = TW + 2, PS = PR * PC, CK = CONV_CK, CT = MT * 32;
+  constexpr int PT = 128 * NG, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CK = CONV_CK, CT = MT * 32;
+  static_assert(NI == 1 || IH * NI * TW == PT, "tile must hold whole images");
   constexpr int NSLOT = (PS + 255) / 256;
   constexpr int WROWS = 9 * CK;
   constexpr int WV4 = WROWS * CT / 4;            // float4s of one weight chunk
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ot = bid % a.n_otiles; bid /= a.n_otiles;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int ty = bid % a.tiles_y; const int b = (bid / a.tiles_y) * NI;
   const int y0 = ty * TR, x0 = tx * TW, o0 = ot * CT;
   const int H = a.H, W = a.W;
   const int Hs = a.up ? H >> 1 : H, Ws = a.up ? W >> 1 : W;
@@ -60,9 +64,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   int src_off[NSLOT]; bool inb[NSLOT];
 #pragma unroll
   for (int s = 0; s < NSLOT; ++s) {
-    const int e = tid + 256 * s, r = e / PC, c = e - r * PC, yy = y0 + r - 1, xx = x0 + c - 1;
-    inb[s] = e < PS && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    src_off[s] = a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx;
+    const int e = tid + 256 * s, rr = e / PC, c = e - rr * PC;
+    const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
+    const int yy = y0 + r - 1, xx = x0 + c - 1;
+    inb[s] = e < PS && yy >= 0 && yy < H && xx >= 0 && xx < W && b + img < a.B;
+    src_off[s] = (a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx) + img * a.Cin * (int)HWs;
   }
   const float* in_base = a.in + (size_t)b * a.Cin * HWs;
 
@@ -112,7 +118,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   int pixoff[NG];
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
+    const int p = (wave * NG + ng) * 32 + l31, prr = p / TW, pc = p - prr * TW;
+    const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;      // skip the two padding rows between stacked images
     pixoff[ng] = pr * PC + pc + h * PS;
   }
   const int aoff = h * CT + l31;
@@ -148,9 +155,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   // epilogue: C/D map of the 32x32 MFMA: column (pixel) = lane&31, row (channel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
+    const int p = (wave * NG + ng) * 32 + l31, prr = p / TW, pc = p - prr * TW;
+    const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
     const int y = y0 + pr, x = x0 + pc;
-    if (y < H && x < W) {
+    if (y < H && x < W && b + img < a.B) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -158,40 +166,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
           const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (o < a.Cout) {
             const float bv = a.bias ? a.bias[o] : 0.f;
-            a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = acc[mt][ng][r] + bv;
+            a.out[(((size_t)(b + img) * a.Cout + o) * H + y) * W + x] = acc[mt][ng][r] + bv;
           }
         }
     }
   }
 }
 
-template <int MT, int TW>
+template <int MT, int TW, int NG, int NI = 1>
 static void launch_conv_t(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
-  constexpr int TR = 256 / TW, PS = (TR + 2) * (TW + 2), CT = MT * 32;
+  constexpr int TR = 128 * NG / TW, IH = 128 * NG / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = MT * 32;
   a.tiles_x = (a.W + TW - 1) / TW;
-  a.tiles_y = (a.H + TR - 1) / TR;
+  a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;
   a.n_otiles = a.cout_pad / CT;
   const size_t lds = sizeof(float) * (2 * CONV_CK * PS + 2 * 9 * CONV_CK * CT);
-  const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
+  const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<MT, TW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<MT, TW, NG, NI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  static const std::string name = "conv3x3_mfma_kernel<" + std::to_string(MT) + ", " + std::to_string(TW) + ">";
+  static const std::string name = "conv3x3_mfma_kernel<" + std::to_string(MT) + ", " + std::to_string(TW) + ", " + std::to_string(NG) + (NI > 1 ? ", " + std::to_string(NI) : std::string()) + ">";
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0,
              4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<MT, TW>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<MT, TW, NG, NI>), dim3(grid), dim3(256), lds, s, a);
 }
 
-template <int MT>
+int g_conv_variant = 0;   // tuning hook (GR_CONV_VARIANT env): 0 = default heuristics
+template <int MT, int NG>
 static void launch_conv_mt(const ConvArgs& a, hipStream_t s) {
-  if (a.W <= 8) launch_conv_t<MT, 8>(a, s);
-  else if (a.W <= 16) launch_conv_t<MT, 16>(a, s);
-  else launch_conv_t<MT, 32>(a, s);
+  if (a.W <= 8) launch_conv_t<MT, 8, 2>(a, s);
+  else if (a.W <= 16) launch_conv_t<MT, 16, NG>(a, s);
+  else launch_conv_t<MT, 32, NG>(a, s);
 }
 
 void launch_conv3x3(const float* in, const float* wt, const float* bias, float* out,
@@ -201,8 +210,19 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
   a.in = in; a.wt = wt; a.bias = bias; a.out = out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
   a.nchunks = L.cin_pad / CONV_CK; a.cout_pad = L.cout_pad;
-  if (L.cout_pad % 64 == 0) launch_conv_mt<2>(a, s);
-  else launch_conv_mt<1>(a, s);
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("GR_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
+  const bool big_img = (long)H * W >= 512;            // a 512-pixel tile needs at least that many pixels per image
+  if (L.cout_pad % 64 != 0) { launch_conv_mt<1, 2>(a, s); return; }
+  // measured on MI355X (B=256): 512-pixel tiles (NG=4) beat 256-pixel ones on 32x32 planes (G.convB 1333 -> 1198 us);
+  // 128-channel row blocks with one workgroup per CU (MT=4) do not (G.convA 1212 -> 1269 us).
+  if (variant == 1 && L.cout_pad % 128 == 0) launch_conv_mt<4, 2>(a, s);
+  else if (variant == 2) launch_conv_mt<2, 2>(a, s);
+  else if (big_img && W >= 32) launch_conv_mt<2, 4>(a, s);
+  // two stacked 16x16 images per 512-pixel tile: correct, but register-staged prefetch spills at 128 accumulators
+  // (R.conv5 172 -> 318 us); kept behind the tuning hook until the staging moves to LDS-DMA
+  else if (variant == 4 && H == 16 && W == 16 && B >= 2) launch_conv_t<2, 16, 4, 2>(a, s);
+  else launch_conv_mt<2, 2>(a, s);
 }
 
 // ---------------------------------------------------------------- weight layout preparation
