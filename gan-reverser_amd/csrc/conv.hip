@@ -173,6 +173,93 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- few output channels (G's last conv, models.lua:132: 128 -> 1/3)
+// M = Cout <= 4 would waste 7/8 of a 32-row MFMA block and the layer is HBM-bound anyway (reads 128 planes to emit 1-3), so
+// this is a VALU kernel: one thread = 4 consecutive output pixels x all CO channels; input channels stream through LDS in
+// chunks of 8 (register-prefetched float4 rows + scalar halo columns), weights come in through the scalar cache.
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const float* __restrict__ w_native) {
+  constexpr int TW = 32, TRr = 32, CK = 8, PR = TRr + 2, PCS = 40, PS = PR * PCS;   // interior columns at [4, 36), halo at 3 and 36
+  constexpr int NV = (CK * PR * (TW / 4) + 255) / 256;     // float4 loads per thread per chunk (interior)
+  constexpr int NHL = (CK * PR * 2 + 255) / 256;           // scalar loads per thread per chunk (halo columns)
+  __shared__ __attribute__((aligned(16))) float patch[CK * PS];
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int y0 = ty * TRr, x0 = tx * TW, H = a.H, W = a.W;
+  const size_t HW = (size_t)H * W;
+  const float* in_base = a.in + (size_t)b * a.Cin * HW;
+  const int row = tid >> 3, strip = tid & 7;               // this thread's 4 output pixels: (y0+row, x0+4*strip ..+3)
+  float acc[CO][4];
+#pragma unroll
+  for (int o = 0; o < CO; ++o)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+  float4 xv[NV]; float hv[NHL];
+#define GR_FO_LOAD(ch_)                                                                          \
+  {                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                             \
+      const int f = tid + 256 * i, q = f & 7, rr = (f >> 3) % PR, cil = (f >> 3) / PR;           \
+      const int ci = (ch_) * CK + cil, yy = y0 + rr - 1, xx = x0 + 4 * q;                        \
+      xv[i] = (cil < CK && ci < a.Cin && yy >= 0 && yy < H && xx < W)                            \
+                  ? *reinterpret_cast<const float4*>(in_base + (size_t)ci * HW + (size_t)yy * W + xx) \
+                  : make_float4(0.f, 0.f, 0.f, 0.f);                                             \
+    }                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NHL; ++i) {                                            \
+      const int e = tid + 256 * i, side = e & 1, rr = (e >> 1) % PR, cil = (e >> 1) / PR;        \
+      const int ci = (ch_) * CK + cil, yy = y0 + rr - 1, xx = side ? x0 + TW : x0 - 1;           \
+      hv[i] = (cil < CK && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)                 \
+                  ? in_base[(size_t)ci * HW + (size_t)yy * W + xx] : 0.f;                        \
+    }                                                                                            \
+  }
+  GR_FO_LOAD(0)
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + 256 * i, q = f & 7, rr = (f >> 3) % PR, cil = (f >> 3) / PR;
+      if (cil < CK) *reinterpret_cast<float4*>(patch + cil * PS + rr * PCS + 4 + 4 * q) = xv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NHL; ++i) {
+      const int e = tid + 256 * i, side = e & 1, rr = (e >> 1) % PR, cil = (e >> 1) / PR;
+      if (cil < CK) patch[cil * PS + rr * PCS + (side ? 36 : 3)] = hv[i];
+    }
+    __syncthreads();
+    if (ch + 1 < a.nchunks) GR_FO_LOAD(ch + 1)
+#pragma unroll
+    for (int cil = 0; cil < CK; ++cil) {
+      const int ci = ch * CK + cil;
+      if (ci < a.Cin) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* pr = patch + cil * PS + (row + ky) * PCS + 4 * strip;
+          const float4 m = *reinterpret_cast<const float4*>(pr + 4);
+          const float v[6] = {pr[3], m.x, m.y, m.z, m.w, pr[8]};
+#pragma unroll
+          for (int o = 0; o < CO; ++o) {
+            const float* wp = w_native + ((size_t)o * a.Cin + ci) * 9 + ky * 3;
+            const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[o][j] += w0 * v[j] + w1 * v[j + 1] + w2 * v[j + 2];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#undef GR_FO_LOAD
+  const int y = y0 + row, x = x0 + 4 * strip;
+  if (y < H && x < W) {
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const float bv = a.bias ? a.bias[o] : 0.f;
+      *reinterpret_cast<float4*>(a.out + (((size_t)b * a.Cout + o) * H + y) * W + x) =
+          make_float4(acc[o][0] + bv, acc[o][1] + bv, acc[o][2] + bv, acc[o][3] + bv);
+    }
+  }
+}
+
 template <int MT, int TW, int NG, int NI = 1>
 static void launch_conv_t(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
@@ -204,12 +291,25 @@ static void launch_conv_mt(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_conv3x3(const float* in, const float* wt, const float* bias, float* out,
-                    int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s) {
+                    int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const float* w_native) {
   const ConvWeightLayout L = conv_weight_layout(Cin, Cout);
   ConvArgs a{};
   a.in = in; a.wt = wt; a.bias = bias; a.out = out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
   a.nchunks = L.cin_pad / CONV_CK; a.cout_pad = L.cout_pad;
+  if (w_native && Cout <= 4 && !up && W % 4 == 0 && W >= 16) {
+    a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 31) / 32; a.n_otiles = 1;
+    const int grid = B * a.tiles_x * a.tiles_y;
+    const double px = (double)B * H * W;
+    KtScope kt("conv3x3_fewout_kernel", 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
+    switch (Cout) {
+      case 1: hipLaunchKernelGGL(conv3x3_fewout_kernel<1>, dim3(grid), dim3(256), 0, s, a, w_native); break;
+      case 2: hipLaunchKernelGGL(conv3x3_fewout_kernel<2>, dim3(grid), dim3(256), 0, s, a, w_native); break;
+      case 3: hipLaunchKernelGGL(conv3x3_fewout_kernel<3>, dim3(grid), dim3(256), 0, s, a, w_native); break;
+      default: hipLaunchKernelGGL(conv3x3_fewout_kernel<4>, dim3(grid), dim3(256), 0, s, a, w_native); break;
+    }
+    return;
+  }
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("GR_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
   const bool big_img = (long)H * W >= 512;            // a 512-pixel tile needs at least that many pixels per image

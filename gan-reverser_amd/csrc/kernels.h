@@ -39,8 +39,10 @@ void launch_conv_weight_prep(const float* w_native, float* wt, int cin, int cout
 
 // out[B,Cout,H,W] = conv3x3(in) (+bias).  `up`: in is [B,Cin,H/2,W/2] and is nearest-upsampled x2 while staged.
 // wt is the k-major layout for (Cin -> Cout).
+// w_native (nullable): the same weights in the module's own [Cout][Cin][3][3] layout; lets few-output-channel layers
+// (Cout <= 4) take the HBM-bound VALU kernel instead of a 32-row MFMA block.
 void launch_conv3x3(const float* in, const float* wt, const float* bias, float* out,
-                    int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s);
+                    int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const float* w_native = nullptr);
 
 // weight gradient: slab workspace sized by conv_wgrad_workspace(); result accumulated (+=) into gw native layout
 size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W);

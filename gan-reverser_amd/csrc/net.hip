@@ -526,7 +526,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     s.x_in = x;
     if (s.kind == ST_CONV) {
       r = prep_weights(n, s); if (r) return r;
-      launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream);
+      launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off);
     } else if (s.kind == ST_LINEAR) {
       const size_t wsb = gemm_workspace_bytes(B, s.Cout, s.Cin);
       r = ensure_ws(c, wsb); if (r) return r;
@@ -847,7 +847,7 @@ static int with_prepped(gr_ctx* c, const float* w, int cin, int cout, bool bwd, 
 extern "C" int gr_conv3_forward_dev(gr_ctx* c, const float* in, const float* w, const float* bias, float* out, int B, int cin, int cout, int h, int wd, int up) {
   if (!c || !in || !w || !out) return GR_ERR_INVALID;
   float* wt = nullptr; int r = with_prepped(c, w, cin, cout, false, &wt); if (r) return r;
-  launch_conv3x3(in, wt, bias, out, B, cin, cout, h, wd, up != 0, c->stream);
+  launch_conv3x3(in, wt, bias, out, B, cin, cout, h, wd, up != 0, c->stream, w);
   hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(wt);
   return e == hipSuccess ? GR_OK : fail(c, GR_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
 }
@@ -877,7 +877,7 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   int r = with_prepped(c, w, cin, cout, which == 1, &wt); if (r) return r;
   r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd)); if (r) return r;
   auto run = [&]() {
-    if (which == 0) launch_conv3x3(x, wt, nullptr, y, B, cin, cout, h, wd, false, c->stream);
+    if (which == 0) launch_conv3x3(x, wt, nullptr, y, B, cin, cout, h, wd, false, c->stream, w);
     else if (which == 1) launch_conv3x3(y, wt, nullptr, x, B, cout, cin, h, wd, false, c->stream);
     else launch_conv3x3_wgrad(x, y, gw, c->ws, B, cin, cout, h, wd, c->stream);
   };
