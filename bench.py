@@ -78,6 +78,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GANREV_ALL_RANKS_ON_DEVICE0"):     # test hook: exercise the N>1 code path on a 1-GPU box
+        local_rank = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -105,13 +107,16 @@ def main():
     gnet, rnet = G._net, R._net
     rnet.set_seed(1 + rank)                                              # independent dropout noise per rank
     rnet.adam_reset()
-    if world > 1:
+    shared_gpu = bool(os.environ.get("GANREV_ALL_RANKS_ON_DEVICE0")) and world > 1
+    if world > 1 and not shared_gpu:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], world, rank)
+        ctx.comm_init(uid[0], world, rank)                                # RCCL over xGMI, inside libganrev.so
         rnet.broadcast_params(0)
     hyper = L.Hyper()
     GB = B * world
+    from ganrev.parallel import DeviceTrainer, host_allreduce_grads
+    trainer = DeviceTrainer(ctx, gnet, rnet, hyper, B, world, rank)
 
     def barrier():
         if world > 1:
@@ -123,8 +128,10 @@ def main():
     def step(want_loss=False):
         nonlocal t_adam
         t_adam += 1
-        ctx.fill_normal(dnoise, B * nd, (t_adam << 8) + rank)            # createNoiseInputs (utils/nn_utils.lua:39-51), on device
-        return L.train_r_step(gnet, rnet, dnoise, B, GB, hyper, t_adam, want_loss=want_loss)
+        trainer.new_noise((t_adam << 8) + rank)                          # createNoiseInputs (utils/nn_utils.lua:39-51), on device
+        if shared_gpu:   # test hook only: ranks share GPU 0, RCCL refuses duplicate devices -> reduce through gloo
+            return trainer.step_decomposed(host_allreduce_grads(dist))
+        return trainer.step(want_loss=want_loss)
 
     for _ in range(args.warmup):
         step()
@@ -140,13 +147,16 @@ def main():
         dt = float(t.item())
     loss = step(want_loss=True)
 
+    # ---- roofline leg: per-kernel HIP events (on the launch stream) over extra steps of the same workload.
+    # Every rank runs these steps (they contain the collective); only rank 0 instruments and reports.
+    nprof = 3
+    if rank == 0:
+        ctx.set_timing(2)
+    for _ in range(nprof):
+        step()
+    barrier()
     out = None
     if rank == 0:
-        # ---- roofline leg: per-kernel HIP events (on the launch stream) over extra steps of the same workload
-        ctx.set_timing(2)
-        nprof = 3
-        for _ in range(nprof):
-            step()
         kt = ctx.kernel_times()
         ctx.set_timing(0)
         fl_img, g_fl, r_fl = step_flops_per_image(dims, nd)
@@ -193,7 +203,8 @@ def main():
             out["cpu_baseline"] = None
     if world > 1:
         dist.barrier()
-        ctx.comm_destroy()
+        if not shared_gpu:
+            ctx.comm_destroy()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))

@@ -25,6 +25,8 @@ struct gr_ctx {
   std::string err;
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
+  hipStream_t comm_stream = nullptr;          // gradient buckets are reduced here, behind the rest of backward
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   void* ws = nullptr; size_t ws_bytes = 0;
   double* d_loss = nullptr;     // device scalar
   double* h_loss = nullptr;     // pinned host scalar
@@ -104,6 +106,9 @@ extern "C" int gr_init(int device, gr_ctx** out) {
     delete c; return GR_ERR_HIP;
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
+  (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
   *out = c;
   return GR_OK;
 }
@@ -116,6 +121,9 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   if (c->ws) (void)hipFree(c->ws);
   (void)hipFree(c->d_loss); (void)hipHostFree(c->h_loss);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
   (void)hipStreamDestroy(c->stream);
   delete c;
   return GR_OK;
@@ -600,10 +608,25 @@ extern "C" int gr_net_layer_output(gr_net* n, int layer, float* host, int64_t cn
   return fail(c, GR_ERR_UNSUPPORTED, "layer %d is fused into its stage; its output is never materialised", layer);
 }
 
-static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, int B, float* gin_dev) {
+// Gradient bucket [lo, hi) of the flat vector is final: reduce it over RCCL on the comm stream while the compute stream
+// keeps running the backward of the earlier layers (the flat order is layer order, backward walks it from the end, so a
+// finished bucket is always a suffix range; fc1's 90-97 % of the bytes are ready first).
+static int reduce_bucket(gr_net* n, int64_t lo, int64_t hi) {
+  gr_ctx* c = n->ctx;
+  if (hi <= lo) return GR_OK;
+  HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+  NCCLCHK(c, ncclAllReduce(n->grads + lo, n->grads + lo, (size_t)(hi - lo), ncclFloat, ncclSum, c->comm, c->comm_stream));
+  return GR_OK;
+}
+constexpr int64_t BUCKET_MIN_ELEMS = 1 << 20;
+
+static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, int B, float* gin_dev, bool reduce = false) {
   gr_ctx* c = n->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   if (B != n->lastB) return fail(c, GR_ERR_STATE, "backward batch %d does not match the last forward (%d)", B, n->lastB);
+  reduce = reduce && c->comm != nullptr;
+  int64_t bucket_hi = n->n_params;            // everything in [stage first offset, bucket_hi) is final but not yet reduced
   const float* g = gout_dev;
   for (int si = (int)n->st.size() - 1; si >= 0; --si) {
     Stage& s = n->st[si];
@@ -641,6 +664,21 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       LAUNCHCHK(c);
     }
     g = gin;
+    if (reduce) {
+      // lowest parameter offset this stage owns (its BN parameters follow its main op in flat order)
+      int64_t lo = -1;
+      if (s.w_off >= 0) lo = s.w_off; else if (s.g_off >= 0) lo = s.g_off;
+      if (lo >= 0 && (bucket_hi - lo >= BUCKET_MIN_ELEMS || si == 0)) {
+        int r = reduce_bucket(n, lo, bucket_hi); if (r) return r;
+        bucket_hi = lo;
+      }
+    }
+  }
+  if (reduce) {
+    int r = reduce_bucket(n, 0, bucket_hi); if (r) return r;
+    // Adam (compute stream) must see every reduced bucket
+    HIPCHK(c, hipEventRecord(c->ev_done, c->comm_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
   }
   return GR_OK;
 }
@@ -773,14 +811,17 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   if (tm) (void)hipEventRecord(c->ev[2], c->stream);
   launch_mse(rn->st.back().out, noise_dev, (long)B * nd, (long)GB * nd, c->d_loss, rn->gout_buf, c->stream);  // :147,150
   LAUNCHCHK(c);
-  if (tm) (void)hipEventRecord(c->ev[3], c->stream);
-  r = backward_impl(rn, images, rn->gout_buf, B, nullptr); if (r) return r;   // :151
-  if (tm) (void)hipEventRecord(c->ev[4], c->stream);
-  if (c->nranks > 1 && c->comm) {
-    // the penalty and the clamp are non-linear in g (train_r.lua:154-165): reduce first
-    NCCLCHK(c, ncclAllReduce(rn->grads, rn->grads, (size_t)rn->n_params, ncclFloat, ncclSum, c->comm, c->stream));
-    NCCLCHK(c, ncclAllReduce(c->d_loss, c->d_loss, 1, ncclDouble, ncclSum, c->comm, c->stream));
+  if (c->comm) {   // global MSE = sum of the ranks' partial means (same communicator, same stream as the gradient buckets)
+    HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
+    NCCLCHK(c, ncclAllReduce(c->d_loss, c->d_loss, 1, ncclDouble, ncclSum, c->comm, c->comm_stream));
   }
+  if (tm) (void)hipEventRecord(c->ev[3], c->stream);
+  // the penalty and the clamp are non-linear in g (train_r.lua:154-165): the SUM over ranks comes first.  It is issued
+  // bucket by bucket from inside backward on the comm stream; the compute stream waits for it only here.
+  r = backward_impl(rn, images, rn->gout_buf, B, nullptr, /*reduce=*/true); if (r) return r;   // :151
+  if (tm) (void)hipEventRecord(c->ev[4], c->stream);
+
   if (tm) (void)hipEventRecord(c->ev[5], c->stream);
   r = gr_adam_step(rn, h, t); if (r) return r;                 // :153-170
   if (tm) (void)hipEventRecord(c->ev[6], c->stream);

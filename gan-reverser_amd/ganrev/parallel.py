@@ -89,3 +89,60 @@ def train_r_step_decomposed(g_forward, r_forward_backward, penalty_clamp_adam, c
     loss = comm.allreduce_scalar(loss_local)
     penalty_clamp_adam(grad, t)                                            # :153-170 on the reduced gradient
     return loss
+
+
+class DeviceTrainer:
+    """train_r.lua:131-170 on one GPU of a data-parallel job, everything resident in HBM.
+
+    step()            -> the production path: one gr_train_r_step call (RCCL buckets overlapped with backward inside).
+    step_decomposed() -> the same iteration spelled out through the individual ABI calls, with a pluggable gradient
+                         reduction; used to check the fused path and to run the N>1 control flow where RCCL cannot
+                         (several ranks on one GPU).
+    """
+
+    def __init__(self, ctx, gnet, rnet, hyper, per_gpu_batch, world=1, rank=0):
+        from . import _lib as L
+        self.L, self.ctx, self.gnet, self.rnet, self.hyper = L, ctx, gnet, rnet, hyper
+        self.B, self.world, self.rank, self.t = int(per_gpu_batch), int(world), int(rank), 0
+        self.nd = int(np.prod(rnet.out_dims))
+        self.noise = ctx.malloc(4 * self.B * self.nd)
+        self.dfdo = ctx.malloc(4 * self.B * self.nd)
+        self.loss_dev = ctx.malloc(64)
+
+    def new_noise(self, seed):
+        self.ctx.fill_normal(self.noise, self.B * self.nd, seed)      # createNoiseInputs, on device
+
+    def step(self, want_loss=False):
+        self.t += 1
+        return self.L.train_r_step(self.gnet, self.rnet, self.noise, self.B, self.B * self.world, self.hyper, self.t, want_loss=want_loss)
+
+    def step_decomposed(self, reduce_grads=None, reduce_scalar=None):
+        L, g, r, B = self.L, self.gnet, self.rnet, self.B
+        self.t += 1
+        g.set_training(False)
+        images = g.forward_dev(self.noise, B)                                           # train_r.lua:139
+        r.set_training(True)
+        r.zero_grads()                                                                  # :143
+        preds = r.forward_dev(images, B)                                                # :146
+        n = B * self.nd
+        self.ctx.check(self.ctx.lib.gr_mse_dev(self.ctx.h, L._ptr(preds), L._ptr(self.noise), n, n * self.world,
+                                               L._ptr(self.loss_dev), L._ptr(self.dfdo)), "gr_mse_dev")   # :147,150
+        r.backward_dev(images, self.dfdo, B)                                            # :151
+        if reduce_grads is not None:
+            reduce_grads(r)                                                             # SUM over ranks before the non-linear part
+        r.adam_step(self.hyper, self.t)                                                 # :153-170
+        loss = float(self.ctx.download(self.loss_dev, (1,), np.float64)[0])
+        return reduce_scalar(loss) if reduce_scalar is not None else loss
+
+
+def host_allreduce_grads(dist):
+    """Gradient reduction through host memory over an initialised torch.distributed group (gloo): the control-flow stand-in
+    for RCCL when several ranks share one GPU (RCCL refuses duplicate devices)."""
+    import torch
+
+    def fn(rnet):
+        g = rnet.get_grads()
+        t = torch.from_numpy(g)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rnet.set_grads(t.numpy())
+    return fn

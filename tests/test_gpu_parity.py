@@ -354,3 +354,35 @@ def test_train_step_vs_golden(ctx, oracle):
     assert abs(loss - float(_GOLD["step_gray32/losses"][0])) < 1e-5 * max(1.0, abs(loss))
     g = R._net.get_grads()
     assert_close(g[::_STRIDE], _GOLD["step_gray32/grads_sample1"], 2e-5, "clamped gradient sample")
+
+
+def test_fused_step_equals_decomposed_and_comm_path(ctx, oracle):
+    """gr_train_r_step (a) == the same iteration through the individual ABI calls, and (b) is unchanged when an RCCL
+    communicator (nranks = 1, all a 1-GPU box can run) is active, i.e. with the bucketed all-reduce overlapped with backward
+    on the comm stream."""
+    import ganrev._lib as L
+    from ganrev import models, synth
+    from ganrev.parallel import DeviceTrainer
+    dims, nd, B = (1, 32, 32), 32, 8
+    results = []
+    for mode in ("fused", "decomposed", "fused+comm"):
+        G = models.create_G(dims, nd); synth.init_params(G, 5)
+        R = models.create_R(dims, nd); synth.init_params(R, 6)
+        G.evaluate(); G.forward(synth.normal((2, nd), 1))
+        R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
+        R._net.set_seed(123); R._net.adam_reset()
+        if mode == "fused+comm":
+            ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+        try:
+            tr = DeviceTrainer(ctx, G._net, R._net, L.Hyper(), B)
+            losses = []
+            for t in range(3):
+                tr.new_noise(900 + t)
+                losses.append(tr.step_decomposed() if mode == "decomposed" else tr.step(want_loss=True))
+            results.append((losses, R._net.get_params(), R._net.get_grads()))
+        finally:
+            if mode == "fused+comm":
+                ctx.comm_destroy()
+    for other in results[1:]:
+        assert results[0][0] == other[0], "loss trajectories differ"
+        assert np.array_equal(results[0][1], other[1]) and np.array_equal(results[0][2], other[2])
