@@ -45,34 +45,42 @@ __global__ __launch_bounds__(ROWS) void cos_keys_kernel(const float* __restrict_
                                                          const float* __restrict__ needles, const float* __restrict__ w22,
                                                          int q0, int Q, unsigned long long* __restrict__ keys) {
   typedef typename std::conditional<ACCF, float, double>::type acc_t;
-  __shared__ float tile[ROWS * (DC + 1)];
-  __shared__ float nd[QG * DC];
+  __shared__ __attribute__((aligned(16))) float tile[ROWS * (DC + 1)];
   const int tid = threadIdx.x;
   const long r0 = (long)blockIdx.x * ROWS;
   const int nq = min(QG, Q - q0);
+  const bool vec = (d & 3) == 0;                 // rows are 16-byte aligned: stage with float4 loads
   acc_t s1[QG], s3 = 0;
 #pragma unroll
   for (int q = 0; q < QG; ++q) s1[q] = 0;
   for (int c0 = 0; c0 < d; c0 += DC) {
     const int dc = min(DC, d - c0);
-    // coalesced stage: 32 consecutive lanes read one row segment
-    for (int e = tid; e < ROWS * DC; e += ROWS) {
-      const int r = e / DC, c = e - r * DC;
-      float v = 0.f;
-      if (r0 + r < N && c < dc) v = emb[(r0 + r) * (long)d + c0 + c];
-      tile[r * (DC + 1) + c] = v;
-    }
-    for (int e = tid; e < QG * DC; e += ROWS) {
-      const int q = e / DC, c = e - q * DC;
-      nd[e] = (q < nq && c < dc) ? needles[(long)(q0 + q) * d + c0 + c] : 0.f;
+    if (vec) {
+      // 8 lanes cover one 128-byte row segment
+      for (int e = tid; e < ROWS * (DC / 4); e += ROWS) {
+        const int r = e / (DC / 4), c = (e - r * (DC / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < N && c < dc) v = *reinterpret_cast<const float4*>(emb + (r0 + r) * (long)d + c0 + c);
+        float* t = tile + r * (DC + 1) + c;
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+      }
+    } else {
+      for (int e = tid; e < ROWS * DC; e += ROWS) {
+        const int r = e / DC, c = e - r * DC;
+        float v = 0.f;
+        if (r0 + r < N && c < dc) v = emb[(r0 + r) * (long)d + c0 + c];
+        tile[r * (DC + 1) + c] = v;
+      }
     }
     __syncthreads();
     const float* row = tile + tid * (DC + 1);
+    const float* nd = needles + (long)q0 * d + c0;      // wave-uniform addresses: the needle values travel in SGPRs
     for (int c = 0; c < dc; ++c) {
       const float b = row[c];
       s3 += (acc_t)(b * b);
 #pragma unroll
-      for (int q = 0; q < QG; ++q) s1[q] += (acc_t)(nd[q * DC + c] * b);
+      for (int q = 0; q < QG; ++q)
+        if (q < nq) s1[q] += (acc_t)(nd[(long)q * d + c] * b);
     }
     __syncthreads();
   }
@@ -146,6 +154,7 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
   else hipLaunchKernelGGL(needle_prep_kernel<false>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22);
   const unsigned nb = (unsigned)((N + ROWS - 1) / ROWS);
   for (int q0 = 0; q0 < Q; q0 += QG) {
+    KtScope kt("cos_keys_kernel", 2.0 * N * d * (Q - q0 < QG ? Q - q0 : QG), 4.0 * N * d + 8.0 * N * (Q - q0 < QG ? Q - q0 : QG), s);
     if (accf) hipLaunchKernelGGL(cos_keys_kernel<true>, dim3(nb), dim3(ROWS), 0, s, emb, N, d, needles, w22, q0, Q, keysA);
     else hipLaunchKernelGGL(cos_keys_kernel<false>, dim3(nb), dim3(ROWS), 0, s, emb, N, d, needles, w22, q0, Q, keysA);
   }
@@ -155,6 +164,7 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
   while (true) {
     const long nch = chunks_of(n_cur), n_out = nch * k;
     unsigned long long* out = bufs[which];
+    KtScope kt("topk_pass_kernel", 0.0, 8.0 * Q * (n_cur + n_out), s);
     hipLaunchKernelGGL(topk_pass_kernel, dim3((unsigned)nch, Q), dim3(1024), 0, s, cur, n_cur, k, out, n_out);
     cur = out; n_cur = n_out; which ^= 1;
     if (nch == 1) break;

@@ -20,6 +20,11 @@ for (N, d, k, Q) in [(10000, 32, 100, 5), (1000000, 100, 50, 5), (1000000, 100, 
     for _ in range(reps):
         idx, sc = ctx.cosine_topk(None, q, k, emb_dev=dev, n=N, d=d)
     dt = (time.perf_counter() - t0) / reps
+    ctx.set_timing(2)
+    for _ in range(reps):
+        ctx.cosine_topk(None, q, k, emb_dev=dev, n=N, d=d)
+    kt = ctx.kernel_times(); ctx.set_timing(0)
+    print("   " + "; ".join(f"{x['kernel']}: {x['total_ms']/reps*1e3:.1f} us ({x['launches']//reps} launches, {x['bytes']/max(x['total_ms'],1e-9)/1e6:.0f} GB/s)" for x in kt))
     t1 = time.perf_counter()
     ridx, rsc = oracle.cosine_topk(emb, q, k)
     tc = time.perf_counter() - t1
