@@ -18,6 +18,8 @@ for _p in (os.path.join(ROOT, "gan-reverser_amd"), ROOT):
         sys.path.insert(0, _p)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
+BF16X6_PASSES = 6                  # bf16x6 mode: six bf16 MFMA products per fp32-accurate product
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -72,6 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "bf16x6"), choices=["f32", "bf16x6"],
+                    help="convolution arithmetic (both meet the 1e-4 parity bar; see DESIGN.md)")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
     args = ap.parse_args()
 
@@ -96,6 +100,7 @@ def main():
     wl = WORKLOADS[args.workload]
     dims, nd, B = wl["dims"], wl["nd"], wl["batch"]
     ctx = L.Context(local_rank)
+    ctx.set_conv_mode(args.conv_mode)
     G = models.create_G(dims, nd); synth.init_params(G, 1)               # random-init weights of the named architecture
     R = models.create_R(dims, nd); synth.init_params(R, 2)
     dnoise = ctx.malloc(4 * B * nd)
@@ -160,10 +165,14 @@ def main():
         kt = ctx.kernel_times()
         ctx.set_timing(0)
         fl_img, g_fl, r_fl = step_flops_per_image(dims, nd)
-        mfma = [k for k in kt if k["kernel"].startswith(("conv3x3_mfma", "conv3x3_wgrad_kernel"))]
+        mfma = [k for k in kt if k["kernel"].startswith("conv3x3_") and k["flops"] > 1e9 and "reduce" not in k["kernel"]
+                and "fewout" not in k["kernel"] and "small" not in k["kernel"]]
         dom = max(mfma, key=lambda k: k["total_ms"])
         avg_ms = dom["total_ms"] / dom["launches"]
         achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+        split = "bf16x6" in dom["kernel"]
+        # bf16x6: the kernel issues 6 bf16 MFMA products per algorithmic multiply-add; its ceiling for ALGORITHMIC flops is peak/6
+        peak = PEAK_BF16_MFMA_TFLOPS / BF16X6_PASSES if split else PEAK_FP32_MFMA_TFLOPS
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
@@ -171,8 +180,11 @@ def main():
                 traffic = json.load(open(tfile)).get(args.workload, {}).get(dom["kernel"])
             except Exception:
                 traffic = None
-        roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+        roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
+                        frac=round(achieved / peak, 4), traffic=traffic,
+                        peak_note=("dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32-accurate multiply-add (bf16x6 split); "
+                                   "issued MFMA rate = 6 x achieved") if split else "fp32 MFMA v_mfma_f32_32x32x2_f32",
+                        frac_of_fp32_mfma_peak=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                         avg_launch_ms=round(avg_ms, 4), launches_per_step=dom["launches"] / nprof,
                         algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3))
         conv_ms = sum(k["total_ms"] for k in mfma) / nprof
@@ -185,7 +197,8 @@ def main():
         out = {
             "metric": "images/sec G+R fwd/bwd", "value": round(GB * args.steps / dt, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if ctx.conv_mode() == "f32" else "f32 via bf16x6 (3-term bf16 split, 6 MFMA products, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": wl["name"], "global_batch": GB, "per_gpu_batch": B,
                        "parallelism": f"dp{world}" + (" (RCCL all-reduce of R's flat gradient)" if world > 1 else ""),
                        "bn": "per-rank batch statistics"},

@@ -325,6 +325,211 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
   else launch_conv_mt<2, 2>(a, s);
 }
 
+// ---------------------------------------------------------------- fp32-accurate convolution on the bf16 MFMA ("bf16x6")
+// Every fp32 operand is split into three bf16 terms x = x0 + x1 + x2 (|x - x0 - x1 - x2| <= 2^-27 |x|); the product keeps the
+// six terms of order < 3 (x0w0, x0w1, x1w0, x0w2, x1w1, x2w0), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped
+// terms are below 2^-24 relative, i.e. the result carries fp32-level error (measured against float64: the same 2e-6 as the
+// fp32 MFMA path), while the matrix pipe runs 16x faster per instruction: 16/6 = 2.7x the fp32-MFMA ceiling.
+// Tile: 256 pixels x 32 output channels per workgroup, K walked in chunks of 16 input channels: one MFMA = one tap x 16
+// channels (lanes 0-31 take channels 0-7, lanes 32-63 channels 8-15).
+//   LDS patch image  [3 terms][2 halves][pixel][8 ch] bf16  (16 B per lane, consecutive pixels -> conflict-free b128 reads)
+//   LDS weight image [3 terms][9 taps][2 halves][32 o][8 ch] bf16, copied verbatim from the prepped global image.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BF_CK = 16;
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float x) { const __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
+  constexpr int NG = 2, PT = 256, TR = PT / TW, PR = TR + 2, PC = TW + 2, PS = PR * PC, CT = 32;
+  constexpr int NEH = 2 * PS, NSL = (NEH + 255) / 256;           // (pixel, half) pairs staged per thread
+  constexpr int WROWS = 3 * 9 * 2, WV = WROWS * CT, NWV = (WV + 255) / 256;   // 16-byte weight vectors per chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [3][2][PS]   (one uint4 = 8 bf16)
+  uint4* wts = patch + 3 * 2 * PS;                                // [3][9][2][CT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * CT;
+  const int H = a.H, W = a.W;
+  const int Hs = a.up ? H >> 1 : H, Ws = a.up ? W >> 1 : W;
+  const size_t HWs = (size_t)Hs * Ws;
+  int src_off[NSL]; bool inb[NSL]; int sh[NSL];
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) {
+    const int eh = tid + 256 * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, r = e / PC, c = e - r * PC;
+    const int yy = y0 + r - 1, xx = x0 + c - 1;
+    inb[s] = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    src_off[s] = a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx;
+    sh[s] = hh;
+  }
+  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
+  float pv[NSL][8];
+  uint4 wv[NWV];
+#define GR_BF_LOAD(ch_)                                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                       \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                     \
+        const int ci = (ch_) * BF_CK + 8 * sh[s] + j;                                                     \
+        pv[s][j] = (inb[s] && ci < a.Cin) ? in_base[(size_t)ci * HWs + src_off[s]] : 0.f;                 \
+      }                                                                                                   \
+    const uint4* wp_ = wsplit + (size_t)(ch_) * WROWS * a.cout_pad + o0;                                  \
+    _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
+      const int f = tid + 256 * i, row = f / CT, col = f - row * CT;                                      \
+      wv[i] = f < WV ? wp_[(size_t)row * a.cout_pad + col] : make_uint4(0, 0, 0, 0);                      \
+    }                                                                                                     \
+  }
+#define GR_BF_STORE()                                                                                     \
+  {                                                                                                       \
+    _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
+      const int eh = tid + 256 * s;                                                                       \
+      if (eh < NEH) {                                                                                     \
+        unsigned short t0[8], t1[8], t2[8];                                                               \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+          const float x = pv[s][j];                                                                       \
+          t0[j] = f32_to_bf16(x); const float r1 = x - bf16_to_f32(t0[j]);                                \
+          t1[j] = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(t1[j]);                              \
+          t2[j] = f32_to_bf16(r2);                                                                        \
+        }                                                                                                 \
+        const int hh = eh >= PS ? 1 : 0, e = eh - hh * PS;                                                \
+        patch[(0 * 2 + hh) * PS + e] = make_uint4(t0[0] | (unsigned)t0[1] << 16, t0[2] | (unsigned)t0[3] << 16, t0[4] | (unsigned)t0[5] << 16, t0[6] | (unsigned)t0[7] << 16); \
+        patch[(1 * 2 + hh) * PS + e] = make_uint4(t1[0] | (unsigned)t1[1] << 16, t1[2] | (unsigned)t1[3] << 16, t1[4] | (unsigned)t1[5] << 16, t1[6] | (unsigned)t1[7] << 16); \
+        patch[(2 * 2 + hh) * PS + e] = make_uint4(t2[0] | (unsigned)t2[1] << 16, t2[2] | (unsigned)t2[3] << 16, t2[4] | (unsigned)t2[5] << 16, t2[6] | (unsigned)t2[7] << 16); \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
+      const int f = tid + 256 * i;                                                                        \
+      if (f < WV) wts[f] = wv[i];                                                                         \
+    }                                                                                                     \
+  }
+
+  f32x16 acc[NG];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ng][r] = 0.f;
+  int pix[NG];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
+    pix[ng] = h * PS + pr * PC + pc;
+  }
+  const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
+  GR_BF_LOAD(0)
+  for (int ch = 0; ch < nchunks; ++ch) {
+    GR_BF_STORE()
+    __syncthreads();
+    if (ch + 1 < nchunks) GR_BF_LOAD(ch + 1)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3, toff = ky * PC + kx;
+      bf16x8 av[3], bv[NG][3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const uint4 t = wts[((s * 9 + tap) * 2 + h) * CT + l31];
+        av[s] = __builtin_bit_cast(bf16x8, t);
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng) {
+          const uint4 u = patch[s * 2 * PS + pix[ng] + toff];
+          bv[ng][s] = __builtin_bit_cast(bf16x8, u);
+        }
+      }
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) {
+        // smallest terms first
+        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[ng][0], acc[ng], 0, 0, 0);
+        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[ng][1], acc[ng], 0, 0, 0);
+        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[ng][2], acc[ng], 0, 0, 0);
+        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[ng][0], acc[ng], 0, 0, 0);
+        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[ng][1], acc[ng], 0, 0, 0);
+        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[ng][0], acc[ng], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#undef GR_BF_LOAD
+#undef GR_BF_STORE
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
+    const int y = y0 + pr, x = x0 + pc;
+    if (y < H && x < W) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (o < a.Cout) {
+          const float bvv = a.bias ? a.bias[o] : 0.f;
+          a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = acc[ng][r] + bvv;
+        }
+      }
+    }
+  }
+}
+
+// native fp32 [cout][cin][3][3] -> split image [cin_pad16/16][3 terms][9 taps][2 halves][cout_pad32][8 ch] bf16
+// (backward-data: the transposed + flipped weights, as in conv_weight_prep_kernel)
+__global__ void conv_weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst,
+                                         int cin, int cout, int CI, int CO, int cin_pad, int cout_pad, int bwd) {
+  const long n = (long)(cin_pad / BF_CK) * 9 * 2 * cout_pad * 8;     // one thread per (chunk, tap, half, o, j): writes 3 terms
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7); long r = i >> 3;
+    const int oo = (int)(r % cout_pad); r /= cout_pad;
+    const int hh = (int)(r & 1); r >>= 1;
+    const int tap = (int)(r % 9); const int ch = (int)(r / 9);
+    const int ci = ch * BF_CK + 8 * hh + j;
+    float v = 0.f;
+    if (ci < CI && oo < CO) v = bwd ? w[((long)ci * cin + oo) * 9 + (8 - tap)] : w[((long)oo * cin + ci) * 9 + tap];
+    const unsigned short t0 = f32_to_bf16(v); const float r1 = v - bf16_to_f32(t0);
+    const unsigned short t1 = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(t1);
+    const unsigned short t2 = f32_to_bf16(r2);
+    const long base = (long)ch * 3 * 9 * 2 * cout_pad * 8;
+    const long within = (((long)tap * 2 + hh) * cout_pad + oo) * 8 + j, term = (long)9 * 2 * cout_pad * 8;
+    dst[base + within] = t0; dst[base + term + within] = t1; dst[base + 2 * term + within] = t2;
+  }
+}
+
+size_t conv_weight_split_bytes(int cin, int cout, bool bwd) {
+  const int CI = bwd ? cout : cin, CO = bwd ? cin : cout;
+  return (size_t)round_up(CI, BF_CK) * 9 * round_up(CO, 32) * 3 * sizeof(unsigned short);
+}
+void launch_conv_weight_split(const float* w_native, void* dst, int cin, int cout, bool bwd, hipStream_t s) {
+  const int CI = bwd ? cout : cin, CO = bwd ? cin : cout;
+  const int cin_pad = round_up(CI, BF_CK), cout_pad = round_up(CO, 32);
+  const long n = (long)(cin_pad / BF_CK) * 9 * 2 * cout_pad * 8;
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  KtScope kt("conv_weight_split_kernel", 0.0, 4.0 * 9.0 * cin * cout + 6.0 * (double)n, s);
+  hipLaunchKernelGGL(conv_weight_split_kernel, dim3(grid), dim3(256), 0, s, w_native, reinterpret_cast<unsigned short*>(dst),
+                     cin, cout, CI, CO, cin_pad, cout_pad, bwd ? 1 : 0);
+}
+
+template <int TW>
+static void launch_conv_bf16x6_t(ConvArgs a, const void* wsplit, hipStream_t s) {
+  constexpr int TR = 256 / TW, PS = (TR + 2) * (TW + 2), CT = 32;
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TR - 1) / TR;
+  a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
+  const size_t lds = 16 * (size_t)(3 * 2 * PS + 3 * 9 * 2 * CT);
+  const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = "conv3x3_bf16x6_kernel<" + std::to_string(TW) + ">";
+  const double px = (double)a.B * a.H * a.W;
+  KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+  hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TW>), dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
+}
+
+void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bias, float* out,
+                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s) {
+  ConvArgs a{};
+  a.in = in; a.wt = nullptr; a.bias = bias; a.out = out;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
+  if (W <= 8) launch_conv_bf16x6_t<8>(a, wsplit, s);
+  else if (W <= 16) launch_conv_bf16x6_t<16>(a, wsplit, s);
+  else launch_conv_bf16x6_t<32>(a, wsplit, s);
+}
+
 // ---------------------------------------------------------------- weight layout preparation
 // dst[((ch*9 + tap)*8 + cil)*cout_pad + oo]
 //   forward:        = W[oo][ci][tap]                (ci = ch*8+cil over Cin, oo over Cout)

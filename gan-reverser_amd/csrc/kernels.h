@@ -44,6 +44,13 @@ void launch_conv_weight_prep(const float* w_native, float* wt, int cin, int cout
 void launch_conv3x3(const float* in, const float* wt, const float* bias, float* out,
                     int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const float* w_native = nullptr);
 
+// fp32-accurate convolution on the bf16 MFMA: operands split into 3 bf16 terms, 6 products, fp32 accumulation ("bf16x6").
+// wsplit = image made by launch_conv_weight_split (forward or backward-data flavour, like launch_conv_weight_prep).
+size_t conv_weight_split_bytes(int cin, int cout, bool for_backward_data);
+void launch_conv_weight_split(const float* w_native, void* wsplit, int cin, int cout, bool for_backward_data, hipStream_t s);
+void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bias, float* out,
+                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s);
+
 // weight gradient: slab workspace sized by conv_wgrad_workspace(); result accumulated (+=) into gw native layout
 size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W);
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,

@@ -31,6 +31,7 @@ struct gr_ctx {
   double* d_loss = nullptr;     // device scalar
   double* h_loss = nullptr;     // pinned host scalar
   bool timing = false;
+  int conv_mode = 0;            // 0 = exact fp32 MFMA, 1 = bf16x6 split (fp32-accurate, bf16 MFMA)
   hipEvent_t ev[7] = {};
   float times[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -106,6 +107,7 @@ extern "C" int gr_init(int device, gr_ctx** out) {
     delete c; return GR_ERR_HIP;
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
+  { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "bf16x6") || !strcmp(m, "1")) ? 1 : 0; }
   (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
@@ -139,6 +141,12 @@ extern "C" int gr_device_info(gr_ctx* c, char* buf, int n) {
            p.totalGlobalMem >> 20, rv);
   return GR_OK;
 }
+extern "C" int gr_set_conv_mode(gr_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 1) return GR_ERR_INVALID;
+  c->conv_mode = mode;
+  return GR_OK;
+}
+extern "C" int gr_get_conv_mode(gr_ctx* c) { return c ? c->conv_mode : GR_ERR_INVALID; }
 extern "C" int gr_set_timing(gr_ctx* c, int en) {
   if (!c) return GR_ERR_INVALID;
   c->timing = en == 1;
@@ -200,6 +208,7 @@ struct Stage {
   int outC = 0, outH = 0, outW = 0;
   float *y = nullptr, *out = nullptr; uint8_t* pool_idx = nullptr;
   float *wt_fwd = nullptr, *wt_bwd = nullptr; uint64_t wt_version = 0;
+  void *ws_fwd = nullptr, *ws_bwd = nullptr; uint64_t ws_version = 0;     // bf16x6 split images
   float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr;
   float *run_mean = nullptr, *run_var = nullptr;
   const float* x_in = nullptr;              // input of the last forward
@@ -234,7 +243,7 @@ extern "C" int gr_net_destroy(gr_net* n) {
   for (auto& s : n->st) {
     if (s.kind != ST_ELEM) (void)hipFree(s.y);
     if (s.has_post) (void)hipFree(s.out);
-    (void)hipFree(s.pool_idx); (void)hipFree(s.wt_fwd); (void)hipFree(s.wt_bwd);
+    (void)hipFree(s.pool_idx); (void)hipFree(s.wt_fwd); (void)hipFree(s.wt_bwd); (void)hipFree(s.ws_fwd); (void)hipFree(s.ws_bwd);
     (void)hipFree(s.mean); (void)hipFree(s.invstd); (void)hipFree(s.coef); (void)hipFree(s.partials);
     (void)hipFree(s.run_mean); (void)hipFree(s.run_var);
   }
@@ -355,6 +364,7 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
       const ConvWeightLayout lf = s.fullconv ? conv_weight_layout(s.Cin, s.Cout) : conv_weight_layout(s.Cin, s.Cout);
       const ConvWeightLayout lb = conv_weight_layout(s.Cout, s.Cin);
       if (hipMalloc((void**)&s.wt_fwd, sizeof(float) * lf.elems()) || hipMalloc((void**)&s.wt_bwd, sizeof(float) * lb.elems())) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
+      if (!s.fullconv && (hipMalloc(&s.ws_fwd, conv_weight_split_bytes(s.Cin, s.Cout, false)) || hipMalloc(&s.ws_bwd, conv_weight_split_bytes(s.Cin, s.Cout, true)))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
     }
     const size_t ye = (size_t)vol3(s.Cout, s.H, s.W), ie = (size_t)vol3(s.inC, s.inH, s.inW);
     if (ye > n->max_y) n->max_y = ye;
@@ -476,10 +486,18 @@ static int ensure_batch(gr_net* n, int B) {
   return GR_OK;
 }
 
+static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode == 1 && s.kind == ST_CONV && !s.fullconv && s.Cout > 4; }
 static int prep_weights(gr_net* n, Stage& s) {
-  if (s.kind != ST_CONV || s.wt_version == n->params_version) return GR_OK;
+  if (s.kind != ST_CONV) return GR_OK;
   gr_ctx* c = n->ctx;
   const float* w = n->params + s.w_off;
+  if (n->ctx->conv_mode == 1 && !s.fullconv && s.ws_version != n->params_version) {
+    launch_conv_weight_split(w, s.ws_fwd, s.Cin, s.Cout, false, c->stream);
+    launch_conv_weight_split(w, s.ws_bwd, s.Cin, s.Cout, true, c->stream);
+    LAUNCHCHK(c);
+    s.ws_version = n->params_version;
+  }
+  if (s.wt_version == n->params_version) return GR_OK;
   if (!s.fullconv) {
     launch_conv_weight_prep(w, s.wt_fwd, s.Cin, s.Cout, false, c->stream);
     launch_conv_weight_prep(w, s.wt_bwd, s.Cin, s.Cout, true, c->stream);
@@ -534,7 +552,8 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     s.x_in = x;
     if (s.kind == ST_CONV) {
       r = prep_weights(n, s); if (r) return r;
-      launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off);
+      if (use_bf16x6(n, s)) launch_conv3x3_bf16x6(x, s.ws_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream);
+      else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off);
     } else if (s.kind == ST_LINEAR) {
       const size_t wsb = gemm_workspace_bytes(B, s.Cout, s.Cin);
       r = ensure_ws(c, wsb); if (r) return r;
@@ -650,7 +669,11 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       if (s.fullconv) return fail(c, GR_ERR_UNSUPPORTED, "SpatialFullConvolution backward is not implemented");
       int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W)); if (r) return r;
       launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream);
-      if (need_gin) launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+      if (need_gin) {
+        // backward-data = the same convolution on the transposed + flipped weights (Cout -> Cin)
+        if (n->ctx->conv_mode == 1 && s.Cin > 4) launch_conv3x3_bf16x6(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+        else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+      }
       LAUNCHCHK(c);
     } else if (s.kind == ST_LINEAR) {
       size_t wsb = gemm_workspace_bytes(s.Cout, s.Cin, B);
@@ -885,8 +908,20 @@ static int with_prepped(gr_ctx* c, const float* w, int cin, int cout, bool bwd, 
   LAUNCHCHK(c);
   return GR_OK;
 }
+static int conv_split_once(gr_ctx* c, const float* w, int cin, int cout, bool bwd, void** ws) {
+  HIPCHK(c, hipMalloc(ws, conv_weight_split_bytes(cin, cout, bwd)));
+  launch_conv_weight_split(w, *ws, cin, cout, bwd, c->stream);
+  LAUNCHCHK(c);
+  return GR_OK;
+}
 extern "C" int gr_conv3_forward_dev(gr_ctx* c, const float* in, const float* w, const float* bias, float* out, int B, int cin, int cout, int h, int wd, int up) {
   if (!c || !in || !w || !out) return GR_ERR_INVALID;
+  if (c->conv_mode == 1 && cout > 4) {
+    void* ws = nullptr; int r = conv_split_once(c, w, cin, cout, false, &ws); if (r) return r;
+    launch_conv3x3_bf16x6(in, ws, bias, out, B, cin, cout, h, wd, up != 0, c->stream);
+    hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(ws);
+    return e == hipSuccess ? GR_OK : fail(c, GR_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
+  }
   float* wt = nullptr; int r = with_prepped(c, w, cin, cout, false, &wt); if (r) return r;
   launch_conv3x3(in, wt, bias, out, B, cin, cout, h, wd, up != 0, c->stream, w);
   hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(wt);
@@ -894,6 +929,12 @@ extern "C" int gr_conv3_forward_dev(gr_ctx* c, const float* in, const float* w, 
 }
 extern "C" int gr_conv3_backward_data_dev(gr_ctx* c, const float* gout, const float* w, float* gin, int B, int cin, int cout, int h, int wd) {
   if (!c || !gout || !w || !gin) return GR_ERR_INVALID;
+  if (c->conv_mode == 1 && cin > 4) {
+    void* ws = nullptr; int r = conv_split_once(c, w, cin, cout, true, &ws); if (r) return r;
+    launch_conv3x3_bf16x6(gout, ws, nullptr, gin, B, cout, cin, h, wd, false, c->stream);
+    hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(ws);
+    return e == hipSuccess ? GR_OK : fail(c, GR_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
+  }
   float* wt = nullptr; int r = with_prepped(c, w, cin, cout, true, &wt); if (r) return r;
   launch_conv3x3(gout, wt, nullptr, gin, B, cout, cin, h, wd, false, c->stream);
   hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(wt);
@@ -916,9 +957,14 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   launch_fill_normal(x, (long)nin, 11, c->stream); launch_fill_normal(y, (long)nout, 12, c->stream); launch_fill_normal(w, (long)nw, 13, c->stream);
   (void)hipMemsetAsync(gw, 0, sizeof(float) * nw, c->stream);
   int r = with_prepped(c, w, cin, cout, which == 1, &wt); if (r) return r;
+  void* wsp = nullptr;
+  const bool split = c->conv_mode == 1 && which != 2 && (which == 0 ? cout > 4 : cin > 4);
+  if (split) { r = conv_split_once(c, w, cin, cout, which == 1, &wsp); if (r) return r; }
   r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd)); if (r) return r;
   auto run = [&]() {
-    if (which == 0) launch_conv3x3(x, wt, nullptr, y, B, cin, cout, h, wd, false, c->stream, w);
+    if (split && which == 0) launch_conv3x3_bf16x6(x, wsp, nullptr, y, B, cin, cout, h, wd, false, c->stream);
+    else if (split && which == 1) launch_conv3x3_bf16x6(y, wsp, nullptr, x, B, cout, cin, h, wd, false, c->stream);
+    else if (which == 0) launch_conv3x3(x, wt, nullptr, y, B, cin, cout, h, wd, false, c->stream, w);
     else if (which == 1) launch_conv3x3(y, wt, nullptr, x, B, cout, cin, h, wd, false, c->stream);
     else launch_conv3x3_wgrad(x, y, gw, c->ws, B, cin, cout, h, wd, c->stream);
   };
@@ -931,7 +977,7 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
   *avg_ms = ms / iters;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(wt); (void)hipFree(gw);
+  (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(wt); (void)hipFree(gw); (void)hipFree(wsp);
   LAUNCHCHK(c);
   return GR_OK;
 }

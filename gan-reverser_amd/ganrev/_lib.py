@@ -97,6 +97,8 @@ _SIGS = {
     "gr_allreduce_dev": (C.c_int, [_P, _P, C.c_int64]),
     "gr_broadcast_params": (C.c_int, [_P, C.c_int]),
     "gr_train_r_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(Hyper), C.c_int, C.POINTER(C.c_double)]),
+    "gr_set_conv_mode": (C.c_int, [_P, C.c_int]),
+    "gr_get_conv_mode": (C.c_int, [_P]),
     "gr_set_timing": (C.c_int, [_P, C.c_int]),
     "gr_last_step_times": (C.c_int, [_P, _P]),
     "gr_kernel_times": (C.c_int, [_P, C.c_char_p, C.c_int]),
@@ -248,6 +250,14 @@ class Context:
 
     def allreduce(self, dptr, n):
         self.check(self.lib.gr_allreduce_dev(self.h, _ptr(dptr), int(n)), "gr_allreduce_dev")
+
+    def set_conv_mode(self, mode):
+        """0 / "f32": exact fp32 MFMA; 1 / "bf16x6": fp32-accurate 3-term bf16 split on the bf16 MFMA."""
+        mode = {"f32": 0, "bf16x6": 1}.get(mode, mode)
+        self.check(self.lib.gr_set_conv_mode(self.h, int(mode)), "gr_set_conv_mode")
+
+    def conv_mode(self):
+        return ("f32", "bf16x6")[self.lib.gr_get_conv_mode(self.h)]
 
     def set_timing(self, mode):
         self.check(self.lib.gr_set_timing(self.h, int(mode)), "gr_set_timing")
