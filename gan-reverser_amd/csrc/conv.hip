@@ -340,15 +340,16 @@ constexpr int BF_CK = 16;
 __device__ __forceinline__ unsigned short f32_to_bf16(float x) { const __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
 __device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
-template <int TW>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
-  constexpr int NG = 2, PT = 256, TR = PT / TW, PR = TR + 2, PC = TW + 2, PS = PR * PC, CT = 32;
-  constexpr int NEH = 2 * PS, NSL = (NEH + 255) / 256;           // (pixel, half) pairs staged per thread
-  constexpr int WROWS = 3 * 9 * 2, WV = WROWS * CT, NWV = (WV + 255) / 256;   // 16-byte weight vectors per chunk
+template <int TW, int MT>
+__global__ __launch_bounds__(256 * MT, 2) void conv3x3_bf16x6_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
+  constexpr int NT = 256 * MT;                                    // MT = 2: 8 waves = 2 channel blocks x 4 pixel quarters
+  constexpr int NG = 2, PT = 256, TR = PT / TW, PR = TR + 2, PC = TW + 2, PS = PR * PC, CT = 32 * MT;
+  constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
+  constexpr int WROWS = 3 * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [3][2][PS]   (one uint4 = 8 bf16)
   uint4* wts = patch + 3 * 2 * PS;                                // [3][9][2][CT]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wmt = tid >> 8, l31 = lane & 31, h = lane >> 5;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ot = bid % a.n_otiles; bid /= a.n_otiles;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(ConvArgs a, cons
   int src_off[NSL]; bool inb[NSL]; int sh[NSL];
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
-    const int eh = tid + 256 * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, r = e / PC, c = e - r * PC;
+    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, r = e / PC, c = e - r * PC;
     const int yy = y0 + r - 1, xx = x0 + c - 1;
     inb[s] = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W;
     src_off[s] = a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx;
@@ -378,14 +379,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(ConvArgs a, cons
       }                                                                                                   \
     const uint4* wp_ = wsplit + (size_t)(ch_) * WROWS * a.cout_pad + o0;                                  \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
-      const int f = tid + 256 * i, row = f / CT, col = f - row * CT;                                      \
+      const int f = tid + NT * i, row = f / CT, col = f - row * CT;                                       \
       wv[i] = f < WV ? wp_[(size_t)row * a.cout_pad + col] : make_uint4(0, 0, 0, 0);                      \
     }                                                                                                     \
   }
 #define GR_BF_STORE()                                                                                     \
   {                                                                                                       \
     _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
-      const int eh = tid + 256 * s;                                                                       \
+      const int eh = tid + NT * s;                                                                        \
       if (eh < NEH) {                                                                                     \
         unsigned short t0[8], t1[8], t2[8];                                                               \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(ConvArgs a, cons
       }                                                                                                   \
     }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
-      const int f = tid + 256 * i;                                                                        \
+      const int f = tid + NT * i;                                                                         \
       if (f < WV) wts[f] = wv[i];                                                                         \
     }                                                                                                     \
   }
@@ -423,31 +424,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(ConvArgs a, cons
     GR_BF_STORE()
     __syncthreads();
     if (ch + 1 < nchunks) GR_BF_LOAD(ch + 1)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3, toff = ky * PC + kx;
-      bf16x8 av[3], bv[NG][3];
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const uint4 t = wts[((s * 9 + tap) * 2 + h) * CT + l31];
-        av[s] = __builtin_bit_cast(bf16x8, t);
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng) {
-          const uint4 u = patch[s * 2 * PS + pix[ng] + toff];
-          bv[ng][s] = __builtin_bit_cast(bf16x8, u);
-        }
-      }
-#pragma unroll
-      for (int ng = 0; ng < NG; ++ng) {
-        // smallest terms first
-        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[ng][0], acc[ng], 0, 0, 0);
-        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[ng][1], acc[ng], 0, 0, 0);
-        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[ng][2], acc[ng], 0, 0, 0);
-        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[ng][0], acc[ng], 0, 0, 0);
-        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[ng][1], acc[ng], 0, 0, 0);
-        acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[ng][0], acc[ng], 0, 0, 0);
-      }
+    // operand fetch for tap t+1 is issued before the 12 MFMAs of tap t (two register sets, statically indexed)
+    bf16x8 avA[3], bvA[NG][3], avB[3], bvB[NG][3];
+#define GR_BF_OPS(tap_, av_, bv_)                                                                        \
+    {                                                                                                     \
+      const int toff_ = ((tap_) / 3) * PC + ((tap_) % 3);                                                 \
+      _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                     \
+        const uint4 t_ = wts[((s * 9 + (tap_)) * 2 + h) * CT + wmt * 32 + l31];                           \
+        av_[s] = __builtin_bit_cast(bf16x8, t_);                                                          \
+        _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) {                                               \
+          const uint4 u_ = patch[s * 2 * PS + pix[ng] + toff_];                                           \
+          bv_[ng][s] = __builtin_bit_cast(bf16x8, u_);                                                    \
+        }                                                                                                 \
+      }                                                                                                   \
     }
+#define GR_BF_MMA(av_, bv_)                                                                               \
+    _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) {                                                   \
+      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[2], bv_[ng][0], acc[ng], 0, 0, 0);            \
+      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[1], bv_[ng][1], acc[ng], 0, 0, 0);            \
+      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[0], bv_[ng][2], acc[ng], 0, 0, 0);            \
+      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[1], bv_[ng][0], acc[ng], 0, 0, 0);            \
+      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[0], bv_[ng][1], acc[ng], 0, 0, 0);            \
+      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[0], bv_[ng][0], acc[ng], 0, 0, 0);            \
+    }
+#define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, 9, 0); __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    GR_BF_OPS(0, avA, bvA)
+    GR_BF_OPS(1, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+    GR_BF_OPS(2, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+    GR_BF_OPS(3, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+    GR_BF_OPS(4, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+    GR_BF_OPS(5, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+    GR_BF_OPS(6, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+    GR_BF_OPS(7, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+    GR_BF_OPS(8, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+    GR_BF_MMA(avA, bvA)
+#undef GR_BF_OPS
+#undef GR_BF_MMA
+#undef GR_BF_PIN
     __syncthreads();
   }
 #undef GR_BF_LOAD
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x6_kernel(ConvArgs a, cons
     if (y < H && x < W) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int o = o0 + wmt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (o < a.Cout) {
           const float bvv = a.bias ? a.bias[o] : 0.f;
           a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = acc[ng][r] + bvv;
@@ -505,19 +518,19 @@ void launch_conv_weight_split(const float* w_native, void* dst, int cin, int cou
                      cin, cout, CI, CO, cin_pad, cout_pad, bwd ? 1 : 0);
 }
 
-template <int TW>
+template <int TW, int MT>
 static void launch_conv_bf16x6_t(ConvArgs a, const void* wsplit, hipStream_t s) {
-  constexpr int TR = 256 / TW, PS = (TR + 2) * (TW + 2), CT = 32;
+  constexpr int TR = 256 / TW, PS = (TR + 2) * (TW + 2), CT = 32 * MT;
   a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
   const size_t lds = 16 * (size_t)(3 * 2 * PS + 3 * 9 * 2 * CT);
   const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  static const std::string name = "conv3x3_bf16x6_kernel<" + std::to_string(TW) + ">";
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6_kernel<TW, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = "conv3x3_bf16x6_kernel<" + std::to_string(TW) + ", " + std::to_string(MT) + ">";
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TW>), dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
+  hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TW, MT>), dim3(grid), dim3(256 * MT), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
 }
 
 void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bias, float* out,
@@ -525,9 +538,12 @@ void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bia
   ConvArgs a{};
   a.in = in; a.wt = nullptr; a.bias = bias; a.out = out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
-  if (W <= 8) launch_conv_bf16x6_t<8>(a, wsplit, s);
-  else if (W <= 16) launch_conv_bf16x6_t<16>(a, wsplit, s);
-  else launch_conv_bf16x6_t<32>(a, wsplit, s);
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("GR_BF16X6_VARIANT"); variant = e ? atoi(e) : 0; }
+  const bool wide = round_up(Cout, 32) % 64 == 0 && variant != 1;      // 64 output channels per workgroup (8 waves share one patch)
+  if (W <= 8) launch_conv_bf16x6_t<8, 1>(a, wsplit, s);
+  else if (W <= 16) { if (wide) launch_conv_bf16x6_t<16, 2>(a, wsplit, s); else launch_conv_bf16x6_t<16, 1>(a, wsplit, s); }
+  else { if (wide) launch_conv_bf16x6_t<32, 2>(a, wsplit, s); else launch_conv_bf16x6_t<32, 1>(a, wsplit, s); }
 }
 
 // ---------------------------------------------------------------- weight layout preparation

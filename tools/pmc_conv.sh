@@ -4,7 +4,7 @@ export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
 F=${1:-conv2}; B=${2:-256}
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   tag=$(echo $set | cut -d' ' -f1)
-  timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/tools/bench_kernels.py $B $F > $R/gpurun_out/pmc_$tag.log 2>&1
+  GR_CONV_MODE=${GR_CONV_MODE:-f32} timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/tools/bench_kernels.py $B $F > $R/gpurun_out/pmc_$tag.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
