@@ -576,6 +576,56 @@ void launch_conv_weight_prep(const float* w_native, float* wt, int cin, int cout
                      L.cin_pad, L.cout_pad, bwd ? 1 : 0);
 }
 
+// One launch prepares every convolution of a net (forward + backward-data images, either flavour): blockIdx.y = job.
+__global__ void conv_weight_prep_batch_kernel(const PrepJob* __restrict__ jobs, const float* __restrict__ params) {
+  const PrepJob j = jobs[blockIdx.y];
+  const float* w = params + j.w_off;
+  if (j.split) {
+    unsigned short* dst = reinterpret_cast<unsigned short*>(j.dst);
+    const long n = (long)(j.cin_pad / BF_CK) * 9 * 2 * j.cout_pad * 8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+      const int jj = (int)(i & 7); long r = i >> 3;
+      const int oo = (int)(r % j.cout_pad); r /= j.cout_pad;
+      const int hh = (int)(r & 1); r >>= 1;
+      const int tap = (int)(r % 9); const int ch = (int)(r / 9);
+      const int ci = ch * BF_CK + 8 * hh + jj;
+      float v = 0.f;
+      if (ci < j.CI && oo < j.CO) v = j.bwd ? w[((long)ci * j.cin + oo) * 9 + (8 - tap)] : w[((long)oo * j.cin + ci) * 9 + tap];
+      const unsigned short t0 = f32_to_bf16(v); const float r1 = v - bf16_to_f32(t0);
+      const unsigned short t1 = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(t1);
+      const unsigned short t2 = f32_to_bf16(r2);
+      const long base = (long)ch * 3 * 9 * 2 * j.cout_pad * 8;
+      const long within = (((long)tap * 2 + hh) * j.cout_pad + oo) * 8 + jj, term = (long)9 * 2 * j.cout_pad * 8;
+      dst[base + within] = t0; dst[base + term + within] = t1; dst[base + 2 * term + within] = t2;
+    }
+  } else {
+    float* dst = reinterpret_cast<float*>(j.dst);
+    const long n = (long)j.cin_pad * 9 * j.cout_pad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+      const int oo = (int)(i % j.cout_pad); long r = i / j.cout_pad;
+      const int cil = (int)(r % CONV_CK); r /= CONV_CK;
+      const int tap = (int)(r % 9); const int ch = (int)(r / 9);
+      const int ci = ch * CONV_CK + cil;
+      float v = 0.f;
+      if (ci < j.CI && oo < j.CO) v = j.bwd ? w[((long)ci * j.cin + oo) * 9 + (8 - tap)] : w[((long)oo * j.cin + ci) * 9 + tap];
+      dst[i] = v;
+    }
+  }
+}
+
+PrepJob make_prep_job(long w_off, void* dst, int cin, int cout, bool bwd, bool split) {
+  PrepJob j{};
+  j.w_off = w_off; j.dst = dst; j.cin = cin; j.cout = cout; j.bwd = bwd ? 1 : 0; j.split = split ? 1 : 0;
+  j.CI = bwd ? cout : cin; j.CO = bwd ? cin : cout;
+  j.cin_pad = round_up(j.CI, split ? BF_CK : CONV_CK); j.cout_pad = round_up(j.CO, 32);
+  return j;
+}
+void launch_conv_weight_prep_batch(const PrepJob* jobs_dev, int njobs, const float* params, hipStream_t s) {
+  if (njobs <= 0) return;
+  KtScope kt("conv_weight_prep_batch_kernel", 0.0, 0.0, s);
+  hipLaunchKernelGGL(conv_weight_prep_batch_kernel, dim3(96, njobs), dim3(256), 0, s, jobs_dev, params);
+}
+
 // ---------------------------------------------------------------- backward-weight
 // gw[o][ci][tap] += sum_{b,y,x} dy[b,o,y,x] * x[b,ci,y+ky-1,x+kx-1]
 // GEMM view: M = Cout, N = (tap, ci), K = B*H*W.  A workgroup owns a 64(o) x 64(ci) x 9(tap) block and a

@@ -51,6 +51,11 @@ void launch_conv_weight_split(const float* w_native, void* wsplit, int cin, int 
 void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bias, float* out,
                            int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s);
 
+// all weight images of a net in one launch
+struct PrepJob { long w_off; void* dst; int cin, cout, CI, CO, cin_pad, cout_pad, bwd, split; };
+PrepJob make_prep_job(long w_off, void* dst, int cin, int cout, bool for_backward_data, bool split);
+void launch_conv_weight_prep_batch(const PrepJob* jobs_dev, int njobs, const float* params, hipStream_t s);
+
 // weight gradient: slab workspace sized by conv_wgrad_workspace(); result accumulated (+=) into gw native layout
 size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W);
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,

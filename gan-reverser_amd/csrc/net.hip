@@ -230,6 +230,8 @@ struct gr_net {
   float *in_buf = nullptr, *gout_buf = nullptr, *dy_buf = nullptr, *g_buf[2] = {nullptr, nullptr};
   size_t max_y = 0, max_in = 0;      // per-sample element counts
   uint8_t* mask_stage = nullptr; size_t mask_stage_cap = 0;
+  PrepJob* jobs_dev[2] = {nullptr, nullptr}; int njobs[2] = {0, 0};   // [0] fp32 k-major images, [1] bf16x6 split images
+  uint64_t prepped_version[2] = {0, 0};
 };
 
 static int64_t vol3(int c, int h, int w) { return (int64_t)c * h * w; }
@@ -250,7 +252,7 @@ extern "C" int gr_net_destroy(gr_net* n) {
   for (auto& m : n->masks) (void)hipFree(m.bits);
   (void)hipFree(n->params); (void)hipFree(n->grads); (void)hipFree(n->adam_m); (void)hipFree(n->adam_v);
   (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
-  (void)hipFree(n->mask_stage);
+  (void)hipFree(n->mask_stage); (void)hipFree(n->jobs_dev[0]); (void)hipFree(n->jobs_dev[1]);
   delete n;
   return GR_OK;
 }
@@ -370,6 +372,30 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
     if (ye > n->max_y) n->max_y = ye;
     if (ie > n->max_in) n->max_in = ie;
   }
+  {
+    std::vector<PrepJob> jf, js;
+    for (auto& s : n->st) {
+      if (s.kind != ST_CONV) continue;
+      if (!s.fullconv) {
+        jf.push_back(make_prep_job(s.w_off, s.wt_fwd, s.Cin, s.Cout, false, false));
+        jf.push_back(make_prep_job(s.w_off, s.wt_bwd, s.Cin, s.Cout, true, false));
+        js.push_back(make_prep_job(s.w_off, s.ws_fwd, s.Cin, s.Cout, false, true));
+        js.push_back(make_prep_job(s.w_off, s.ws_bwd, s.Cin, s.Cout, true, true));
+      } else {
+        // SpatialFullConvolution weight is [Cin][Cout][3][3]: its forward is the backward-data of a (Cout -> Cin) conv
+        jf.push_back(make_prep_job(s.w_off, s.wt_fwd, s.Cout, s.Cin, true, false));
+        jf.push_back(make_prep_job(s.w_off, s.wt_bwd, s.Cout, s.Cin, false, false));
+      }
+    }
+    for (int m = 0; m < 2; ++m) {
+      std::vector<PrepJob>& v = m ? js : jf;
+      n->njobs[m] = (int)v.size();
+      if (!v.empty()) {
+        HIPCHK(c, hipMalloc((void**)&n->jobs_dev[m], sizeof(PrepJob) * v.size()));
+        HIPCHK(c, hipMemcpy(n->jobs_dev[m], v.data(), sizeof(PrepJob) * v.size(), hipMemcpyHostToDevice));
+      }
+    }
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *out = n;
   return GR_OK;
@@ -486,28 +512,24 @@ static int ensure_batch(gr_net* n, int B) {
   return GR_OK;
 }
 
-static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode == 1 && s.kind == ST_CONV && !s.fullconv && s.Cout > 4; }
-static int prep_weights(gr_net* n, Stage& s) {
-  if (s.kind != ST_CONV) return GR_OK;
+// bf16x6 mode: every plain convolution runs on the split kernel except few-output-channel layers the HBM-bound VALU
+// kernel covers (same predicate as launch_conv3x3); only the split images are kept current in that mode.
+static bool fewout_applies(const Stage& s) { return s.Cout <= 4 && !s.up && s.W % 4 == 0 && s.W >= 16; }
+static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode == 1 && s.kind == ST_CONV && !s.fullconv && !fewout_applies(s); }
+// Re-lay every convolution's weights (one launch) when the parameters changed since the last time.  bf16x6 mode needs the
+// split images; the fp32 k-major images are still needed there by SpatialFullConvolution stages (no split kernel).
+static int prep_weights(gr_net* n) {
   gr_ctx* c = n->ctx;
-  const float* w = n->params + s.w_off;
-  if (n->ctx->conv_mode == 1 && !s.fullconv && s.ws_version != n->params_version) {
-    launch_conv_weight_split(w, s.ws_fwd, s.Cin, s.Cout, false, c->stream);
-    launch_conv_weight_split(w, s.ws_bwd, s.Cin, s.Cout, true, c->stream);
+  const int mode = c->conv_mode == 1 ? 1 : 0;
+  bool any_full = false;
+  for (auto& s : n->st) any_full |= s.kind == ST_CONV && s.fullconv;
+  for (int m = 0; m < 2; ++m) {
+    if (!(m == mode || (m == 0 && any_full))) continue;
+    if (n->prepped_version[m] == n->params_version) continue;
+    launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream);
     LAUNCHCHK(c);
-    s.ws_version = n->params_version;
+    n->prepped_version[m] = n->params_version;
   }
-  if (s.wt_version == n->params_version) return GR_OK;
-  if (!s.fullconv) {
-    launch_conv_weight_prep(w, s.wt_fwd, s.Cin, s.Cout, false, c->stream);
-    launch_conv_weight_prep(w, s.wt_bwd, s.Cin, s.Cout, true, c->stream);
-  } else {
-    // SpatialFullConvolution weight is [Cin][Cout][3][3]: its forward is the backward-data of a (Cout -> Cin) conv
-    launch_conv_weight_prep(w, s.wt_fwd, s.Cout, s.Cin, true, c->stream);
-    launch_conv_weight_prep(w, s.wt_bwd, s.Cout, s.Cin, false, c->stream);
-  }
-  LAUNCHCHK(c);
-  s.wt_version = n->params_version;
   return GR_OK;
 }
 
@@ -548,10 +570,10 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
   int r = ensure_batch(n, B); if (r) return r;
   const float* x = in_dev;
   n->fwd_counter++;
+  r = prep_weights(n); if (r) return r;
   for (auto& s : n->st) {
     s.x_in = x;
     if (s.kind == ST_CONV) {
-      r = prep_weights(n, s); if (r) return r;
       if (use_bf16x6(n, s)) launch_conv3x3_bf16x6(x, s.ws_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream);
       else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off);
     } else if (s.kind == ST_LINEAR) {
@@ -671,7 +693,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream);
       if (need_gin) {
         // backward-data = the same convolution on the transposed + flipped weights (Cout -> Cin)
-        if (n->ctx->conv_mode == 1 && s.Cin > 4) launch_conv3x3_bf16x6(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+        if (n->ctx->conv_mode == 1) launch_conv3x3_bf16x6(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
         else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
       }
       LAUNCHCHK(c);
