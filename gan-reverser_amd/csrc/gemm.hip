@@ -17,18 +17,47 @@ struct GemmArgs {
   int M, N, K, klen, nsplit, accumulate;
 };
 
-// stage a 64(rows) x 32(k) operand tile into LDS as T[k][row] (row stride 65)
+// A 64(rows) x 32(k) operand tile is fetched into 8 registers per thread (one float4 pair along k when the operand is
+// K-contiguous and 16-byte aligned, scalars otherwise) while the MFMAs of the previous tile run, then written to LDS as
+// T[k][row] (row stride 65: conflict-free both for the transposing writes and for the MFMA operand reads).
 template <bool KCONTIG>
-__device__ __forceinline__ void stage_tile(const float* __restrict__ P, long rs, long ks, int row0, int nrows,
-                                           int k0, int kend, float* T, int tid) {
+__device__ __forceinline__ void tile_load(const float* __restrict__ P, long rs, long ks, int row0, int nrows,
+                                          int k0, int kend, bool vec, float (&v)[8], int tid) {
+  if (KCONTIG && vec) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    int r, k;
-    if (KCONTIG) { k = tid & 31; r = (tid >> 5) + 8 * i; }
-    else { r = tid & 63; k = (tid >> 6) + 4 * i; }
-    float v = 0.f;
-    if (row0 + r < nrows && k0 + k < kend) v = P[(long)(row0 + r) * rs + (long)(k0 + k) * ks];
-    T[k * 65 + r] = v;
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i, r = f >> 3, k = (f & 7) * 4;     // 8 float4 per row
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < nrows && k0 + k < kend) t = *reinterpret_cast<const float4*>(P + (long)(row0 + r) * rs + k0 + k);
+      v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int r, k;
+      if (KCONTIG) { k = tid & 31; r = (tid >> 5) + 8 * i; }
+      else { r = tid & 63; k = (tid >> 6) + 4 * i; }
+      v[i] = (row0 + r < nrows && k0 + k < kend) ? P[(long)(row0 + r) * rs + (long)(k0 + k) * ks] : 0.f;
+    }
+  }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_store(float* T, bool vec, const float (&v)[8], int tid) {
+  if (KCONTIG && vec) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i, r = f >> 3, k = (f & 7) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) T[(k + j) * 65 + r] = v[4 * i + j];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int r, k;
+      if (KCONTIG) { k = tid & 31; r = (tid >> 5) + 8 * i; }
+      else { r = tid & 63; k = (tid >> 6) + 4 * i; }
+      T[k * 65 + r] = v[i];
+    }
   }
 }
 
@@ -41,18 +70,27 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const int kbeg = blockIdx.z * a.klen;
   const int kend = min(a.K, kbeg + a.klen);
+  const bool avec = AK && (a.rsA & 3) == 0 && (kbeg & 3) == 0 && (a.K & 3) == 0 && ((uintptr_t)a.A & 15) == 0;
+  const bool bvec = BK && (a.rsB & 3) == 0 && (kbeg & 3) == 0 && (a.K & 3) == 0 && ((uintptr_t)a.Bm & 15) == 0;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float av[8], bv[8];
+  tile_load<AK>(a.A, a.rsA, a.ksA, m0, a.M, kbeg, kend, avec, av, tid);
+  tile_load<BK>(a.Bm, a.rsB, a.ksB, n0, a.N, kbeg, kend, bvec, bv, tid);
   for (int k0 = kbeg; k0 < kend; k0 += 32) {
-    stage_tile<AK>(a.A, a.rsA, a.ksA, m0, a.M, k0, kend, As, tid);
-    stage_tile<BK>(a.Bm, a.rsB, a.ksB, n0, a.N, k0, kend, Bs, tid);
+    tile_store<AK>(As, avec, av, tid);
+    tile_store<BK>(Bs, bvec, bv, tid);
     __syncthreads();
+    if (k0 + 32 < kend) {
+      tile_load<AK>(a.A, a.rsA, a.ksA, m0, a.M, k0 + 32, kend, avec, av, tid);
+      tile_load<BK>(a.Bm, a.rsB, a.ksB, n0, a.N, k0 + 32, kend, bvec, bv, tid);
+    }
 #pragma unroll
     for (int kk = 0; kk < 32; kk += 2) {
-      const float av = As[(kk + h) * 65 + wm * 32 + l31];
-      const float bv = Bs[(kk + h) * 65 + wn * 32 + l31];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      const float x = As[(kk + h) * 65 + wm * 32 + l31];
+      const float y = Bs[(kk + h) * 65 + wn * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc, 0, 0, 0);
     }
     __syncthreads();
   }
