@@ -570,6 +570,20 @@ void launch_fill_normal(float* dst, long n, uint64_t seed, hipStream_t s) {
   hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, dst, n, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// torch.dist(a_i, b_i) per row (apply_r.lua:369: 1 - torch.dist(images[i], fixedImage)): sqrt(sum (a-b)^2), fp32 difference and
+// square, fp64 sum (TH accreal), one workgroup per row.
+__global__ __launch_bounds__(256) void l2_distance_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, long d, double* __restrict__ out) {
+  __shared__ double sh[8];
+  const float* pa = a + blockIdx.x * d; const float* pb = b + blockIdx.x * d;
+  double s = 0;
+  for (long i = threadIdx.x; i < d; i += blockDim.x) { const float t = fabsf(pa[i] - pb[i]); s += (double)(t * t); }
+  s = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = sqrt(s);
+}
+void launch_l2_distance_rows(const float* a, const float* b, long n, long d, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(l2_distance_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, a, b, d, out);
+}
+
 __global__ void scale_copy_kernel(const float* src, float* dst, long n, float scale) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
 }

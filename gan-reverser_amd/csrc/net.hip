@@ -922,6 +922,21 @@ extern "C" int gr_cosine_similarity_host(gr_ctx* c, const float* a, const float*
   return GR_OK;
 }
 
+// ------------------------------------------------------------------ apply_r.lua:355-372 detectAnomalies' distance
+extern "C" int gr_l2_distance_rows_host(gr_ctx* c, const float* a, const float* b, int64_t n, int64_t d, double* out) {
+  if (!c || !a || !b || !out || n <= 0 || d <= 0) return GR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t nb = sizeof(float) * (size_t)n * d;
+  int r = ensure_ws(c, 2 * nb + sizeof(double) * (size_t)n + 256); if (r) return r;
+  float* da = (float*)c->ws; float* db = da + (size_t)n * d; double* dout = (double*)((char*)c->ws + ((2 * nb + 255) & ~(size_t)255));
+  HIPCHK(c, hipMemcpyAsync(da, a, nb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(db, b, nb, hipMemcpyHostToDevice, c->stream));
+  launch_l2_distance_rows(da, db, n, d, dout, c->stream); LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(out, dout, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+
 // ------------------------------------------------------------------ single-kernel entry points
 static int with_prepped(gr_ctx* c, const float* w, int cin, int cout, bool bwd, float** wt) {
   const ConvWeightLayout L = bwd ? conv_weight_layout(cout, cin) : conv_weight_layout(cin, cout);

@@ -7,6 +7,6 @@ the GPU, calling it without the library or without a gfx950 device raises Ganrev
 """
 from . import _lib  # noqa: F401
 from ._lib import GanrevError, Hyper  # noqa: F401
-from . import nn, models, optim, nn_utils, weight_init, synth  # noqa: F401
+from . import nn, models, optim, nn_utils, weight_init, synth, apply_r, parallel  # noqa: F401
 
-__all__ = ["nn", "models", "optim", "nn_utils", "weight_init", "synth", "GanrevError", "Hyper"]
+__all__ = ["nn", "models", "optim", "nn_utils", "weight_init", "synth", "apply_r", "parallel", "GanrevError", "Hyper"]

@@ -105,6 +105,7 @@ _SIGS = {
     "gr_cosine_topk_host": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "gr_cosine_topk_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "gr_cosine_similarity_host": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float)]),
+    "gr_l2_distance_rows_host": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
     "gr_malloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "gr_free": (C.c_int, [_P, _P]),
     "gr_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_int64]),
@@ -234,6 +235,15 @@ class Context:
         out = C.c_float()
         self.check(self.lib.gr_cosine_similarity_host(self.h, _ptr(a), _ptr(b), a.size, C.byref(out)), "gr_cosine_similarity_host")
         return out.value
+
+    def l2_distance_rows(self, a, b):
+        """torch.dist(a[i], b[i]) for every row i (apply_r.lua:369)."""
+        a, b = f32(a), f32(b)
+        n = a.shape[0]
+        a2, b2 = a.reshape(n, -1), b.reshape(n, -1)
+        out = np.empty(n, dtype=np.float64)
+        self.check(self.lib.gr_l2_distance_rows_host(self.h, _ptr(a2), _ptr(b2), n, a2.shape[1], _ptr(out)), "gr_l2_distance_rows_host")
+        return out
 
     # ---- data parallel
     def comm_unique_id(self):

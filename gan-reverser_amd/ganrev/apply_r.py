@@ -1,0 +1,67 @@
+"""Mirror of the analysis steps of the reference's apply_r.lua that sit on (or right next to) the hot path.
+
+  embed                        apply_r.lua:145-153   images = G(noise); attributes = R(images)   (forwardBatched, batch 32)
+  createSimilaritySearch       apply_r.lua:265-318   needle rows i*100, cosine top-n on recovered noise / on raw pixels
+  cosineSimilarity             apply_r.lua:396-400
+  fixFaces                     apply_r.lua:324-352   noise -> G -> image -> R_fixer -> noise -> G -> image
+  detectAnomalies              apply_r.lua:355-390   1 - torch.dist(image, fixed image), lowest `threshold` share = anomalies
+
+Everything image-writing (image.toDisplayTensor / image.save / colour conversion) is out of scope: these functions return
+the tensors / index lists the reference would have rendered.
+"""
+import math
+
+import numpy as np
+
+from . import _lib as L
+from .nn_utils import forwardBatched
+
+
+def embed(model_g, model_r, noise, batchSize=32, model_r_fixer=None):
+    """apply_r.lua:145-153.  Returns (images, attributes[, attributesFixer])."""
+    model_g.evaluate()
+    images = forwardBatched(model_g, noise, batchSize)                      # :146
+    model_r.evaluate()
+    attributes = forwardBatched(model_r, images, batchSize)                 # :152
+    if model_r_fixer is None:
+        return images, attributes
+    model_r_fixer.evaluate()                                                # the fixer's first Dropout stays on (models.lua:402-405)
+    return images, attributes, forwardBatched(model_r_fixer, images, batchSize)   # :153
+
+
+def cosineSimilarity(v1, v2):
+    """apply_r.lua:396-400."""
+    return L.default_context().cosine_similarity(v1, v2)
+
+
+def createSimilaritySearch(nbSimilarNeedles, nbShowMax, images, attributes):
+    """apply_r.lua:265-318.  -> (idx_by_attributes, idx_by_pixels): for needle i (row i*100, 1-based in the reference) the
+    row indices (0-based here) of the min(nbShowMax, N) most similar rows, best first, ties by ascending index."""
+    N = len(attributes)
+    needles = np.array([i * 100 - 1 for i in range(1, nbSimilarNeedles + 1)], dtype=np.int64)   # face_i_idx = i*100 (1-based)
+    if needles.max() >= N:
+        raise IndexError(f"needle row {needles.max() + 1} out of range for {N} rows")           # the reference would index nil
+    n = min(nbShowMax, N)
+    ctx = L.default_context()
+    by_attr, _ = ctx.cosine_topk(attributes, needles, n)                                        # similarityMeasureAttributes
+    by_pix, _ = ctx.cosine_topk(np.asarray(images, np.float32).reshape(N, -1), needles, n)      # similarityMeasurePixelwise
+    return by_attr, by_pix
+
+
+def fixFaces(nbFixedImages, model_g, attributesFixer, batchSize=32):
+    """apply_r.lua:344-351: the G(R_fixer(G(z))) images of the first nbFixedImages rows."""
+    model_g.evaluate()
+    return forwardBatched(model_g, attributesFixer[:nbFixedImages], batchSize)
+
+
+def detectAnomalies(nbImagesCalculations, threshold, images, model_g, attributesFixer, batchSize=32):
+    """apply_r.lua:355-390.  -> (distances, anomalyBelow, isAnomaly) with distances[i] = 1 - torch.dist(images[i], fixed[i]).
+    The reference forwards each row in a batch of two (:361-363, BatchNorm needs a batch) — G is in evaluate() mode, so the
+    result does not depend on the batch composition and the rows are forwarded in normal batches here."""
+    n = nbImagesCalculations
+    model_g.evaluate()
+    fixed = forwardBatched(model_g, attributesFixer[:n], batchSize)
+    dist = 1.0 - L.default_context().l2_distance_rows(images[:n], fixed)
+    srt = np.sort(dist)                                                     # table.sort(distancesForSort)
+    anomalyBelow = srt[max(int(math.floor(n * threshold)) - 1, 0)]          # distancesForSort[floor(#*threshold)]  (1-based)
+    return dist, anomalyBelow, dist <= anomalyBelow

@@ -209,8 +209,8 @@ class Module:
             self._seed_applied = True
         if self._flat is not None:
             net.set_params(self._flat[0])      # host storage is authoritative after getParameters()
-        mods = self.leaves()
-        net.set_training(any(m.train for m in mods) if len(mods) > 1 else self.train)
+        mods = [m for m in self.leaves() if not getattr(m, "always_on", False)] or self.leaves()
+        net.set_training(any(m.train for m in mods))     # the fixer's always-on Dropout does not make the net "training"
         self._sync_modes(net)
         for module, keep in self._pending_masks.values():
             net.set_mask(self._leaf_layer(module), keep)

@@ -153,6 +153,9 @@ int gr_cosine_topk_dev(gr_ctx* ctx, const float* emb_dev, int64_t n, int d, cons
                        int64_t* idx_out_host, float* score_out_host, int accumulate_in_float);
 int gr_cosine_similarity_host(gr_ctx* ctx, const float* a_host, const float* b_host, int d, float* out);
 
+/* ---- apply_r.lua:355-372 (detectAnomalies): out[i] = torch.dist(a[i], b[i]) = sqrt(sum_j (a_ij - b_ij)^2), rows of length d ---- */
+int gr_l2_distance_rows_host(gr_ctx* ctx, const float* a_host, const float* b_host, int64_t n, int64_t d, double* out_host);
+
 /* ---- device memory helpers for hosts without a tensor library (LuaJIT FFI, ctypes) ---- */
 int gr_malloc(gr_ctx* ctx, int64_t bytes, void** out_dev);
 int gr_free(gr_ctx* ctx, void* dev);

@@ -69,6 +69,7 @@ def lib():
         L.go_cosine_similarity.restype = C.c_float
         L.go_cosine_similarity.argtypes = [_P, _P, C.c_int, C.c_int]
         L.go_cosine_topk.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]
+        L.go_l2_distance_rows.argtypes = [_P, _P, C.c_int64, C.c_int64, _P]
         L.go_conv3_forward.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
         L.go_conv3_backward_data.argtypes = [_P, _P, _P] + [C.c_int] * 5
         L.go_conv3_backward_weight.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
@@ -201,6 +202,15 @@ def cosine_topk(emb, query_rows, k, accumulate_in_float=False):
     sc = np.empty((q.size, k), np.float32)
     lib().go_cosine_topk(_p(emb), n, d, _p(q), q.size, k, _p(idx), _p(sc), int(accumulate_in_float))
     return idx, sc
+
+
+def l2_distance_rows(a, b):
+    a, b = f32(a), f32(b)
+    n = a.shape[0]
+    a2, b2 = a.reshape(n, -1), b.reshape(n, -1)
+    out = np.empty(n, np.float64)
+    lib().go_l2_distance_rows(_p(a2), _p(b2), n, a2.shape[1], _p(out))
+    return out
 
 
 # ---- single operators

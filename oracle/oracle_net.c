@@ -529,3 +529,12 @@ void go_cosine_topk(const float* emb, int64_t N, int d, const int64_t* query_row
     free(c);
   }
 }
+
+/* TH THTensor_(dist)(a, b, 2): sum += pow(fabs(a-b), 2) in accreal (double), result pow(sum, 1/2)   — apply_r.lua:369 */
+void go_l2_distance_rows(const float* a, const float* b, int64_t n, int64_t d, double* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    double s = 0;
+    for (int64_t j = 0; j < d; ++j) { const float t = fabsf(a[i * d + j] - b[i * d + j]); s += (double)(t * t); }
+    out[i] = sqrt(s);
+  }
+}

@@ -24,3 +24,15 @@ def oracle():
 def ctx():
     import ganrev._lib as L
     return L.default_context()
+
+
+@pytest.fixture(params=["f32", "bf16x6"])
+def conv_mode(request):
+    """Run the test once per convolution arithmetic: exact fp32 MFMA, and the fp32-accurate 3-term bf16 split (bf16x6) that
+    bench.py uses by default.  Same tolerances for both."""
+    import ganrev._lib as L
+    c = L.default_context()
+    prev = c.conv_mode()
+    c.set_conv_mode(request.param)
+    yield request.param
+    c.set_conv_mode(prev)

@@ -33,7 +33,7 @@ CONV_SHAPES = [
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", CONV_SHAPES)
-def test_conv3_kernels_vs_oracle(ctx, oracle, B, Cin, Cout, H, W):
+def test_conv3_kernels_vs_oracle(ctx, oracle, conv_mode, B, Cin, Cout, H, W):
     from ganrev import synth
     x = synth.normal((B, Cin, H, W), 11)
     w = synth.uniform((Cout, Cin, 3, 3), 12, -1, 1) / np.float32(np.sqrt(Cin * 9))
@@ -62,7 +62,7 @@ def test_conv3_kernels_vs_oracle(ctx, oracle, B, Cin, Cout, H, W):
         ctx.free(p)
 
 
-def test_conv3_upsample_fused(ctx, oracle):
+def test_conv3_upsample_fused(ctx, oracle, conv_mode):
     from ganrev import synth
     B, Cin, Cout, H, W = 2, 32, 64, 16, 16      # input is 8x8, upsampled x2 while staged
     xs = synth.normal((B, Cin, H // 2, W // 2), 21)
@@ -81,7 +81,7 @@ R_CASES = [((1, 8, 8), 6, 8, "normal", False), ((1, 32, 32), 32, 8, "normal", Fa
 
 
 @pytest.mark.parametrize("dims,nd,B,method,fixer", R_CASES)
-def test_R_forward_backward_vs_oracle(oracle, dims, nd, B, method, fixer):
+def test_R_forward_backward_vs_oracle(oracle, conv_mode, dims, nd, B, method, fixer):
     from ganrev import models, synth
     from helpers import pools_well_conditioned
     R = models.create_R(dims, nd, method, fixer)
@@ -110,7 +110,7 @@ def test_R_forward_backward_vs_oracle(oracle, dims, nd, B, method, fixer):
     assert_close(grads, onet.grads, 2 * TOL * max(1.0, gmax), f"R flat gradient (max |g| = {gmax:.3g})")
 
 
-def test_R_eval_forward_and_running_stats(oracle):
+def test_R_eval_forward_and_running_stats(oracle, conv_mode):
     from ganrev import models, synth
     dims, nd, B = (1, 16, 16), 8, 6
     R = models.create_R(dims, nd)
@@ -133,7 +133,7 @@ def test_R_eval_forward_and_running_stats(oracle):
 
 
 @pytest.mark.parametrize("dims,nd,B", [((1, 32, 32), 32, 4), ((3, 16, 16), 10, 3), ((3, 64, 64), 100, 2)])
-def test_G_forward_vs_oracle(oracle, dims, nd, B):
+def test_G_forward_vs_oracle(oracle, conv_mode, dims, nd, B):
     from ganrev import models, synth
     G = models.create_G(dims, nd)
     synth.init_params(G, 2)
@@ -182,7 +182,7 @@ def _make_pair(oracle, dims, nd, seed):
 
 
 @pytest.mark.parametrize("dims,nd,B", [((1, 32, 32), 32, 8), ((3, 16, 16), 12, 8)])
-def test_train_r_steps_vs_oracle(ctx, oracle, dims, nd, B):
+def test_train_r_steps_vs_oracle(ctx, oracle, conv_mode, dims, nd, B):
     """train_r.lua:138-170, three iterations.  Each iteration starts from the ORACLE's state (theta, m, v): Adam's
     normalised update turns rounding-level gradient differences on entries whose gradient is itself rounding noise
     (every conv bias under BatchNorm has an exactly-zero true gradient) into +-lr parameter differences, and a 1e-3
@@ -290,7 +290,7 @@ _GOLD = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "gol
 
 
 @pytest.mark.parametrize("name", [n for n, c in sorted(_CASES.items()) if c["kind"] in ("R", "G")])
-def test_nets_vs_golden(name):
+def test_nets_vs_golden(conv_mode, name):
     from ganrev import synth
     case = _CASES[name]
     model, in_dims, x, masks = _build_case(case)
@@ -331,7 +331,7 @@ def test_search_vs_golden(ctx):
         assert np.array_equal(idx[:, :50], _GOLD[f"{name}/idx"][:, :50])      # BASELINE.json: top-50 exact match
 
 
-def test_train_step_vs_golden(ctx, oracle):
+def test_train_step_vs_golden(ctx, oracle, conv_mode):
     """First iteration of the golden 3-step trajectory (identical initial state): images, loss, clamped gradient."""
     import ganrev._lib as L
     from ganrev import models, synth
@@ -356,7 +356,7 @@ def test_train_step_vs_golden(ctx, oracle):
     assert_close(g[::_STRIDE], _GOLD["step_gray32/grads_sample1"], 2e-5, "clamped gradient sample")
 
 
-def test_fused_step_equals_decomposed_and_comm_path(ctx, oracle):
+def test_fused_step_equals_decomposed_and_comm_path(ctx, oracle, conv_mode):
     """gr_train_r_step (a) == the same iteration through the individual ABI calls, and (b) is unchanged when an RCCL
     communicator (nranks = 1, all a 1-GPU box can run) is active, i.e. with the bucketed all-reduce overlapped with backward
     on the comm stream."""
@@ -386,3 +386,60 @@ def test_fused_step_equals_decomposed_and_comm_path(ctx, oracle):
     for other in results[1:]:
         assert results[0][0] == other[0], "loss trajectories differ"
         assert np.array_equal(results[0][1], other[1]) and np.array_equal(results[0][2], other[2])
+
+
+def test_apply_r_pipeline_vs_oracle(oracle, conv_mode):
+    """apply_r.lua:145-153 (embed), :265-318 (search on attributes and on pixels), :324-352 (fix faces), :355-390 (anomalies):
+    the Python mirror over libganrev against the same composition on the oracle."""
+    from ganrev import apply_r, models, nn_utils, synth
+    dims, nd, N = (1, 16, 16), 8, 600
+    G = models.create_G(dims, nd); synth.init_params(G, 3)
+    R = models.create_R(dims, nd); synth.init_params(R, 4)
+    Rf = models.create_R(dims, nd, "normal", True); synth.init_params(Rf, 5)
+    oG, oR, oRf = oracle.from_model(G, (nd, 1, 1)), oracle.from_model(R, dims), oracle.from_model(Rf, dims)
+    for o in (oG, oR, oRf):
+        o.set_training(False)
+    noise = nn_utils.createNoiseInputs(N, nd, "normal", seed=7)
+    # the fixer's always-on dropout noise (one mask per forwardBatched chunk of 32 rows) is injected on both sides
+    drop = Rf.modules[1]
+    li = oRf.layer_index[id(drop)]
+    G.evaluate(); images = nn_utils.forwardBatched(G, noise, 32)
+    ref_images = np.concatenate([oG.forward(noise[s:s + 32]) for s in range(0, N, 32)])
+    assert_close(images, ref_images, TOL, "G images (forwardBatched)")
+    R.evaluate(); attributes = nn_utils.forwardBatched(R, images, 32)
+    ref_attr = np.concatenate([oR.forward(ref_images[s:s + 32]) for s in range(0, N, 32)])
+    assert_close(attributes, ref_attr, TOL, "attributes")
+    Rf.evaluate()
+    att_fix, ref_fix = [], []
+    for s in range(0, N, 32):
+        chunk = images[s:s + 32]
+        keep = synth.bernoulli_keep((chunk.size,), 1000 + s, 0.5)
+        Rf.setNoise(drop, keep); oRf.set_mask(li, keep)
+        att_fix.append(Rf.forward(chunk).copy()); ref_fix.append(oRf.forward(ref_images[s:s + 32]))
+    att_fix, ref_fix = np.concatenate(att_fix), np.concatenate(ref_fix)
+    assert_close(att_fix, ref_fix, TOL, "attributesFixer (always-on v1 dropout)")
+    # search: identical inputs on both sides -> indices bit-exact
+    by_attr, by_pix = apply_r.createSimilaritySearch(5, 100, images, attributes)
+    needles = np.array([99, 199, 299, 399, 499])
+    ra, _ = oracle.cosine_topk(attributes, needles, 100)
+    rp, _ = oracle.cosine_topk(images.reshape(N, -1), needles, 100)
+    assert np.array_equal(by_attr, ra) and np.array_equal(by_pix, rp)
+    # fix faces + anomalies
+    fixed = apply_r.fixFaces(64, G, att_fix)
+    ref_fixed = np.concatenate([oG.forward(ref_fix[s:s + 32]) for s in range(0, 64, 32)])
+    assert_close(fixed, ref_fixed, TOL, "fixed faces G(R_fixer(G(z)))")
+    dist, below, is_anom = apply_r.detectAnomalies(256, 0.15, images, G, att_fix)
+    ref_fixed_all = np.concatenate([oG.forward(ref_fix[s:s + 32]) for s in range(0, 256, 32)])
+    ref_dist = 1.0 - oracle.l2_distance_rows(ref_images[:256], ref_fixed_all)
+    assert_close(dist, ref_dist, TOL, "1 - torch.dist")
+    assert int(is_anom.sum()) == int(np.floor(256 * 0.15))
+    assert np.array_equal(np.argsort(dist)[:10], np.argsort(ref_dist)[:10]) or maxdiff(np.sort(dist)[:10], np.sort(ref_dist)[:10]) < 1e-5
+
+
+def test_l2_distance_rows(ctx, oracle):
+    from ganrev import synth
+    a, b = synth.normal((37, 3, 16, 16), 1), synth.normal((37, 3, 16, 16), 2)
+    d = ctx.l2_distance_rows(a, b)
+    r = oracle.l2_distance_rows(a, b)
+    assert np.max(np.abs(d - r)) <= 1e-12 * np.max(r)
+    assert np.allclose(r, np.sqrt(((a.astype(np.float64) - b) ** 2).reshape(37, -1).sum(1)), rtol=1e-6)
