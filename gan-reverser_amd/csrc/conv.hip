@@ -34,7 +34,22 @@ struct ConvArgs {
   const float* in; const float* wt; const float* bias; float* out;
   int B, Cin, Cout, H, W;
   int up, nchunks, cout_pad, tiles_x, tiles_y, n_otiles;
+  ConvEpilogue ep;      // ep.mean != nullptr: evaluate()-mode BatchNorm + activation applied before the store
 };
+
+// out = act(((conv + bias - mean) * invstd) * gamma + beta): the per-channel pipeline of an evaluate()-mode stage
+// (G on this path: models.lua:122-124,128-130), same operation order and roundings as the stand-alone pipeline kernel.
+__device__ __forceinline__ float conv_epilogue(const ConvEpilogue& ep, float v, int o) {
+  if (ep.mean) v = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v, ep.mean[o]), ep.invstd[o]), ep.gamma[o]), ep.beta[o]);
+  switch (ep.act) {
+    case ACT_ELU: return v <= 0.f ? (expf(v) - 1.f) : v;
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_LEAKYRELU: return v > 0.f ? v : __fmul_rn(v, ep.slope);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
 
 // NI > 1: the tile is NI whole images of IH = PT/(NI*TW) rows each (planes too small to fill a tile on their own, e.g. 16x16);
 // their zero-padded patches are stacked in LDS, so tap offsets never cross from one image into the next.
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
           const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           if (o < a.Cout) {
             const float bv = a.bias ? a.bias[o] : 0.f;
-            a.out[(((size_t)(b + img) * a.Cout + o) * H + y) * W + x] = acc[mt][ng][r] + bv;
+            a.out[(((size_t)(b + img) * a.Cout + o) * H + y) * W + x] = conv_epilogue(a.ep, acc[mt][ng][r] + bv, o);
           }
         }
     }
@@ -255,7 +270,8 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const f
     for (int o = 0; o < CO; ++o) {
       const float bv = a.bias ? a.bias[o] : 0.f;
       *reinterpret_cast<float4*>(a.out + (((size_t)b * a.Cout + o) * H + y) * W + x) =
-          make_float4(acc[o][0] + bv, acc[o][1] + bv, acc[o][2] + bv, acc[o][3] + bv);
+          make_float4(conv_epilogue(a.ep, acc[o][0] + bv, o), conv_epilogue(a.ep, acc[o][1] + bv, o),
+                      conv_epilogue(a.ep, acc[o][2] + bv, o), conv_epilogue(a.ep, acc[o][3] + bv, o));
     }
   }
 }
@@ -291,9 +307,10 @@ static void launch_conv_mt(const ConvArgs& a, hipStream_t s) {
 }
 
 void launch_conv3x3(const float* in, const float* wt, const float* bias, float* out,
-                    int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const float* w_native) {
+                    int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const float* w_native, const ConvEpilogue* ep) {
   const ConvWeightLayout L = conv_weight_layout(Cin, Cout);
   ConvArgs a{};
+  if (ep) a.ep = *ep;
   a.in = in; a.wt = wt; a.bias = bias; a.out = out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
   a.nchunks = L.cin_pad / CONV_CK; a.cout_pad = L.cout_pad;
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_bf16x6_kernel(ConvArgs a,
         const int o = o0 + wmt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (o < a.Cout) {
           const float bvv = a.bias ? a.bias[o] : 0.f;
-          a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = acc[ng][r] + bvv;
+          a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = conv_epilogue(a.ep, acc[ng][r] + bvv, o);
         }
       }
     }
@@ -534,8 +551,9 @@ static void launch_conv_bf16x6_t(ConvArgs a, const void* wsplit, hipStream_t s) 
 }
 
 void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bias, float* out,
-                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s) {
+                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep) {
   ConvArgs a{};
+  if (ep) a.ep = *ep;
   a.in = in; a.wt = nullptr; a.bias = bias; a.out = out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
   static int variant = -1;

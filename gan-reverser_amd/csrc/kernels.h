@@ -34,6 +34,9 @@ struct ConvWeightLayout {
 inline ConvWeightLayout conv_weight_layout(int cin, int cout) {
   return ConvWeightLayout{round_up(cin, CONV_CK), round_up(cout, 32)};
 }
+// optional fused epilogue of the conv kernels (evaluate()-mode BatchNorm + activation); mean == nullptr: BN skipped
+struct ConvEpilogue { const float *mean = nullptr, *invstd = nullptr, *gamma = nullptr, *beta = nullptr; int act = 0; float slope = 0.f; };
+
 // native [cout][cin][3][3] -> k-major (forward) ; or the transposed+flipped k-major the backward-data pass needs
 void launch_conv_weight_prep(const float* w_native, float* wt, int cin, int cout, bool for_backward_data, hipStream_t s);
 
@@ -42,14 +45,15 @@ void launch_conv_weight_prep(const float* w_native, float* wt, int cin, int cout
 // w_native (nullable): the same weights in the module's own [Cout][Cin][3][3] layout; lets few-output-channel layers
 // (Cout <= 4) take the HBM-bound VALU kernel instead of a 32-row MFMA block.
 void launch_conv3x3(const float* in, const float* wt, const float* bias, float* out,
-                    int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const float* w_native = nullptr);
+                    int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const float* w_native = nullptr,
+                    const ConvEpilogue* ep = nullptr);
 
 // fp32-accurate convolution on the bf16 MFMA: operands split into 3 bf16 terms, 6 products, fp32 accumulation ("bf16x6").
 // wsplit = image made by launch_conv_weight_split (forward or backward-data flavour, like launch_conv_weight_prep).
 size_t conv_weight_split_bytes(int cin, int cout, bool for_backward_data);
 void launch_conv_weight_split(const float* w_native, void* wsplit, int cin, int cout, bool for_backward_data, hipStream_t s);
 void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bias, float* out,
-                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s);
+                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep = nullptr);
 
 // all weight images of a net in one launch
 struct PrepJob { long w_off; void* dst; int cin, cout, CI, CO, cin_pad, cout_pad, bwd, split; };

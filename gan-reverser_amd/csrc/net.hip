@@ -212,6 +212,7 @@ struct Stage {
   float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr;
   float *run_mean = nullptr, *run_var = nullptr;
   const float* x_in = nullptr;              // input of the last forward
+  bool fused_epilogue = false;              // last forward wrote `out` straight from the conv epilogue (y not materialised)
 };
 
 struct gr_net {
@@ -573,9 +574,23 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
   r = prep_weights(n); if (r) return r;
   for (auto& s : n->st) {
     s.x_in = x;
+    s.fused_epilogue = false;
     if (s.kind == ST_CONV) {
-      if (use_bf16x6(n, s)) launch_conv3x3_bf16x6(x, s.ws_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream);
-      else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off);
+      // evaluate() mode: BatchNorm is a per-channel affine map of running statistics, so BN + activation ride in the conv
+      // epilogue and the raw conv output is never written (G on this path).  Needs: no pool, no active dropout noise.
+      ConvEpilogue ep; const ConvEpilogue* epp = nullptr; float* dst = s.y;
+      bool nb1 = false, nb2 = false;
+      const MaskRef r1 = mask_ref(n, s.m1, nb1), r2 = mask_ref(n, s.m2, nb2);
+      if (!n->training && s.has_post && !s.pool && !s.fullconv && r1.kind == MASK_NONE && r2.kind == MASK_NONE) {
+        if (s.has_bn) {
+          launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream);
+          ep.mean = s.mean; ep.invstd = s.invstd; ep.gamma = n->params + s.g_off; ep.beta = n->params + s.be_off;
+        }
+        ep.act = s.act; ep.slope = s.slope; epp = &ep; dst = s.out; s.fused_epilogue = true;
+      }
+      if (use_bf16x6(n, s)) launch_conv3x3_bf16x6(x, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, epp);
+      else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off, epp);
+      if (s.fused_epilogue) { LAUNCHCHK(c); x = s.out; continue; }
     } else if (s.kind == ST_LINEAR) {
       const size_t wsb = gemm_workspace_bytes(B, s.Cout, s.Cin);
       r = ensure_ws(c, wsb); if (r) return r;
@@ -637,7 +652,7 @@ extern "C" int gr_net_layer_output(gr_net* n, int layer, float* host, int64_t cn
   gr_ctx* c = n->ctx;
   for (auto& s : n->st) {
     const float* p = nullptr; int64_t e = 0;
-    if (layer == s.main_layer) { p = s.y; e = (int64_t)n->lastB * vol3(s.Cout, s.H, s.W); }
+    if (layer == s.main_layer && !s.fused_epilogue) { p = s.y; e = (int64_t)n->lastB * vol3(s.Cout, s.H, s.W); }
     else if (layer == s.last && s.has_post) { p = s.out; e = (int64_t)n->lastB * vol3(s.outC, s.outH, s.outW); }
     if (p) {
       if (cnt != e) return fail(c, GR_ERR_INVALID, "layer %d output has %lld elements", layer, (long long)e);
