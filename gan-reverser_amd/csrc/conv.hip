@@ -851,6 +851,166 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_vec_kernel(WgradArgs a) 
     }
 }
 
+// Weight gradient on the bf16 MFMA with the same fp32-accurate 3-term split ("bf16x6").  K = pixels: one MFMA consumes 16
+// consecutive pixels of one image row (lanes 0-31 the first 8, lanes 32-63 the next 8), so both operands are 16-byte vectors
+// of 8 bf16 along x.  dy vectors are aligned; the x vector of tap kx is the aligned vector shifted by kx-1 columns, built in
+// registers from the aligned vector and its left/right neighbour with v_alignbit (no shifted copies in LDS).
+// Workgroup = 64 o x 64 ci x 9 taps over a strided set of 32-pixel tiles (1 row x 32 or 2 rows x 16), waves (mt, cg) keep
+// nine 32x32 accumulators; two workgroups per CU overlap one's split/convert/store phase with the other's MFMAs.
+template <int TW, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv3x3_wgrad_bf16x6_kernel(WgradArgs a) {
+  constexpr int PT = 32, TR = PT / TW, PR = TR + 2, GI = TW / 8, GR = GI + 2;     // interior / total 8-pixel groups per row
+  constexpr int XS = PR * GR + ((PR * GR) % 2 == 0 ? 1 : 0);                      // 16-byte units per channel, odd
+  constexpr int DU = PT / 8, DS = DU + ((DU % 2 == 0) ? 1 : 0);                   // dy units per channel, odd
+  constexpr int NXV = 64 * PR * GI / 256;        // interior vectors (8 floats) per thread
+  constexpr int NHV = (64 * PR * 2 + 255) / 256; // halo scalars per thread
+  static_assert((64 * PR * GI) % 256 == 0 && 64 * DU == 256, "staging shape");
+  __shared__ uint4 xs[3 * 64 * XS];
+  __shared__ uint4 ds[3 * 64 * DS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int mt = wave >> 1, cg = wave & 1;
+  int bid = blockIdx.x;
+  const int cb = bid % a.n_cb; bid /= a.n_cb;
+  const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
+  const int o0 = ob * 64, c0 = cb * 64;
+  const int H = a.H, W = a.W;
+  const size_t HW = (size_t)H * W;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  float xv[NXV][8], hv[NHV], dv[8];
+#define GR_WB_LOAD(tile_)                                                                                     \
+  {                                                                                                           \
+    long t_ = (tile_);                                                                                        \
+    const int tx_ = (int)(t_ % a.tiles_x); t_ /= a.tiles_x;                                                   \
+    const int ty_ = (int)(t_ % a.tiles_y); const int b_ = (int)(t_ / a.tiles_y);                              \
+    const int y0_ = ty_ * TR, x0_ = tx_ * TW;                                                                 \
+    const float* xb_ = a.x + ((size_t)b_ * a.Cin) * HW;                                                       \
+    _Pragma("unroll") for (int i = 0; i < NXV; ++i) {                                                         \
+      const int f = tid + 256 * i, q = f % GI, r = (f / GI) % PR, ci = f / (GI * PR);                         \
+      const int yy = y0_ + r - 1, xx = x0_ + 8 * q;                                                           \
+      const bool ok = c0 + ci < a.Cin && yy >= 0 && yy < H && xx < W;                                         \
+      const float4* p_ = reinterpret_cast<const float4*>(xb_ + (size_t)(c0 + ci) * HW + (size_t)yy * W + xx); \
+      const float4 u0 = ok ? p_[0] : make_float4(0.f, 0.f, 0.f, 0.f), u1 = ok ? p_[1] : make_float4(0.f, 0.f, 0.f, 0.f); \
+      xv[i][0] = u0.x; xv[i][1] = u0.y; xv[i][2] = u0.z; xv[i][3] = u0.w;                                     \
+      xv[i][4] = u1.x; xv[i][5] = u1.y; xv[i][6] = u1.z; xv[i][7] = u1.w;                                     \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < NHV; ++i) {                                                         \
+      const int e = tid + 256 * i, side = e & 1, r = (e >> 1) % PR, ci = (e >> 1) / PR;                       \
+      const int yy = y0_ + r - 1, xx = side ? x0_ + TW : x0_ - 1;                                             \
+      hv[i] = (e < 64 * PR * 2 && c0 + ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)                  \
+                  ? xb_[(size_t)(c0 + ci) * HW + (size_t)yy * W + xx] : 0.f;                                  \
+    }                                                                                                         \
+    {                                                                                                         \
+      const int q = tid % DU, o = tid / DU, px = 8 * q, pr = px / TW, pc = px - pr * TW;                      \
+      const int y = y0_ + pr, x = x0_ + pc;                                                                   \
+      const bool ok = o0 + o < a.Cout && y < H && x < W;                                                      \
+      const float4* p_ = reinterpret_cast<const float4*>(a.dy + ((size_t)b_ * a.Cout + o0 + o) * HW + (size_t)y * W + x); \
+      const float4 u0 = ok ? p_[0] : make_float4(0.f, 0.f, 0.f, 0.f), u1 = ok ? p_[1] : make_float4(0.f, 0.f, 0.f, 0.f); \
+      dv[0] = u0.x; dv[1] = u0.y; dv[2] = u0.z; dv[3] = u0.w; dv[4] = u1.x; dv[5] = u1.y; dv[6] = u1.z; dv[7] = u1.w; \
+    }                                                                                                         \
+  }
+  // split 8 floats into the three bf16 term vectors
+#define GR_SPLIT8(src_, t0_, t1_, t2_)                                                                       \
+  {                                                                                                           \
+    unsigned short s0_[8], s1_[8], s2_[8];                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                           \
+      const float x_ = src_[j];                                                                               \
+      s0_[j] = f32_to_bf16(x_); const float r1_ = x_ - bf16_to_f32(s0_[j]);                                   \
+      s1_[j] = f32_to_bf16(r1_); const float r2_ = r1_ - bf16_to_f32(s1_[j]);                                 \
+      s2_[j] = f32_to_bf16(r2_);                                                                              \
+    }                                                                                                         \
+    t0_ = make_uint4(s0_[0] | (unsigned)s0_[1] << 16, s0_[2] | (unsigned)s0_[3] << 16, s0_[4] | (unsigned)s0_[5] << 16, s0_[6] | (unsigned)s0_[7] << 16); \
+    t1_ = make_uint4(s1_[0] | (unsigned)s1_[1] << 16, s1_[2] | (unsigned)s1_[3] << 16, s1_[4] | (unsigned)s1_[5] << 16, s1_[6] | (unsigned)s1_[7] << 16); \
+    t2_ = make_uint4(s2_[0] | (unsigned)s2_[1] << 16, s2_[2] | (unsigned)s2_[3] << 16, s2_[4] | (unsigned)s2_[5] << 16, s2_[6] | (unsigned)s2_[7] << 16); \
+  }
+
+  long tile = split;
+  bool have = tile < a.tiles_total;
+  if (have) GR_WB_LOAD(tile)
+  while (have) {
+    // registers -> split -> LDS
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int f = tid + 256 * i, q = f % GI, r = (f / GI) % PR, ci = f / (GI * PR);
+      uint4 t0, t1, t2;
+      GR_SPLIT8(xv[i], t0, t1, t2)
+      const int u = ci * XS + r * GR + q + 1;
+      xs[u] = t0; xs[64 * XS + u] = t1; xs[2 * 64 * XS + u] = t2;
+    }
+#pragma unroll
+    for (int i = 0; i < NHV; ++i) {
+      const int e = tid + 256 * i, side = e & 1, r = (e >> 1) % PR, ci = (e >> 1) / PR;
+      if (e < 64 * PR * 2) {
+        // left halo group: only its last element (column x0-1) is ever read; right halo group: only its first (column x0+TW)
+        const float x_ = hv[i];
+        const unsigned short s0 = f32_to_bf16(x_); const float r1 = x_ - bf16_to_f32(s0);
+        const unsigned short s1 = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(s1);
+        const unsigned short s2 = f32_to_bf16(r2);
+        const int u = ci * XS + r * GR + (side ? GR - 1 : 0);
+        xs[u] = side ? make_uint4(s0, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s0 << 16);
+        xs[64 * XS + u] = side ? make_uint4(s1, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s1 << 16);
+        xs[2 * 64 * XS + u] = side ? make_uint4(s2, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s2 << 16);
+      }
+    }
+    {
+      const int q = tid % DU, o = tid / DU;
+      uint4 t0, t1, t2;
+      GR_SPLIT8(dv, t0, t1, t2)
+      const int u = o * DS + q;
+      ds[u] = t0; ds[64 * DS + u] = t1; ds[2 * 64 * DS + u] = t2;
+    }
+    __syncthreads();
+    const long next = tile + a.nsplit;
+    const bool have_next = next < a.tiles_total;
+    if (have_next) GR_WB_LOAD(next)
+    // compute: k16 steps = (tile row, 16-pixel half of the row)
+#pragma unroll
+    for (int ks = 0; ks < PT / 16; ++ks) {
+      const int pr = (16 * ks) / TW, g = ((16 * ks) % TW) / 8 + h;          // this lane's 8-pixel group in row pr
+      bf16x8 av[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) av[s] = __builtin_bit_cast(bf16x8, ds[(s * 64 + mt * 32 + l31) * DS + pr * GI + g]);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int ub = (cg * 32 + l31) * XS + (pr + ky) * GR + g;            // left neighbour unit; +1 current, +2 right neighbour
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {                                        // term of x; pairs with dy terms 0 .. 2-t
+          const uint4 vl = xs[t * 64 * XS + ub], vc = xs[t * 64 * XS + ub + 1], vr = xs[t * 64 * XS + ub + 2];
+          uint4 k0, k2;
+          k0.x = __builtin_amdgcn_alignbit(vc.x, vl.w, 16); k0.y = __builtin_amdgcn_alignbit(vc.y, vc.x, 16);
+          k0.z = __builtin_amdgcn_alignbit(vc.z, vc.y, 16); k0.w = __builtin_amdgcn_alignbit(vc.w, vc.z, 16);
+          k2.x = __builtin_amdgcn_alignbit(vc.y, vc.x, 16); k2.y = __builtin_amdgcn_alignbit(vc.z, vc.y, 16);
+          k2.z = __builtin_amdgcn_alignbit(vc.w, vc.z, 16); k2.w = __builtin_amdgcn_alignbit(vr.x, vc.w, 16);
+          const bf16x8 b0 = __builtin_bit_cast(bf16x8, k0), b1 = __builtin_bit_cast(bf16x8, vc), b2 = __builtin_bit_cast(bf16x8, k2);
+#pragma unroll
+          for (int sA = 2 - t; sA >= 0; --sA) {
+            acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b0, acc[ky * 3 + 0], 0, 0, 0);
+            acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b1, acc[ky * 3 + 1], 0, 0, 0);
+            acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b2, acc[ky * 3 + 2], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    tile = next; have = have_next;
+  }
+#undef GR_WB_LOAD
+#undef GR_SPLIT8
+  float* sl = a.slab + (size_t)split * 9 * a.coutp * a.cinp;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int ci = c0 + cg * 32 + l31;
+      sl[((size_t)tap * a.coutp + o) * a.cinp + ci] = acc[tap][r];
+    }
+}
+
 // Few input channels (9*Cin <= 32: R.conv1 on gray / RGB images, models.lua:409): the whole (ci, tap) axis fits ONE
 // 32-wide MFMA column block, so the GEMM is M = Cout, N = 32 (9*Cin used), K = pixels and the kernel is HBM-bound on dy.
 // Wave (mt, kh): output-channel block mt, pixel half kh of each 64-pixel tile; the two halves meet in LDS at the end.
@@ -1010,9 +1170,11 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, floa
 
 static bool wgrad_use_vec(int W) { return W >= 16 && W % 4 == 0; }
 static bool wgrad_use_small(int Cin, int W) { return Cin <= 3 && W >= 16 && W % 4 == 0; }
-static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a, int& TW) {
+static bool wgrad_use_bf16x6(int mode, int Cin, int W) { return mode == 1 && Cin > 3 && W >= 16 && W % 8 == 0; }
+static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a, int& TW, int mode = 0) {
   TW = W <= 8 ? 8 : (W <= 16 ? 16 : 32);
-  const int TR = 64 / TW;
+  const bool split = wgrad_use_bf16x6(mode, Cin, W);
+  const int TR = (split ? 32 : 64) / TW;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TR - 1) / TR;
   a.tiles_total = (long)B * a.tiles_x * a.tiles_y;
@@ -1020,23 +1182,44 @@ static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a,
   a.n_ob = a.coutp / 64; a.n_cb = a.cinp / 64;
   long want = (wgrad_use_vec(W) ? 256 : 512) / (a.n_ob * a.n_cb);   // vec kernel: one software-pipelined workgroup per CU
   if (wgrad_use_small(Cin, W)) want = 1024 / a.n_ob;
+  // measured (B=256): 32-wide planes 512 splits (two workgroups per CU overlap convert/store with MFMAs), 16-wide planes 256
+  else if (split) { const char* e = getenv("GR_WGRAD_SPLITS"); want = (e ? atoi(e) : (TW == 32 ? 512 : 256)) / (a.n_ob * a.n_cb); }
   if (want < 1) want = 1;
   if (want > a.tiles_total) want = a.tiles_total;
   a.nsplit = (int)want;
 }
 
-size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W) {
+size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int mode) {
   WgradArgs a{}; int TW;
-  wgrad_geometry(B, Cin, Cout, H, W, a, TW);
+  wgrad_geometry(B, Cin, Cout, H, W, a, TW, mode);
   if (wgrad_use_small(Cin, W)) return sizeof(float) * (size_t)a.nsplit * 32 * a.coutp;
   return sizeof(float) * (size_t)a.nsplit * 9 * a.coutp * a.cinp;
 }
 
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,
-                          int B, int Cin, int Cout, int H, int W, hipStream_t s) {
+                          int B, int Cin, int Cout, int H, int W, hipStream_t s, int mode) {
   WgradArgs a{}; int TW;
-  wgrad_geometry(B, Cin, Cout, H, W, a, TW);
+  wgrad_geometry(B, Cin, Cout, H, W, a, TW, mode);
   a.x = x; a.dy = dy; a.slab = reinterpret_cast<float*>(workspace);
+  if (wgrad_use_bf16x6(mode, Cin, W) && !wgrad_use_small(Cin, W)) {
+    const double px_ = (double)B * H * W;
+    {
+      KtScope kt(TW == 16 ? "conv3x3_wgrad_bf16x6_kernel<16>" : "conv3x3_wgrad_bf16x6_kernel<32>", 2.0 * px_ * Cout * Cin * 9.0,
+                 4.0 * (px_ * Cin + px_ * Cout + 9.0 * Cin * Cout), s);
+      const int grid_ = a.nsplit * a.n_ob * a.n_cb;
+      static int wv = -1;
+      if (wv < 0) { const char* e = getenv("GR_WGRAD_VARIANT"); wv = e ? atoi(e) : 1; }   // 1: accumulators in AGPRs, no spills
+      if (TW == 16) { if (wv == 1) hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<16, 1>), dim3(grid_), dim3(256), 0, s, a);
+                      else hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<16, 2>), dim3(grid_), dim3(256), 0, s, a); }
+      else { if (wv == 1) hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<32, 1>), dim3(grid_), dim3(256), 0, s, a);
+             else hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<32, 2>), dim3(grid_), dim3(256), 0, s, a); }
+    }
+    const long n_ = (long)9 * Cout * a.cinp;
+    KtScope kt("conv3x3_wgrad_reduce8_kernel", (double)n_ * a.nsplit, 4.0 * n_ * (a.nsplit + 2.0), s);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce8_kernel, dim3((unsigned)((n_ + 31) / 32)), dim3(256), 0, s,
+                       a.slab, gw, Cin, Cout, a.cinp, a.coutp, a.nsplit);
+    return;
+  }
   if (wgrad_use_small(Cin, W)) {
     const double px_ = (double)B * H * W;
     {

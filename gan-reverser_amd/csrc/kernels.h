@@ -61,9 +61,10 @@ PrepJob make_prep_job(long w_off, void* dst, int cin, int cout, bool for_backwar
 void launch_conv_weight_prep_batch(const PrepJob* jobs_dev, int njobs, const float* params, hipStream_t s);
 
 // weight gradient: slab workspace sized by conv_wgrad_workspace(); result accumulated (+=) into gw native layout
-size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W);
+// mode 1: bf16x6 split on the bf16 MFMA where the shape allows (W % 8 == 0, Cin > 3); 0: fp32 MFMA
+size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int mode = 0);
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,
-                          int B, int Cin, int Cout, int H, int W, hipStream_t s);
+                          int B, int Cin, int Cout, int H, int W, hipStream_t s, int mode = 0);
 
 // ---------------------------------------------------------------- GEMM (Linear) on fp32 MFMA
 // C[m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  A(m,k) = A[m*rsA + k*ksA], B(n,k) = Bm[n*rsB + k*ksB]

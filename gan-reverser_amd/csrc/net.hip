@@ -704,8 +704,8 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     if (s.kind == ST_CONV) {
       if (s.up) return fail(c, GR_ERR_UNSUPPORTED, "backward through the fused UpSamplingNearest is not implemented (G is forward-only on this path)");
       if (s.fullconv) return fail(c, GR_ERR_UNSUPPORTED, "SpatialFullConvolution backward is not implemented");
-      int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W)); if (r) return r;
-      launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream);
+      int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W, c->conv_mode)); if (r) return r;
+      launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode);
       if (need_gin) {
         // backward-data = the same convolution on the transposed + flipped weights (Cout -> Cin)
         if (n->ctx->conv_mode == 1) launch_conv3x3_bf16x6(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
@@ -994,8 +994,8 @@ extern "C" int gr_conv3_backward_data_dev(gr_ctx* c, const float* gout, const fl
 }
 extern "C" int gr_conv3_backward_weight_dev(gr_ctx* c, const float* in, const float* gout, float* gw, int B, int cin, int cout, int h, int wd) {
   if (!c || !in || !gout || !gw) return GR_ERR_INVALID;
-  int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd)); if (r) return r;
-  launch_conv3x3_wgrad(in, gout, gw, c->ws, B, cin, cout, h, wd, c->stream);
+  int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd, c->conv_mode)); if (r) return r;
+  launch_conv3x3_wgrad(in, gout, gw, c->ws, B, cin, cout, h, wd, c->stream, c->conv_mode);
   LAUNCHCHK(c);
   return GR_OK;
 }
@@ -1012,13 +1012,13 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   void* wsp = nullptr;
   const bool split = c->conv_mode == 1 && which != 2 && (which == 0 ? cout > 4 : cin > 4);
   if (split) { r = conv_split_once(c, w, cin, cout, which == 1, &wsp); if (r) return r; }
-  r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd)); if (r) return r;
+  r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd, c->conv_mode)); if (r) return r;
   auto run = [&]() {
     if (split && which == 0) launch_conv3x3_bf16x6(x, wsp, nullptr, y, B, cin, cout, h, wd, false, c->stream);
     else if (split && which == 1) launch_conv3x3_bf16x6(y, wsp, nullptr, x, B, cout, cin, h, wd, false, c->stream);
     else if (which == 0) launch_conv3x3(x, wt, nullptr, y, B, cin, cout, h, wd, false, c->stream, w);
     else if (which == 1) launch_conv3x3(y, wt, nullptr, x, B, cout, cin, h, wd, false, c->stream);
-    else launch_conv3x3_wgrad(x, y, gw, c->ws, B, cin, cout, h, wd, c->stream);
+    else launch_conv3x3_wgrad(x, y, gw, c->ws, B, cin, cout, h, wd, c->stream, c->conv_mode);
   };
   for (int i = 0; i < 3; ++i) run();
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
