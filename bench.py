@@ -42,10 +42,10 @@ def step_flops_per_image(dims, nd):
 
 def cpu_baseline(dims, nd, sample_batch, threads):
     """The oracle (CPU restatement of the Torch7 nn path) timed on this box's host cores on a bounded sample."""
-    os.environ["OMP_NUM_THREADS"] = str(threads)
     import numpy as np
     from ganrev import models, synth
     from oracle import oracle
+    threads = oracle.set_threads(threads)      # libgomp is already initialised (torch): the env var would be ignored
     G = models.create_G(dims, nd); synth.init_params(G, 1)
     R = models.create_R(dims, nd); synth.init_params(R, 2)
     oG, oR = oracle.from_model(G, (nd, 1, 1)), oracle.from_model(R, dims)
@@ -210,7 +210,9 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
+            # 16-32 OpenMP threads measured fastest for the oracle on the 2x64-core box (tools/cpu_baseline_sweep.py:
+            # 74 img/s at 16-32 threads, 51-62 at 64, 28-37 at 128-256); the reference's own default is 8 (train_r.lua:21)
+            threads = min(32, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(dims, nd, args.cpu_sample_batch, threads)
         else:
             out["cpu_baseline"] = None

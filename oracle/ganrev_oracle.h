@@ -108,6 +108,9 @@ float go_cosine_similarity(const float* a, const float* b, int d, int accumulate
 void go_cosine_topk(const float* emb, int64_t N, int d, const int64_t* query_rows, int Q, int k,
                     int64_t* idx_out, float* score_out, int accumulate_in_float);
 
+void go_set_threads(int n);       /* OpenMP threads used by the oracle (torch.setnumthreads, train_r.lua:41-43) */
+int go_get_max_threads(void);
+
 /* apply_r.lua:369  torch.dist(images[i], fixedImage): sqrt(sum (a-b)^2), fp32 difference/square, fp64 sum, per row */
 void go_l2_distance_rows(const float* a, const float* b, int64_t n, int64_t d, double* out);
 

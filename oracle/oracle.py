@@ -165,6 +165,11 @@ class Net:
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
 
 
+def set_threads(n):
+    lib().go_set_threads(int(n))
+    return lib().go_get_max_threads()
+
+
 def mse(x, t, n_global=None):
     x, t = f32(x), f32(t)
     g = np.empty_like(x)

@@ -12,6 +12,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 
 /* ------------------------------------------------------------------ BatchNormalization
  * THNN BatchNormalization.c: per feature f over n = B*HW elements (accreal = double sums, two-pass variance):
@@ -538,3 +539,7 @@ void go_l2_distance_rows(const float* a, const float* b, int64_t n, int64_t d, d
     out[i] = sqrt(s);
   }
 }
+
+/* thread count of the OpenMP loops (the process may have initialised libgomp before OMP_NUM_THREADS could be set) */
+void go_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int go_get_max_threads(void) { return omp_get_max_threads(); }
