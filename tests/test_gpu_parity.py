@@ -77,7 +77,9 @@ def test_conv3_upsample_fused(ctx, oracle, conv_mode):
 
 
 R_CASES = [((1, 8, 8), 6, 8, "normal", False), ((1, 32, 32), 32, 8, "normal", False),
-           ((3, 16, 16), 10, 6, "uniform", False), ((1, 16, 16), 8, 16, "normal", True)]
+           ((3, 16, 16), 10, 6, "uniform", False), ((1, 16, 16), 8, 16, "normal", True),
+           ((2, 12, 20), 5, 3, "normal", False),      # ragged: H, W not powers of two, odd batch -> scalar / non-vector fallbacks
+           ((3, 64, 64), 100, 2, "normal", False)]    # cfg3 geometry (two column tiles per row)
 
 
 @pytest.mark.parametrize("dims,nd,B,method,fixer", R_CASES)
@@ -443,3 +445,17 @@ def test_l2_distance_rows(ctx, oracle):
     r = oracle.l2_distance_rows(a, b)
     assert np.max(np.abs(d - r)) <= 1e-12 * np.max(r)
     assert np.allclose(r, np.sqrt(((a.astype(np.float64) - b) ** 2).reshape(37, -1).sum(1)), rtol=1e-6)
+
+
+def test_train_r_script_learns_to_recover_noise(conv_mode):
+    """ganrev.train_r (the train_r.lua mirror): R's MSE against the noise falls over 60 iterations on a fixed random G, in the
+    fast (device-resident) loop; and the --compat loop (host tensors, fevalR closure, optim.adam as written in the reference)
+    runs the same iteration."""
+    from ganrev import train_r
+    _, _, losses = train_r.main(["--nbBatches", "60", "--batchSize", "32", "--height", "16", "--width", "16", "--noiseDim", "8",
+                                 "--quiet", "--conv-mode", conv_mode])
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-10:]) < 0.8 * np.mean(losses[:5]), (losses[:5], losses[-10:])
+    _, _, closs = train_r.main(["--nbBatches", "4", "--batchSize", "16", "--height", "16", "--width", "16", "--noiseDim", "8",
+                                "--quiet", "--compat", "--conv-mode", conv_mode])
+    assert np.isfinite(closs).all() and len(closs) == 4
