@@ -17,7 +17,7 @@ except Exception:  # pragma: no cover - torch is optional plumbing
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libganrev.so")
+LIB_PATH = os.environ.get("GANREV_LIB") or os.path.join(_HERE, "libganrev.so")   # GANREV_LIB: A/B-testing hook
 
 
 class GanrevError(RuntimeError):
