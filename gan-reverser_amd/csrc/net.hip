@@ -31,7 +31,7 @@ struct gr_ctx {
   double* d_loss = nullptr;     // device scalar
   double* h_loss = nullptr;     // pinned host scalar
   bool timing = false;
-  int conv_mode = 0;            // 0 = exact fp32 MFMA, 1 = bf16x6 split (fp32-accurate, bf16 MFMA)
+  int conv_mode = 1;            // 1 = bf16x6 split (fp32-accurate, bf16 MFMA; default), 0 = exact fp32 MFMA
   hipEvent_t ev[7] = {};
   float times[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -107,7 +107,7 @@ extern "C" int gr_init(int device, gr_ctx** out) {
     delete c; return GR_ERR_HIP;
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
-  { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "bf16x6") || !strcmp(m, "1")) ? 1 : 0; }
+  { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "f32") || !strcmp(m, "0")) ? 0 : 1; }
   (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
