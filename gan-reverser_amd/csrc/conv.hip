@@ -501,10 +501,11 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_bf16x6_kernel(ConvArgs a,
 
 // 512-pixel x 64-channel tile: all 8 waves keep BOTH 32-channel blocks (4 accumulators each) for their own 64 pixels, so one
 // weight fetch and one patch conversion feed twice the MFMAs of the 256-pixel tile and every operand read feeds two MFMAs.
-template <int TW>
+// NI > 1: the tile is NI whole images (16x16 planes: two of them), their zero-padded patches stacked in LDS.
+template <int TW, int NI = 1>
 __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
   constexpr int NT = 512, MT = 2;
-  constexpr int NG = 2, PT = 512, TR = PT / TW, PR = TR + 2, PC = TW + 2, PS = PR * PC, CT = 32 * MT;
+  constexpr int NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
   constexpr int WROWS = 3 * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ot = bid % a.n_otiles; bid /= a.n_otiles;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int ty = bid % a.tiles_y; const int b = (bid / a.tiles_y) * NI;
   const int y0 = ty * TR, x0 = tx * TW, o0 = ot * CT;
   const int H = a.H, W = a.W;
   const int Hs = a.up ? H >> 1 : H, Ws = a.up ? W >> 1 : W;
@@ -522,10 +523,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
   int src_off[NSL]; bool inb[NSL]; int sh[NSL];
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
-    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, r = e / PC, c = e - r * PC;
+    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
+    const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
     const int yy = y0 + r - 1, xx = x0 + c - 1;
-    inb[s] = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    src_off[s] = a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx;
+    inb[s] = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W && b + img < a.B;
+    src_off[s] = (a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx) + img * a.Cin * (int)HWs;
     sh[s] = hh;
   }
   const float* in_base = a.in + (size_t)b * a.Cin * HWs;
@@ -578,7 +580,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
   int pix[NG];
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
+    const int p = (wave * NG + ng) * 32 + l31, prr = p / TW, pc = p - prr * TW;
+    const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;                   // skip the padding rows between stacked images
     pix[ng] = h * PS + pr * PC + pc;
   }
   const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
@@ -626,9 +629,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
 #undef GR_BF_STORE
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
+    const int p = (wave * NG + ng) * 32 + l31, prr = p / TW, pc = p - prr * TW;
+    const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
     const int y = y0 + pr, x = x0 + pc;
-    if (y < H && x < W) {
+    if (y < H && x < W && b + img < a.B) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
         const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (o < a.Cout) {
           const float bvv = a.bias ? a.bias[o] : 0.f;
-          a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = conv_epilogue(a.ep, acc[mt][ng][r] + bvv, o);
+          a.out[(((size_t)(b + img) * a.Cout + o) * H + y) * W + x] = conv_epilogue(a.ep, acc[mt][ng][r] + bvv, o);
         }
       }
     }
@@ -694,19 +698,19 @@ static void launch_conv_bf16x6_t(ConvArgs a, const void* wsplit, hipStream_t s) 
   hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TW, MT>), dim3(grid), dim3(256 * MT), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
 }
 
-template <int TW>
+template <int TW, int NI = 1>
 static void launch_conv_bf16x6_wide(ConvArgs a, const void* wsplit, hipStream_t s) {
-  constexpr int TR = 512 / TW, PS = (TR + 2) * (TW + 2), CT = 64;
-  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TR - 1) / TR;
+  constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
   const size_t lds = 16 * (size_t)(3 * 2 * PS + 3 * 9 * 2 * CT);
-  const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
+  const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6_wide_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  static const std::string name = "conv3x3_bf16x6_wide_kernel<" + std::to_string(TW) + ">";
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6_wide_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = "conv3x3_bf16x6_wide_kernel<" + std::to_string(TW) + (NI > 1 ? ", " + std::to_string(NI) : std::string()) + ">";
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_bf16x6_wide_kernel<TW>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
+  hipLaunchKernelGGL((conv3x3_bf16x6_wide_kernel<TW, NI>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
 }
 
 void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bias, float* out,
@@ -719,8 +723,12 @@ void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bia
   if (variant < 0) { const char* e = getenv("GR_BF16X6_VARIANT"); variant = e ? atoi(e) : 0; }
   const bool wide = round_up(Cout, 32) % 64 == 0 && variant != 1;      // 64 output channels per workgroup (8 waves share one patch)
   if (W <= 8) launch_conv_bf16x6_t<8, 1>(a, wsplit, s);
-  else if (W <= 16) { if (wide) launch_conv_bf16x6_t<16, 2>(a, wsplit, s); else launch_conv_bf16x6_t<16, 1>(a, wsplit, s); }
-  else if (wide && variant != 4 && (long)H * W >= 512) launch_conv_bf16x6_wide<32>(a, wsplit, s);   // measured: -6 % vs the 256-pixel tile
+  else if (W <= 16) {
+    // two stacked 16x16 images per 512-pixel tile (G.convA 799 -> 716 us) when that still leaves a workgroup for every CU
+    if (wide && variant != 4 && H == 16 && W == 16 && (long)((B + 1) / 2) * (round_up(Cout, 32) / 64) >= 256) launch_conv_bf16x6_wide<16, 2>(a, wsplit, s);
+    else if (wide) launch_conv_bf16x6_t<16, 2>(a, wsplit, s); else launch_conv_bf16x6_t<16, 1>(a, wsplit, s);
+  }
+  else if (wide && variant != 4 && (long)H * W >= 512 && (long)B * ((H * W + 511) / 512) * (round_up(Cout, 32) / 64) >= 256) launch_conv_bf16x6_wide<32>(a, wsplit, s);   // measured: -6 % vs the 256-pixel tile
   else { if (wide) launch_conv_bf16x6_t<32, 2>(a, wsplit, s); else launch_conv_bf16x6_t<32, 1>(a, wsplit, s); }
 }
 

@@ -29,6 +29,9 @@ CONV_SHAPES = [
     (2, 20, 64, 4, 4),       # tiny spatial (tile mostly masked)
     (1, 8, 32, 64, 64),      # W = 64 (two column tiles)
     (2, 12, 32, 24, 20),     # non power-of-two H, W
+    (257, 16, 128, 16, 16),  # enough workgroups for the stacked two-image 512-pixel tile; odd batch -> half-empty last tile
+    (64, 8, 128, 32, 32),    # enough workgroups for the 512-pixel tile on 32-wide planes
+    (32, 8, 64, 64, 64),     # 512-pixel tiles, two column tiles per row (cfg3 geometry)
 ]
 
 
