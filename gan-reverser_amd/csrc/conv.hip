@@ -1179,6 +1179,170 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wgrad_bf16x6_kernel(WgradArg
     }
 }
 
+// Rolling-window variant of the bf16x6 weight gradient: a workgroup walks a run of consecutive image rows, so each x row is
+// split/converted ONCE (into a ring of row groups in LDS) instead of once per tile that touches it (3x for one-row tiles).
+// Per step: TR rows of dy and TR new rows of x are fetched behind the previous step's 108 MFMAs per wave.
+template <int TW>
+__global__ __launch_bounds__(256, TW == 32 ? 2 : 1) void conv3x3_wgrad_bf16x6_roll_kernel(WgradArgs a, int rows_per_seg) {
+  constexpr int PT = 32, TR = PT / TW, NGP = (TR + 2) / TR, RR = NGP * TR, GI = TW / 8, GR = GI + 2;  // ring: NGP groups of TR rows
+  constexpr int XS = RR * GR + ((RR * GR) % 2 == 0 ? 1 : 0);
+  constexpr int DU = PT / 8, DS = DU + ((DU % 2 == 0) ? 1 : 0);
+  static_assert(64 * TR * GI == 256 && 64 * DU == 256 && (TR + 2) % TR == 0, "one interior vector and one dy vector per thread");
+  __shared__ uint4 xs[3 * 64 * XS];
+  __shared__ uint4 ds[3 * 64 * DS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int mt = wave >> 1, cg = wave & 1;
+  int bid = blockIdx.x;
+  const int cb = bid % a.n_cb; bid /= a.n_cb;
+  const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
+  const int o0 = ob * 64, c0 = cb * 64;
+  const int H = a.H, W = a.W;
+  const size_t HW = (size_t)H * W;
+  const int nspi = H / rows_per_seg, tiles_x = a.tiles_x;
+  const long nsegs = (long)a.B * nspi * tiles_x;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // this thread's share of a row group: interior vector (ci, row in group, 8-pixel group q), halo scalar, dy vector
+  const int xq = tid % GI, xr = (tid / GI) % TR, xci = tid / (GI * TR);
+  const int hside = tid & 1, hr = (tid >> 1) % TR, hci = (tid >> 1) / TR;     // valid for tid < 64*TR*2
+  const int dq = tid % DU, dO = tid / DU;
+  float xv[8], hv, dv[8];
+#define GR_SPLIT8(src_, t0_, t1_, t2_)                                                                       \
+  {                                                                                                           \
+    unsigned short s0_[8], s1_[8], s2_[8];                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                           \
+      const float x_ = src_[j];                                                                               \
+      s0_[j] = f32_to_bf16(x_); const float r1_ = x_ - bf16_to_f32(s0_[j]);                                   \
+      s1_[j] = f32_to_bf16(r1_); const float r2_ = r1_ - bf16_to_f32(s1_[j]);                                 \
+      s2_[j] = f32_to_bf16(r2_);                                                                              \
+    }                                                                                                         \
+    t0_ = make_uint4(s0_[0] | (unsigned)s0_[1] << 16, s0_[2] | (unsigned)s0_[3] << 16, s0_[4] | (unsigned)s0_[5] << 16, s0_[6] | (unsigned)s0_[7] << 16); \
+    t1_ = make_uint4(s1_[0] | (unsigned)s1_[1] << 16, s1_[2] | (unsigned)s1_[3] << 16, s1_[4] | (unsigned)s1_[5] << 16, s1_[6] | (unsigned)s1_[7] << 16); \
+    t2_ = make_uint4(s2_[0] | (unsigned)s2_[1] << 16, s2_[2] | (unsigned)s2_[3] << 16, s2_[4] | (unsigned)s2_[5] << 16, s2_[6] | (unsigned)s2_[7] << 16); \
+  }
+  // fetch x rows [ybase_, ybase_+TR) of image b_ (columns x0_..x0_+TW-1 plus the two halo columns) into registers
+#define GR_ROLL_LOAD_X(b_, ybase_, x0_)                                                                       \
+  {                                                                                                           \
+    const float* xb_ = a.x + ((size_t)(b_) * a.Cin) * HW;                                                     \
+    const int yy_ = (ybase_) + xr, xx_ = (x0_) + 8 * xq;                                                      \
+    const bool ok_ = c0 + xci < a.Cin && yy_ >= 0 && yy_ < H && xx_ < W;                                      \
+    const float4* p_ = reinterpret_cast<const float4*>(xb_ + (size_t)(c0 + xci) * HW + (size_t)yy_ * W + xx_); \
+    const float4 u0 = ok_ ? p_[0] : make_float4(0.f, 0.f, 0.f, 0.f), u1 = ok_ ? p_[1] : make_float4(0.f, 0.f, 0.f, 0.f); \
+    xv[0] = u0.x; xv[1] = u0.y; xv[2] = u0.z; xv[3] = u0.w; xv[4] = u1.x; xv[5] = u1.y; xv[6] = u1.z; xv[7] = u1.w; \
+    const int hy_ = (ybase_) + hr, hx_ = hside ? (x0_) + TW : (x0_) - 1;                                      \
+    hv = (tid < 64 * TR * 2 && c0 + hci < a.Cin && hy_ >= 0 && hy_ < H && hx_ >= 0 && hx_ < W)                \
+             ? xb_[(size_t)(c0 + hci) * HW + (size_t)hy_ * W + hx_] : 0.f;                                    \
+  }
+#define GR_ROLL_LOAD_DY(b_, y_, x0_)                                                                          \
+  {                                                                                                           \
+    const int px_ = 8 * dq, pr_ = px_ / TW, pc_ = px_ - pr_ * TW, yy_ = (y_) + pr_, xx_ = (x0_) + pc_;        \
+    const bool ok_ = o0 + dO < a.Cout && yy_ < H && xx_ < W;                                                  \
+    const float4* p_ = reinterpret_cast<const float4*>(a.dy + ((size_t)(b_) * a.Cout + o0 + dO) * HW + (size_t)yy_ * W + xx_); \
+    const float4 u0 = ok_ ? p_[0] : make_float4(0.f, 0.f, 0.f, 0.f), u1 = ok_ ? p_[1] : make_float4(0.f, 0.f, 0.f, 0.f); \
+    dv[0] = u0.x; dv[1] = u0.y; dv[2] = u0.z; dv[3] = u0.w; dv[4] = u1.x; dv[5] = u1.y; dv[6] = u1.z; dv[7] = u1.w; \
+  }
+  // registers -> split -> ring slot `slot_` (rows slot_*TR .. slot_*TR+TR-1 of the ring)
+#define GR_ROLL_STORE_X(slot_)                                                                                \
+  {                                                                                                           \
+    uint4 t0, t1, t2;                                                                                         \
+    GR_SPLIT8(xv, t0, t1, t2)                                                                                 \
+    const int u = xci * XS + ((slot_) * TR + xr) * GR + xq + 1;                                               \
+    xs[u] = t0; xs[64 * XS + u] = t1; xs[2 * 64 * XS + u] = t2;                                               \
+    if (tid < 64 * TR * 2) {                                                                                  \
+      const unsigned short s0 = f32_to_bf16(hv); const float r1 = hv - bf16_to_f32(s0);                       \
+      const unsigned short s1 = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(s1);                       \
+      const unsigned short s2 = f32_to_bf16(r2);                                                              \
+      const int uh = hci * XS + ((slot_) * TR + hr) * GR + (hside ? GR - 1 : 0);                              \
+      xs[uh] = hside ? make_uint4(s0, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s0 << 16);                     \
+      xs[64 * XS + uh] = hside ? make_uint4(s1, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s1 << 16);           \
+      xs[2 * 64 * XS + uh] = hside ? make_uint4(s2, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s2 << 16);       \
+    }                                                                                                         \
+  }
+#define GR_ROLL_STORE_DY()                                                                                    \
+  {                                                                                                           \
+    uint4 t0, t1, t2;                                                                                         \
+    GR_SPLIT8(dv, t0, t1, t2)                                                                                 \
+    const int u = dO * DS + dq;                                                                               \
+    ds[u] = t0; ds[64 * DS + u] = t1; ds[2 * 64 * DS + u] = t2;                                               \
+  }
+
+  for (long seg = split; seg < nsegs; seg += a.nsplit) {
+    long t_ = seg;
+    const int tx = (int)(t_ % tiles_x); t_ /= tiles_x;
+    const int sp = (int)(t_ % nspi); const int b = (int)(t_ / nspi);
+    const int ys = sp * rows_per_seg, x0 = tx * TW, nsteps = rows_per_seg / TR;
+    __syncthreads();                                            // previous segment's last MFMA phase is done with LDS
+    // prime the ring with row groups 0 .. NGP-1 (rows ys-1 ...) and dy of step 0
+#pragma unroll
+    for (int g = 0; g < NGP; ++g) {
+      GR_ROLL_LOAD_X(b, ys - 1 + g * TR, x0)
+      GR_ROLL_STORE_X(g)
+    }
+    GR_ROLL_LOAD_DY(b, ys, x0)
+    GR_ROLL_STORE_DY()
+    __syncthreads();
+    if (nsteps > 1) { GR_ROLL_LOAD_X(b, ys - 1 + NGP * TR, x0) GR_ROLL_LOAD_DY(b, ys + TR, x0) }
+    for (int st = 0; st < nsteps; ++st) {
+      // ring row of tile-relative row i = pr + ky (0 .. TR+1): group (st + i / TR) % NGP, row i % TR inside it
+      int rowoff[TR + 2];
+#pragma unroll
+      for (int i = 0; i < TR + 2; ++i) rowoff[i] = (((st + i / TR) % NGP) * TR + i % TR) * GR;
+#pragma unroll
+      for (int ks = 0; ks < PT / 16; ++ks) {
+        const int pr = (16 * ks) / TW, g = ((16 * ks) % TW) / 8 + h;
+        bf16x8 av[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) av[s] = __builtin_bit_cast(bf16x8, ds[(s * 64 + mt * 32 + l31) * DS + pr * GI + g]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int ub = (cg * 32 + l31) * XS + rowoff[pr + ky] + g;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const uint4 vl = xs[t * 64 * XS + ub], vc = xs[t * 64 * XS + ub + 1], vr = xs[t * 64 * XS + ub + 2];
+            uint4 k0, k2;
+            k0.x = __builtin_amdgcn_alignbit(vc.x, vl.w, 16); k0.y = __builtin_amdgcn_alignbit(vc.y, vc.x, 16);
+            k0.z = __builtin_amdgcn_alignbit(vc.z, vc.y, 16); k0.w = __builtin_amdgcn_alignbit(vc.w, vc.z, 16);
+            k2.x = __builtin_amdgcn_alignbit(vc.y, vc.x, 16); k2.y = __builtin_amdgcn_alignbit(vc.z, vc.y, 16);
+            k2.z = __builtin_amdgcn_alignbit(vc.w, vc.z, 16); k2.w = __builtin_amdgcn_alignbit(vr.x, vc.w, 16);
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, k0), b1 = __builtin_bit_cast(bf16x8, vc), b2 = __builtin_bit_cast(bf16x8, k2);
+#pragma unroll
+            for (int sA = 2 - t; sA >= 0; --sA) {
+              acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b0, acc[ky * 3 + 0], 0, 0, 0);
+              acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b1, acc[ky * 3 + 1], 0, 0, 0);
+              acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b2, acc[ky * 3 + 2], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (st + 1 < nsteps) {
+        __syncthreads();                                        // all waves done reading the oldest group and dy
+        GR_ROLL_STORE_X(st % NGP)                               // group st is dead: its slot takes group st + NGP
+        GR_ROLL_STORE_DY()
+        __syncthreads();
+        if (st + 2 < nsteps) { GR_ROLL_LOAD_X(b, ys - 1 + (st + 1 + NGP) * TR, x0) GR_ROLL_LOAD_DY(b, ys + (st + 2) * TR, x0) }
+      }
+    }
+  }
+#undef GR_SPLIT8
+#undef GR_ROLL_LOAD_X
+#undef GR_ROLL_LOAD_DY
+#undef GR_ROLL_STORE_X
+#undef GR_ROLL_STORE_DY
+  float* sl = a.slab + (size_t)split * 9 * a.coutp * a.cinp;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int ci = c0 + cg * 32 + l31;
+      sl[((size_t)tap * a.coutp + o) * a.cinp + ci] = acc[tap][r];
+    }
+}
+
 // Few input channels (9*Cin <= 32: R.conv1 on gray / RGB images, models.lua:409): the whole (ci, tap) axis fits ONE
 // 32-wide MFMA column block, so the GEMM is M = Cout, N = 32 (9*Cin used), K = pixels and the kernel is HBM-bound on dy.
 // Wave (mt, kh): output-channel block mt, pixel half kh of each 64-pixel tile; the two halves meet in LDS at the end.
@@ -1372,11 +1536,26 @@ void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* work
   if (wgrad_use_bf16x6(mode, Cin, W) && !wgrad_use_small(Cin, W)) {
     const double px_ = (double)B * H * W;
     {
-      KtScope kt(TW == 16 ? "conv3x3_wgrad_bf16x6_kernel<16>" : "conv3x3_wgrad_bf16x6_kernel<32>", 2.0 * px_ * Cout * Cin * 9.0,
-                 4.0 * (px_ * Cin + px_ * Cout + 9.0 * Cin * Cout), s);
       const int grid_ = a.nsplit * a.n_ob * a.n_cb;
       static int wv = -1;
-      if (wv < 0) { const char* e = getenv("GR_WGRAD_VARIANT"); wv = e ? atoi(e) : 1; }   // 1: accumulators in AGPRs, no spills
+      if (wv < 0) { const char* e = getenv("GR_WGRAD_VARIANT"); wv = e ? atoi(e) : 2; }   // 2: rolling-window kernel; 1: per-tile kernel (AGPR accumulators)
+      const int TRr = 32 / TW;
+      int rps = 0;                                                 // rows per segment of the rolling-window kernel
+      if (wv == 2 && H % TRr == 0) {
+        // longest run of rows (a divisor of H, multiple of TR) that still yields >= grid_ segments
+        for (int cand = H; cand >= TRr; --cand)
+          if (H % cand == 0 && cand % TRr == 0) {
+            const long nsegs = (long)B * (H / cand) * a.tiles_x;         // balanced: a multiple of the splits, or many per split
+            if (nsegs >= a.nsplit && (nsegs % a.nsplit == 0 || nsegs >= 4L * a.nsplit || cand == TRr)) { rps = cand; break; }
+          }
+      }
+      const char* nm_ = rps > 0 ? (TW == 16 ? "conv3x3_wgrad_bf16x6_roll_kernel<16>" : "conv3x3_wgrad_bf16x6_roll_kernel<32>")
+                                : (TW == 16 ? "conv3x3_wgrad_bf16x6_kernel<16>" : "conv3x3_wgrad_bf16x6_kernel<32>");
+      KtScope kt(nm_, 2.0 * px_ * Cout * Cin * 9.0, 4.0 * (px_ * Cin + px_ * Cout + 9.0 * Cin * Cout), s);
+      if (rps > 0) {
+        if (TW == 16) hipLaunchKernelGGL(conv3x3_wgrad_bf16x6_roll_kernel<16>, dim3(grid_), dim3(256), 0, s, a, rps);
+        else hipLaunchKernelGGL(conv3x3_wgrad_bf16x6_roll_kernel<32>, dim3(grid_), dim3(256), 0, s, a, rps);
+      } else
       if (TW == 16) { if (wv == 1) hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<16, 1>), dim3(grid_), dim3(256), 0, s, a);
                       else hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<16, 2>), dim3(grid_), dim3(256), 0, s, a); }
       else { if (wv == 1) hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<32, 1>), dim3(grid_), dim3(256), 0, s, a);
