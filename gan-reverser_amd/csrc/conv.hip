@@ -520,30 +520,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
   const int H = a.H, W = a.W;
   const int Hs = a.up ? H >> 1 : H, Ws = a.up ? W >> 1 : W;
   const size_t HWs = (size_t)Hs * Ws;
-  int src_off[NSL]; bool inb[NSL]; int sh[NSL];
+  // Staging loads go through buffer descriptors: one 32-bit byte offset per staged (pixel, half) pair, the channel /
+  // chunk part of the address in the scalar offset, and padding / out-of-image positions parked past the descriptor's
+  // range (the hardware returns 0 for them) - no 64-bit pointers, no exec-masked branches around the loads.
+  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
+  const size_t in_left = (size_t)(a.B - b) * a.Cin * HWs * sizeof(float);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
+      (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
+  const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wsplit), 0,
+      (int)((size_t)nchunks * (3 * 9 * 2) * a.cout_pad * 16), 0x00020000);
+  int voff[NSL], clim[NSL];
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
     const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
     const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
     const int yy = y0 + r - 1, xx = x0 + c - 1;
-    inb[s] = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W && b + img < a.B;
-    src_off[s] = (a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx) + img * a.Cin * (int)HWs;
-    sh[s] = hh;
+    const bool inb = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W && b + img < a.B;
+    const int so = (a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx) + (img * a.Cin + 8 * hh) * (int)HWs;
+    voff[s] = inb ? so * 4 : (int)0x7FFFF000;
+    clim[s] = a.Cin - 8 * hh;                                      // channel j of chunk ch is real iff ch*16 + j < clim
   }
-  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
+  const int wvoff = ((tid >> 6) * a.cout_pad + o0 + (tid & 63)) * 16;   // weight vector f = tid + NT*i: row (tid>>6) + 8i
   float pv[NSL][8];
   uint4 wv[NWV];
+  static_assert(CT == 64 && NT % CT == 0, "weight rows advance by NT / CT per staging slot");
 #define GR_BF_LOAD(ch_)                                                                                   \
   {                                                                                                       \
-    _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                       \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                     \
-        const int ci = (ch_) * BF_CK + 8 * sh[s] + j;                                                     \
-        pv[s][j] = (inb[s] && ci < a.Cin) ? in_base[(size_t)ci * HWs + src_off[s]] : 0.f;                 \
+    const bool tail_ = ((ch_) + 1) * BF_CK > a.Cin;                                                       \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
+      const int soff_ = (int)(((ch_) * BF_CK + j) * HWs * 4);                                             \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                   \
+        const float v_ = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
+        pv[s][j] = (tail_ && (ch_) * BF_CK + j >= clim[s]) ? 0.f : v_;                                    \
       }                                                                                                   \
-    const uint4* wp_ = wsplit + (size_t)(ch_) * WROWS * a.cout_pad + o0;                                  \
+    }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
-      const int f = tid + NT * i, row = f / CT, col = f - row * CT;                                       \
-      wv[i] = f < WV ? wp_[(size_t)row * a.cout_pad + col] : make_uint4(0, 0, 0, 0);                      \
+      const int soff_ = (((ch_) * WROWS + (NT / CT) * i) * a.cout_pad) * 16;                              \
+      wv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rwt, wvoff, soff_, 0));     \
     }                                                                                                     \
   }
 #define GR_BF_STORE()                                                                                     \
@@ -584,13 +598,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
     const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;                   // skip the padding rows between stacked images
     pix[ng] = h * PS + pr * PC + pc;
   }
-  const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
   GR_BF_LOAD(0)
   for (int ch = 0; ch < nchunks; ++ch) {
     GR_BF_STORE()
     __syncthreads();
     if (ch + 1 < nchunks) GR_BF_LOAD(ch + 1)
-    // operand fetch for tap t+1 is issued before the 12 MFMAs of tap t (two register sets, statically indexed)
     bf16x8 avA[MT][3], bvA[NG][3];
 #define GR_BF_OPS(tap_, av_, bv_)                                                                        \
     {                                                                                                     \
@@ -617,7 +629,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
       acc[mt][ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[mt][0], bv_[ng][0], acc[mt][ng], 0, 0, 0); \
     }
 #define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, 12, 0); __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
-    // one operand set per tap (two would spill at 64 accumulator registers); the sibling wave on the SIMD covers the fetch
+    // one operand set: a second set (tap t+1 fetched behind tap t's MFMAs) measured no faster - on random data these
+    // kernels run at the clock the chip holds under MFMA load, not at an issue or latency limit
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) { GR_BF_OPS(tap, avA, bvA) GR_BF_MMA(avA, bvA) }
 #undef GR_BF_OPS

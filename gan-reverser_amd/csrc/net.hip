@@ -1007,6 +1007,9 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   HIPCHK(c, hipMalloc((void**)&x, sizeof(float) * nin)); HIPCHK(c, hipMalloc((void**)&y, sizeof(float) * nout));
   HIPCHK(c, hipMalloc((void**)&w, sizeof(float) * nw)); HIPCHK(c, hipMalloc((void**)&gw, sizeof(float) * nw));
   launch_fill_normal(x, (long)nin, 11, c->stream); launch_fill_normal(y, (long)nout, 12, c->stream); launch_fill_normal(w, (long)nw, 13, c->stream);
+  if (getenv("GR_BENCH_ZERO")) {   // DVFS diagnostic: all-zero operands draw less power (MI355X_MICROARCH.md, DVFS give-back item 1)
+    (void)hipMemsetAsync(x, 0, sizeof(float) * nin, c->stream); (void)hipMemsetAsync(y, 0, sizeof(float) * nout, c->stream); (void)hipMemsetAsync(w, 0, sizeof(float) * nw, c->stream);
+  }
   (void)hipMemsetAsync(gw, 0, sizeof(float) * nw, c->stream);
   int r = with_prepped(c, w, cin, cout, which == 1, &wt); if (r) return r;
   void* wsp = nullptr;

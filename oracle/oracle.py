@@ -102,6 +102,7 @@ class Net:
         if not self.h:
             raise ValueError("oracle: shape mismatch in layer list")
         self.in_dims = tuple(in_dims)
+        self.n_layers = len(descs)
         oc, oh, ow = C.c_int(), C.c_int(), C.c_int()
         self.L.go_net_out_dim(self.h, C.byref(oc), C.byref(oh), C.byref(ow))
         self.out_dims = (oc.value, oh.value, ow.value)
