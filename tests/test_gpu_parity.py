@@ -250,7 +250,7 @@ def test_full_size_cfg2_step_vs_oracle(ctx, oracle, conv_mode):
     tolerance; upstream of a pooling layer a full batch always contains a few windows whose two largest activations are equal
     to rounding (about 6.5M windows, gaps down to 1e-7), two correct implementations may route those few gradient elements to
     different positions, and with noise-like gradient sums one such element is ~1/sqrt(262144) of a filter's gradient - so
-    there the bound is the flip budget, and the exact check at this size is test_full_size_cfg2_backward_is_linear."""
+    there the bound is the flip budget, and the exact check at this size is test_full_size_backward_is_linear."""
     import os
     import ganrev._lib as L
     from ganrev import synth, nn
@@ -293,13 +293,16 @@ def test_full_size_cfg2_step_vs_oracle(ctx, oracle, conv_mode):
     ctx.free(dn)
 
 
-def test_full_size_cfg2_backward_is_linear(ctx, conv_mode):
-    """Size-independent property at BASELINE.json configs[1]'s full size: with the forward state fixed (batch statistics,
+FULL_SIZES = [pytest.param((1, 32, 32), 32, 256, id="cfg2"), pytest.param((3, 64, 64), 100, 512, id="cfg3")]
+
+
+@pytest.mark.parametrize("dims,nd,B", FULL_SIZES)
+def test_full_size_backward_is_linear(ctx, conv_mode, dims, nd, B):
+    """Size-independent property at the full sizes of BASELINE.json configs[1] and configs[2]: with the forward state fixed (batch statistics,
     dropout masks, pool argmax) nn.Sequential:backward is linear in gradOutput, for gradInput and for every gradParameter
     (train_r.lua:150-152).  Exercises the full-size launch geometry of every backward kernel - data gradients, weight
     gradients with their split-and-reduce, BatchNorm and bias reductions - with no oracle and no pooling ambiguity."""
     from ganrev import models, synth
-    dims, nd, B = (1, 32, 32), 32, 256
     R = models.create_R(dims, nd); synth.init_params(R, 31)
     x = synth.uniform((B,) + dims, 32, 0, 1)
     R.training(); R.manualSeed(5)
@@ -322,6 +325,30 @@ def test_full_size_cfg2_backward_is_linear(ctx, conv_mode):
         assert maxdiff(got, ref) <= 2e-5 * scale, f"{what}: backward not linear at full size ({maxdiff(got, ref)} vs max {scale})"
     gi_u2, gp_u2 = backward(u)                        # and deterministic: the same bits on a second run
     assert np.array_equal(gi_u, gi_u2) and np.array_equal(gp_u, gp_u2)
+
+
+@pytest.mark.parametrize("dims,nd,B", FULL_SIZES)
+def test_full_size_forward_is_batch_consistent(ctx, oracle, conv_mode, dims, nd, B):
+    """In evaluate() mode every sample is independent (running statistics, no dropout), so rows of a full-size batch must
+    equal the same rows pushed through as a small batch - bit for bit through the conv stack, whose per-pixel accumulation
+    order does not depend on the batch tiling, and to fp32 reordering noise after nn.Linear, whose split-K plan follows the
+    batch size - and the small batch is checked against the oracle.  Covers G (train_r.lua:139) and R's
+    evaluate() forward (apply_r.lua:120-140) at the full sizes of configs[1] and configs[2]."""
+    from ganrev import models, synth
+    G = models.create_G(dims, nd); synth.init_params(G, 41)
+    R = models.create_R(dims, nd); synth.init_params(R, 42)
+    oG, oR = oracle.from_model(G, (nd, 1, 1)), oracle.from_model(R, dims)
+    G.evaluate(); R.evaluate(); oG.set_training(False); oR.set_training(False)
+    z = synth.normal((B, nd), 43)
+    img = G.forward(z).copy()
+    rec = R.forward(img).copy()
+    rows = np.array([0, 1, B // 2, B - 1])
+    img_s = G.forward(z[rows]).copy()
+    rec_s = R.forward(img[rows]).copy()
+    assert np.array_equal(img[rows], img_s), "G: full-batch rows differ from the same rows as a small batch"
+    assert_close(rec[rows], rec_s, 1e-5, "R: full-batch rows vs the same rows as a small batch")
+    assert_close(img_s, oG.forward(z[rows]), TOL, "G images vs oracle")
+    assert_close(rec_s, oR.forward(img[rows]), TOL, "recovered noise vs oracle")
 
 
 def test_cosine_similarity_and_topk_bit_exact(ctx, oracle):
