@@ -720,7 +720,7 @@ static void launch_conv_bf16x6_wide(ConvArgs a, const void* wsplit, hipStream_t 
   const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6_wide_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  static const std::string name = "conv3x3_bf16x6_wide_kernel<" + std::to_string(TW) + (NI > 1 ? ", " + std::to_string(NI) : std::string()) + ">";
+  static const std::string name = "conv3x3_bf16x6_wide_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";   // as rocprofv3 prints it
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_bf16x6_wide_kernel<TW, NI>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
