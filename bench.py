@@ -20,6 +20,7 @@ for _p in (os.path.join(ROOT, "gan-reverser_amd"), ROOT):
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 256 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the 5 PF marketing figure is 2:1 sparse)
 BF16X6_PASSES = 6                  # bf16x6 mode: six bf16 MFMA products per fp32-accurate product
+F16X3_PASSES = 3                   # f16x3 mode: three f16 MFMA products per fp32-accurate product
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -74,8 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "bf16x6"), choices=["f32", "bf16x6"],
-                    help="convolution arithmetic (both meet the 1e-4 parity bar; see DESIGN.md)")
+    ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "bf16x6"), choices=["f32", "bf16x6", "f16x3"],
+                    help="convolution arithmetic (all meet the 1e-4 parity bar; see DESIGN.md)")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
     args = ap.parse_args()
 
@@ -170,9 +171,11 @@ def main():
         dom = max(mfma, key=lambda k: k["total_ms"])
         avg_ms = dom["total_ms"] / dom["launches"]
         achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-        split = "bf16x6" in dom["kernel"]
-        # bf16x6: the kernel issues 6 bf16 MFMA products per algorithmic multiply-add; its ceiling for ALGORITHMIC flops is peak/6
-        peak = PEAK_BF16_MFMA_TFLOPS / BF16X6_PASSES if split else PEAK_FP32_MFMA_TFLOPS
+        split = "bf16x6" in dom["kernel"] or "f16x3" in dom["kernel"]
+        passes = F16X3_PASSES if "f16x3" in dom["kernel"] else BF16X6_PASSES
+        # split modes: the kernel issues `passes` 16-bit MFMA products per algorithmic multiply-add; its ceiling for
+        # ALGORITHMIC flops is the dense 16-bit MFMA peak / passes
+        peak = PEAK_BF16_MFMA_TFLOPS / passes if split else PEAK_FP32_MFMA_TFLOPS
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
@@ -182,8 +185,8 @@ def main():
                 traffic = None
         roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
                         frac=round(achieved / peak, 4), traffic=traffic,
-                        peak_note=("dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32-accurate multiply-add (bf16x6 split); "
-                                   "issued MFMA rate = 6 x achieved") if split else "fp32 MFMA v_mfma_f32_32x32x2_f32",
+                        peak_note=(f"dense bf16/f16 MFMA 2500 TFLOP/s / {passes} products per fp32-accurate multiply-add "
+                                   f"({'f16x3' if passes == 3 else 'bf16x6'} split); issued MFMA rate = {passes} x achieved") if split else "fp32 MFMA v_mfma_f32_32x32x2_f32",
                         frac_of_fp32_mfma_peak=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                         avg_launch_ms=round(avg_ms, 4), launches_per_step=dom["launches"] / nprof,
                         algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3))
@@ -198,7 +201,9 @@ def main():
             "metric": "images/sec G+R fwd/bwd", "value": round(GB * args.steps / dt, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if ctx.conv_mode() == "f32" else "f32 via bf16x6 (3-term bf16 split, 6 MFMA products, fp32 accumulate)", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x6": "f32 via bf16x6 (3-term bf16 split, 6 MFMA products, fp32 accumulate)",
+                      "f16x3": "f32 via f16x3 (2-term fp16 split of power-of-two-scaled operands, 3 MFMA products, fp32 accumulate)"}[ctx.conv_mode()],
+            "data": "synthetic",
             "config": {"workload": wl["name"], "global_batch": GB, "per_gpu_batch": B,
                        "parallelism": f"dp{world}" + (" (RCCL all-reduce of R's flat gradient)" if world > 1 else ""),
                        "bn": "per-rank batch statistics"},

@@ -35,6 +35,8 @@ struct ConvArgs {
   int B, Cin, Cout, H, W;
   int up, nchunks, cout_pad, tiles_x, tiles_y, n_otiles;
   ConvEpilogue ep;      // ep.mean != nullptr: evaluate()-mode BatchNorm + activation applied before the store
+  const unsigned *amax_in = nullptr, *amax_w = nullptr;   // f16x3 mode: bit patterns of max|in| and max|weights| (device)
+  unsigned* amax_out = nullptr;                           // nullable: slot that receives max|out|
 };
 
 // out = act(((conv + bias - mean) * invstd) * gamma + beta): the per-channel pipeline of an evaluate()-mode stage
@@ -357,15 +359,69 @@ constexpr int BF_CK = 16;
 __device__ __forceinline__ unsigned short f32_to_bf16(float x) { const __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
 __device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
-template <int TW, int MT>
-__global__ __launch_bounds__(256 * MT, 2) void conv3x3_bf16x6_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
+// ---------------------------------------------------------------- fp32-accurate convolution on the f16 MFMA ("f16x3")
+// Two fp16 terms carry 22 significand bits, so x = x0 + x1 with |x - x0 - x1| <= 2^-22 |x| and the three products
+// x0w0, x0w1, x1w0 (the dropped x1w1 is below 2^-22) give fp32-level error with HALF the MFMAs of bf16x6 (measured against
+// float64 on R fwd+bwd: outputs 1.8e-6, gradients 1.6e-6 relative; plain fp32: 1.7e-6 / 2.3e-6 -
+// tools/split_precision_experiment.py).  fp16 has 5 exponent bits, so each tensor is first scaled by a power of two that
+// puts its largest magnitude into [2^14, 2^15) (exact; elements more than 2^17 below the maximum lose relative but not
+// absolute precision: their error stays below 2^-39 of the maximum); the result is scaled back with one v_ldexp_f32.
+// The maxima are tracked on the device (producer kernels or absmax_kernel), never read by the host.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int f16_scale_exp(unsigned amax_bits) {      // k such that max|x| * 2^k lies in [2^14, 2^15)
+  const int e = (int)((amax_bits >> 23) & 0xffu);
+  return e == 0 ? 0 : min(141 - e, 126);
+}
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }   // k in [-126, 127]
+// split 8 scaled floats into the two fp16 term vectors (round-to-nearest both times; x - x0 is exact in fp32)
+__device__ __forceinline__ void split8_f16(const float* x, float sc, uint4& t0, uint4& t1) {
+  unsigned short a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = x[j] * sc;
+    const _Float16 h0 = (_Float16)v; const float r = v - (float)h0; const _Float16 h1 = (_Float16)r;
+    a[j] = __builtin_bit_cast(unsigned short, h0); b[j] = __builtin_bit_cast(unsigned short, h1);
+  }
+  t0 = make_uint4(a[0] | (unsigned)a[1] << 16, a[2] | (unsigned)a[3] << 16, a[4] | (unsigned)a[5] << 16, a[6] | (unsigned)a[7] << 16);
+  t1 = make_uint4(b[0] | (unsigned)b[1] << 16, b[2] | (unsigned)b[3] << 16, b[4] | (unsigned)b[5] << 16, b[6] | (unsigned)b[7] << 16);
+}
+__device__ __forceinline__ void split8_bf16(const float* x, uint4& r0, uint4& r1, uint4& r2) {
+  unsigned short t0[8], t1[8], t2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = x[j];
+    t0[j] = f32_to_bf16(v); const float e1 = v - bf16_to_f32(t0[j]);
+    t1[j] = f32_to_bf16(e1); const float e2 = e1 - bf16_to_f32(t1[j]);
+    t2[j] = f32_to_bf16(e2);
+  }
+  r0 = make_uint4(t0[0] | (unsigned)t0[1] << 16, t0[2] | (unsigned)t0[3] << 16, t0[4] | (unsigned)t0[5] << 16, t0[6] | (unsigned)t0[7] << 16);
+  r1 = make_uint4(t1[0] | (unsigned)t1[1] << 16, t1[2] | (unsigned)t1[3] << 16, t1[4] | (unsigned)t1[5] << 16, t1[6] | (unsigned)t1[7] << 16);
+  r2 = make_uint4(t2[0] | (unsigned)t2[1] << 16, t2[2] | (unsigned)t2[3] << 16, t2[4] | (unsigned)t2[5] << 16, t2[6] | (unsigned)t2[7] << 16);
+}
+// one tap x 16 channels of the split product, smallest terms first
+template <int NTERM>
+__device__ __forceinline__ f32x16 split_mma(const uint4* av, const uint4* bv, f32x16 acc) {
+  if (NTERM == 3) {
+#define GR_M_(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i]), __builtin_bit_cast(bf16x8, bv[j]), acc, 0, 0, 0);
+    GR_M_(2, 0) GR_M_(1, 1) GR_M_(0, 2) GR_M_(1, 0) GR_M_(0, 1) GR_M_(0, 0)
+#undef GR_M_
+  } else {
+#define GR_M_(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]), acc, 0, 0, 0);
+    GR_M_(1, 0) GR_M_(0, 1) GR_M_(0, 0)
+#undef GR_M_
+  }
+  return acc;
+}
+
+template <int TW, int MT, int NTERM>
+__global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
   constexpr int NT = 256 * MT;                                    // MT = 2: 8 waves = 2 channel blocks x 4 pixel quarters
   constexpr int NG = 2, PT = 256, TR = PT / TW, PR = TR + 2, PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
-  constexpr int WROWS = 3 * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
+  constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [3][2][PS]   (one uint4 = 8 bf16)
-  uint4* wts = patch + 3 * 2 * PS;                                // [3][9][2][CT]
+  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [NTERM][2][PS]   (one uint4 = 8 bf16 / f16)
+  uint4* wts = patch + NTERM * 2 * PS;                            // [NTERM][9][2][CT]
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, wmt = tid >> 8, l31 = lane & 31, h = lane >> 5;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ot = bid % a.n_otiles; bid /= a.n_otiles;
@@ -375,6 +431,9 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_bf16x6_kernel(ConvArgs a,
   const int H = a.H, W = a.W;
   const int Hs = a.up ? H >> 1 : H, Ws = a.up ? W >> 1 : W;
   const size_t HWs = (size_t)Hs * Ws;
+  int kin = 0, ktot = 0;
+  if (NTERM == 2) { kin = f16_scale_exp(absmax_read(a.amax_in)); ktot = kin + f16_scale_exp(absmax_read(a.amax_w)); }
+  const float sc_in = pow2f(kin);
   int src_off[NSL]; bool inb[NSL]; int sh[NSL];
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
@@ -405,17 +464,11 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_bf16x6_kernel(ConvArgs a,
     _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
       const int eh = tid + NT * s;                                                                        \
       if (eh < NEH) {                                                                                     \
-        unsigned short t0[8], t1[8], t2[8];                                                               \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
-          const float x = pv[s][j];                                                                       \
-          t0[j] = f32_to_bf16(x); const float r1 = x - bf16_to_f32(t0[j]);                                \
-          t1[j] = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(t1[j]);                              \
-          t2[j] = f32_to_bf16(r2);                                                                        \
-        }                                                                                                 \
         const int hh = eh >= PS ? 1 : 0, e = eh - hh * PS;                                                \
-        patch[(0 * 2 + hh) * PS + e] = make_uint4(t0[0] | (unsigned)t0[1] << 16, t0[2] | (unsigned)t0[3] << 16, t0[4] | (unsigned)t0[5] << 16, t0[6] | (unsigned)t0[7] << 16); \
-        patch[(1 * 2 + hh) * PS + e] = make_uint4(t1[0] | (unsigned)t1[1] << 16, t1[2] | (unsigned)t1[3] << 16, t1[4] | (unsigned)t1[5] << 16, t1[6] | (unsigned)t1[7] << 16); \
-        patch[(2 * 2 + hh) * PS + e] = make_uint4(t2[0] | (unsigned)t2[1] << 16, t2[2] | (unsigned)t2[3] << 16, t2[4] | (unsigned)t2[5] << 16, t2[6] | (unsigned)t2[7] << 16); \
+        uint4 t0, t1, t2;                                                                                 \
+        if (NTERM == 3) { split8_bf16(pv[s], t0, t1, t2); patch[(2 * 2 + hh) * PS + e] = t2; }            \
+        else split8_f16(pv[s], sc_in, t0, t1);                                                            \
+        patch[(0 * 2 + hh) * PS + e] = t0; patch[(1 * 2 + hh) * PS + e] = t1;                             \
       }                                                                                                   \
     }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
@@ -441,30 +494,19 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_bf16x6_kernel(ConvArgs a,
     GR_BF_STORE()
     __syncthreads();
     if (ch + 1 < nchunks) GR_BF_LOAD(ch + 1)
-    // operand fetch for tap t+1 is issued before the 12 MFMAs of tap t (two register sets, statically indexed)
-    bf16x8 avA[3], bvA[NG][3], avB[3], bvB[NG][3];
+    // operand fetch for tap t+1 is issued before the MFMAs of tap t (two register sets, statically indexed)
+    uint4 avA[NTERM], bvA[NG][NTERM], avB[NTERM], bvB[NG][NTERM];
 #define GR_BF_OPS(tap_, av_, bv_)                                                                        \
     {                                                                                                     \
       const int toff_ = ((tap_) / 3) * PC + ((tap_) % 3);                                                 \
-      _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                     \
-        const uint4 t_ = wts[((s * 9 + (tap_)) * 2 + h) * CT + wmt * 32 + l31];                           \
-        av_[s] = __builtin_bit_cast(bf16x8, t_);                                                          \
-        _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) {                                               \
-          const uint4 u_ = patch[s * 2 * PS + pix[ng] + toff_];                                           \
-          bv_[ng][s] = __builtin_bit_cast(bf16x8, u_);                                                    \
-        }                                                                                                 \
+      _Pragma("unroll") for (int s = 0; s < NTERM; ++s) {                                                 \
+        av_[s] = wts[((s * 9 + (tap_)) * 2 + h) * CT + wmt * 32 + l31];                                   \
+        _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) bv_[ng][s] = patch[s * 2 * PS + pix[ng] + toff_]; \
       }                                                                                                   \
     }
 #define GR_BF_MMA(av_, bv_)                                                                               \
-    _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) {                                                   \
-      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[2], bv_[ng][0], acc[ng], 0, 0, 0);            \
-      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[1], bv_[ng][1], acc[ng], 0, 0, 0);            \
-      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[0], bv_[ng][2], acc[ng], 0, 0, 0);            \
-      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[1], bv_[ng][0], acc[ng], 0, 0, 0);            \
-      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[0], bv_[ng][1], acc[ng], 0, 0, 0);            \
-      acc[ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[0], bv_[ng][0], acc[ng], 0, 0, 0);            \
-    }
-#define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, 9, 0); __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) acc[ng] = split_mma<NTERM>(av_, bv_[ng], acc[ng]);
+#define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, 3 * NTERM, 0); __builtin_amdgcn_sched_group_barrier(0x008, NTERM == 3 ? 12 : 6, 0);
     GR_BF_OPS(0, avA, bvA)
     GR_BF_OPS(1, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
     GR_BF_OPS(2, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
@@ -482,6 +524,7 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_bf16x6_kernel(ConvArgs a,
   }
 #undef GR_BF_LOAD
 #undef GR_BF_STORE
+  float omax = 0.f;
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
     const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
@@ -492,25 +535,29 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_bf16x6_kernel(ConvArgs a,
         const int o = o0 + wmt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (o < a.Cout) {
           const float bvv = a.bias ? a.bias[o] : 0.f;
-          a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = conv_epilogue(a.ep, acc[ng][r] + bvv, o);
+          const float v = NTERM == 2 ? ldexpf(acc[ng][r], -ktot) : acc[ng][r];
+          const float res = conv_epilogue(a.ep, v + bvv, o);
+          a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = res;
+          omax = fmaxf(omax, fabsf(res));
         }
       }
     }
   }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
 // 512-pixel x 64-channel tile: all 8 waves keep BOTH 32-channel blocks (4 accumulators each) for their own 64 pixels, so one
 // weight fetch and one patch conversion feed twice the MFMAs of the 256-pixel tile and every operand read feeds two MFMAs.
 // NI > 1: the tile is NI whole images (16x16 planes: two of them), their zero-padded patches stacked in LDS.
-template <int TW, int NI = 1>
-__global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
+template <int TW, int NI, int NTERM>
+__global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
   constexpr int NT = 512, MT = 2;
   constexpr int NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
-  constexpr int WROWS = 3 * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
+  constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [3][2][PS]   (one uint4 = 8 bf16)
-  uint4* wts = patch + 3 * 2 * PS;                                // [3][9][2][CT]
+  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [NTERM][2][PS]   (one uint4 = 8 bf16 / f16)
+  uint4* wts = patch + NTERM * 2 * PS;                            // [NTERM][9][2][CT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ot = bid % a.n_otiles; bid /= a.n_otiles;
@@ -529,7 +576,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
       (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
   const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
   const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wsplit), 0,
-      (int)((size_t)nchunks * (3 * 9 * 2) * a.cout_pad * 16), 0x00020000);
+      (int)((size_t)nchunks * WROWS * a.cout_pad * 16), 0x00020000);
+  int kin = 0, ktot = 0;
+  if (NTERM == 2) { kin = f16_scale_exp(absmax_read(a.amax_in)); ktot = kin + f16_scale_exp(absmax_read(a.amax_w)); }
+  const float sc_in = pow2f(kin);
   int voff[NSL], clim[NSL];
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
@@ -565,17 +615,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
     _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
       const int eh = tid + NT * s;                                                                        \
       if (eh < NEH) {                                                                                     \
-        unsigned short t0[8], t1[8], t2[8];                                                               \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
-          const float x = pv[s][j];                                                                       \
-          t0[j] = f32_to_bf16(x); const float r1 = x - bf16_to_f32(t0[j]);                                \
-          t1[j] = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(t1[j]);                              \
-          t2[j] = f32_to_bf16(r2);                                                                        \
-        }                                                                                                 \
         const int hh = eh >= PS ? 1 : 0, e = eh - hh * PS;                                                \
-        patch[(0 * 2 + hh) * PS + e] = make_uint4(t0[0] | (unsigned)t0[1] << 16, t0[2] | (unsigned)t0[3] << 16, t0[4] | (unsigned)t0[5] << 16, t0[6] | (unsigned)t0[7] << 16); \
-        patch[(1 * 2 + hh) * PS + e] = make_uint4(t1[0] | (unsigned)t1[1] << 16, t1[2] | (unsigned)t1[3] << 16, t1[4] | (unsigned)t1[5] << 16, t1[6] | (unsigned)t1[7] << 16); \
-        patch[(2 * 2 + hh) * PS + e] = make_uint4(t2[0] | (unsigned)t2[1] << 16, t2[2] | (unsigned)t2[3] << 16, t2[4] | (unsigned)t2[5] << 16, t2[6] | (unsigned)t2[7] << 16); \
+        uint4 t0, t1, t2;                                                                                 \
+        if (NTERM == 3) { split8_bf16(pv[s], t0, t1, t2); patch[(2 * 2 + hh) * PS + e] = t2; }            \
+        else split8_f16(pv[s], sc_in, t0, t1);                                                            \
+        patch[(0 * 2 + hh) * PS + e] = t0; patch[(1 * 2 + hh) * PS + e] = t1;                             \
       }                                                                                                   \
     }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
@@ -603,43 +647,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
     GR_BF_STORE()
     __syncthreads();
     if (ch + 1 < nchunks) GR_BF_LOAD(ch + 1)
-    bf16x8 avA[MT][3], bvA[NG][3];
+    uint4 avA[MT][NTERM], bvA[NG][NTERM];
 #define GR_BF_OPS(tap_, av_, bv_)                                                                        \
     {                                                                                                     \
       const int toff_ = ((tap_) / 3) * PC + ((tap_) % 3);                                                 \
-      _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                     \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                               \
-          const uint4 t_ = wts[((s * 9 + (tap_)) * 2 + h) * CT + mt * 32 + l31];                          \
-          av_[mt][s] = __builtin_bit_cast(bf16x8, t_);                                                    \
-        }                                                                                                 \
-        _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) {                                               \
-          const uint4 u_ = patch[s * 2 * PS + pix[ng] + toff_];                                           \
-          bv_[ng][s] = __builtin_bit_cast(bf16x8, u_);                                                    \
-        }                                                                                                 \
+      _Pragma("unroll") for (int s = 0; s < NTERM; ++s) {                                                 \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) av_[mt][s] = wts[((s * 9 + (tap_)) * 2 + h) * CT + mt * 32 + l31]; \
+        _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) bv_[ng][s] = patch[s * 2 * PS + pix[ng] + toff_]; \
       }                                                                                                   \
     }
 #define GR_BF_MMA(av_, bv_)                                                                               \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                     \
-    _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) {                                                   \
-      acc[mt][ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[mt][2], bv_[ng][0], acc[mt][ng], 0, 0, 0); \
-      acc[mt][ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[mt][1], bv_[ng][1], acc[mt][ng], 0, 0, 0); \
-      acc[mt][ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[mt][0], bv_[ng][2], acc[mt][ng], 0, 0, 0); \
-      acc[mt][ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[mt][1], bv_[ng][0], acc[mt][ng], 0, 0, 0); \
-      acc[mt][ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[mt][0], bv_[ng][1], acc[mt][ng], 0, 0, 0); \
-      acc[mt][ng] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av_[mt][0], bv_[ng][0], acc[mt][ng], 0, 0, 0); \
-    }
-#define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, 12, 0); __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+    _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) acc[mt][ng] = split_mma<NTERM>(av_[mt], bv_[ng], acc[mt][ng]);
     // one operand set: a second set (tap t+1 fetched behind tap t's MFMAs) measured no faster - on random data these
     // kernels run at the clock the chip holds under MFMA load, not at an issue or latency limit
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) { GR_BF_OPS(tap, avA, bvA) GR_BF_MMA(avA, bvA) }
 #undef GR_BF_OPS
 #undef GR_BF_MMA
-#undef GR_BF_PIN
     __syncthreads();
   }
 #undef GR_BF_LOAD
 #undef GR_BF_STORE
+  float omax = 0.f;
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
     const int p = (wave * NG + ng) * 32 + l31, prr = p / TW, pc = p - prr * TW;
@@ -653,18 +683,56 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16x6_wide_kernel(ConvArgs a,
         const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (o < a.Cout) {
           const float bvv = a.bias ? a.bias[o] : 0.f;
-          a.out[(((size_t)(b + img) * a.Cout + o) * H + y) * W + x] = conv_epilogue(a.ep, acc[mt][ng][r] + bvv, o);
+          const float v = NTERM == 2 ? ldexpf(acc[mt][ng][r], -ktot) : acc[mt][ng][r];
+          const float res = conv_epilogue(a.ep, v + bvv, o);
+          a.out[(((size_t)(b + img) * a.Cout + o) * H + y) * W + x] = res;
+          omax = fmaxf(omax, fabsf(res));
         }
       }
     }
   }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
-// native fp32 [cout][cin][3][3] -> split image [cin_pad16/16][3 terms][9 taps][2 halves][cout_pad32][8 ch] bf16
-// (backward-data: the transposed + flipped weights, as in conv_weight_prep_kernel)
+// ---------------------------------------------------------------- max|x| of a tensor (f16x3 scale tracking)
+// slot holds the bit pattern of a non-negative float (orders like an unsigned); the caller zeroes it before the first writer
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ slot) {
+  float m = 0.f;
+  const long n4 = n >> 2, stride = (long)gridDim.x * blockDim.x;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+  absmax_commit(m, slot);
+}
+void launch_absmax(const float* x, long n, unsigned* slot, hipStream_t s) {
+  (void)hipMemsetAsync(slot, 0, sizeof(unsigned) * AMAX_WORDS, s);
+  long blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  KtScope kt("absmax_kernel", 0.0, 4.0 * (double)n, s);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, slot);
+}
+
+// native fp32 [cout][cin][3][3] -> split image [cin_pad16/16][NTERM][9 taps][2 halves][cout_pad32][8 ch] of bf16 (3 terms)
+// or scaled f16 (2 terms; amax = bit pattern of max|w|)  (backward-data: the transposed + flipped weights)
+__device__ __forceinline__ void weight_split_store(unsigned short* dst, long base, long within, long term, float v, int nterm, float sc) {
+  if (nterm == 3) {
+    const unsigned short t0 = f32_to_bf16(v); const float r1 = v - bf16_to_f32(t0);
+    const unsigned short t1 = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(t1);
+    const unsigned short t2 = f32_to_bf16(r2);
+    dst[base + within] = t0; dst[base + term + within] = t1; dst[base + 2 * term + within] = t2;
+  } else {
+    const float x = v * sc;
+    const _Float16 h0 = (_Float16)x; const float r = x - (float)h0; const _Float16 h1 = (_Float16)r;
+    dst[base + within] = __builtin_bit_cast(unsigned short, h0); dst[base + term + within] = __builtin_bit_cast(unsigned short, h1);
+  }
+}
 __global__ void conv_weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst,
-                                         int cin, int cout, int CI, int CO, int cin_pad, int cout_pad, int bwd) {
-  const long n = (long)(cin_pad / BF_CK) * 9 * 2 * cout_pad * 8;     // one thread per (chunk, tap, half, o, j): writes 3 terms
+                                         int cin, int cout, int CI, int CO, int cin_pad, int cout_pad, int bwd,
+                                         int nterm, const unsigned* __restrict__ amax) {
+  const long n = (long)(cin_pad / BF_CK) * 9 * 2 * cout_pad * 8;     // one thread per (chunk, tap, half, o, j): writes all terms
+  const float sc = nterm == 2 ? pow2f(f16_scale_exp(absmax_read(amax))) : 1.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int j = (int)(i & 7); long r = i >> 3;
     const int oo = (int)(r % cout_pad); r /= cout_pad;
@@ -673,76 +741,83 @@ __global__ void conv_weight_split_kernel(const float* __restrict__ w, unsigned s
     const int ci = ch * BF_CK + 8 * hh + j;
     float v = 0.f;
     if (ci < CI && oo < CO) v = bwd ? w[((long)ci * cin + oo) * 9 + (8 - tap)] : w[((long)oo * cin + ci) * 9 + tap];
-    const unsigned short t0 = f32_to_bf16(v); const float r1 = v - bf16_to_f32(t0);
-    const unsigned short t1 = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(t1);
-    const unsigned short t2 = f32_to_bf16(r2);
-    const long base = (long)ch * 3 * 9 * 2 * cout_pad * 8;
-    const long within = (((long)tap * 2 + hh) * cout_pad + oo) * 8 + j, term = (long)9 * 2 * cout_pad * 8;
-    dst[base + within] = t0; dst[base + term + within] = t1; dst[base + 2 * term + within] = t2;
+    const long term = (long)9 * 2 * cout_pad * 8;
+    weight_split_store(dst, (long)ch * nterm * term, (((long)tap * 2 + hh) * cout_pad + oo) * 8 + j, term, v, nterm, sc);
   }
 }
 
 size_t conv_weight_split_bytes(int cin, int cout, bool bwd) {
   const int CI = bwd ? cout : cin, CO = bwd ? cin : cout;
-  return (size_t)round_up(CI, BF_CK) * 9 * round_up(CO, 32) * 3 * sizeof(unsigned short);
+  return (size_t)round_up(CI, BF_CK) * 9 * round_up(CO, 32) * 3 * sizeof(unsigned short);   // sized for 3 terms; f16x3 uses 2/3 of it
 }
-void launch_conv_weight_split(const float* w_native, void* dst, int cin, int cout, bool bwd, hipStream_t s) {
+void launch_conv_weight_split(const float* w_native, void* dst, int cin, int cout, bool bwd, hipStream_t s, int nterm, unsigned* amax) {
   const int CI = bwd ? cout : cin, CO = bwd ? cin : cout;
   const int cin_pad = round_up(CI, BF_CK), cout_pad = round_up(CO, 32);
   const long n = (long)(cin_pad / BF_CK) * 9 * 2 * cout_pad * 8;
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-  KtScope kt("conv_weight_split_kernel", 0.0, 4.0 * 9.0 * cin * cout + 6.0 * (double)n, s);
+  if (nterm == 2) launch_absmax(w_native, (long)cin * cout * 9, amax, s);
+  KtScope kt("conv_weight_split_kernel", 0.0, 4.0 * 9.0 * cin * cout + 2.0 * nterm * (double)n, s);
   hipLaunchKernelGGL(conv_weight_split_kernel, dim3(grid), dim3(256), 0, s, w_native, reinterpret_cast<unsigned short*>(dst),
-                     cin, cout, CI, CO, cin_pad, cout_pad, bwd ? 1 : 0);
+                     cin, cout, CI, CO, cin_pad, cout_pad, bwd ? 1 : 0, nterm, amax);
 }
 
-template <int TW, int MT>
-static void launch_conv_bf16x6_t(ConvArgs a, const void* wsplit, hipStream_t s) {
+template <int TW, int MT, int NTERM>
+static void launch_conv_split_t(ConvArgs a, const void* wsplit, hipStream_t s) {
   constexpr int TR = 256 / TW, PS = (TR + 2) * (TW + 2), CT = 32 * MT;
   a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
-  const size_t lds = 16 * (size_t)(3 * 2 * PS + 3 * 9 * 2 * CT);
+  const size_t lds = 16 * (size_t)(NTERM * 2 * PS + NTERM * 9 * 2 * CT);
   const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6_kernel<TW, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  static const std::string name = "conv3x3_bf16x6_kernel<" + std::to_string(TW) + ", " + std::to_string(MT) + ">";
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<TW, MT, NTERM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = std::string(NTERM == 3 ? "conv3x3_bf16x6_kernel<" : "conv3x3_f16x3_kernel<") + std::to_string(TW) + ", " + std::to_string(MT) + ">";
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_bf16x6_kernel<TW, MT>), dim3(grid), dim3(256 * MT), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
+  hipLaunchKernelGGL((conv3x3_split_kernel<TW, MT, NTERM>), dim3(grid), dim3(256 * MT), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
 }
 
-template <int TW, int NI = 1>
-static void launch_conv_bf16x6_wide(ConvArgs a, const void* wsplit, hipStream_t s) {
+template <int TW, int NI, int NTERM>
+static void launch_conv_split_wide(ConvArgs a, const void* wsplit, hipStream_t s) {
   constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
   a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
-  const size_t lds = 16 * (size_t)(3 * 2 * PS + 3 * 9 * 2 * CT);
+  const size_t lds = 16 * (size_t)(NTERM * 2 * PS + NTERM * 9 * 2 * CT);
   const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16x6_wide_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  static const std::string name = "conv3x3_bf16x6_wide_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";   // as rocprofv3 prints it
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_wide_kernel<TW, NI, NTERM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  // the names the timing table and the profiles use (the symbol is conv3x3_split_wide_kernel<TW, NI, NTERM>)
+  static const std::string name = std::string(NTERM == 3 ? "conv3x3_bf16x6_wide_kernel<" : "conv3x3_f16x3_wide_kernel<") + std::to_string(TW) + ", " + std::to_string(NI) + ">";
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_bf16x6_wide_kernel<TW, NI>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
+  hipLaunchKernelGGL((conv3x3_split_wide_kernel<TW, NI, NTERM>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
 }
 
-void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bias, float* out,
-                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep) {
+template <int NTERM>
+static void launch_conv3x3_split_n(const ConvArgs& a, const void* wsplit, hipStream_t s) {
+  const int B = a.B, Cout = a.Cout, H = a.H, W = a.W;
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("GR_BF16X6_VARIANT"); variant = e ? atoi(e) : 0; }
+  const bool wide = round_up(Cout, 32) % 64 == 0 && variant != 1;      // 64 output channels per workgroup (8 waves share one patch)
+  if (W <= 8) launch_conv_split_t<8, 1, NTERM>(a, wsplit, s);
+  else if (W <= 16) {
+    // two stacked 16x16 images per 512-pixel tile (G.convA 799 -> 716 us) when that still leaves a workgroup for every CU
+    if (wide && variant != 4 && H == 16 && W == 16 && (long)((B + 1) / 2) * (round_up(Cout, 32) / 64) >= 256) launch_conv_split_wide<16, 2, NTERM>(a, wsplit, s);
+    else if (wide) launch_conv_split_t<16, 2, NTERM>(a, wsplit, s); else launch_conv_split_t<16, 1, NTERM>(a, wsplit, s);
+  }
+  else if (wide && variant != 4 && (long)H * W >= 512 && (long)B * ((H * W + 511) / 512) * (round_up(Cout, 32) / 64) >= 256) launch_conv_split_wide<32, 1, NTERM>(a, wsplit, s);   // measured: -6 % vs the 256-pixel tile
+  else { if (wide) launch_conv_split_t<32, 2, NTERM>(a, wsplit, s); else launch_conv_split_t<32, 1, NTERM>(a, wsplit, s); }
+}
+
+// nterm 3: bf16x6 (amax_* unused); nterm 2: f16x3, amax_in / amax_w = device slots holding the bit patterns of max|in|, max|w|
+void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias, float* out,
+                          int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep,
+                          int nterm, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out) {
   ConvArgs a{};
   if (ep) a.ep = *ep;
   a.in = in; a.wt = nullptr; a.bias = bias; a.out = out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("GR_BF16X6_VARIANT"); variant = e ? atoi(e) : 0; }
-  const bool wide = round_up(Cout, 32) % 64 == 0 && variant != 1;      // 64 output channels per workgroup (8 waves share one patch)
-  if (W <= 8) launch_conv_bf16x6_t<8, 1>(a, wsplit, s);
-  else if (W <= 16) {
-    // two stacked 16x16 images per 512-pixel tile (G.convA 799 -> 716 us) when that still leaves a workgroup for every CU
-    if (wide && variant != 4 && H == 16 && W == 16 && (long)((B + 1) / 2) * (round_up(Cout, 32) / 64) >= 256) launch_conv_bf16x6_wide<16, 2>(a, wsplit, s);
-    else if (wide) launch_conv_bf16x6_t<16, 2>(a, wsplit, s); else launch_conv_bf16x6_t<16, 1>(a, wsplit, s);
-  }
-  else if (wide && variant != 4 && (long)H * W >= 512 && (long)B * ((H * W + 511) / 512) * (round_up(Cout, 32) / 64) >= 256) launch_conv_bf16x6_wide<32>(a, wsplit, s);   // measured: -6 % vs the 256-pixel tile
-  else { if (wide) launch_conv_bf16x6_t<32, 2>(a, wsplit, s); else launch_conv_bf16x6_t<32, 1>(a, wsplit, s); }
+  a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
+  if (nterm == 2) launch_conv3x3_split_n<2>(a, wsplit, s); else launch_conv3x3_split_n<3>(a, wsplit, s);
 }
 
 // ---------------------------------------------------------------- weight layout preparation
@@ -781,6 +856,8 @@ __global__ void conv_weight_prep_batch_kernel(const PrepJob* __restrict__ jobs, 
   const float* w = params + j.w_off;
   if (j.split) {
     unsigned short* dst = reinterpret_cast<unsigned short*>(j.dst);
+    const int nterm = j.split == 2 ? 2 : 3;
+    const float sc = nterm == 2 ? pow2f(f16_scale_exp(absmax_read(j.amax))) : 1.f;
     const long n = (long)(j.cin_pad / BF_CK) * 9 * 2 * j.cout_pad * 8;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
       const int jj = (int)(i & 7); long r = i >> 3;
@@ -790,12 +867,8 @@ __global__ void conv_weight_prep_batch_kernel(const PrepJob* __restrict__ jobs, 
       const int ci = ch * BF_CK + 8 * hh + jj;
       float v = 0.f;
       if (ci < j.CI && oo < j.CO) v = j.bwd ? w[((long)ci * j.cin + oo) * 9 + (8 - tap)] : w[((long)oo * j.cin + ci) * 9 + tap];
-      const unsigned short t0 = f32_to_bf16(v); const float r1 = v - bf16_to_f32(t0);
-      const unsigned short t1 = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(t1);
-      const unsigned short t2 = f32_to_bf16(r2);
-      const long base = (long)ch * 3 * 9 * 2 * j.cout_pad * 8;
-      const long within = (((long)tap * 2 + hh) * j.cout_pad + oo) * 8 + jj, term = (long)9 * 2 * j.cout_pad * 8;
-      dst[base + within] = t0; dst[base + term + within] = t1; dst[base + 2 * term + within] = t2;
+      const long term = (long)9 * 2 * j.cout_pad * 8;
+      weight_split_store(dst, (long)ch * nterm * term, (((long)tap * 2 + hh) * j.cout_pad + oo) * 8 + jj, term, v, nterm, sc);
     }
   } else {
     float* dst = reinterpret_cast<float*>(j.dst);
@@ -812,15 +885,32 @@ __global__ void conv_weight_prep_batch_kernel(const PrepJob* __restrict__ jobs, 
   }
 }
 
-PrepJob make_prep_job(long w_off, void* dst, int cin, int cout, bool bwd, bool split) {
+// max|w| of every f16x3 job's weight tensor (blockIdx.y = job), slots zeroed by the launcher
+__global__ __launch_bounds__(256) void conv_weight_absmax_batch_kernel(const PrepJob* __restrict__ jobs, const float* __restrict__ params) {
+  const PrepJob j = jobs[blockIdx.y];
+  if (j.split != 2 || j.bwd) return;                 // the backward-data image shares the forward image's slot
+  const float* w = params + j.w_off;
+  const long n = (long)j.cin * j.cout * 9;
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+  absmax_commit(m, j.amax);
+}
+
+PrepJob make_prep_job(long w_off, void* dst, int cin, int cout, bool bwd, int split, unsigned* amax) {
   PrepJob j{};
-  j.w_off = w_off; j.dst = dst; j.cin = cin; j.cout = cout; j.bwd = bwd ? 1 : 0; j.split = split ? 1 : 0;
+  j.w_off = w_off; j.dst = dst; j.cin = cin; j.cout = cout; j.bwd = bwd ? 1 : 0; j.split = split; j.amax = amax;
   j.CI = bwd ? cout : cin; j.CO = bwd ? cin : cout;
   j.cin_pad = round_up(j.CI, split ? BF_CK : CONV_CK); j.cout_pad = round_up(j.CO, 32);
   return j;
 }
-void launch_conv_weight_prep_batch(const PrepJob* jobs_dev, int njobs, const float* params, hipStream_t s) {
+void launch_conv_weight_prep_batch(const PrepJob* jobs_dev, int njobs, const float* params, hipStream_t s,
+                                   unsigned* amax_slots, int n_slots) {
   if (njobs <= 0) return;
+  if (amax_slots) {                                   // f16x3 images: weight maxima first
+    (void)hipMemsetAsync(amax_slots, 0, sizeof(unsigned) * AMAX_WORDS * n_slots, s);
+    KtScope kt("conv_weight_absmax_batch_kernel", 0.0, 0.0, s);
+    hipLaunchKernelGGL(conv_weight_absmax_batch_kernel, dim3(16, njobs), dim3(256), 0, s, jobs_dev, params);
+  }
   KtScope kt("conv_weight_prep_batch_kernel", 0.0, 0.0, s);
   hipLaunchKernelGGL(conv_weight_prep_batch_kernel, dim3(96, njobs), dim3(256), 0, s, jobs_dev, params);
 }
@@ -835,7 +925,31 @@ struct WgradArgs {
   int B, Cin, Cout, H, W;
   int tiles_x, tiles_y, n_ob, n_cb, nsplit, cinp, coutp;
   long tiles_total;
+  const unsigned *amax_x = nullptr, *amax_dy = nullptr;    // f16x3 mode: bit patterns of max|x|, max|dy| (device)
 };
+
+// one scalar -> its split terms (halo columns of the weight-gradient kernels); f16 terms of the scaled value when NTERM == 2
+template <int NTERM>
+__device__ __forceinline__ void split1(float v, float sc, unsigned short* t) {
+  if (NTERM == 3) {
+    t[0] = f32_to_bf16(v); const float r1 = v - bf16_to_f32(t[0]);
+    t[1] = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(t[1]);
+    t[2] = f32_to_bf16(r2);
+  } else {
+    const float x = v * sc;
+    const _Float16 h0 = (_Float16)x; const float r = x - (float)h0; const _Float16 h1 = (_Float16)r;
+    t[0] = __builtin_bit_cast(unsigned short, h0); t[1] = __builtin_bit_cast(unsigned short, h1); t[2] = 0;
+  }
+}
+template <int NTERM>
+__device__ __forceinline__ void split8(const float* x, float sc, uint4* t) {
+  if (NTERM == 3) split8_bf16(x, t[0], t[1], t[2]); else split8_f16(x, sc, t[0], t[1]);
+}
+template <int NTERM>
+__device__ __forceinline__ f32x16 mma16(const uint4& a, const uint4& b, f32x16 acc) {
+  if (NTERM == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
 
 template <int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
@@ -1038,16 +1152,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_vec_kernel(WgradArgs a) 
 // registers from the aligned vector and its left/right neighbour with v_alignbit (no shifted copies in LDS).
 // Workgroup = 64 o x 64 ci x 9 taps over a strided set of 32-pixel tiles (1 row x 32 or 2 rows x 16), waves (mt, cg) keep
 // nine 32x32 accumulators; two workgroups per CU overlap one's split/convert/store phase with the other's MFMAs.
-template <int TW, int WPS>
-__global__ __launch_bounds__(256, WPS) void conv3x3_wgrad_bf16x6_kernel(WgradArgs a) {
+template <int TW, int WPS, int NTERM>
+__global__ __launch_bounds__(256, WPS) void conv3x3_wgrad_split_kernel(WgradArgs a) {
   constexpr int PT = 32, TR = PT / TW, PR = TR + 2, GI = TW / 8, GR = GI + 2;     // interior / total 8-pixel groups per row
   constexpr int XS = PR * GR + ((PR * GR) % 2 == 0 ? 1 : 0);                      // 16-byte units per channel, odd
   constexpr int DU = PT / 8, DS = DU + ((DU % 2 == 0) ? 1 : 0);                   // dy units per channel, odd
   constexpr int NXV = 64 * PR * GI / 256;        // interior vectors (8 floats) per thread
   constexpr int NHV = (64 * PR * 2 + 255) / 256; // halo scalars per thread
   static_assert((64 * PR * GI) % 256 == 0 && 64 * DU == 256, "staging shape");
-  __shared__ uint4 xs[3 * 64 * XS];
-  __shared__ uint4 ds[3 * 64 * DS];
+  __shared__ uint4 xs[NTERM * 64 * XS];
+  __shared__ uint4 ds[NTERM * 64 * DS];
+  int kx_ = 0, kdy_ = 0;
+  if (NTERM == 2) { kx_ = f16_scale_exp(absmax_read(a.amax_x)); kdy_ = f16_scale_exp(absmax_read(a.amax_dy)); }
+  const float sc_x = pow2f(kx_), sc_dy = pow2f(kdy_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int mt = wave >> 1, cg = wave & 1;
   int bid = blockIdx.x;
@@ -1094,21 +1211,6 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wgrad_bf16x6_kernel(WgradArg
       dv[0] = u0.x; dv[1] = u0.y; dv[2] = u0.z; dv[3] = u0.w; dv[4] = u1.x; dv[5] = u1.y; dv[6] = u1.z; dv[7] = u1.w; \
     }                                                                                                         \
   }
-  // split 8 floats into the three bf16 term vectors
-#define GR_SPLIT8(src_, t0_, t1_, t2_)                                                                       \
-  {                                                                                                           \
-    unsigned short s0_[8], s1_[8], s2_[8];                                                                    \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                           \
-      const float x_ = src_[j];                                                                               \
-      s0_[j] = f32_to_bf16(x_); const float r1_ = x_ - bf16_to_f32(s0_[j]);                                   \
-      s1_[j] = f32_to_bf16(r1_); const float r2_ = r1_ - bf16_to_f32(s1_[j]);                                 \
-      s2_[j] = f32_to_bf16(r2_);                                                                              \
-    }                                                                                                         \
-    t0_ = make_uint4(s0_[0] | (unsigned)s0_[1] << 16, s0_[2] | (unsigned)s0_[3] << 16, s0_[4] | (unsigned)s0_[5] << 16, s0_[6] | (unsigned)s0_[7] << 16); \
-    t1_ = make_uint4(s1_[0] | (unsigned)s1_[1] << 16, s1_[2] | (unsigned)s1_[3] << 16, s1_[4] | (unsigned)s1_[5] << 16, s1_[6] | (unsigned)s1_[7] << 16); \
-    t2_ = make_uint4(s2_[0] | (unsigned)s2_[1] << 16, s2_[2] | (unsigned)s2_[3] << 16, s2_[4] | (unsigned)s2_[5] << 16, s2_[6] | (unsigned)s2_[7] << 16); \
-  }
-
   long tile = split;
   bool have = tile < a.tiles_total;
   if (have) GR_WB_LOAD(tile)
@@ -1117,32 +1219,31 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wgrad_bf16x6_kernel(WgradArg
 #pragma unroll
     for (int i = 0; i < NXV; ++i) {
       const int f = tid + 256 * i, q = f % GI, r = (f / GI) % PR, ci = f / (GI * PR);
-      uint4 t0, t1, t2;
-      GR_SPLIT8(xv[i], t0, t1, t2)
+      uint4 tt[3];
+      split8<NTERM>(xv[i], sc_x, tt);
       const int u = ci * XS + r * GR + q + 1;
-      xs[u] = t0; xs[64 * XS + u] = t1; xs[2 * 64 * XS + u] = t2;
+#pragma unroll
+      for (int t = 0; t < NTERM; ++t) xs[t * 64 * XS + u] = tt[t];
     }
 #pragma unroll
     for (int i = 0; i < NHV; ++i) {
       const int e = tid + 256 * i, side = e & 1, r = (e >> 1) % PR, ci = (e >> 1) / PR;
       if (e < 64 * PR * 2) {
         // left halo group: only its last element (column x0-1) is ever read; right halo group: only its first (column x0+TW)
-        const float x_ = hv[i];
-        const unsigned short s0 = f32_to_bf16(x_); const float r1 = x_ - bf16_to_f32(s0);
-        const unsigned short s1 = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(s1);
-        const unsigned short s2 = f32_to_bf16(r2);
+        unsigned short st[3];
+        split1<NTERM>(hv[i], sc_x, st);
         const int u = ci * XS + r * GR + (side ? GR - 1 : 0);
-        xs[u] = side ? make_uint4(s0, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s0 << 16);
-        xs[64 * XS + u] = side ? make_uint4(s1, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s1 << 16);
-        xs[2 * 64 * XS + u] = side ? make_uint4(s2, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s2 << 16);
+#pragma unroll
+        for (int t = 0; t < NTERM; ++t) xs[t * 64 * XS + u] = side ? make_uint4(st[t], 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)st[t] << 16);
       }
     }
     {
       const int q = tid % DU, o = tid / DU;
-      uint4 t0, t1, t2;
-      GR_SPLIT8(dv, t0, t1, t2)
+      uint4 tt[3];
+      split8<NTERM>(dv, sc_dy, tt);
       const int u = o * DS + q;
-      ds[u] = t0; ds[64 * DS + u] = t1; ds[2 * 64 * DS + u] = t2;
+#pragma unroll
+      for (int t = 0; t < NTERM; ++t) ds[t * 64 * DS + u] = tt[t];
     }
     __syncthreads();
     const long next = tile + a.nsplit;
@@ -1152,26 +1253,25 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wgrad_bf16x6_kernel(WgradArg
 #pragma unroll
     for (int ks = 0; ks < PT / 16; ++ks) {
       const int pr = (16 * ks) / TW, g = ((16 * ks) % TW) / 8 + h;          // this lane's 8-pixel group in row pr
-      bf16x8 av[3];
+      uint4 av[NTERM];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) av[s] = __builtin_bit_cast(bf16x8, ds[(s * 64 + mt * 32 + l31) * DS + pr * GI + g]);
+      for (int s = 0; s < NTERM; ++s) av[s] = ds[(s * 64 + mt * 32 + l31) * DS + pr * GI + g];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
         const int ub = (cg * 32 + l31) * XS + (pr + ky) * GR + g;            // left neighbour unit; +1 current, +2 right neighbour
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {                                        // term of x; pairs with dy terms 0 .. 2-t
+        for (int t = 0; t < NTERM; ++t) {                                    // term of x; pairs with dy terms 0 .. NTERM-1-t
           const uint4 vl = xs[t * 64 * XS + ub], vc = xs[t * 64 * XS + ub + 1], vr = xs[t * 64 * XS + ub + 2];
           uint4 k0, k2;
           k0.x = __builtin_amdgcn_alignbit(vc.x, vl.w, 16); k0.y = __builtin_amdgcn_alignbit(vc.y, vc.x, 16);
           k0.z = __builtin_amdgcn_alignbit(vc.z, vc.y, 16); k0.w = __builtin_amdgcn_alignbit(vc.w, vc.z, 16);
           k2.x = __builtin_amdgcn_alignbit(vc.y, vc.x, 16); k2.y = __builtin_amdgcn_alignbit(vc.z, vc.y, 16);
           k2.z = __builtin_amdgcn_alignbit(vc.w, vc.z, 16); k2.w = __builtin_amdgcn_alignbit(vr.x, vc.w, 16);
-          const bf16x8 b0 = __builtin_bit_cast(bf16x8, k0), b1 = __builtin_bit_cast(bf16x8, vc), b2 = __builtin_bit_cast(bf16x8, k2);
 #pragma unroll
-          for (int sA = 2 - t; sA >= 0; --sA) {
-            acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b0, acc[ky * 3 + 0], 0, 0, 0);
-            acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b1, acc[ky * 3 + 1], 0, 0, 0);
-            acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b2, acc[ky * 3 + 2], 0, 0, 0);
+          for (int sA = NTERM - 1 - t; sA >= 0; --sA) {
+            acc[ky * 3 + 0] = mma16<NTERM>(av[sA], k0, acc[ky * 3 + 0]);
+            acc[ky * 3 + 1] = mma16<NTERM>(av[sA], vc, acc[ky * 3 + 1]);
+            acc[ky * 3 + 2] = mma16<NTERM>(av[sA], k2, acc[ky * 3 + 2]);
           }
         }
       }
@@ -1180,7 +1280,6 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wgrad_bf16x6_kernel(WgradArg
     tile = next; have = have_next;
   }
 #undef GR_WB_LOAD
-#undef GR_SPLIT8
   float* sl = a.slab + (size_t)split * 9 * a.coutp * a.cinp;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -1188,21 +1287,24 @@ __global__ __launch_bounds__(256, WPS) void conv3x3_wgrad_bf16x6_kernel(WgradArg
     for (int r = 0; r < 16; ++r) {
       const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       const int ci = c0 + cg * 32 + l31;
-      sl[((size_t)tap * a.coutp + o) * a.cinp + ci] = acc[tap][r];
+      sl[((size_t)tap * a.coutp + o) * a.cinp + ci] = NTERM == 2 ? ldexpf(acc[tap][r], -(kx_ + kdy_)) : acc[tap][r];
     }
 }
 
 // Rolling-window variant of the bf16x6 weight gradient: a workgroup walks a run of consecutive image rows, so each x row is
 // split/converted ONCE (into a ring of row groups in LDS) instead of once per tile that touches it (3x for one-row tiles).
 // Per step: TR rows of dy and TR new rows of x are fetched behind the previous step's 108 MFMAs per wave.
-template <int TW>
-__global__ __launch_bounds__(256, TW == 32 ? 2 : 1) void conv3x3_wgrad_bf16x6_roll_kernel(WgradArgs a, int rows_per_seg) {
+template <int TW, int NTERM>
+__global__ __launch_bounds__(256, TW == 32 ? 2 : 1) void conv3x3_wgrad_split_roll_kernel(WgradArgs a, int rows_per_seg) {
   constexpr int PT = 32, TR = PT / TW, NGP = (TR + 2) / TR, RR = NGP * TR, GI = TW / 8, GR = GI + 2;  // ring: NGP groups of TR rows
   constexpr int XS = RR * GR + ((RR * GR) % 2 == 0 ? 1 : 0);
   constexpr int DU = PT / 8, DS = DU + ((DU % 2 == 0) ? 1 : 0);
   static_assert(64 * TR * GI == 256 && 64 * DU == 256 && (TR + 2) % TR == 0, "one interior vector and one dy vector per thread");
-  __shared__ uint4 xs[3 * 64 * XS];
-  __shared__ uint4 ds[3 * 64 * DS];
+  __shared__ uint4 xs[NTERM * 64 * XS];
+  __shared__ uint4 ds[NTERM * 64 * DS];
+  int kx_ = 0, kdy_ = 0;
+  if (NTERM == 2) { kx_ = f16_scale_exp(absmax_read(a.amax_x)); kdy_ = f16_scale_exp(absmax_read(a.amax_dy)); }
+  const float sc_x = pow2f(kx_), sc_dy = pow2f(kdy_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int mt = wave >> 1, cg = wave & 1;
   int bid = blockIdx.x;
@@ -1224,19 +1326,6 @@ __global__ __launch_bounds__(256, TW == 32 ? 2 : 1) void conv3x3_wgrad_bf16x6_ro
   const int hside = tid & 1, hr = (tid >> 1) % TR, hci = (tid >> 1) / TR;     // valid for tid < 64*TR*2
   const int dq = tid % DU, dO = tid / DU;
   float xv[8], hv, dv[8];
-#define GR_SPLIT8(src_, t0_, t1_, t2_)                                                                       \
-  {                                                                                                           \
-    unsigned short s0_[8], s1_[8], s2_[8];                                                                    \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                           \
-      const float x_ = src_[j];                                                                               \
-      s0_[j] = f32_to_bf16(x_); const float r1_ = x_ - bf16_to_f32(s0_[j]);                                   \
-      s1_[j] = f32_to_bf16(r1_); const float r2_ = r1_ - bf16_to_f32(s1_[j]);                                 \
-      s2_[j] = f32_to_bf16(r2_);                                                                              \
-    }                                                                                                         \
-    t0_ = make_uint4(s0_[0] | (unsigned)s0_[1] << 16, s0_[2] | (unsigned)s0_[3] << 16, s0_[4] | (unsigned)s0_[5] << 16, s0_[6] | (unsigned)s0_[7] << 16); \
-    t1_ = make_uint4(s1_[0] | (unsigned)s1_[1] << 16, s1_[2] | (unsigned)s1_[3] << 16, s1_[4] | (unsigned)s1_[5] << 16, s1_[6] | (unsigned)s1_[7] << 16); \
-    t2_ = make_uint4(s2_[0] | (unsigned)s2_[1] << 16, s2_[2] | (unsigned)s2_[3] << 16, s2_[4] | (unsigned)s2_[5] << 16, s2_[6] | (unsigned)s2_[7] << 16); \
-  }
   // fetch x rows [ybase_, ybase_+TR) of image b_ (columns x0_..x0_+TW-1 plus the two halo columns) into registers
 #define GR_ROLL_LOAD_X(b_, ybase_, x0_)                                                                       \
   {                                                                                                           \
@@ -1261,26 +1350,24 @@ __global__ __launch_bounds__(256, TW == 32 ? 2 : 1) void conv3x3_wgrad_bf16x6_ro
   // registers -> split -> ring slot `slot_` (rows slot_*TR .. slot_*TR+TR-1 of the ring)
 #define GR_ROLL_STORE_X(slot_)                                                                                \
   {                                                                                                           \
-    uint4 t0, t1, t2;                                                                                         \
-    GR_SPLIT8(xv, t0, t1, t2)                                                                                 \
+    uint4 tt_[3];                                                                                             \
+    split8<NTERM>(xv, sc_x, tt_);                                                                             \
     const int u = xci * XS + ((slot_) * TR + xr) * GR + xq + 1;                                               \
-    xs[u] = t0; xs[64 * XS + u] = t1; xs[2 * 64 * XS + u] = t2;                                               \
+    _Pragma("unroll") for (int t = 0; t < NTERM; ++t) xs[t * 64 * XS + u] = tt_[t];                           \
     if (tid < 64 * TR * 2) {                                                                                  \
-      const unsigned short s0 = f32_to_bf16(hv); const float r1 = hv - bf16_to_f32(s0);                       \
-      const unsigned short s1 = f32_to_bf16(r1); const float r2 = r1 - bf16_to_f32(s1);                       \
-      const unsigned short s2 = f32_to_bf16(r2);                                                              \
+      unsigned short st_[3];                                                                                  \
+      split1<NTERM>(hv, sc_x, st_);                                                                           \
       const int uh = hci * XS + ((slot_) * TR + hr) * GR + (hside ? GR - 1 : 0);                              \
-      xs[uh] = hside ? make_uint4(s0, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s0 << 16);                     \
-      xs[64 * XS + uh] = hside ? make_uint4(s1, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s1 << 16);           \
-      xs[2 * 64 * XS + uh] = hside ? make_uint4(s2, 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)s2 << 16);       \
+      _Pragma("unroll") for (int t = 0; t < NTERM; ++t)                                                       \
+        xs[t * 64 * XS + uh] = hside ? make_uint4(st_[t], 0, 0, 0) : make_uint4(0, 0, 0, (unsigned)st_[t] << 16); \
     }                                                                                                         \
   }
 #define GR_ROLL_STORE_DY()                                                                                    \
   {                                                                                                           \
-    uint4 t0, t1, t2;                                                                                         \
-    GR_SPLIT8(dv, t0, t1, t2)                                                                                 \
+    uint4 tt_[3];                                                                                             \
+    split8<NTERM>(dv, sc_dy, tt_);                                                                            \
     const int u = dO * DS + dq;                                                                               \
-    ds[u] = t0; ds[64 * DS + u] = t1; ds[2 * 64 * DS + u] = t2;                                               \
+    _Pragma("unroll") for (int t = 0; t < NTERM; ++t) ds[t * 64 * DS + u] = tt_[t];                           \
   }
 
   for (long seg = split; seg < nsegs; seg += a.nsplit) {
@@ -1307,26 +1394,25 @@ __global__ __launch_bounds__(256, TW == 32 ? 2 : 1) void conv3x3_wgrad_bf16x6_ro
 #pragma unroll
       for (int ks = 0; ks < PT / 16; ++ks) {
         const int pr = (16 * ks) / TW, g = ((16 * ks) % TW) / 8 + h;
-        bf16x8 av[3];
+        uint4 av[NTERM];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) av[s] = __builtin_bit_cast(bf16x8, ds[(s * 64 + mt * 32 + l31) * DS + pr * GI + g]);
+        for (int s = 0; s < NTERM; ++s) av[s] = ds[(s * 64 + mt * 32 + l31) * DS + pr * GI + g];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const int ub = (cg * 32 + l31) * XS + rowoff[pr + ky] + g;
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
+          for (int t = 0; t < NTERM; ++t) {
             const uint4 vl = xs[t * 64 * XS + ub], vc = xs[t * 64 * XS + ub + 1], vr = xs[t * 64 * XS + ub + 2];
             uint4 k0, k2;
             k0.x = __builtin_amdgcn_alignbit(vc.x, vl.w, 16); k0.y = __builtin_amdgcn_alignbit(vc.y, vc.x, 16);
             k0.z = __builtin_amdgcn_alignbit(vc.z, vc.y, 16); k0.w = __builtin_amdgcn_alignbit(vc.w, vc.z, 16);
             k2.x = __builtin_amdgcn_alignbit(vc.y, vc.x, 16); k2.y = __builtin_amdgcn_alignbit(vc.z, vc.y, 16);
             k2.z = __builtin_amdgcn_alignbit(vc.w, vc.z, 16); k2.w = __builtin_amdgcn_alignbit(vr.x, vc.w, 16);
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, k0), b1 = __builtin_bit_cast(bf16x8, vc), b2 = __builtin_bit_cast(bf16x8, k2);
 #pragma unroll
-            for (int sA = 2 - t; sA >= 0; --sA) {
-              acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b0, acc[ky * 3 + 0], 0, 0, 0);
-              acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b1, acc[ky * 3 + 1], 0, 0, 0);
-              acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[sA], b2, acc[ky * 3 + 2], 0, 0, 0);
+            for (int sA = NTERM - 1 - t; sA >= 0; --sA) {
+              acc[ky * 3 + 0] = mma16<NTERM>(av[sA], k0, acc[ky * 3 + 0]);
+              acc[ky * 3 + 1] = mma16<NTERM>(av[sA], vc, acc[ky * 3 + 1]);
+              acc[ky * 3 + 2] = mma16<NTERM>(av[sA], k2, acc[ky * 3 + 2]);
             }
           }
         }
@@ -1340,7 +1426,6 @@ __global__ __launch_bounds__(256, TW == 32 ? 2 : 1) void conv3x3_wgrad_bf16x6_ro
       }
     }
   }
-#undef GR_SPLIT8
 #undef GR_ROLL_LOAD_X
 #undef GR_ROLL_LOAD_DY
 #undef GR_ROLL_STORE_X
@@ -1352,7 +1437,7 @@ __global__ __launch_bounds__(256, TW == 32 ? 2 : 1) void conv3x3_wgrad_bf16x6_ro
     for (int r = 0; r < 16; ++r) {
       const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       const int ci = c0 + cg * 32 + l31;
-      sl[((size_t)tap * a.coutp + o) * a.cinp + ci] = acc[tap][r];
+      sl[((size_t)tap * a.coutp + o) * a.cinp + ci] = NTERM == 2 ? ldexpf(acc[tap][r], -(kx_ + kdy_)) : acc[tap][r];
     }
 }
 
@@ -1515,7 +1600,7 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, floa
 
 static bool wgrad_use_vec(int W) { return W >= 16 && W % 4 == 0; }
 static bool wgrad_use_small(int Cin, int W) { return Cin <= 3 && W >= 16 && W % 4 == 0; }
-static bool wgrad_use_bf16x6(int mode, int Cin, int W) { return mode == 1 && Cin > 3 && W >= 16 && W % 8 == 0; }
+static bool wgrad_use_bf16x6(int mode, int Cin, int W) { return mode >= 1 && Cin > 3 && W >= 16 && W % 8 == 0; }   // either split flavour
 static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a, int& TW, int mode = 0) {
   TW = W <= 8 ? 8 : (W <= 16 ? 16 : 32);
   const bool split = wgrad_use_bf16x6(mode, Cin, W);
@@ -1541,11 +1626,27 @@ size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int mo
   return sizeof(float) * (size_t)a.nsplit * 9 * a.coutp * a.cinp;
 }
 
+template <int NTERM>
+static void launch_wgrad_split(const WgradArgs& a, int TW, int rps, int wv, int grid_, hipStream_t s) {
+  if (rps > 0) {
+    if (TW == 16) hipLaunchKernelGGL((conv3x3_wgrad_split_roll_kernel<16, NTERM>), dim3(grid_), dim3(256), 0, s, a, rps);
+    else hipLaunchKernelGGL((conv3x3_wgrad_split_roll_kernel<32, NTERM>), dim3(grid_), dim3(256), 0, s, a, rps);
+  } else if (TW == 16) {
+    if (wv == 1) hipLaunchKernelGGL((conv3x3_wgrad_split_kernel<16, 1, NTERM>), dim3(grid_), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_split_kernel<16, 2, NTERM>), dim3(grid_), dim3(256), 0, s, a);
+  } else {
+    if (wv == 1) hipLaunchKernelGGL((conv3x3_wgrad_split_kernel<32, 1, NTERM>), dim3(grid_), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_split_kernel<32, 2, NTERM>), dim3(grid_), dim3(256), 0, s, a);
+  }
+}
+
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,
-                          int B, int Cin, int Cout, int H, int W, hipStream_t s, int mode) {
+                          int B, int Cin, int Cout, int H, int W, hipStream_t s, int mode,
+                          const unsigned* amax_x, const unsigned* amax_dy) {
   WgradArgs a{}; int TW;
   wgrad_geometry(B, Cin, Cout, H, W, a, TW, mode);
   a.x = x; a.dy = dy; a.slab = reinterpret_cast<float*>(workspace);
+  a.amax_x = amax_x; a.amax_dy = amax_dy;
   if (wgrad_use_bf16x6(mode, Cin, W) && !wgrad_use_small(Cin, W)) {
     const double px_ = (double)B * H * W;
     {
@@ -1562,17 +1663,9 @@ void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* work
             if (nsegs >= a.nsplit && (nsegs % a.nsplit == 0 || nsegs >= 4L * a.nsplit || cand == TRr)) { rps = cand; break; }
           }
       }
-      const char* nm_ = rps > 0 ? (TW == 16 ? "conv3x3_wgrad_bf16x6_roll_kernel<16>" : "conv3x3_wgrad_bf16x6_roll_kernel<32>")
-                                : (TW == 16 ? "conv3x3_wgrad_bf16x6_kernel<16>" : "conv3x3_wgrad_bf16x6_kernel<32>");
-      KtScope kt(nm_, 2.0 * px_ * Cout * Cin * 9.0, 4.0 * (px_ * Cin + px_ * Cout + 9.0 * Cin * Cout), s);
-      if (rps > 0) {
-        if (TW == 16) hipLaunchKernelGGL(conv3x3_wgrad_bf16x6_roll_kernel<16>, dim3(grid_), dim3(256), 0, s, a, rps);
-        else hipLaunchKernelGGL(conv3x3_wgrad_bf16x6_roll_kernel<32>, dim3(grid_), dim3(256), 0, s, a, rps);
-      } else
-      if (TW == 16) { if (wv == 1) hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<16, 1>), dim3(grid_), dim3(256), 0, s, a);
-                      else hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<16, 2>), dim3(grid_), dim3(256), 0, s, a); }
-      else { if (wv == 1) hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<32, 1>), dim3(grid_), dim3(256), 0, s, a);
-             else hipLaunchKernelGGL((conv3x3_wgrad_bf16x6_kernel<32, 2>), dim3(grid_), dim3(256), 0, s, a); }
+      const std::string nm_ = std::string(mode == 2 ? "conv3x3_wgrad_f16x3_" : "conv3x3_wgrad_bf16x6_") + (rps > 0 ? "roll_kernel<" : "kernel<") + (TW == 16 ? "16>" : "32>");
+      KtScope kt(nm_.c_str(), 2.0 * px_ * Cout * Cin * 9.0, 4.0 * (px_ * Cin + px_ * Cout + 9.0 * Cin * Cout), s);
+      if (mode == 2) launch_wgrad_split<2>(a, TW, rps, wv, grid_, s); else launch_wgrad_split<3>(a, TW, rps, wv, grid_, s);
     }
     const long n_ = (long)9 * Cout * a.cinp;
     KtScope kt("conv3x3_wgrad_reduce8_kernel", (double)n_ * a.nsplit, 4.0 * n_ * (a.nsplit + 2.0), s);

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void post_forward_kernel(PostArgs a) {
   const int H = a.H, W = a.W, Ho = a.pool ? H >> 1 : H, Wo = a.pool ? W >> 1 : W;
   const long HW = (long)H * W, HWo = (long)Ho * Wo;
   const long n = (long)a.B * a.C * HWo;
+  float omax = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long bc = i / HWo; const int po = (int)(i - bc * HWo);
     const int c = (int)(bc % a.C);
@@ -81,8 +82,11 @@ __global__ __launch_bounds__(256) void post_forward_kernel(PostArgs a) {
     } else {
       r = act_fwd(bn_apply(a, a.y[i], c), a.act, a.slope) * mask_mul(a.m1, i, bc);
     }
-    a.out[i] = r * mask_mul(a.m2, i, bc);
+    const float res = r * mask_mul(a.m2, i, bc);
+    a.out[i] = res;
+    omax = fmaxf(omax, fabsf(res));
   }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
 // float4 variant: W % 4 == 0 (W % 8 == 0 with the pool).  One thread per 4 consecutive OUTPUT elements of a row; plane /
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
   const unsigned H = a.H, W = a.W, Ho = a.pool ? H >> 1 : H, Wo = a.pool ? W >> 1 : W;
   const unsigned HW = H * W, HWo = Ho * Wo, q_per_plane = HWo >> 2, wq = Wo >> 2;
   const unsigned n4 = (unsigned)a.B * a.C * q_per_plane;
+  float omax = 0.f;
   for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
     const unsigned bc = i4 / q_per_plane, within = i4 - bc * q_per_plane, c = bc % (unsigned)a.C;
     float mean = 0.f, invstd = 1.f, g = 1.f, bt = 0.f;
@@ -145,8 +150,11 @@ __global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
     } else {
       r = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + eo), mean, invstd, g, bt), mask4(a.m1, eo, bc));
     }
-    *reinterpret_cast<float4*>(a.out + eo) = mul4(r, mask4(a.m2, eo, bc));
+    const float4 res = mul4(r, mask4(a.m2, eo, bc));
+    *reinterpret_cast<float4*>(a.out + eo) = res;
+    omax = absmax4(omax, res);
   }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
 void launch_post_forward(const PostArgs& a, hipStream_t s) {
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(256) void post_backward_a_kernel(PostBwdArgs a, int
   const long j0 = sp * chunk, j1 = min(n, j0 + chunk);
   const float mean = f.has_bn ? f.mean[c] : 0.f;
   double s = 0, q = 0;
+  float dmax = 0.f;
   for (long j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
     const long b = j / HW; const int p = (int)(j - b * HW);
     const long bc = b * f.C + c, e = bc * HW + p;
@@ -286,9 +295,11 @@ __global__ __launch_bounds__(256) void post_backward_a_kernel(PostBwdArgs a, int
     const float av = act_fwd(z, f.act, f.slope);
     const float dz = act_bwd(g, z, av, f.act, f.slope);
     a.dy[e] = dz;
+    dmax = fmaxf(dmax, fabsf(dz));
     s += (double)dz;
     q += (double)(yv - mean) * (double)dz;
   }
+  if (a.amax_dy && !f.has_bn) absmax_commit(dmax, a.amax_dy);      // without BN pass A's dz is the final dy
   s = block_reduce_sum(s, sh);
   q = block_reduce_sum(q, sh);
   if (threadIdx.x == 0) { a.partials[((long)c * STAT_SPLITS + sp) * 2] = s; a.partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
@@ -305,6 +316,7 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
   float mean = 0.f, invstd = 1.f, gm = 1.f, bt = 0.f;
   if (f.has_bn) { mean = f.mean[c]; invstd = f.invstd[c]; gm = f.gamma[c]; bt = f.beta[c]; }
   double s = 0, q = 0;
+  float dmax = 0.f;
   const unsigned tot = (unsigned)(b1 - b0) * q4;
   {
     for (unsigned j = threadIdx.x; j < tot; j += 256) {
@@ -338,11 +350,13 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
       dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, f.slope), f.act, f.slope);
       dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, f.slope), f.act, f.slope);
       *reinterpret_cast<float4*>(a.dy + e) = dz;
+      dmax = absmax4(dmax, dz);
       s += (double)dz.x + (double)dz.y + (double)dz.z + (double)dz.w;
       q += (double)(yv.x - mean) * (double)dz.x + (double)(yv.y - mean) * (double)dz.y +
            (double)(yv.z - mean) * (double)dz.z + (double)(yv.w - mean) * (double)dz.w;
     }
   }
+  if (a.amax_dy && !f.has_bn) absmax_commit(dmax, a.amax_dy);      // without BN pass A's dz is the final dy
   s = block_reduce_sum(s, sh);
   q = block_reduce_sum(q, sh);
   if (threadIdx.x == 0) { a.partials[((long)c * STAT_SPLITS + sp) * 2] = s; a.partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
@@ -356,6 +370,7 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
   const int per = (f.B + splits - 1) / splits, b0 = sp * per, b1 = min(f.B, b0 + per);
   const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], gm = a.coef[2 * c], k = a.coef[2 * c + 1];
   double s = 0;
+  float dmax = 0.f;
   const unsigned tot = (unsigned)(b1 - b0) * q4;
   {
     for (unsigned j = threadIdx.x; j < tot; j += 256) {
@@ -368,9 +383,11 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
       d.x = ((dz.x - gm) - (yv.x - mean) * k) * invstd * w; d.y = ((dz.y - gm) - (yv.y - mean) * k) * invstd * w;
       d.z = ((dz.z - gm) - (yv.z - mean) * k) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * k) * invstd * w;
       dyp[i] = d;
+      dmax = absmax4(dmax, d);
       s += (double)d.x + (double)d.y + (double)d.z + (double)d.w;
     }
   }
+  if (a.amax_dy) absmax_commit(dmax, a.amax_dy);
   s = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) a.partials[((long)c * STAT_SPLITS + sp) * 2] = s;
 }
@@ -402,13 +419,16 @@ __global__ __launch_bounds__(256) void post_backward_b_kernel(PostBwdArgs a, int
   const long j0 = sp * chunk, j1 = min(n, j0 + chunk);
   const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], gm = a.coef[2 * c], k = a.coef[2 * c + 1];
   double s = 0;
+  float dmax = 0.f;
   for (long j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
     const long b = j / HW; const int p = (int)(j - b * HW);
     const long e = (b * f.C + c) * HW + p;
     const float d = ((a.dy[e] - gm) - (f.y[e] - mean) * k) * invstd * w;
     a.dy[e] = d;
+    dmax = fmaxf(dmax, fabsf(d));
     s += (double)d;
   }
+  if (a.amax_dy) absmax_commit(dmax, a.amax_dy);
   s = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) a.partials[((long)c * STAT_SPLITS + sp) * 2] = s;
 }

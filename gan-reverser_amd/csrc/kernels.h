@@ -37,6 +37,36 @@ inline ConvWeightLayout conv_weight_layout(int cin, int cout) {
 // optional fused epilogue of the conv kernels (evaluate()-mode BatchNorm + activation); mean == nullptr: BN skipped
 struct ConvEpilogue { const float *mean = nullptr, *invstd = nullptr, *gamma = nullptr, *beta = nullptr; int act = 0; float slope = 0.f; };
 
+// f16x3 scale tracking: a slot holds bit patterns of max|tensor| (a non-negative float orders like an unsigned).  A slot is
+// AMAX_ENTRIES words, each on its own 128-byte line; a producer workgroup folds its maximum into entry (linear block id %
+// AMAX_ENTRIES).  Workgroups are dispatched round-robin over the 8 XCDs, so one entry is only ever touched from one XCD
+// and its atomics stay in that XCD's L2 (one shared word ping-pongs between the eight L2s: measured 180 us per launch on a
+// 67 MB tensor against 20 us for the kernel itself).  The slot is zeroed before the producer runs; consumers take the
+// maximum over the entries.  The pre-check may read a stale (only ever smaller) value: at worst a redundant atomic.
+constexpr int AMAX_ENTRIES = 32, AMAX_STRIDE = 32, AMAX_WORDS = AMAX_ENTRIES * AMAX_STRIDE;   // 4 KB per tensor slot
+#if defined(__HIPCC__)
+__device__ __forceinline__ void absmax_commit(float m, unsigned* slot) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned b = __float_as_uint(m);
+    const unsigned lb = blockIdx.x + blockIdx.y * gridDim.x;
+    unsigned* e = slot + (lb % AMAX_ENTRIES) * AMAX_STRIDE;
+    if (b > __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(e, b);
+  }
+}
+// maximum over the entries of a slot; every lane of a fully active wave receives it
+__device__ __forceinline__ unsigned absmax_read(const unsigned* slot) {
+  unsigned v = slot[(threadIdx.x & (AMAX_ENTRIES - 1)) * AMAX_STRIDE];
+#pragma unroll
+  for (int o = AMAX_ENTRIES / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+  return v;
+}
+__device__ __forceinline__ float absmax4(float m, const float4& v) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+#endif
+
 // native [cout][cin][3][3] -> k-major (forward) ; or the transposed+flipped k-major the backward-data pass needs
 void launch_conv_weight_prep(const float* w_native, float* wt, int cin, int cout, bool for_backward_data, hipStream_t s);
 
@@ -51,20 +81,32 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
 // fp32-accurate convolution on the bf16 MFMA: operands split into 3 bf16 terms, 6 products, fp32 accumulation ("bf16x6").
 // wsplit = image made by launch_conv_weight_split (forward or backward-data flavour, like launch_conv_weight_prep).
 size_t conv_weight_split_bytes(int cin, int cout, bool for_backward_data);
-void launch_conv_weight_split(const float* w_native, void* wsplit, int cin, int cout, bool for_backward_data, hipStream_t s);
-void launch_conv3x3_bf16x6(const float* in, const void* wsplit, const float* bias, float* out,
-                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep = nullptr);
+// nterm 3 = bf16x6; nterm 2 = "f16x3": two fp16 terms of the power-of-two-scaled operands, 3 products.  The scales come from
+// device slots holding the bit pattern of max|tensor| (amax_*), filled by launch_absmax or by the producing kernel.
+void launch_absmax(const float* x, long n, unsigned* slot, hipStream_t s);       // zeroes the slot, then max|x| -> slot
+void launch_conv_weight_split(const float* w_native, void* wsplit, int cin, int cout, bool for_backward_data, hipStream_t s,
+                              int nterm = 3, unsigned* amax_w = nullptr);        // nterm 2: also computes amax_w
+void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias, float* out,
+                          int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep = nullptr,
+                          int nterm = 3, const unsigned* amax_in = nullptr, const unsigned* amax_w = nullptr,
+                          unsigned* amax_out = nullptr /* nullable: max|out| is folded into this slot by the epilogue */);
 
 // all weight images of a net in one launch
-struct PrepJob { long w_off; void* dst; int cin, cout, CI, CO, cin_pad, cout_pad, bwd, split; };
-PrepJob make_prep_job(long w_off, void* dst, int cin, int cout, bool for_backward_data, bool split);
-void launch_conv_weight_prep_batch(const PrepJob* jobs_dev, int njobs, const float* params, hipStream_t s);
+// split: 0 = fp32 k-major image, 1 = bf16 3-term image, 2 = f16 2-term image scaled by the slot `amax` (max|w|)
+struct PrepJob { long w_off; void* dst; int cin, cout, CI, CO, cin_pad, cout_pad, bwd, split; unsigned* amax; };
+PrepJob make_prep_job(long w_off, void* dst, int cin, int cout, bool for_backward_data, int split, unsigned* amax = nullptr);
+// amax_slots != null (f16 images): the n_slots weight maxima are recomputed first
+void launch_conv_weight_prep_batch(const PrepJob* jobs_dev, int njobs, const float* params, hipStream_t s,
+                                   unsigned* amax_slots = nullptr, int n_slots = 0);
 
 // weight gradient: slab workspace sized by conv_wgrad_workspace(); result accumulated (+=) into gw native layout
-// mode 1: bf16x6 split on the bf16 MFMA where the shape allows (W % 8 == 0, Cin > 3); 0: fp32 MFMA
+// mode 1: bf16x6 split on the bf16 MFMA where the shape allows (W % 8 == 0, Cin > 3); 2: f16x3 split (needs the maxima of
+// x and dy in device slots); 0: fp32 MFMA
 size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int mode = 0);
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,
-                          int B, int Cin, int Cout, int H, int W, hipStream_t s, int mode = 0);
+                          int B, int Cin, int Cout, int H, int W, hipStream_t s, int mode = 0,
+                          const unsigned* amax_x = nullptr, const unsigned* amax_dy = nullptr);
+inline bool conv_wgrad_is_split(int mode, int Cin, int W) { return mode >= 1 && Cin > 3 && W >= 16 && W % 8 == 0; }
 
 // ---------------------------------------------------------------- GEMM (Linear) on fp32 MFMA
 // C[m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  A(m,k) = A[m*rsA + k*ksA], B(n,k) = Bm[n*rsB + k*ksB]
@@ -89,6 +131,7 @@ struct PostArgs {
   int pool;                // 2x2 max pool, stride 2
   uint8_t* pool_idx;       // [B,C,Ho,Wo] argmax 0..3
   MaskRef m2;              // applied after the pool, indexed at [B,C,Ho,Wo] / [B,C]
+  unsigned* amax_out;      // nullable: max|out| is folded into this slot (f16x3 scale of the consuming convolution)
 };
 void launch_post_forward(const PostArgs& a, hipStream_t s);
 
@@ -106,6 +149,7 @@ struct PostBwdArgs {
   float* coef;             // [C][2] : gm, k   (BN backward coefficients)
   float* ggamma; float* gbeta;   // += (BN)
   float* gbias;            // += sum dy per channel (conv / linear bias), nullable
+  unsigned* amax_dy;       // nullable: max|dy| is folded into this slot (f16x3 scale of the weight / data gradients)
 };
 void launch_post_backward(const PostBwdArgs& a, hipStream_t s);
 

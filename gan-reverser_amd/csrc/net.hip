@@ -31,7 +31,8 @@ struct gr_ctx {
   double* d_loss = nullptr;     // device scalar
   double* h_loss = nullptr;     // pinned host scalar
   bool timing = false;
-  int conv_mode = 1;            // 1 = bf16x6 split (fp32-accurate, bf16 MFMA; default), 0 = exact fp32 MFMA
+  int conv_mode = 1;            // 1 = bf16x6 split (fp32-accurate, bf16 MFMA; default), 2 = f16x3 split (fp32-accurate, f16 MFMA), 0 = exact fp32 MFMA
+  unsigned* amax = nullptr;     // 4 scratch slots for the single-kernel entry points (f16x3 scales)
   hipEvent_t ev[7] = {};
   float times[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -103,11 +104,11 @@ extern "C" int gr_init(int device, gr_ctx** out) {
   gr_ctx* c = new gr_ctx();
   c->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&c->d_loss, 64) != hipSuccess || hipHostMalloc((void**)&c->h_loss, 64) != hipSuccess) {
+      hipMalloc((void**)&c->d_loss, 64) != hipSuccess || hipMalloc((void**)&c->amax, sizeof(unsigned) * 4 * AMAX_WORDS) != hipSuccess || hipHostMalloc((void**)&c->h_loss, 64) != hipSuccess) {
     delete c; return GR_ERR_HIP;
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
-  { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "f32") || !strcmp(m, "0")) ? 0 : 1; }
+  { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "f32") || !strcmp(m, "0")) ? 0 : ((!strcmp(m, "f16x3") || !strcmp(m, "2")) ? 2 : 1); }
   (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
@@ -121,7 +122,7 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
   if (c->ws) (void)hipFree(c->ws);
-  (void)hipFree(c->d_loss); (void)hipHostFree(c->h_loss);
+  (void)hipFree(c->d_loss); (void)hipFree(c->amax); (void)hipHostFree(c->h_loss);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
@@ -142,7 +143,7 @@ extern "C" int gr_device_info(gr_ctx* c, char* buf, int n) {
   return GR_OK;
 }
 extern "C" int gr_set_conv_mode(gr_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 1) return GR_ERR_INVALID;
+  if (!c || mode < 0 || mode > 2) return GR_ERR_INVALID;
   c->conv_mode = mode;
   return GR_OK;
 }
@@ -208,7 +209,9 @@ struct Stage {
   int outC = 0, outH = 0, outW = 0;
   float *y = nullptr, *out = nullptr; uint8_t* pool_idx = nullptr;
   float *wt_fwd = nullptr, *wt_bwd = nullptr; uint64_t wt_version = 0;
-  void *ws_fwd = nullptr, *ws_bwd = nullptr; uint64_t ws_version = 0;     // bf16x6 split images
+  void *ws_fwd = nullptr, *ws_bwd = nullptr; uint64_t ws_version = 0;     // bf16x6 / f16x3 split images
+  uint64_t amax_x_fwd = 0;                  // forward counter at which amax_x was last taken
+  unsigned *amax_x = nullptr, *amax_dy = nullptr, *amax_w = nullptr;   // f16x3: slots (in gr_net::amax) for max|x_in|, max|dy|, max|w|
   float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr;
   float *run_mean = nullptr, *run_var = nullptr;
   const float* x_in = nullptr;              // input of the last forward
@@ -231,8 +234,9 @@ struct gr_net {
   float *in_buf = nullptr, *gout_buf = nullptr, *dy_buf = nullptr, *g_buf[2] = {nullptr, nullptr};
   size_t max_y = 0, max_in = 0;      // per-sample element counts
   uint8_t* mask_stage = nullptr; size_t mask_stage_cap = 0;
-  PrepJob* jobs_dev[2] = {nullptr, nullptr}; int njobs[2] = {0, 0};   // [0] fp32 k-major images, [1] bf16x6 split images
-  uint64_t prepped_version[2] = {0, 0};
+  PrepJob* jobs_dev[3] = {nullptr, nullptr, nullptr}; int njobs[3] = {0, 0, 0};   // [0] fp32 k-major images, [1] bf16x6, [2] f16x3 split images
+  uint64_t prepped_version[3] = {0, 0, 0};
+  unsigned* amax = nullptr;          // f16x3 scale tracking: [nst] x slots, [nst] dy slots, [nst] weight slots
 };
 
 static int64_t vol3(int c, int h, int w) { return (int64_t)c * h * w; }
@@ -253,7 +257,7 @@ extern "C" int gr_net_destroy(gr_net* n) {
   for (auto& m : n->masks) (void)hipFree(m.bits);
   (void)hipFree(n->params); (void)hipFree(n->grads); (void)hipFree(n->adam_m); (void)hipFree(n->adam_v);
   (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
-  (void)hipFree(n->mask_stage); (void)hipFree(n->jobs_dev[0]); (void)hipFree(n->jobs_dev[1]);
+  (void)hipFree(n->mask_stage); (void)hipFree(n->jobs_dev[0]); (void)hipFree(n->jobs_dev[1]); (void)hipFree(n->jobs_dev[2]); (void)hipFree(n->amax);
   delete n;
   return GR_OK;
 }
@@ -374,22 +378,27 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
     if (ie > n->max_in) n->max_in = ie;
   }
   {
-    std::vector<PrepJob> jf, js;
+    std::vector<PrepJob> jf, js, jh;
+    HIPCHK(c, hipMalloc((void**)&n->amax, sizeof(unsigned) * AMAX_WORDS * 3 * n->st.size()));
+    HIPCHK(c, hipMemset(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * 3 * n->st.size()));
+    for (size_t si = 0, ns = n->st.size(); si < ns; ++si) { Stage& s = n->st[si]; s.amax_x = n->amax + AMAX_WORDS * si; s.amax_dy = n->amax + AMAX_WORDS * (ns + si); s.amax_w = n->amax + AMAX_WORDS * (2 * ns + si); }
     for (auto& s : n->st) {
       if (s.kind != ST_CONV) continue;
       if (!s.fullconv) {
-        jf.push_back(make_prep_job(s.w_off, s.wt_fwd, s.Cin, s.Cout, false, false));
-        jf.push_back(make_prep_job(s.w_off, s.wt_bwd, s.Cin, s.Cout, true, false));
-        js.push_back(make_prep_job(s.w_off, s.ws_fwd, s.Cin, s.Cout, false, true));
-        js.push_back(make_prep_job(s.w_off, s.ws_bwd, s.Cin, s.Cout, true, true));
+        jf.push_back(make_prep_job(s.w_off, s.wt_fwd, s.Cin, s.Cout, false, 0));
+        jf.push_back(make_prep_job(s.w_off, s.wt_bwd, s.Cin, s.Cout, true, 0));
+        js.push_back(make_prep_job(s.w_off, s.ws_fwd, s.Cin, s.Cout, false, 1));
+        js.push_back(make_prep_job(s.w_off, s.ws_bwd, s.Cin, s.Cout, true, 1));
+        jh.push_back(make_prep_job(s.w_off, s.ws_fwd, s.Cin, s.Cout, false, 2, s.amax_w));
+        jh.push_back(make_prep_job(s.w_off, s.ws_bwd, s.Cin, s.Cout, true, 2, s.amax_w));
       } else {
         // SpatialFullConvolution weight is [Cin][Cout][3][3]: its forward is the backward-data of a (Cout -> Cin) conv
-        jf.push_back(make_prep_job(s.w_off, s.wt_fwd, s.Cout, s.Cin, true, false));
-        jf.push_back(make_prep_job(s.w_off, s.wt_bwd, s.Cout, s.Cin, false, false));
+        jf.push_back(make_prep_job(s.w_off, s.wt_fwd, s.Cout, s.Cin, true, 0));
+        jf.push_back(make_prep_job(s.w_off, s.wt_bwd, s.Cout, s.Cin, false, 0));
       }
     }
-    for (int m = 0; m < 2; ++m) {
-      std::vector<PrepJob>& v = m ? js : jf;
+    for (int m = 0; m < 3; ++m) {
+      std::vector<PrepJob>& v = m == 0 ? jf : (m == 1 ? js : jh);
       n->njobs[m] = (int)v.size();
       if (!v.empty()) {
         HIPCHK(c, hipMalloc((void**)&n->jobs_dev[m], sizeof(PrepJob) * v.size()));
@@ -516,20 +525,23 @@ static int ensure_batch(gr_net* n, int B) {
 // bf16x6 mode: every plain convolution runs on the split kernel except few-output-channel layers the HBM-bound VALU
 // kernel covers (same predicate as launch_conv3x3); only the split images are kept current in that mode.
 static bool fewout_applies(const Stage& s) { return s.Cout <= 4 && !s.up && s.W % 4 == 0 && s.W >= 16; }
-static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode == 1 && s.kind == ST_CONV && !s.fullconv && !fewout_applies(s); }
+static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode >= 1 && s.kind == ST_CONV && !s.fullconv && !fewout_applies(s); }   // either split flavour
 // Re-lay every convolution's weights (one launch) when the parameters changed since the last time.  bf16x6 mode needs the
 // split images; the fp32 k-major images are still needed there by SpatialFullConvolution stages (no split kernel).
 static int prep_weights(gr_net* n) {
   gr_ctx* c = n->ctx;
-  const int mode = c->conv_mode == 1 ? 1 : 0;
+  const int mode = c->conv_mode;
   bool any_full = false;
   for (auto& s : n->st) any_full |= s.kind == ST_CONV && s.fullconv;
-  for (int m = 0; m < 2; ++m) {
+  for (int m = 0; m < 3; ++m) {
     if (!(m == mode || (m == 0 && any_full))) continue;
     if (n->prepped_version[m] == n->params_version) continue;
-    launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream);
+    // the bf16 and f16 images share their buffers: switching the mode invalidates the other flavour
+    if (m == 2) launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream, n->amax + AMAX_WORDS * 2 * n->st.size(), (int)n->st.size());
+    else launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream);
     LAUNCHCHK(c);
     n->prepped_version[m] = n->params_version;
+    if (m >= 1) n->prepped_version[3 - m] = 0;
   }
   return GR_OK;
 }
@@ -562,6 +574,7 @@ static PostArgs post_args(gr_net* n, Stage& s, int B) {
   bool nb;
   a.m1 = mask_ref(n, s.m1, nb); a.m2 = mask_ref(n, s.m2, nb);
   a.pool = s.pool ? 1 : 0; a.pool_idx = s.pool_idx;
+  a.amax_out = nullptr;
   return a;
 }
 
@@ -572,7 +585,14 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
   const float* x = in_dev;
   n->fwd_counter++;
   r = prep_weights(n); if (r) return r;
-  for (auto& s : n->st) {
+  const bool f16 = c->conv_mode == 2;
+  const size_t nst = n->st.size();
+  if (f16) HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst, c->stream));     // the x slots; producers fold maxima in
+  for (size_t si = 0; si < nst; ++si) {
+    Stage& s = n->st[si];
+    // f16x3: the kernel that writes this stage's output also tracks its max|.| for the convolution that consumes it
+    Stage* nx = (f16 && si + 1 < nst && use_bf16x6(n, n->st[si + 1])) ? &n->st[si + 1] : nullptr;
+    unsigned* amax_next = nx ? nx->amax_x : nullptr;
     s.x_in = x;
     s.fused_epilogue = false;
     if (s.kind == ST_CONV) {
@@ -588,7 +608,15 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         }
         ep.act = s.act; ep.slope = s.slope; epp = &ep; dst = s.out; s.fused_epilogue = true;
       }
-      if (use_bf16x6(n, s)) launch_conv3x3_bf16x6(x, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, epp);
+      if (use_bf16x6(n, s)) {
+        const int nterm = c->conv_mode == 2 ? 2 : 3;
+        // input not produced by a tracking kernel (the net's own input, a GEMM, a VALU conv): take its maximum now
+        if (nterm == 2 && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream); s.amax_x_fwd = n->fwd_counter; }
+        const bool last_writer = s.fused_epilogue || !s.has_post;
+        launch_conv3x3_split(x, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, epp, nterm, s.amax_x, s.amax_w,
+                             last_writer ? amax_next : nullptr);
+        if (last_writer && nx) nx->amax_x_fwd = n->fwd_counter;
+      }
       else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off, epp);
       if (s.fused_epilogue) { LAUNCHCHK(c); x = s.out; continue; }
     } else if (s.kind == ST_LINEAR) {
@@ -618,7 +646,10 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         m.n_last = elems;
       }
     }
-    launch_post_forward(post_args(n, s, B), c->stream);
+    PostArgs pa = post_args(n, s, B);
+    pa.amax_out = amax_next;
+    launch_post_forward(pa, c->stream);
+    if (nx) nx->amax_x_fwd = n->fwd_counter;
     LAUNCHCHK(c);
     x = s.out;
   }
@@ -683,6 +714,9 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
   if (B != n->lastB) return fail(c, GR_ERR_STATE, "backward batch %d does not match the last forward (%d)", B, n->lastB);
   reduce = reduce && c->comm != nullptr;
   int64_t bucket_hi = n->n_params;            // everything in [stage first offset, bucket_hi) is final but not yet reduced
+  { int r = prep_weights(n); if (r) return r; }   // no-op unless the arithmetic mode changed since the forward
+  const bool f16 = c->conv_mode == 2;
+  if (f16) HIPCHK(c, hipMemsetAsync(n->amax + AMAX_WORDS * n->st.size(), 0, sizeof(unsigned) * AMAX_WORDS * n->st.size(), c->stream));   // the dy slots
   const float* g = gout_dev;
   for (int si = (int)n->st.size() - 1; si >= 0; --si) {
     Stage& s = n->st[si];
@@ -699,16 +733,22 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     pb.partials = s.partials; pb.coef = s.coef;
     pb.ggamma = s.has_bn ? n->grads + s.g_off : nullptr; pb.gbeta = s.has_bn ? n->grads + s.be_off : nullptr;
     pb.gbias = s.kind == ST_ELEM ? nullptr : n->grads + s.b_off;
+    pb.amax_dy = (f16 && s.kind == ST_CONV && !s.up && !s.fullconv) ? s.amax_dy : nullptr;
     launch_post_backward(pb, c->stream);
     LAUNCHCHK(c);
     if (s.kind == ST_CONV) {
       if (s.up) return fail(c, GR_ERR_UNSUPPORTED, "backward through the fused UpSamplingNearest is not implemented (G is forward-only on this path)");
       if (s.fullconv) return fail(c, GR_ERR_UNSUPPORTED, "SpatialFullConvolution backward is not implemented");
       int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W, c->conv_mode)); if (r) return r;
-      launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode);
+      if (c->conv_mode == 2) {
+        // max|dy| was folded into s.amax_dy by the pipeline-backward kernel that wrote dy_buf
+        // x's maximum is current when this stage's forward ran on the f16x3 kernel; otherwise (few-channel input, mode switched) take it now
+        if (conv_wgrad_is_split(2, s.Cin, s.W) && s.amax_x_fwd != n->fwd_counter) launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream);
+      }
+      launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode, s.amax_x, s.amax_dy);
       if (need_gin) {
         // backward-data = the same convolution on the transposed + flipped weights (Cout -> Cin)
-        if (n->ctx->conv_mode == 1) launch_conv3x3_bf16x6(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+        if (c->conv_mode >= 1) launch_conv3x3_split(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
         else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
       }
       LAUNCHCHK(c);
@@ -960,17 +1000,19 @@ static int with_prepped(gr_ctx* c, const float* w, int cin, int cout, bool bwd, 
   LAUNCHCHK(c);
   return GR_OK;
 }
+// f16x3: the weight maximum goes to c->amax[2]
 static int conv_split_once(gr_ctx* c, const float* w, int cin, int cout, bool bwd, void** ws) {
   HIPCHK(c, hipMalloc(ws, conv_weight_split_bytes(cin, cout, bwd)));
-  launch_conv_weight_split(w, *ws, cin, cout, bwd, c->stream);
+  launch_conv_weight_split(w, *ws, cin, cout, bwd, c->stream, c->conv_mode == 2 ? 2 : 3, c->amax + 2 * AMAX_WORDS);
   LAUNCHCHK(c);
   return GR_OK;
 }
 extern "C" int gr_conv3_forward_dev(gr_ctx* c, const float* in, const float* w, const float* bias, float* out, int B, int cin, int cout, int h, int wd, int up) {
   if (!c || !in || !w || !out) return GR_ERR_INVALID;
-  if (c->conv_mode == 1 && cout > 4) {
+  if (c->conv_mode >= 1 && cout > 4) {
     void* ws = nullptr; int r = conv_split_once(c, w, cin, cout, false, &ws); if (r) return r;
-    launch_conv3x3_bf16x6(in, ws, bias, out, B, cin, cout, h, wd, up != 0, c->stream);
+    if (c->conv_mode == 2) launch_absmax(in, (long)B * cin * (up ? (h / 2) * (wd / 2) : h * wd), c->amax, c->stream);
+    launch_conv3x3_split(in, ws, bias, out, B, cin, cout, h, wd, up != 0, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, c->amax, c->amax + 2 * AMAX_WORDS);
     hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(ws);
     return e == hipSuccess ? GR_OK : fail(c, GR_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
   }
@@ -981,9 +1023,10 @@ extern "C" int gr_conv3_forward_dev(gr_ctx* c, const float* in, const float* w, 
 }
 extern "C" int gr_conv3_backward_data_dev(gr_ctx* c, const float* gout, const float* w, float* gin, int B, int cin, int cout, int h, int wd) {
   if (!c || !gout || !w || !gin) return GR_ERR_INVALID;
-  if (c->conv_mode == 1 && cin > 4) {
+  if (c->conv_mode >= 1 && cin > 4) {
     void* ws = nullptr; int r = conv_split_once(c, w, cin, cout, true, &ws); if (r) return r;
-    launch_conv3x3_bf16x6(gout, ws, nullptr, gin, B, cout, cin, h, wd, false, c->stream);
+    if (c->conv_mode == 2) launch_absmax(gout, (long)B * cout * h * wd, c->amax + AMAX_WORDS, c->stream);
+    launch_conv3x3_split(gout, ws, nullptr, gin, B, cout, cin, h, wd, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, c->amax + AMAX_WORDS, c->amax + 2 * AMAX_WORDS);
     hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(ws);
     return e == hipSuccess ? GR_OK : fail(c, GR_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
   }
@@ -995,7 +1038,11 @@ extern "C" int gr_conv3_backward_data_dev(gr_ctx* c, const float* gout, const fl
 extern "C" int gr_conv3_backward_weight_dev(gr_ctx* c, const float* in, const float* gout, float* gw, int B, int cin, int cout, int h, int wd) {
   if (!c || !in || !gout || !gw) return GR_ERR_INVALID;
   int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd, c->conv_mode)); if (r) return r;
-  launch_conv3x3_wgrad(in, gout, gw, c->ws, B, cin, cout, h, wd, c->stream, c->conv_mode);
+  if (c->conv_mode == 2 && conv_wgrad_is_split(2, cin, wd)) {
+    launch_absmax(in, (long)B * cin * h * wd, c->amax, c->stream);
+    launch_absmax(gout, (long)B * cout * h * wd, c->amax + AMAX_WORDS, c->stream);
+  }
+  launch_conv3x3_wgrad(in, gout, gw, c->ws, B, cin, cout, h, wd, c->stream, c->conv_mode, c->amax, c->amax + AMAX_WORDS);
   LAUNCHCHK(c);
   return GR_OK;
 }
@@ -1013,15 +1060,20 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   (void)hipMemsetAsync(gw, 0, sizeof(float) * nw, c->stream);
   int r = with_prepped(c, w, cin, cout, which == 1, &wt); if (r) return r;
   void* wsp = nullptr;
-  const bool split = c->conv_mode == 1 && which != 2 && (which == 0 ? cout > 4 : cin > 4);
+  const bool split = c->conv_mode >= 1 && which != 2 && (which == 0 ? cout > 4 : cin > 4);
+  const int nterm = c->conv_mode == 2 ? 2 : 3;
   if (split) { r = conv_split_once(c, w, cin, cout, which == 1, &wsp); if (r) return r; }
   r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd, c->conv_mode)); if (r) return r;
+  // f16x3 scales: taken once outside the timed loop (in a net the producing kernel tracks them), or per launch with GR_BENCH_ABSMAX
+  const bool amax_each = getenv("GR_BENCH_ABSMAX") != nullptr;
+  if (c->conv_mode == 2) { launch_absmax(x, (long)nin, c->amax, c->stream); launch_absmax(y, (long)nout, c->amax + AMAX_WORDS, c->stream); }
   auto run = [&]() {
-    if (split && which == 0) launch_conv3x3_bf16x6(x, wsp, nullptr, y, B, cin, cout, h, wd, false, c->stream);
-    else if (split && which == 1) launch_conv3x3_bf16x6(y, wsp, nullptr, x, B, cout, cin, h, wd, false, c->stream);
+    if (amax_each && c->conv_mode == 2) { if (which != 1) launch_absmax(x, (long)nin, c->amax, c->stream); if (which != 0) launch_absmax(y, (long)nout, c->amax + AMAX_WORDS, c->stream); }
+    if (split && which == 0) launch_conv3x3_split(x, wsp, nullptr, y, B, cin, cout, h, wd, false, c->stream, nullptr, nterm, c->amax, c->amax + 2 * AMAX_WORDS);
+    else if (split && which == 1) launch_conv3x3_split(y, wsp, nullptr, x, B, cout, cin, h, wd, false, c->stream, nullptr, nterm, c->amax + AMAX_WORDS, c->amax + 2 * AMAX_WORDS);
     else if (which == 0) launch_conv3x3(x, wt, nullptr, y, B, cin, cout, h, wd, false, c->stream, w);
     else if (which == 1) launch_conv3x3(y, wt, nullptr, x, B, cout, cin, h, wd, false, c->stream);
-    else launch_conv3x3_wgrad(x, y, gw, c->ws, B, cin, cout, h, wd, c->stream, c->conv_mode);
+    else launch_conv3x3_wgrad(x, y, gw, c->ws, B, cin, cout, h, wd, c->stream, c->conv_mode, c->amax, c->amax + AMAX_WORDS);
   };
   for (int i = 0; i < 3; ++i) run();
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);

@@ -262,12 +262,13 @@ class Context:
         self.check(self.lib.gr_allreduce_dev(self.h, _ptr(dptr), int(n)), "gr_allreduce_dev")
 
     def set_conv_mode(self, mode):
-        """0 / "f32": exact fp32 MFMA; 1 / "bf16x6": fp32-accurate 3-term bf16 split on the bf16 MFMA."""
-        mode = {"f32": 0, "bf16x6": 1}.get(mode, mode)
+        """0 / "f32": exact fp32 MFMA; 1 / "bf16x6": fp32-accurate 3-term bf16 split on the bf16 MFMA (6 products);
+        2 / "f16x3": fp32-accurate 2-term fp16 split of power-of-two-scaled operands on the f16 MFMA (3 products)."""
+        mode = {"f32": 0, "bf16x6": 1, "f16x3": 2}.get(mode, mode)
         self.check(self.lib.gr_set_conv_mode(self.h, int(mode)), "gr_set_conv_mode")
 
     def conv_mode(self):
-        return ("f32", "bf16x6")[self.lib.gr_get_conv_mode(self.h)]
+        return ("f32", "bf16x6", "f16x3")[self.lib.gr_get_conv_mode(self.h)]
 
     def set_timing(self, mode):
         self.check(self.lib.gr_set_timing(self.h, int(mode)), "gr_set_timing")

@@ -135,7 +135,10 @@ int gr_train_r_step(gr_net* gnet, gr_net* rnet, const float* noise_dev, int batc
 /* per-phase device times (ms) of the last gr_train_r_step when timing is enabled: [G fwd, R fwd, loss, R bwd, allreduce, adam] */
 /* convolution arithmetic: 1 = "bf16x6" (default): every fp32 operand split into three bf16 terms, six products on
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-level error (same parity bars), 2.7x the matrix rate;
- * 0 = exact fp32 on v_mfma_f32_32x32x2_f32.  Also settable with the environment variable GR_CONV_MODE=f32|bf16x6 before gr_init. */
+ * 2 = "f16x3": every operand tensor scaled by a power of two (its device-tracked max|.| -> [2^14, 2^15)) and split into two
+ * fp16 terms (22 significand bits), three products on v_mfma_f32_32x32x16_f16, result scaled back exactly — fp32-level
+ * error (same parity bars) with half the MFMAs of bf16x6;
+ * 0 = exact fp32 on v_mfma_f32_32x32x2_f32.  Also settable with the environment variable GR_CONV_MODE=f32|bf16x6|f16x3 before gr_init. */
 int gr_set_conv_mode(gr_ctx* ctx, int mode);
 int gr_get_conv_mode(gr_ctx* ctx);
 int gr_set_timing(gr_ctx* ctx, int mode /*0 off, 1 per-phase events in gr_train_r_step, 2 per-kernel events*/);

@@ -26,7 +26,7 @@ def ctx():
     return L.default_context()
 
 
-@pytest.fixture(params=["f32", "bf16x6"])
+@pytest.fixture(params=["f32", "bf16x6", "f16x3"])
 def conv_mode(request):
     """Run the test once per convolution arithmetic: exact fp32 MFMA, and the fp32-accurate 3-term bf16 split (bf16x6) that
     bench.py uses by default.  Same tolerances for both."""

@@ -11,6 +11,13 @@ from ganrev import models, synth
 import torch_twin as tt
 
 def split(x, n):
+    if SplitConv.dtype is torch.float16:
+        # fp16 terms need the tensor scaled into range: power-of-two scale putting max|x| into [2^14, 2^15)
+        m = float(x.abs().max()); sc = 2.0 ** (14 - np.floor(np.log2(m))) if m > 0 else 1.0
+        parts, r = [], x * sc
+        for _ in range(n):
+            p = r.to(torch.float16).to(torch.float32); parts.append(p / sc); r = r - p
+        return parts
     parts, r = [], x
     for _ in range(n):
         p = r.to(torch.bfloat16).to(torch.float32); parts.append(p); r = r - p
@@ -18,6 +25,7 @@ def split(x, n):
 
 class SplitConv(torch.autograd.Function):
     n = 2
+    dtype = torch.bfloat16
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
@@ -75,12 +83,12 @@ running = [(m.running_mean.copy(), m.running_var.copy()) for m in R.leaves() if 
 x = synth.uniform((B,) + dims, 5, 0, 1)
 ref = tt.Twin(descs, dims, R._flat_host(), running, True, masks)
 out64 = ref.forward(x); gy = synth.normal(out64.shape, 9) * np.float32(0.1); g64 = ref.backward(gy)
-for mode, n in (("fp32", 0), ("split", 2), ("split", 3)):
+for mode, n, dt in (("fp32", 0, None), ("split", 2, torch.bfloat16), ("split", 3, torch.bfloat16), ("split", 2, torch.float16)):
     t = Twin32(descs, dims, R._flat_host(), running, True, masks)
     t.params = [None if p is None else tuple(q.detach().float().requires_grad_(True) for q in p) for p in t.params]
-    t.mode = mode; SplitConv.n = n
+    t.mode = mode; SplitConv.n = n; SplitConv.dtype = dt
     o = t.forward(x)
     flat_p = [q for p in t.params if p is not None for q in p]
     grads = torch.autograd.grad(t.out, flat_p, torch.tensor(gy), allow_unused=True)
     g = np.concatenate([(gg if gg is not None else torch.zeros_like(q)).reshape(-1).numpy() for gg, q in zip(grads, flat_p)])
-    print(f"{mode:5s} n={n}: out max|err| {np.abs(o - out64).max():.3e}   grad max|err| {np.abs(g - g64).max():.3e} (max|g| {np.abs(g64).max():.3f})  rel-to-max {np.abs(g-g64).max()/np.abs(g64).max():.3e}")
+    print(f"{mode:5s} n={n} {str(dt):15s}: out max|err| {np.abs(o - out64).max():.3e}   grad max|err| {np.abs(g - g64).max():.3e} (max|g| {np.abs(g64).max():.3f})  rel-to-max {np.abs(g-g64).max()/np.abs(g64).max():.3e}")
