@@ -549,13 +549,15 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
 // 512-pixel x 64-channel tile: all 8 waves keep BOTH 32-channel blocks (4 accumulators each) for their own 64 pixels, so one
 // weight fetch and one patch conversion feed twice the MFMAs of the 256-pixel tile and every operand read feeds two MFMAs.
 // NI > 1: the tile is NI whole images (16x16 planes: two of them), their zero-padded patches stacked in LDS.
-template <int TW, int NI, int NTERM>
+template <int TW, int NI, int NTERM, bool DB>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
   constexpr int NT = 512, MT = 2;
   constexpr int NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
   constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // DB: two LDS images; chunk c+1 is converted and stored in the middle of chunk c's MFMA phase (one barrier per chunk)
+  constexpr int LBUF = NTERM * 2 * PS + WROWS * CT;               // uint4s of one (patch, weights) image
   uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [NTERM][2][PS]   (one uint4 = 8 bf16 / f16)
   uint4* wts = patch + NTERM * 2 * PS;                            // [NTERM][9][2][CT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -597,21 +599,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
   static_assert(CT == 64 && NT % CT == 0, "weight rows advance by NT / CT per staging slot");
 #define GR_BF_LOAD(ch_)                                                                                   \
   {                                                                                                       \
-    const bool tail_ = ((ch_) + 1) * BF_CK > a.Cin;                                                       \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
       const int soff_ = (int)(((ch_) * BF_CK + j) * HWs * 4);                                             \
-      _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                   \
-        const float v_ = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
-        pv[s][j] = (tail_ && (ch_) * BF_CK + j >= clim[s]) ? 0.f : v_;                                    \
-      }                                                                                                   \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
+        pv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
     }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
       const int soff_ = (((ch_) * WROWS + (NT / CT) * i) * a.cout_pad) * 16;                              \
       wv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rwt, wvoff, soff_, 0));     \
     }                                                                                                     \
   }
-#define GR_BF_STORE()                                                                                     \
+#define GR_BF_STORE(patch, wts, ch_)                                                                      \
   {                                                                                                       \
+    if (((ch_) + 1) * BF_CK > a.Cin) {   /* last, partial chunk: channels past Cin read the next image - zero them */ \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) if ((ch_) * BF_CK + j >= clim[s]) pv[s][j] = 0.f;   \
+    }                                                                                                     \
     _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
       const int eh = tid + NT * s;                                                                        \
       if (eh < NEH) {                                                                                     \
@@ -642,13 +645,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
     const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;                   // skip the padding rows between stacked images
     pix[ng] = h * PS + pr * PC + pc;
   }
-  GR_BF_LOAD(0)
-  for (int ch = 0; ch < nchunks; ++ch) {
-    GR_BF_STORE()
-    __syncthreads();
-    if (ch + 1 < nchunks) GR_BF_LOAD(ch + 1)
-    uint4 avA[MT][NTERM], bvA[NG][NTERM];
-#define GR_BF_OPS(tap_, av_, bv_)                                                                        \
+#define GR_BF_OPS(patch, wts, tap_, av_, bv_)                                                            \
     {                                                                                                     \
       const int toff_ = ((tap_) / 3) * PC + ((tap_) % 3);                                                 \
       _Pragma("unroll") for (int s = 0; s < NTERM; ++s) {                                                 \
@@ -659,14 +656,65 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
 #define GR_BF_MMA(av_, bv_)                                                                               \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                     \
     _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) acc[mt][ng] = split_mma<NTERM>(av_[mt], bv_[ng], acc[mt][ng]);
-    // one operand set: a second set (tap t+1 fetched behind tap t's MFMAs) measured no faster - on random data these
-    // kernels run at the clock the chip holds under MFMA load, not at an issue or latency limit
+  // one tap's worth: (MT + NG) * NTERM LDS reads (for the next tap) first, then MT * NG * (NTERM == 3 ? 6 : 3) MFMAs
+#define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, (MT + NG) * NTERM, 0); __builtin_amdgcn_sched_group_barrier(0x008, MT * NG * (NTERM == 3 ? 6 : 3), 0);
+  GR_BF_LOAD(0)
+  if (DB) {
+    GR_BF_STORE(patch, wts, 0)
+    if (nchunks > 1) GR_BF_LOAD(1)
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      uint4* pc_ = patch + (ch & 1) * LBUF; uint4* wc_ = wts + (ch & 1) * LBUF;
+      uint4* pn_ = patch + ((ch + 1) & 1) * LBUF; uint4* wn_ = wts + ((ch + 1) & 1) * LBUF;
+      uint4 avA[MT][NTERM], bvA[NG][NTERM], avB[MT][NTERM], bvB[NG][NTERM];
+      // operands of tap t+1 are fetched before the MFMAs of tap t (two register sets, pinned order)
+      GR_BF_OPS(pc_, wc_, 0, avA, bvA)
+      GR_BF_OPS(pc_, wc_, 1, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 2, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 3, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 4, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+      // the other image is free since the last barrier: convert + store chunk ch+1 while the matrix pipe drains the taps
+      // above (the partner wave on this SIMD keeps it busy meanwhile), then fetch chunk ch+2 behind the remaining taps
+      if (ch + 1 < nchunks) GR_BF_STORE(pn_, wn_, ch + 1)
+      if (ch + 2 < nchunks) GR_BF_LOAD(ch + 2)
+      GR_BF_OPS(pc_, wc_, 5, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 6, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 7, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 8, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+      GR_BF_MMA(avA, bvA)
+      __syncthreads();
+    }
+  } else {
+    for (int ch = 0; ch < nchunks; ++ch) {
+      GR_BF_STORE(patch, wts, ch)
+      __syncthreads();
+      if (ch + 1 < nchunks) GR_BF_LOAD(ch + 1)
+      if (NTERM == 3) {
+        // one operand set: a second set (tap t+1 fetched behind tap t's MFMAs) measured no faster on bf16x6 - on random data
+        // those kernels run at the clock the chip holds under MFMA load, not at an issue or latency limit
+        uint4 avA[MT][NTERM], bvA[NG][NTERM];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) { GR_BF_OPS(tap, avA, bvA) GR_BF_MMA(avA, bvA) }
+        for (int tap = 0; tap < 9; ++tap) { GR_BF_OPS(patch, wts, tap, avA, bvA) GR_BF_MMA(avA, bvA) }
+      } else {
+        // f16x3 has twice the LDS reads per MFMA: with one set the compiler waits on lgkmcnt(0) three times per tap
+        uint4 avA[MT][NTERM], bvA[NG][NTERM], avB[MT][NTERM], bvB[NG][NTERM];
+        GR_BF_OPS(patch, wts, 0, avA, bvA)
+        GR_BF_OPS(patch, wts, 1, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+        GR_BF_OPS(patch, wts, 2, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+        GR_BF_OPS(patch, wts, 3, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+        GR_BF_OPS(patch, wts, 4, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+        GR_BF_OPS(patch, wts, 5, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+        GR_BF_OPS(patch, wts, 6, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+        GR_BF_OPS(patch, wts, 7, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+        GR_BF_OPS(patch, wts, 8, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+        GR_BF_MMA(avA, bvA)
+      }
+      __syncthreads();
+    }
+  }
 #undef GR_BF_OPS
 #undef GR_BF_MMA
-    __syncthreads();
-  }
+#undef GR_BF_PIN
 #undef GR_BF_LOAD
 #undef GR_BF_STORE
   float omax = 0.f;
@@ -776,20 +824,29 @@ static void launch_conv_split_t(ConvArgs a, const void* wsplit, hipStream_t s) {
   hipLaunchKernelGGL((conv3x3_split_kernel<TW, MT, NTERM>), dim3(grid), dim3(256 * MT), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
 }
 
-template <int TW, int NI, int NTERM>
-static void launch_conv_split_wide(ConvArgs a, const void* wsplit, hipStream_t s) {
+template <int TW, int NI, int NTERM, bool DB>
+static void launch_conv_split_wide_db(ConvArgs a, const void* wsplit, hipStream_t s) {
   constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
   a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
-  const size_t lds = 16 * (size_t)(NTERM * 2 * PS + NTERM * 9 * 2 * CT);
+  const size_t lds = (DB ? 2 : 1) * 16 * (size_t)(NTERM * 2 * PS + NTERM * 9 * 2 * CT);
+  static_assert((DB ? 2 : 1) * 16 * (NTERM * 2 * PS + NTERM * 9 * 2 * CT) <= 160 * 1024, "LDS");
   const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_wide_kernel<TW, NI, NTERM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  // the names the timing table and the profiles use (the symbol is conv3x3_split_wide_kernel<TW, NI, NTERM>)
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_wide_kernel<TW, NI, NTERM, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  // the names the timing table and the profiles use (the symbol is conv3x3_split_wide_kernel<TW, NI, NTERM, DB>)
   static const std::string name = std::string(NTERM == 3 ? "conv3x3_bf16x6_wide_kernel<" : "conv3x3_f16x3_wide_kernel<") + std::to_string(TW) + ", " + std::to_string(NI) + ">";
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_split_wide_kernel<TW, NI, NTERM>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
+  hipLaunchKernelGGL((conv3x3_split_wide_kernel<TW, NI, NTERM, DB>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
+}
+template <int TW, int NI, int NTERM>
+static void launch_conv_split_wide(const ConvArgs& a, const void* wsplit, hipStream_t s) {
+  // two f16x3 images fit the 160 KB LDS (152-157 KB): double-buffered; three-term bf16 images do not
+  static int db = -1;
+  if (db < 0) { const char* e = getenv("GR_CONV_DB"); db = e ? atoi(e) : 1; }
+  if (NTERM == 2 && db) launch_conv_split_wide_db<TW, NI, 2, true>(a, wsplit, s);
+  else launch_conv_split_wide_db<TW, NI, NTERM, false>(a, wsplit, s);
 }
 
 template <int NTERM>
