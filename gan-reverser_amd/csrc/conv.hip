@@ -546,6 +546,19 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
+// Which pixel of the 512-pixel tile lane l of 32-lane group g = p / 32 owns (p = 32 g + l).  ds_read_b128 serves a wave in four
+// fixed 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...): it is conflict-free when lane l reads 16-byte slot
+// (base + l) mod 16 of the 256-byte bank row.  A 32-wide tile row does that by itself.  A 16-wide tile puts lanes 16-31 on
+// another patch row: rows 8 apart are 8 * 18 slots = 0 (mod 16) apart (adjacent rows are 18 = 2 apart: 2-way conflicts, a
+// third of all LDS cycles on the counters).  An 8-wide tile (patch rows of 10 slots, 8 stacked images) needs row offsets
+// 0, 8, 0, 8 (mod 16): rows q, q+4 of image i and of image i+4.
+template <int TW>
+__device__ __forceinline__ void tile_pixel(int p, int& prr, int& pc) {
+  if (TW == 16) { const int g = p >> 5, l = p & 31; prr = (g >> 3) * 16 + (g & 7) + 8 * (l >> 4); pc = l & 15; }
+  else if (TW == 8) { const int g = p >> 5, l = p & 31, j = l >> 3; prr = ((g >> 2) + 4 * (j >> 1)) * 8 + (g & 3) + 4 * (j & 1); pc = l & 7; }
+  else { prr = p / TW; pc = p - prr * TW; }
+}
+
 // 512-pixel x 64-channel tile: all 8 waves keep BOTH 32-channel blocks (4 accumulators each) for their own 64 pixels, so one
 // weight fetch and one patch conversion feed twice the MFMAs of the 256-pixel tile and every operand read feeds two MFMAs.
 // NI > 1: the tile is NI whole images (16x16 planes: two of them), their zero-padded patches stacked in LDS.
@@ -555,6 +568,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
   constexpr int NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
   constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
+  static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2), "tile_pixel assumes these tilings");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // DB: two LDS images; chunk c+1 is converted and stored in the middle of chunk c's MFMA phase (one barrier per chunk)
   constexpr int LBUF = NTERM * 2 * PS + WROWS * CT;               // uint4s of one (patch, weights) image
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
   int pix[NG];
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31, prr = p / TW, pc = p - prr * TW;
+    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
     const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;                   // skip the padding rows between stacked images
     pix[ng] = h * PS + pr * PC + pc;
   }
@@ -720,7 +734,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
   float omax = 0.f;
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31, prr = p / TW, pc = p - prr * TW;
+    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
     const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
     const int y = y0 + pr, x = x0 + pc;
     if (y < H && x < W && b + img < a.B) {
@@ -740,6 +754,246 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
     }
   }
   if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+
+// ---------------------------------------------------------------- nearest x2 up-sampling + 3x3 convolution as four 2x2 convolutions
+// nn.SpatialUpSamplingNearest(2) followed by the 3x3 convolution (G: models.lua:121-122,127-128) reads every source pixel
+// through several taps: for output pixel (2y+a, 2x+b) the three tap rows 2y+a-1 .. 2y+a+1 of the up-sampled plane are only
+// TWO source rows (y-1+a and y+a), and likewise the columns.  Summing the taps that land on the same source pixel turns the
+// layer into four 2x2 convolutions of the SOURCE plane, one per output phase (a, b): 4 multiply-adds per output instead
+// of 9 (2.25x fewer MFMAs), identical zero-padding behaviour (a tap group never straddles the border), and the only
+// numerical difference is the order in which up to four weights are added (done in double by the prep kernel).
+// Workgroup: 512 source pixels x 32 output channels x all four phases (a 128-row "virtual channel" block: accumulator
+// block [a][b], so a lane ends up with the 2x2 outputs of its source pixel and stores two float2).  K is walked in chunks
+// of 16 input channels like the plain kernel; per chunk 3 rows x 3 source columns of B operands feed 16 weight slots
+// (a, dy, b, dx) - one patch conversion serves 96 MFMAs per wave.  f16x3 arithmetic only.
+//   LDS patch   [2 terms][2 halves][PS] (zero-padded source patch, 1-pixel halo; NI whole images stacked)
+//   LDS weights [2 terms][2 a][8 slots = (dy, b, dx)][2 halves][32 o]
+template <int TW, int NI>
+__global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, const uint4* __restrict__ wup) {
+  constexpr int NT = 512, NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
+  constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;
+  constexpr int WV = 2 * 2 * 8 * 2 * 32, NWV = WV / NT;           // 2048 weight vectors per chunk: 4 per thread
+  static_assert(NI == 1 || IH * NI * TW == PT, "tile must hold whole images");
+  static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2) || (TW == 8 && NI == 8), "tile_pixel assumes these tilings");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [2][2][PS]
+  uint4* wts = patch + 2 * 2 * PS;                                // [2 terms][2 a][8 slots][2 halves][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = (bid / a.tiles_y) * NI;
+  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * 32;
+  const int Hs = a.H >> 1, Ws = a.W >> 1;                        // source plane
+  const size_t HWs = (size_t)Hs * Ws;
+  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
+  const size_t in_left = (size_t)(a.B - b) * a.Cin * HWs * sizeof(float);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
+      (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
+  const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
+  // weight image [chunk][term][a][slot][half][cout_pad]: 64 rows per chunk, this workgroup takes its 32 channels of each
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wup), 0,
+      (int)((size_t)nchunks * 64 * a.cout_pad * 16), 0x00020000);
+  const int kin = f16_scale_exp(absmax_read(a.amax_in));
+  const int ktot = kin + f16_scale_exp(absmax_read(a.amax_w)) - 2;   // summed weights: up to 4 max|w|
+  const float sc_in = pow2f(kin);
+  int voff[NSL], clim[NSL];
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) {
+    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
+    const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
+    const int yy = y0 + r - 1, xx = x0 + c - 1;
+    const bool inb = eh < NEH && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws && b + img < a.B;
+    const int so = yy * Ws + xx + (img * a.Cin + 8 * hh) * (int)HWs;
+    voff[s] = inb ? so * 4 : (int)0x7FFFF000;
+    clim[s] = a.Cin - 8 * hh;
+  }
+  const int wvoff = ((tid >> 5) * a.cout_pad + o0 + (tid & 31)) * 16;   // weight vector f = tid + NT*i: row (tid>>5) + 16i
+  float pv[NSL][8];
+  uint4 wv[NWV];
+#define GR_UP_LOAD(ch_)                                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
+      const int soff_ = (int)(((ch_) * BF_CK + j) * HWs * 4);                                             \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
+        pv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
+    }                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NWV; ++i)                                                       \
+      wv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rwt, wvoff, ((ch_) * 64 + 16 * i) * a.cout_pad * 16, 0)); \
+  }
+#define GR_UP_STORE(ch_)                                                                                  \
+  {                                                                                                       \
+    if (((ch_) + 1) * BF_CK > a.Cin) {                                                                    \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) if ((ch_) * BF_CK + j >= clim[s]) pv[s][j] = 0.f;   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
+      const int eh = tid + NT * s;                                                                        \
+      if (eh < NEH) {                                                                                     \
+        const int hh = eh >= PS ? 1 : 0, e = eh - hh * PS;                                                \
+        uint4 t0, t1;                                                                                     \
+        split8_f16(pv[s], sc_in, t0, t1);                                                                 \
+        patch[(0 * 2 + hh) * PS + e] = t0; patch[(1 * 2 + hh) * PS + e] = t1;                             \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NWV; ++i) wts[tid + NT * i] = wv[i];                            \
+  }
+  f32x16 acc[2][2][NG];                                            // [row phase a][column phase b][pixel group]
+#pragma unroll
+  for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pa][pb][ng][r] = 0.f;
+  int pix[NG];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;
+    pix[ng] = h * PS + pr * PC + pc;                               // patch row pr = source row y - 1
+  }
+  GR_UP_LOAD(0)
+  for (int ch = 0; ch < nchunks; ++ch) {
+    GR_UP_STORE(ch)
+    __syncthreads();
+    if (ch + 1 < nchunks) GR_UP_LOAD(ch + 1)
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) {                               // source rows y-1, y, y+1
+      uint4 bv[3][NG][2];                                          // source columns x-1, x, x+1
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3)
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bv[c3][ng][t] = patch[t * 2 * PS + pix[ng] + r3 * PC + c3];
+#pragma unroll
+      for (int pa = 0; pa < 2; ++pa) {
+        const int dy = r3 - pa;                                    // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
+        if (dy < 0 || dy > 1) continue;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            uint4 av[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = wts[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[pb + dx][ng], acc[pa][pb][ng]);
+          }
+      }
+    }
+    __syncthreads();
+  }
+#undef GR_UP_LOAD
+#undef GR_UP_STORE
+  // per-channel epilogue operands first (16 channels per lane), then the stores: two output rows x float2 per lane
+  float omax = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (o < a.Cout) {
+      const float bvv = a.bias ? a.bias[o] : 0.f;
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) {
+        const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+        const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
+        const int y = y0 + pr, x = x0 + pc;
+        if (y < Hs && x < Ws && b + img < a.B) {
+#pragma unroll
+          for (int pa = 0; pa < 2; ++pa) {
+            float2 res;
+            res.x = conv_epilogue(a.ep, ldexpf(acc[pa][0][ng][r], -ktot) + bvv, o);
+            res.y = conv_epilogue(a.ep, ldexpf(acc[pa][1][ng][r], -ktot) + bvv, o);
+            *reinterpret_cast<float2*>(a.out + (((size_t)(b + img) * a.Cout + o) * a.H + 2 * y + pa) * a.W + 2 * x) = res;
+            omax = fmaxf(omax, fmaxf(fabsf(res.x), fabsf(res.y)));
+          }
+        }
+      }
+    }
+  }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+
+// weight image of the up-sampling kernel: [cin_pad16/16][2 terms][2 a][8 slots (dy, b, dx)][2 halves][cout_pad32][8 ch] f16,
+// slot weight = sum of the taps (ky, kx) that read source pixel (y - 1 + a + dy, x - 1 + b + dx): ky in {0} / {1,2} (a = 0) or
+// {0,1} / {2} (a = 1) for dy = 0 / 1, the same for kx with (b, dx); summed in double, scaled by 2^(k_w - 2), split in two terms.
+__device__ __forceinline__ void up2_taps(int phase, int d, int& k0, int& k1) {
+  if (phase == 0) { if (d == 0) { k0 = 0; k1 = 0; } else { k0 = 1; k1 = 2; } }
+  else { if (d == 0) { k0 = 0; k1 = 1; } else { k0 = 2; k1 = 2; } }
+}
+__device__ void weight_up2_split(const float* __restrict__ w, unsigned short* __restrict__ dst, int cin, int cout, int cin_pad, int cout_pad,
+                                 const unsigned* amax, long i0, long stride) {
+  const float sc = pow2f(f16_scale_exp(absmax_read(amax)) - 2);
+  const long n = (long)(cin_pad / BF_CK) * 2 * 8 * 2 * cout_pad * 8;     // one thread per (chunk, a, slot, half, o, j): writes both terms
+  for (long i = i0; i < n; i += stride) {
+    const int j = (int)(i & 7); long r = i >> 3;
+    const int oo = (int)(r % cout_pad); r /= cout_pad;
+    const int hh = (int)(r & 1); r >>= 1;
+    const int slot = (int)(r & 7); r >>= 3;
+    const int pa = (int)(r & 1); const int ch = (int)(r >> 1);
+    const int dy = slot >> 2, pb = (slot >> 1) & 1, dx = slot & 1;
+    const int ci = ch * BF_CK + 8 * hh + j;
+    double v = 0.0;
+    if (ci < cin && oo < cout) {
+      int ky0, ky1, kx0, kx1;
+      up2_taps(pa, dy, ky0, ky1); up2_taps(pb, dx, kx0, kx1);
+      const float* wp = w + ((long)oo * cin + ci) * 9;
+      for (int ky = ky0; ky <= ky1; ++ky) for (int kx = kx0; kx <= kx1; ++kx) v += (double)wp[ky * 3 + kx];
+    }
+    const double x = v * (double)sc;
+    const _Float16 h0 = (_Float16)x; const double rr = x - (double)h0; const _Float16 h1 = (_Float16)rr;
+    const long term = (long)2 * 8 * 2 * cout_pad * 8;                  // elements of one term plane of a chunk
+    const long within = ((((long)pa * 8 + slot) * 2 + hh) * cout_pad + oo) * 8 + j;
+    dst[(long)ch * 2 * term + within] = __builtin_bit_cast(unsigned short, h0);
+    dst[(long)ch * 2 * term + term + within] = __builtin_bit_cast(unsigned short, h1);
+  }
+}
+__global__ void conv_weight_up2_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int cin, int cout,
+                                             int cin_pad, int cout_pad, const unsigned* __restrict__ amax) {
+  weight_up2_split(w, dst, cin, cout, cin_pad, cout_pad, amax, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+size_t conv_weight_up2_bytes(int cin, int cout) { return (size_t)(round_up(cin, BF_CK) / BF_CK) * 64 * round_up(cout, 32) * 16; }
+bool conv_up2_supported(int Cin, int Cout, int H, int W) {
+  const int Hs = H / 2, Ws = W / 2;
+  if (H % 2 || W % 2 || Cout <= 4) return false;
+  return (Hs == 8 && Ws == 8) || (Hs == 16 && Ws == 16) || Ws >= 17;
+}
+void launch_conv_weight_up2_split(const float* w_native, void* dst, int cin, int cout, hipStream_t s, unsigned* amax_w, bool take_absmax) {
+  if (take_absmax) launch_absmax(w_native, (long)cin * cout * 9, amax_w, s);
+  KtScope kt("conv_weight_up2_split_kernel", 0.0, 0.0, s);
+  hipLaunchKernelGGL(conv_weight_up2_split_kernel, dim3(512), dim3(256), 0, s, w_native, reinterpret_cast<unsigned short*>(dst), cin, cout,
+                     round_up(cin, BF_CK), round_up(cout, 32), amax_w);
+}
+template <int TW, int NI>
+static void launch_conv_up2_t(ConvArgs a, const void* wup, hipStream_t s) {
+  constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2);
+  const int Hs = a.H / 2, Ws = a.W / 2;
+  a.tiles_x = (Ws + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (Hs + TR - 1) / TR;
+  a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / 32;
+  const size_t lds = 16 * (size_t)(2 * 2 * PS + 2 * 2 * 8 * 2 * 32);
+  const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_f16x3_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = "conv3x3_up2_f16x3_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";
+  const double px = (double)a.B * a.H * a.W;
+  // FLOPs reported = those of the layer as the reference defines it (9 taps per output); the kernel issues 4/9 of them
+  KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+  hipLaunchKernelGGL((conv3x3_up2_f16x3_kernel<TW, NI>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wup));
+}
+// in: [B, Cin, H/2, W/2]; out: [B, Cout, H, W] = conv3x3(nearest-upsample x2 (in)); wup from launch_conv_weight_up2_split
+void launch_conv3x3_up2_f16x3(const float* in, const void* wup, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                              hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out) {
+  ConvArgs a{};
+  if (ep) a.ep = *ep;
+  a.in = in; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = 1;
+  a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
+  const int Ws = W / 2;
+  if (Ws == 8) launch_conv_up2_t<8, 8>(a, wup, s);
+  else if (Ws == 16) launch_conv_up2_t<16, 2>(a, wup, s);
+  else launch_conv_up2_t<32, 1>(a, wup, s);
 }
 
 // ---------------------------------------------------------------- max|x| of a tensor (f16x3 scale tracking)

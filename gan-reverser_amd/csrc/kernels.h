@@ -91,6 +91,15 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
                           int nterm = 3, const unsigned* amax_in = nullptr, const unsigned* amax_w = nullptr,
                           unsigned* amax_out = nullptr /* nullable: max|out| is folded into this slot by the epilogue */);
 
+// nearest x2 up-sampling + conv3x3 as four 2x2 convolutions of the source plane (f16x3 arithmetic; forward only):
+// 4 instead of 9 multiply-adds per output.  Shapes: source plane 8x8, 16x16 or at least 17 wide; Cout > 4.
+bool conv_up2_supported(int Cin, int Cout, int H, int W);
+size_t conv_weight_up2_bytes(int cin, int cout);
+void launch_conv_weight_up2_split(const float* w_native, void* wup, int cin, int cout, hipStream_t s, unsigned* amax_w,
+                                  bool take_absmax = true);   // take_absmax: recompute the slot max|w| first
+void launch_conv3x3_up2_f16x3(const float* in, const void* wup, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                              hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out);
+
 // all weight images of a net in one launch
 // split: 0 = fp32 k-major image, 1 = bf16 3-term image, 2 = f16 2-term image scaled by the slot `amax` (max|w|)
 struct PrepJob { long w_off; void* dst; int cin, cout, CI, CO, cin_pad, cout_pad, bwd, split; unsigned* amax; };

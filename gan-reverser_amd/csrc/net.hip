@@ -210,6 +210,7 @@ struct Stage {
   float *y = nullptr, *out = nullptr; uint8_t* pool_idx = nullptr;
   float *wt_fwd = nullptr, *wt_bwd = nullptr; uint64_t wt_version = 0;
   void *ws_fwd = nullptr, *ws_bwd = nullptr; uint64_t ws_version = 0;     // bf16x6 / f16x3 split images
+  void* ws_up = nullptr; uint64_t ws_up_version = 0;   // f16x3 image of the fused up-sampling kernel (four 2x2 convolutions)
   uint64_t amax_x_fwd = 0;                  // forward counter at which amax_x was last taken
   unsigned *amax_x = nullptr, *amax_dy = nullptr, *amax_w = nullptr;   // f16x3: slots (in gr_net::amax) for max|x_in|, max|dy|, max|w|
   float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr;
@@ -250,7 +251,7 @@ extern "C" int gr_net_destroy(gr_net* n) {
   for (auto& s : n->st) {
     if (s.kind != ST_ELEM) (void)hipFree(s.y);
     if (s.has_post) (void)hipFree(s.out);
-    (void)hipFree(s.pool_idx); (void)hipFree(s.wt_fwd); (void)hipFree(s.wt_bwd); (void)hipFree(s.ws_fwd); (void)hipFree(s.ws_bwd);
+    (void)hipFree(s.pool_idx); (void)hipFree(s.wt_fwd); (void)hipFree(s.wt_bwd); (void)hipFree(s.ws_fwd); (void)hipFree(s.ws_up); (void)hipFree(s.ws_bwd);
     (void)hipFree(s.mean); (void)hipFree(s.invstd); (void)hipFree(s.coef); (void)hipFree(s.partials);
     (void)hipFree(s.run_mean); (void)hipFree(s.run_var);
   }
@@ -372,6 +373,7 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
       const ConvWeightLayout lb = conv_weight_layout(s.Cout, s.Cin);
       if (hipMalloc((void**)&s.wt_fwd, sizeof(float) * lf.elems()) || hipMalloc((void**)&s.wt_bwd, sizeof(float) * lb.elems())) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
       if (!s.fullconv && (hipMalloc(&s.ws_fwd, conv_weight_split_bytes(s.Cin, s.Cout, false)) || hipMalloc(&s.ws_bwd, conv_weight_split_bytes(s.Cin, s.Cout, true)))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
+      if (!s.fullconv && s.up && conv_up2_supported(s.Cin, s.Cout, s.H, s.W) && hipMalloc(&s.ws_up, conv_weight_up2_bytes(s.Cin, s.Cout))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
     }
     const size_t ye = (size_t)vol3(s.Cout, s.H, s.W), ie = (size_t)vol3(s.inC, s.inH, s.inW);
     if (ye > n->max_y) n->max_y = ye;
@@ -543,6 +545,13 @@ static int prep_weights(gr_net* n) {
     n->prepped_version[m] = n->params_version;
     if (m >= 1) n->prepped_version[3 - m] = 0;
   }
+  if (mode == 2)            // up-sampling stages: the pre-summed four-phase image (its max|w| slot was just refreshed by the batch)
+    for (auto& s : n->st)
+      if (s.ws_up && s.ws_up_version != n->params_version) {
+        launch_conv_weight_up2_split(n->params + s.w_off, s.ws_up, s.Cin, s.Cout, c->stream, s.amax_w, false);
+        LAUNCHCHK(c);
+        s.ws_up_version = n->params_version;
+      }
   return GR_OK;
 }
 
@@ -613,8 +622,13 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         // input not produced by a tracking kernel (the net's own input, a GEMM, a VALU conv): take its maximum now
         if (nterm == 2 && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream); s.amax_x_fwd = n->fwd_counter; }
         const bool last_writer = s.fused_epilogue || !s.has_post;
-        launch_conv3x3_split(x, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, epp, nterm, s.amax_x, s.amax_w,
-                             last_writer ? amax_next : nullptr);
+        static const bool up2_on = !getenv("GR_NO_UP2");
+        if (nterm == 2 && s.up && s.ws_up && up2_on)
+          launch_conv3x3_up2_f16x3(x, s.ws_up, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, s.amax_x, s.amax_w,
+                                   last_writer ? amax_next : nullptr);
+        else
+          launch_conv3x3_split(x, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, epp, nterm, s.amax_x, s.amax_w,
+                               last_writer ? amax_next : nullptr);
         if (last_writer && nx) nx->amax_x_fwd = n->fwd_counter;
       }
       else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off, epp);
@@ -1067,7 +1081,14 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   // f16x3 scales: taken once outside the timed loop (in a net the producing kernel tracks them), or per launch with GR_BENCH_ABSMAX
   const bool amax_each = getenv("GR_BENCH_ABSMAX") != nullptr;
   if (c->conv_mode == 2) { launch_absmax(x, (long)nin, c->amax, c->stream); launch_absmax(y, (long)nout, c->amax + AMAX_WORDS, c->stream); }
+  void* wup = nullptr;
+  if (which == 3) {      // fused up-sampling layer: x is the source plane [B, cin, h/2, wd/2] (a quarter of the buffer), y the output
+    if (c->conv_mode != 2 || !conv_up2_supported(cin, cout, h, wd)) return fail(c, GR_ERR_UNSUPPORTED, "up2 bench needs f16x3 mode and a supported shape");
+    HIPCHK(c, hipMalloc(&wup, conv_weight_up2_bytes(cin, cout)));
+    launch_conv_weight_up2_split(w, wup, cin, cout, c->stream, c->amax + 2 * AMAX_WORDS, true);
+  }
   auto run = [&]() {
+    if (which == 3) { launch_conv3x3_up2_f16x3(x, wup, nullptr, y, B, cin, cout, h, wd, c->stream, nullptr, c->amax, c->amax + 2 * AMAX_WORDS, nullptr); return; }
     if (amax_each && c->conv_mode == 2) { if (which != 1) launch_absmax(x, (long)nin, c->amax, c->stream); if (which != 0) launch_absmax(y, (long)nout, c->amax + AMAX_WORDS, c->stream); }
     if (split && which == 0) launch_conv3x3_split(x, wsp, nullptr, y, B, cin, cout, h, wd, false, c->stream, nullptr, nterm, c->amax, c->amax + 2 * AMAX_WORDS);
     else if (split && which == 1) launch_conv3x3_split(y, wsp, nullptr, x, B, cout, cin, h, wd, false, c->stream, nullptr, nterm, c->amax + AMAX_WORDS, c->amax + 2 * AMAX_WORDS);
@@ -1084,7 +1105,7 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
   *avg_ms = ms / iters;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(wt); (void)hipFree(gw); (void)hipFree(wsp);
+  (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(wt); (void)hipFree(gw); (void)hipFree(wsp); (void)hipFree(wup);
   LAUNCHCHK(c);
   return GR_OK;
 }
