@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "bf16x6"), choices=["f32", "bf16x6", "f16x3"],
+    ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "f16x3"), choices=["f32", "bf16x6", "f16x3"],
                     help="convolution arithmetic (all meet the 1e-4 parity bar; see DESIGN.md)")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
     args = ap.parse_args()
@@ -167,15 +167,27 @@ def main():
         ctx.set_timing(0)
         fl_img, g_fl, r_fl = step_flops_per_image(dims, nd)
         mfma = [k for k in kt if k["kernel"].startswith("conv3x3_") and k["flops"] > 1e9 and "reduce" not in k["kernel"]
-                and "fewout" not in k["kernel"] and "small" not in k["kernel"]]
+                and "fewout" not in k["kernel"] and "fewin" not in k["kernel"] and "small" not in k["kernel"]]
         dom = max(mfma, key=lambda k: k["total_ms"])
         avg_ms = dom["total_ms"] / dom["launches"]
         achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-        split = "bf16x6" in dom["kernel"] or "f16x3" in dom["kernel"]
-        passes = F16X3_PASSES if "f16x3" in dom["kernel"] else BF16X6_PASSES
+        # kernel names are the symbols rocprofv3 prints; the split kernels carry their number of terms as a template argument
+        # (conv3x3_split_wide_kernel<TW, NI, NTERM, DB>, conv3x3_split_kernel<TW, MT, NTERM>, conv3x3_wgrad_split_*<..., NTERM>)
+        kname = dom["kernel"]
+        passes = 0
+        if "_split_" in kname:
+            targs = [t.strip() for t in kname[kname.index("<") + 1:kname.rindex(">")].split(",")]
+            nterm = int(targs[2]) if ("split_wide" in kname or kname.startswith("conv3x3_split_kernel")) else int(targs[-1])
+            passes = {3: BF16X6_PASSES, 2: F16X3_PASSES}[nterm]
+        elif "f16x3" in kname:
+            passes = F16X3_PASSES
+        split = passes > 0
         # split modes: the kernel issues `passes` 16-bit MFMA products per algorithmic multiply-add; its ceiling for
         # ALGORITHMIC flops is the dense 16-bit MFMA peak / passes
         peak = PEAK_BF16_MFMA_TFLOPS / passes if split else PEAK_FP32_MFMA_TFLOPS
+        up2 = "up2" in kname
+        if up2:     # fused up-sampling layer: the reference's 9 taps per output collapse to 4 (conv.hip), so the ceiling for the
+            peak *= 9.0 / 4.0   # reference-algorithm FLOPs this line is quoted in is 9/4 of the issued-FLOP ceiling
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
@@ -186,7 +198,8 @@ def main():
         roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
                         frac=round(achieved / peak, 4), traffic=traffic,
                         peak_note=(f"dense bf16/f16 MFMA 2500 TFLOP/s / {passes} products per fp32-accurate multiply-add "
-                                   f"({'f16x3' if passes == 3 else 'bf16x6'} split); issued MFMA rate = {passes} x achieved") if split else "fp32 MFMA v_mfma_f32_32x32x2_f32",
+                                   f"({'f16x3' if passes == 3 else 'bf16x6'} split); issued MFMA rate = {passes} x achieved"
+                                   + (" x 4/9 (up-sampling taps pre-summed: four 2x2 convolutions)" if up2 else "")) if split else "fp32 MFMA v_mfma_f32_32x32x2_f32",
                         frac_of_fp32_mfma_peak=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                         avg_launch_ms=round(avg_ms, 4), launches_per_step=dom["launches"] / nprof,
                         algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3))

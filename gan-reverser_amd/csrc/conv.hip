@@ -41,6 +41,33 @@ struct ConvArgs {
 
 // out = act(((conv + bias - mean) * invstd) * gamma + beta): the per-channel pipeline of an evaluate()-mode stage
 // (G on this path: models.lua:122-124,128-130), same operation order and roundings as the stand-alone pipeline kernel.
+// the same epilogue for a whole register block: the (workgroup-uniform) activation switch is taken once, not per element
+template <int N>
+__device__ __forceinline__ void conv_act_block(const ConvEpilogue& ep, float (&v)[N]) {
+  switch (ep.act) {
+    case ACT_ELU:
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = v[i] <= 0.f ? (expf(v[i]) - 1.f) : v[i];
+      break;
+    case ACT_RELU:
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+      break;
+    case ACT_LEAKYRELU:
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = v[i] > 0.f ? v[i] : __fmul_rn(v[i], ep.slope);
+      break;
+    case ACT_SIGMOID:
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = 1.f / (1.f + expf(-v[i]));
+      break;
+    case ACT_TANH:
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = tanhf(v[i]);
+      break;
+    default: break;
+  }
+}
 __device__ __forceinline__ float conv_epilogue(const ConvEpilogue& ep, float v, int o) {
   if (ep.mean) v = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v, ep.mean[o]), ep.invstd[o]), ep.gamma[o]), ep.beta[o]);
   switch (ep.act) {
@@ -278,6 +305,76 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const f
   }
 }
 
+// Few input channels (Cin <= 3: R's first convolution on gray / RGB images, models.lua:409): 9*Cin multiply-adds per output
+// cannot feed a matrix pipe (a 16-channel MFMA chunk would be 13/16 or 15/16 zeros); the layer is bound by writing its 64
+// output planes.  VALU kernel: a workgroup owns a 32x32 output tile of one image, a thread 4 consecutive pixels of a row;
+// its 3 x 6 x Cin input window lives in registers, weights arrive through the scalar cache (uniform per workgroup), every
+// output channel costs 36*Cin FMAs and one float4 store.  Accumulation order: (ci, ky, kx) ascending, fp32 FMA.
+template <int CI>
+__global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const float* __restrict__ w_native) {
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int H = a.H, W = a.W;
+  const size_t HW = (size_t)H * W;
+  const int y = ty * 32 + (tid >> 3), x = tx * 32 + 4 * (tid & 7);
+  const bool pin = y < H && x < W;                            // W % 4 == 0: the four pixels are in or out together
+  float v[CI][3][6];
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+      const bool rin = pin && yy >= 0 && yy < H;
+      const float* rp = a.in + ((size_t)b * CI + ci) * HW + (size_t)(rin ? yy : 0) * W + (pin ? x : 0);
+      const float4 m = rin ? *reinterpret_cast<const float4*>(rp) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[ci][ky][0] = (rin && x > 0) ? rp[-1] : 0.f;
+      v[ci][ky][1] = m.x; v[ci][ky][2] = m.y; v[ci][ky][3] = m.z; v[ci][ky][4] = m.w;
+      v[ci][ky][5] = (rin && x + 4 < W) ? rp[4] : 0.f;
+    }
+  float omax = 0.f;
+  for (int o = 0; o < a.Cout; ++o) {
+    const float* wp = w_native + (size_t)o * CI * 9;          // uniform address: scalar loads
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float wv = wp[(ci * 3 + ky) * 3 + kx];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, v[ci][ky][j + kx], acc[j]);
+        }
+    const float bv = a.bias ? a.bias[o] : 0.f;
+    float4 r = make_float4(conv_epilogue(a.ep, acc[0] + bv, o), conv_epilogue(a.ep, acc[1] + bv, o),
+                           conv_epilogue(a.ep, acc[2] + bv, o), conv_epilogue(a.ep, acc[3] + bv, o));
+    if (pin) {
+      *reinterpret_cast<float4*>(a.out + (((size_t)b * a.Cout + o) * H + y) * W + x) = r;
+      omax = absmax4(omax, r);
+    }
+  }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+bool conv_fewin_applies(int Cin, int W, bool up) { return Cin <= 3 && !up && W % 4 == 0 && W >= 4; }
+void launch_conv3x3_fewin(const float* in, const float* w_native, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                          hipStream_t s, const ConvEpilogue* ep, unsigned* amax_out) {
+  ConvArgs a{};
+  if (ep) a.ep = *ep;
+  a.in = in; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.amax_out = amax_out;
+  a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 31) / 32;
+  const int grid = B * a.tiles_x * a.tiles_y;
+  const double px = (double)B * H * W;
+  const std::string name = "conv3x3_fewin_kernel<" + std::to_string(Cin) + ">";
+  KtScope kt(name.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
+  switch (Cin) {
+    case 1: hipLaunchKernelGGL(conv3x3_fewin_kernel<1>, dim3(grid), dim3(256), 0, s, a, w_native); break;
+    case 2: hipLaunchKernelGGL(conv3x3_fewin_kernel<2>, dim3(grid), dim3(256), 0, s, a, w_native); break;
+    default: hipLaunchKernelGGL(conv3x3_fewin_kernel<3>, dim3(grid), dim3(256), 0, s, a, w_native); break;
+  }
+}
+
 template <int MT, int TW, int NG, int NI = 1>
 static void launch_conv_t(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
@@ -320,7 +417,8 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
     a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 31) / 32; a.n_otiles = 1;
     const int grid = B * a.tiles_x * a.tiles_y;
     const double px = (double)B * H * W;
-    KtScope kt("conv3x3_fewout_kernel", 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
+    const std::string fo_name = "conv3x3_fewout_kernel<" + std::to_string(Cout <= 3 ? Cout : 4) + ">";
+    KtScope kt(fo_name.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
     switch (Cout) {
       case 1: hipLaunchKernelGGL(conv3x3_fewout_kernel<1>, dim3(grid), dim3(256), 0, s, a, w_native); break;
       case 2: hipLaunchKernelGGL(conv3x3_fewout_kernel<2>, dim3(grid), dim3(256), 0, s, a, w_native); break;
@@ -889,24 +987,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
   }
 #undef GR_UP_LOAD
 #undef GR_UP_STORE
-  // per-channel epilogue operands first (16 channels per lane), then the stores: two output rows x float2 per lane
+  // epilogue: scale back + bias (+ evaluate()-mode BatchNorm) per channel, one activation switch per block, then two output
+  // rows x float2 per lane
   float omax = 0.f;
+  const bool has_bn = a.ep.mean != nullptr;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (o < a.Cout) {
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
+    const int y = y0 + pr, x = x0 + pc;
+    const bool pin = y < Hs && x < Ws && b + img < a.B;
+    float v[64];                                                   // [r][pa][pb]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = min(o0 + (r & 3) + 8 * (r >> 2) + 4 * h, a.Cout - 1);
       const float bvv = a.bias ? a.bias[o] : 0.f;
+      float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
+      if (has_bn) { mean = a.ep.mean[o]; invstd = a.ep.invstd[o]; gam = a.ep.gamma[o]; bet = a.ep.beta[o]; }
 #pragma unroll
-      for (int ng = 0; ng < NG; ++ng) {
-        const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
-        const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
-        const int y = y0 + pr, x = x0 + pc;
-        if (y < Hs && x < Ws && b + img < a.B) {
+      for (int q = 0; q < 4; ++q) {
+        float t = ldexpf(acc[q >> 1][q & 1][ng][r], -ktot) + bvv;
+        if (has_bn) t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t, mean), invstd), gam), bet);   // same order as conv_epilogue
+        v[r * 4 + q] = t;
+      }
+    }
+    conv_act_block<64>(a.ep, v);
+    if (pin) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (o < a.Cout) {
 #pragma unroll
           for (int pa = 0; pa < 2; ++pa) {
-            float2 res;
-            res.x = conv_epilogue(a.ep, ldexpf(acc[pa][0][ng][r], -ktot) + bvv, o);
-            res.y = conv_epilogue(a.ep, ldexpf(acc[pa][1][ng][r], -ktot) + bvv, o);
+            const float2 res = make_float2(v[r * 4 + pa * 2], v[r * 4 + pa * 2 + 1]);
             *reinterpret_cast<float2*>(a.out + (((size_t)(b + img) * a.Cout + o) * a.H + 2 * y + pa) * a.W + 2 * x) = res;
             omax = fmaxf(omax, fmaxf(fabsf(res.x), fabsf(res.y)));
           }
@@ -1072,7 +1185,7 @@ static void launch_conv_split_t(ConvArgs a, const void* wsplit, hipStream_t s) {
   const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<TW, MT, NTERM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  static const std::string name = std::string(NTERM == 3 ? "conv3x3_bf16x6_kernel<" : "conv3x3_f16x3_kernel<") + std::to_string(TW) + ", " + std::to_string(MT) + ">";
+  static const std::string name = "conv3x3_split_kernel<" + std::to_string(TW) + ", " + std::to_string(MT) + ", " + std::to_string(NTERM) + ">";   // as rocprofv3 prints it (NTERM 3 = bf16x6, 2 = f16x3)
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_split_kernel<TW, MT, NTERM>), dim3(grid), dim3(256 * MT), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
@@ -1088,8 +1201,8 @@ static void launch_conv_split_wide_db(ConvArgs a, const void* wsplit, hipStream_
   const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_wide_kernel<TW, NI, NTERM, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  // the names the timing table and the profiles use (the symbol is conv3x3_split_wide_kernel<TW, NI, NTERM, DB>)
-  static const std::string name = std::string(NTERM == 3 ? "conv3x3_bf16x6_wide_kernel<" : "conv3x3_f16x3_wide_kernel<") + std::to_string(TW) + ", " + std::to_string(NI) + ">";
+  // as rocprofv3 prints it: <TW, NI, NTERM (3 = bf16x6, 2 = f16x3), double-buffered>
+  static const std::string name = "conv3x3_split_wide_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ", " + std::to_string(NTERM) + (DB ? ", true>" : ", false>");
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_split_wide_kernel<TW, NI, NTERM, DB>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
@@ -1974,7 +2087,9 @@ void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* work
             if (nsegs >= a.nsplit && (nsegs % a.nsplit == 0 || nsegs >= 4L * a.nsplit || cand == TRr)) { rps = cand; break; }
           }
       }
-      const std::string nm_ = std::string(mode == 2 ? "conv3x3_wgrad_f16x3_" : "conv3x3_wgrad_bf16x6_") + (rps > 0 ? "roll_kernel<" : "kernel<") + (TW == 16 ? "16>" : "32>");
+      const std::string nt_ = mode == 2 ? "2>" : "3>";      // as rocprofv3 prints them: last template argument = number of split terms
+      const std::string nm_ = rps > 0 ? std::string("conv3x3_wgrad_split_roll_kernel<") + (TW == 16 ? "16, " : "32, ") + nt_
+                                      : std::string("conv3x3_wgrad_split_kernel<") + (TW == 16 ? "16, " : "32, ") + (wv == 1 ? "1, " : "2, ") + nt_;
       KtScope kt(nm_.c_str(), 2.0 * px_ * Cout * Cin * 9.0, 4.0 * (px_ * Cin + px_ * Cout + 9.0 * Cin * Cout), s);
       if (mode == 2) launch_wgrad_split<2>(a, TW, rps, wv, grid_, s); else launch_wgrad_split<3>(a, TW, rps, wv, grid_, s);
     }

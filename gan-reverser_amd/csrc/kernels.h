@@ -78,6 +78,11 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
                     int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const float* w_native = nullptr,
                     const ConvEpilogue* ep = nullptr);
 
+// Cin <= 3 forward (R's first layer): HBM-bound VALU kernel on the native weights, any arithmetic mode
+bool conv_fewin_applies(int Cin, int W, bool up);
+void launch_conv3x3_fewin(const float* in, const float* w_native, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                          hipStream_t s, const ConvEpilogue* ep = nullptr, unsigned* amax_out = nullptr);
+
 // fp32-accurate convolution on the bf16 MFMA: operands split into 3 bf16 terms, 6 products, fp32 accumulation ("bf16x6").
 // wsplit = image made by launch_conv_weight_split (forward or backward-data flavour, like launch_conv_weight_prep).
 size_t conv_weight_split_bytes(int cin, int cout, bool for_backward_data);

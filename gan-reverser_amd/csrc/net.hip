@@ -31,7 +31,7 @@ struct gr_ctx {
   double* d_loss = nullptr;     // device scalar
   double* h_loss = nullptr;     // pinned host scalar
   bool timing = false;
-  int conv_mode = 1;            // 1 = bf16x6 split (fp32-accurate, bf16 MFMA; default), 2 = f16x3 split (fp32-accurate, f16 MFMA), 0 = exact fp32 MFMA
+  int conv_mode = 2;            // 2 = f16x3 split (fp32-accurate, f16 MFMA; default), 1 = bf16x6 split (fp32-accurate, bf16 MFMA), 0 = exact fp32 MFMA
   unsigned* amax = nullptr;     // 4 scratch slots for the single-kernel entry points (f16x3 scales)
   hipEvent_t ev[7] = {};
   float times[6] = {0, 0, 0, 0, 0, 0};
@@ -108,7 +108,7 @@ extern "C" int gr_init(int device, gr_ctx** out) {
     delete c; return GR_ERR_HIP;
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
-  { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "f32") || !strcmp(m, "0")) ? 0 : ((!strcmp(m, "f16x3") || !strcmp(m, "2")) ? 2 : 1); }
+  { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "f32") || !strcmp(m, "0")) ? 0 : ((!strcmp(m, "bf16x6") || !strcmp(m, "1")) ? 1 : 2); }
   (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
@@ -617,7 +617,12 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         }
         ep.act = s.act; ep.slope = s.slope; epp = &ep; dst = s.out; s.fused_epilogue = true;
       }
-      if (use_bf16x6(n, s)) {
+      static const bool fewin_on = !getenv("GR_NO_FEWIN");
+      if (fewin_on && !s.fullconv && conv_fewin_applies(s.Cin, s.W, s.up)) {
+        const bool last_writer = s.fused_epilogue || !s.has_post;
+        launch_conv3x3_fewin(x, n->params + s.w_off, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, last_writer ? amax_next : nullptr);
+        if (last_writer && nx) nx->amax_x_fwd = n->fwd_counter;
+      } else if (use_bf16x6(n, s)) {
         const int nterm = c->conv_mode == 2 ? 2 : 3;
         // input not produced by a tracking kernel (the net's own input, a GEMM, a VALU conv): take its maximum now
         if (nterm == 2 && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream); s.amax_x_fwd = n->fwd_counter; }

@@ -56,7 +56,7 @@ def parse(argv=None):
     p.add_argument("--width", type=int, default=32)
     p.add_argument("--channels", type=int, default=1)
     p.add_argument("--compat", action="store_true")
-    p.add_argument("--conv-mode", default="bf16x6", choices=["f32", "bf16x6", "f16x3"])
+    p.add_argument("--conv-mode", default="f16x3", choices=["f32", "bf16x6", "f16x3"])
     p.add_argument("--quiet", action="store_true")
     return p.parse_args(argv)
 

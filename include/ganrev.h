@@ -133,7 +133,7 @@ int gr_broadcast_params(gr_net* net, int root);             /* make replicas ide
 int gr_train_r_step(gr_net* gnet, gr_net* rnet, const float* noise_dev, int batch, int global_batch,
                     const gr_hyper* h, int t, double* loss_out /*nullable: skipping it avoids a host sync*/);
 /* per-phase device times (ms) of the last gr_train_r_step when timing is enabled: [G fwd, R fwd, loss, R bwd, allreduce, adam] */
-/* convolution arithmetic: 1 = "bf16x6" (default): every fp32 operand split into three bf16 terms, six products on
+/* convolution arithmetic (default 2): 1 = "bf16x6": every fp32 operand split into three bf16 terms, six products on
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation — fp32-level error (same parity bars), 2.7x the matrix rate;
  * 2 = "f16x3": every operand tensor scaled by a power of two (its device-tracked max|.| -> [2^14, 2^15)) and split into two
  * fp16 terms (22 significand bits), three products on v_mfma_f32_32x32x16_f16, result scaled back exactly — fp32-level

@@ -39,10 +39,16 @@ def rel_close(a, b, rtol, what=""):
     assert d <= rtol, f"{what}: max rel diff = {d:.3e} > {rtol:g}"
 
 
+GAPS = (1e-5, 2e-6)     # tried in this order by the tests that search for a well-conditioned input
+
+
 def pools_well_conditioned(model, onet, B, gap=2e-6):
     """True when no 2x2 max-pool window of the oracle's last forward has its two largest values closer than `gap`
     without being exactly equal.  A near-tie lets fp32 rounding pick a different argmax on the two sides, which re-routes
-    a gradient: a legitimate difference that an element-wise tolerance cannot express."""
+    a gradient: a legitimate difference that an element-wise tolerance cannot express.  The forward error of a correct fp32
+    implementation at the pooling inputs is 2-3e-6 (all arithmetic modes), so two values closer than about 1e-5 can swap
+    order; small cases can afford that gap (see pick_well_conditioned), a million-window tensor always holds a few such
+    pairs and only the 2e-6 default is satisfiable there."""
     leaves = model.leaves()
     for i, m in enumerate(leaves):
         if m.typename != "nn.SpatialMaxPooling":
