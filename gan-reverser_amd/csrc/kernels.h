@@ -184,4 +184,13 @@ size_t cosine_topk_workspace_bytes(long N, int d, int Q, int k);
 int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_dev, int Q, int k,
                        long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s);
 
+// ---------------------------------------------------------------- k-means + nearest-centroid pass (apply_r.lua:197-217)
+size_t kmeans_workspace_bytes(long N, int d, int k);
+// all pointers device; cent [k][d] holds the initial centroids on entry and the final ones on return; returns 1 when the
+// shape is unsupported (k > 32, d > 256)
+int launch_kmeans(const float* x, long N, int d, int k, int niter, float* cent, float* c2, float* counts, float* totalcounts,
+                  int* labels_out, void* workspace, hipStream_t s);
+int launch_cosine_assign(const float* x, long N, int d, const float* cent, int k, int take_min, float* w32_scratch,
+                         int* labels, float* sims, hipStream_t s);
+
 }  // namespace gr

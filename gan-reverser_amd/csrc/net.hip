@@ -996,6 +996,49 @@ extern "C" int gr_cosine_similarity_host(gr_ctx* c, const float* a, const float*
   return GR_OK;
 }
 
+// ------------------------------------------------------------------ apply_r.lua:197-217 clustering of the recovered noise
+extern "C" int gr_kmeans_host(gr_ctx* c, const float* x, int64_t n, int d, int k, int niter, float* cent, float* totalcounts, int32_t* labels) {
+  if (!c || !x || !cent || n <= 0 || d <= 0 || k <= 0 || niter < 0) return GR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t xb = sizeof(float) * (size_t)n * d, cb = sizeof(float) * (size_t)k * d, wsb = kmeans_workspace_bytes(n, d, k);
+  int r = ensure_ws(c, wsb + xb + cb + sizeof(float) * 3 * (size_t)k + sizeof(int) * (size_t)n + 1024); if (r) return r;
+  char* p = (char*)c->ws + ((wsb + 255) & ~(size_t)255);
+  float* dx = (float*)p; p += xb;
+  float* dc = (float*)p; p += cb;
+  float* dc2 = (float*)p; float* dcnt = dc2 + k; float* dtot = dcnt + k; p += sizeof(float) * 3 * (size_t)k;
+  int* dlab = (int*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  HIPCHK(c, hipMemcpyAsync(dx, x, xb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dc, cent, cb, hipMemcpyHostToDevice, c->stream));
+  if (launch_kmeans(dx, n, d, k, niter, dc, dc2, dcnt, dtot, dlab, c->ws, c->stream)) return fail(c, GR_ERR_UNSUPPORTED, "kmeans: k <= 32 and d <= 256 only");
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(cent, dc, cb, hipMemcpyDeviceToHost, c->stream));
+  if (totalcounts) HIPCHK(c, hipMemcpyAsync(totalcounts, dtot, sizeof(float) * k, hipMemcpyDeviceToHost, c->stream));
+  if (labels && niter > 0) HIPCHK(c, hipMemcpyAsync(labels, dlab, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+extern "C" int gr_cosine_assign_host(gr_ctx* c, const float* x, int64_t n, int d, const float* cent, int k, int take_min, int32_t* labels, float* sims) {
+  if (!c || !x || !cent || !labels || !sims || n <= 0 || d <= 0 || k <= 0) return GR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t xb = sizeof(float) * (size_t)n * d, cb = sizeof(float) * (size_t)k * d;
+  int r = ensure_ws(c, xb + cb + sizeof(float) * (size_t)k + (sizeof(int) + sizeof(float)) * (size_t)n + 1024); if (r) return r;
+  char* p = (char*)c->ws;
+  float* dx = (float*)p; p += xb;
+  float* dc = (float*)p; p += cb;
+  float* dw = (float*)p; p += sizeof(float) * (size_t)k;
+  p = (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  int* dlab = (int*)p; p += sizeof(int) * (size_t)n;
+  float* dsim = (float*)p;
+  HIPCHK(c, hipMemcpyAsync(dx, x, xb, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dc, cent, cb, hipMemcpyHostToDevice, c->stream));
+  if (launch_cosine_assign(dx, n, d, dc, k, take_min, dw, dlab, dsim, c->stream)) return fail(c, GR_ERR_UNSUPPORTED, "cosine_assign: unsupported size");
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(labels, dlab, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(sims, dsim, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GR_OK;
+}
+
 // ------------------------------------------------------------------ apply_r.lua:355-372 detectAnomalies' distance
 extern "C" int gr_l2_distance_rows_host(gr_ctx* c, const float* a, const float* b, int64_t n, int64_t d, double* out) {
   if (!c || !a || !b || !out || n <= 0 || d <= 0) return GR_ERR_INVALID;

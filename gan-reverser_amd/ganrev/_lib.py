@@ -106,6 +106,8 @@ _SIGS = {
     "gr_cosine_topk_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "gr_cosine_similarity_host": (C.c_int, [_P, _P, _P, C.c_int, C.POINTER(C.c_float)]),
     "gr_l2_distance_rows_host": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P]),
+    "gr_kmeans_host": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "gr_cosine_assign_host": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "gr_malloc": (C.c_int, [_P, C.c_int64, C.POINTER(_P)]),
     "gr_free": (C.c_int, [_P, _P]),
     "gr_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_int64]),
@@ -244,6 +246,26 @@ class Context:
         out = np.empty(n, dtype=np.float64)
         self.check(self.lib.gr_l2_distance_rows_host(self.h, _ptr(a2), _ptr(b2), n, a2.shape[1], _ptr(out)), "gr_l2_distance_rows_host")
         return out
+
+    def kmeans(self, x, k, niter, centroids0):
+        """unsup.kmeans(x, k, niter) (apply_r.lua:198) from the given initial centroids -> (centroids, totalcounts, labels)."""
+        x = f32(x)
+        n, d = x.shape
+        cent = np.array(centroids0, dtype=np.float32, order="C", copy=True).reshape(k, d)
+        tot = np.zeros(k, np.float32)
+        lab = np.zeros(n, np.int32)
+        self.check(self.lib.gr_kmeans_host(self.h, _ptr(x), n, d, int(k), int(niter), _ptr(cent), _ptr(tot), _ptr(lab)), "gr_kmeans_host")
+        return cent, tot, lab
+
+    def cosine_assign(self, x, centroids, take_min=True):
+        """apply_r.lua:205-217: per row the centroid with the minimum (reference behaviour) or maximum cosine similarity."""
+        x, cent = f32(x), f32(centroids)
+        n, d = x.shape
+        lab = np.zeros(n, np.int32)
+        sim = np.zeros(n, np.float32)
+        self.check(self.lib.gr_cosine_assign_host(self.h, _ptr(x), n, d, _ptr(cent), cent.shape[0], int(take_min), _ptr(lab), _ptr(sim)),
+                   "gr_cosine_assign_host")
+        return lab, sim
 
     # ---- data parallel
     def comm_unique_id(self):

@@ -5,6 +5,7 @@
   cosineSimilarity             apply_r.lua:396-400
   fixFaces                     apply_r.lua:324-352   noise -> G -> image -> R_fixer -> noise -> G -> image
   detectAnomalies              apply_r.lua:355-390   1 - torch.dist(image, fixed image), lowest `threshold` share = anomalies
+  createClusterImages          apply_r.lua:197-231   unsup.kmeans on the recovered noise, nearest-centroid pass, per-cluster lists
 
 Everything image-writing (image.toDisplayTensor / image.save / colour conversion) is out of scope: these functions return
 the tensors / index lists the reference would have rendered.
@@ -65,3 +66,38 @@ def detectAnomalies(nbImagesCalculations, threshold, images, model_g, attributes
     srt = np.sort(dist)                                                     # table.sort(distancesForSort)
     anomalyBelow = srt[max(int(math.floor(n * threshold)) - 1, 0)]          # distancesForSort[floor(#*threshold)]  (1-based)
     return dist, anomalyBelow, dist <= anomalyBelow
+
+
+def initialCentroids(nbClusters, nDims, seed=1):
+    """unsup.kmeans draws its initial centroids as `x.new(k, ndims):normal()` and divides each row by its norm.  Torch's
+    Mersenne-twister stream is not reproducible here; the same distribution from the package's counter RNG."""
+    from . import synth
+    c = synth.normal((nbClusters, nDims), seed).astype(np.float32)
+    return c / np.linalg.norm(c.astype(np.float64), axis=1, keepdims=True).astype(np.float32)
+
+
+def createClusterImages(nbClusters, nbIterations, nbMaxPerCluster, images, attributes, centroids0=None, seed=1, closest=False):
+    """apply_r.lua:197-231 without the image writing.  -> (centroids, counts, clusters, averageFaces): clusters[j] is the list
+    of (row index, similarity) kept for cluster j, sorted like the reference (similarity descending, first nbMaxPerCluster);
+    averageFaces[j] the mean image of those rows (zeros / NaN-free for an empty cluster: the reference divides by zero there
+    and skips the cluster when saving, :243,:251).
+
+    Reference behaviour preserved: a row joins the centroid with the MINIMUM cosine similarity (:207-214 keep `dist <
+    minDist` of a similarity).  closest=True assigns to the most similar centroid instead."""
+    attributes = np.asarray(attributes, np.float32)
+    N, d = attributes.shape
+    if centroids0 is None:
+        centroids0 = initialCentroids(nbClusters, d, seed)
+    ctx = L.default_context()
+    centroids, counts, _ = ctx.kmeans(attributes, nbClusters, nbIterations, centroids0)            # :198
+    label, sim = ctx.cosine_assign(attributes, centroids, take_min=not closest)                     # :205-217
+    clusters, faces = [], []
+    images = np.asarray(images, np.float32)
+    for j in range(nbClusters):
+        rows = np.nonzero(label == j)[0]
+        order = np.argsort(-sim[rows], kind="stable")                                               # :221 (a[2] > b[2]); ties by row
+        keep = rows[order][:nbMaxPerCluster]                                                        # :223-227
+        clusters.append([(int(r), float(sim[r])) for r in keep])
+        faces.append(images[keep].mean(axis=0, dtype=np.float64).astype(np.float32) if len(keep)
+                     else np.zeros(images.shape[1:], np.float32))                                   # :233-243
+    return centroids, counts, clusters, faces

@@ -159,6 +159,19 @@ int gr_cosine_similarity_host(gr_ctx* ctx, const float* a_host, const float* b_h
 /* ---- apply_r.lua:355-372 (detectAnomalies): out[i] = torch.dist(a[i], b[i]) = sqrt(sum_j (a_ij - b_ij)^2), rows of length d ---- */
 int gr_l2_distance_rows_host(gr_ctx* ctx, const float* a_host, const float* b_host, int64_t n, int64_t d, double* out_host);
 
+/* ---- apply_r.lua:197-217 (createClusterImages): clustering of the recovered noise vectors ----
+ * gr_kmeans_host replaces `unsup.kmeans(attributes, nbClusters, nbIterations)` (apply_r.lua:198; un-vendored luarock, restated
+ * from memory - see csrc/kmeans.hip): centroids_inout [k x d] carries the INITIAL centroids in (upstream draws them from
+ * Torch's RNG and normalises each row) and the final ones out; total_counts_out [k] = members summed over the iterations
+ * (upstream's second return value); labels_out [n] (nullable) = assignment of the last iteration.  k <= 32, d <= 256.
+ * gr_cosine_assign_host replaces the loop apply_r.lua:205-217: for every row the cosine similarity (nn.CosineDistance op order)
+ * to each centroid, keeping the MINIMUM when take_min != 0 - what the reference does (`dist < minDist`), although it names the
+ * variable a distance - or the maximum otherwise; ties keep the first centroid. */
+int gr_kmeans_host(gr_ctx* ctx, const float* x_host, int64_t n, int d, int k, int niter, float* centroids_inout_host,
+                   float* total_counts_out_host, int32_t* labels_out_host);
+int gr_cosine_assign_host(gr_ctx* ctx, const float* x_host, int64_t n, int d, const float* centroids_host, int k, int take_min,
+                          int32_t* labels_out_host, float* sims_out_host);
+
 /* ---- device memory helpers for hosts without a tensor library (LuaJIT FFI, ctypes) ---- */
 int gr_malloc(gr_ctx* ctx, int64_t bytes, void** out_dev);
 int gr_free(gr_ctx* ctx, void* dev);

@@ -113,6 +113,9 @@ int go_get_max_threads(void);
 
 /* apply_r.lua:369  torch.dist(images[i], fixedImage): sqrt(sum (a-b)^2), fp32 difference/square, fp64 sum, per row */
 void go_l2_distance_rows(const float* a, const float* b, int64_t n, int64_t d, double* out);
+/* unsup.kmeans (apply_r.lua:198; restated from memory, see oracle_net.c) and the nearest-centroid loop apply_r.lua:205-217 */
+void go_kmeans(const float* x, int64_t N, int d, int k, int niter, float* centroids_inout, float* totalcounts, int32_t* labels);
+void go_cosine_assign(const float* x, int64_t N, int d, const float* centroids, int k, int take_min, int32_t* labels, float* sims);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,8 @@ def lib():
         L.go_cosine_similarity.argtypes = [_P, _P, C.c_int, C.c_int]
         L.go_cosine_topk.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]
         L.go_l2_distance_rows.argtypes = [_P, _P, C.c_int64, C.c_int64, _P]
+        L.go_kmeans.argtypes = [_P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P]
+        L.go_cosine_assign.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P]
         L.go_conv3_forward.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
         L.go_conv3_backward_data.argtypes = [_P, _P, _P] + [C.c_int] * 5
         L.go_conv3_backward_weight.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
@@ -217,6 +219,26 @@ def l2_distance_rows(a, b):
     out = np.empty(n, np.float64)
     lib().go_l2_distance_rows(_p(a2), _p(b2), n, a2.shape[1], _p(out))
     return out
+
+
+def kmeans(x, k, niter, centroids0):
+    """unsup.kmeans(x, k, niter) from the given initial centroids -> (centroids, totalcounts, labels of the last iteration)."""
+    x = f32(x)
+    n, d = x.shape
+    cent = np.array(centroids0, dtype=np.float32, order="C", copy=True).reshape(k, d)
+    tot = np.zeros(k, np.float32)
+    lab = np.zeros(n, np.int32)
+    lib().go_kmeans(_p(x), n, d, k, niter, _p(cent), _p(tot), _p(lab))
+    return cent, tot, lab
+
+
+def cosine_assign(x, centroids, take_min=True):
+    x, cent = f32(x), f32(centroids)
+    n, d = x.shape
+    lab = np.zeros(n, np.int32)
+    sim = np.zeros(n, np.float32)
+    lib().go_cosine_assign(_p(x), n, d, _p(cent), cent.shape[0], int(take_min), _p(lab), _p(sim))
+    return lab, sim
 
 
 # ---- single operators

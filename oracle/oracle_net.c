@@ -540,6 +540,66 @@ void go_l2_distance_rows(const float* a, const float* b, int64_t n, int64_t d, d
   }
 }
 
+/* ------------------------------------------------------------------ unsup.kmeans, called at apply_r.lua:198
+ * unsup is an un-vendored, un-pinned luarock (koraykv/unsup, kmeans.lua).  [upstream, from memory]: per iteration
+ *   c2 = sum(pow(centroids,2),2)*0.5 ; tmp = centroids * batch^T - c2 ; val,labels = max(tmp,1) (first maximum) ;
+ *   summation += S^T * batch ; counts += sum(S,1) ; centroids[i] = summation[i]:div(counts[i]) where counts[i] ~= 0 ;
+ *   totalcounts += counts.
+ * Upstream's sgemm / fp32 accumulation order is BLAS-defined; restated with sequential fp32 dot products (no contraction)
+ * and fp64 member sums rounded to fp32 once.  The initial centroids (upstream: normal() rows divided by their norm, from
+ * Torch's RNG) are an input.  labels (nullable) receives the assignment of the last iteration. */
+void go_kmeans(const float* x, int64_t N, int d, int k, int niter, float* cent, float* totalcounts, int32_t* labels) {
+  float* c2 = (float*)malloc(sizeof(float) * k);
+  double* sum = (double*)malloc(sizeof(double) * (size_t)k * d);
+  int64_t* cnt = (int64_t*)malloc(sizeof(int64_t) * k);
+  int32_t* lab = labels ? labels : (int32_t*)malloc(sizeof(int32_t) * N);
+  for (int j = 0; j < k; ++j) totalcounts[j] = 0.f;
+  for (int it = 0; it < niter; ++it) {
+    for (int j = 0; j < k; ++j) {
+      double s = 0;
+      for (int t = 0; t < d; ++t) { const float p = cent[(size_t)j * d + t] * cent[(size_t)j * d + t]; s += (double)p; }
+      c2[j] = (float)s * 0.5f;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+      float best = 0.f; int bi = 0;
+      for (int j = 0; j < k; ++j) {
+        float s = 0.f;
+        for (int t = 0; t < d; ++t) s = s + cent[(size_t)j * d + t] * x[i * d + t];
+        const float v = s - c2[j];
+        if (j == 0 || v > best) { best = v; bi = j; }
+      }
+      lab[i] = bi;
+    }
+    memset(sum, 0, sizeof(double) * (size_t)k * d); memset(cnt, 0, sizeof(int64_t) * k);
+    for (int64_t i = 0; i < N; ++i) {
+      double* sj = sum + (size_t)lab[i] * d;
+      for (int t = 0; t < d; ++t) sj[t] += (double)x[i * d + t];
+      cnt[lab[i]]++;
+    }
+    for (int j = 0; j < k; ++j) {
+      if (cnt[j] != 0)
+        for (int t = 0; t < d; ++t) cent[(size_t)j * d + t] = (float)sum[(size_t)j * d + t] / (float)cnt[j];
+      totalcounts[j] += (float)cnt[j];
+    }
+  }
+  free(c2); free(sum); free(cnt); if (!labels) free(lab);
+}
+
+/* apply_r.lua:205-217: for every row the centroid with the MINIMUM cosineSimilarity (take_min, what the reference does) or
+ * the maximum; the first one on ties */
+void go_cosine_assign(const float* x, int64_t N, int d, const float* cent, int k, int take_min, int32_t* labels, float* sims) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < N; ++i) {
+    float best = 0.f; int bi = 0;
+    for (int j = 0; j < k; ++j) {
+      const float s = go_cosine_similarity(x + i * d, cent + (size_t)j * d, d, 0);
+      if (j == 0 || (take_min ? s < best : s > best)) { best = s; bi = j; }
+    }
+    labels[i] = bi; sims[i] = best;
+  }
+}
+
 /* thread count of the OpenMP loops (the process may have initialised libgomp before OMP_NUM_THREADS could be set) */
 void go_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int go_get_max_threads(void) { return omp_get_max_threads(); }

@@ -611,3 +611,43 @@ def test_train_r_script_learns_to_recover_noise(conv_mode):
     _, _, closs = train_r.main(["--nbBatches", "4", "--batchSize", "16", "--height", "16", "--width", "16", "--noiseDim", "8",
                                 "--quiet", "--compat", "--conv-mode", conv_mode])
     assert np.isfinite(closs).all() and len(closs) == 4
+
+
+@pytest.mark.parametrize("N,d,k,niter", [(10000, 32, 20, 15), (1237, 100, 7, 4), (200000, 100, 20, 3)])
+def test_kmeans_and_cluster_assignment(ctx, oracle, N, d, k, niter):
+    """apply_r.lua:197-217: unsup.kmeans(attributes, 20, 15) and the (minimum-similarity) nearest-centroid pass.  Labels and
+    counts exactly, centroids to fp32 rounding of the fp64 member sums (the device adds them in blocks of 512 rows), cosine
+    scores bit for bit (same op order as the search)."""
+    from ganrev import synth
+    x = synth.normal((N, d), 71)
+    x[: N // 3] += 1.5                                # some structure so that clusters differ in size
+    c0 = synth.normal((k, d), 72)
+    c0 /= np.linalg.norm(c0, axis=1, keepdims=True)
+    cent, tot, lab = ctx.kmeans(x, k, niter, c0)
+    rcent, rtot, rlab = oracle.kmeans(x, k, niter, c0)
+    assert np.array_equal(lab, rlab) and np.array_equal(tot, rtot)
+    assert maxdiff(cent, rcent) <= 1e-6
+    for take_min in (True, False):
+        la, si = ctx.cosine_assign(x, rcent, take_min)
+        rla, rsi = oracle.cosine_assign(x, rcent, take_min)
+        assert np.array_equal(la, rla) and np.array_equal(si, rsi)
+
+
+def test_create_cluster_images_mirror(ctx, oracle):
+    """ganrev.apply_r.createClusterImages against the same composition on the oracle (apply_r.lua:197-243)."""
+    from ganrev import apply_r, synth
+    N, d, k = 2000, 32, 20
+    attrs = synth.normal((N, d), 81)
+    images = synth.uniform((N, 1, 8, 8), 82, 0, 1)
+    c0 = apply_r.initialCentroids(k, d, seed=5)
+    cent, counts, clusters, faces = apply_r.createClusterImages(k, 15, 50, images, attrs, centroids0=c0)
+    rcent, rtot, _ = oracle.kmeans(attrs, k, 15, c0)
+    assert maxdiff(cent, rcent) <= 1e-6 and np.array_equal(counts, rtot)
+    rla, rsi = oracle.cosine_assign(attrs, rcent, True)
+    assert sum(len(c) for c in clusters) <= N and all(len(c) <= 50 for c in clusters)
+    for j, members in enumerate(clusters):
+        rows = np.nonzero(rla == j)[0]
+        ref = rows[np.argsort(-rsi[rows], kind="stable")][:50]
+        assert [r for r, _ in members] == list(ref)
+        if len(ref):
+            assert maxdiff(faces[j], images[ref].mean(0)) <= 1e-6

@@ -180,3 +180,33 @@ def test_bn_groups_model_per_rank_statistics(oracle):
             per = k.size // B
             small.set_mask(li, k[r * (B // P) * per:(r + 1) * (B // P) * per])
         assert np.array_equal(small.forward(x[r * (B // P):(r + 1) * (B // P)]), out[r * (B // P):(r + 1) * (B // P)])
+
+
+def test_kmeans_and_cosine_assign_vs_float64():
+    """unsup.kmeans (apply_r.lua:198, restated from memory) and the nearest-centroid loop (apply_r.lua:205-217) of the oracle
+    against an independent float64 numpy evaluation of the same algorithm; an empty cluster keeps its centroid."""
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3000, 32)).astype(np.float32)
+    k, niter = 20, 15
+    c0 = rng.standard_normal((k, 32)).astype(np.float32)
+    c0 /= np.linalg.norm(c0, axis=1, keepdims=True)
+    c0[7] = 100.0                                     # far away: never wins a row
+    cent, tot, lab = oracle.kmeans(x, k, niter, c0)
+    c = c0.astype(np.float64).copy(); totn = np.zeros(k)
+    xd = x.astype(np.float64)
+    for _ in range(niter):
+        lbl = np.argmax(xd @ c.T - 0.5 * (c ** 2).sum(1), axis=1)
+        for j in range(k):
+            if (lbl == j).any():
+                c[j] = xd[lbl == j].mean(0)
+        totn += np.bincount(lbl, minlength=k)
+    assert np.array_equal(lab, lbl)
+    assert np.abs(cent - c).max() < 1e-6 and np.array_equal(tot, totn.astype(np.float32))
+    assert np.array_equal(cent[7], c0[7]) and tot[7] == 0
+    for take_min in (True, False):
+        la, si = oracle.cosine_assign(x, cent, take_min)
+        S = (xd @ cent.astype(np.float64).T) / np.sqrt((xd ** 2).sum(1, keepdims=True) * (cent.astype(np.float64) ** 2).sum(1))
+        ref = S.argmin(1) if take_min else S.argmax(1)
+        assert np.array_equal(la, ref)
+        assert np.abs(si - (S.min(1) if take_min else S.max(1))).max() < 1e-6
