@@ -305,6 +305,42 @@ __global__ __launch_bounds__(256) void post_backward_a_kernel(PostBwdArgs a, int
   if (threadIdx.x == 0) { a.partials[((long)c * STAT_SPLITS + sp) * 2] = s; a.partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
 }
 
+// dz (gradient wrt the BatchNorm output, or wrt y without BN) of four consecutive pre-pool elements e .. e+3 of plane bc:
+// gradOutput routed back through mask 2, the pool argmax, mask 1 and the activation.  Pass A sums it, pass B needs it again:
+// with BatchNorm both passes call this (bit-identical results) and dz is never written to memory - one tensor write and one
+// tensor read less than storing it.
+__device__ __forceinline__ float4 post_bwd_dz4(const PostBwdArgs& a, unsigned bc, unsigned e, unsigned i, unsigned obase, unsigned wq, unsigned Wo,
+                                               float mean, float invstd, float gm, float bt, float4& yv) {
+  const PostArgs& f = a.f;
+  float4 g;
+  if (f.pool) {
+    const unsigned yy = i / wq, xx = (i - yy * wq) * 4, eo = obase + (yy >> 1) * Wo + (xx >> 1);
+    const float2 go = *reinterpret_cast<const float2*>(a.gout + eo);
+    const uint32_t id2 = *reinterpret_cast<const uint16_t*>(f.pool_idx + eo);
+    const float m20 = mask_mul(f.m2, eo, bc), m21 = mask_mul(f.m2, eo + 1, bc);
+    const uint32_t t0 = (yy & 1) << 1;
+    g.x = ((id2 & 0xff) == t0) ? go.x * m20 : 0.f;
+    g.y = ((id2 & 0xff) == (t0 | 1)) ? go.x * m20 : 0.f;
+    g.z = ((id2 >> 8) == t0) ? go.y * m21 : 0.f;
+    g.w = ((id2 >> 8) == (t0 | 1)) ? go.y * m21 : 0.f;
+  } else {
+    g = mul4(*reinterpret_cast<const float4*>(a.gout + e), mask4(f.m2, e, bc));
+  }
+  g = mul4(g, mask4(f.m1, e, bc));
+  yv = *reinterpret_cast<const float4*>(f.y + e);
+  float4 z = yv;
+  if (f.has_bn) {
+    z.x = ((yv.x - mean) * invstd) * gm + bt; z.y = ((yv.y - mean) * invstd) * gm + bt;
+    z.z = ((yv.z - mean) * invstd) * gm + bt; z.w = ((yv.w - mean) * invstd) * gm + bt;
+  }
+  float4 dz;
+  dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, f.slope), f.act, f.slope);
+  dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, f.slope), f.act, f.slope);
+  dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, f.slope), f.act, f.slope);
+  dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, f.slope), f.act, f.slope);
+  return dz;
+}
+
 // float4 variants of pass A / pass B: block (c, split) walks its images, threads take consecutive pre-pool float4s.
 __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a, int splits) {
   __shared__ double sh[8];
@@ -323,33 +359,9 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
       const unsigned bb = j / q4, i = j - bb * q4;
       const unsigned bc = (unsigned)(b0 + bb) * f.C + c, pbase = bc * HW, obase = bc * HWo;
       const unsigned e = pbase + i * 4;
-      float4 g;
-      if (f.pool) {
-        const unsigned yy = i / wq, xx = (i - yy * wq) * 4, eo = obase + (yy >> 1) * Wo + (xx >> 1);
-        const float2 go = *reinterpret_cast<const float2*>(a.gout + eo);
-        const uint32_t id2 = *reinterpret_cast<const uint16_t*>(f.pool_idx + eo);
-        const float m20 = mask_mul(f.m2, eo, bc), m21 = mask_mul(f.m2, eo + 1, bc);
-        const uint32_t t0 = (yy & 1) << 1;
-        g.x = ((id2 & 0xff) == t0) ? go.x * m20 : 0.f;
-        g.y = ((id2 & 0xff) == (t0 | 1)) ? go.x * m20 : 0.f;
-        g.z = ((id2 >> 8) == t0) ? go.y * m21 : 0.f;
-        g.w = ((id2 >> 8) == (t0 | 1)) ? go.y * m21 : 0.f;
-      } else {
-        g = mul4(*reinterpret_cast<const float4*>(a.gout + e), mask4(f.m2, e, bc));
-      }
-      g = mul4(g, mask4(f.m1, e, bc));
-      const float4 yv = *reinterpret_cast<const float4*>(f.y + e);
-      float4 z = yv;
-      if (f.has_bn) {
-        z.x = ((yv.x - mean) * invstd) * gm + bt; z.y = ((yv.y - mean) * invstd) * gm + bt;
-        z.z = ((yv.z - mean) * invstd) * gm + bt; z.w = ((yv.w - mean) * invstd) * gm + bt;
-      }
-      float4 dz;
-      dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, f.slope), f.act, f.slope);
-      dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, f.slope), f.act, f.slope);
-      dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, f.slope), f.act, f.slope);
-      dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, f.slope), f.act, f.slope);
-      *reinterpret_cast<float4*>(a.dy + e) = dz;
+      float4 yv;
+      const float4 dz = post_bwd_dz4(a, bc, e, i, obase, wq, Wo, mean, invstd, gm, bt, yv);
+      if (!f.has_bn) *reinterpret_cast<float4*>(a.dy + e) = dz;     // with BatchNorm pass B recomputes dz: nothing stored here
       dmax = absmax4(dmax, dz);
       s += (double)dz.x + (double)dz.y + (double)dz.z + (double)dz.w;
       q += (double)(yv.x - mean) * (double)dz.x + (double)(yv.y - mean) * (double)dz.y +
@@ -366,19 +378,20 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
   __shared__ double sh[8];
   const PostArgs& f = a.f;
   const int c = blockIdx.x, sp = blockIdx.y;
-  const unsigned HW = (unsigned)f.H * f.W, q4 = HW >> 2;
+  const unsigned H = f.H, W = f.W, Wo = f.pool ? W >> 1 : W, HW = H * W, HWo = f.pool ? (H >> 1) * Wo : HW, q4 = HW >> 2, wq = W >> 2;
   const int per = (f.B + splits - 1) / splits, b0 = sp * per, b1 = min(f.B, b0 + per);
-  const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], gm = a.coef[2 * c], k = a.coef[2 * c + 1];
+  const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], bt = f.beta[c], gm = a.coef[2 * c], k = a.coef[2 * c + 1];
   double s = 0;
   float dmax = 0.f;
   const unsigned tot = (unsigned)(b1 - b0) * q4;
   {
     for (unsigned j = threadIdx.x; j < tot; j += 256) {
       const unsigned bb = j / q4, i = j - bb * q4;
-      const size_t base = ((size_t)(b0 + bb) * f.C + c) * HW;
+      const unsigned bc = (unsigned)(b0 + bb) * f.C + c;
+      const size_t base = (size_t)bc * HW;
       float4* dyp = reinterpret_cast<float4*>(a.dy + base);
-      const float4* yp = reinterpret_cast<const float4*>(f.y + base);
-      const float4 dz = dyp[i], yv = yp[i];
+      float4 yv;
+      const float4 dz = post_bwd_dz4(a, bc, bc * HW + i * 4, i, bc * HWo, wq, Wo, mean, invstd, w, bt, yv);   // as pass A computed it
       float4 d;
       d.x = ((dz.x - gm) - (yv.x - mean) * k) * invstd * w; d.y = ((dz.y - gm) - (yv.y - mean) * k) * invstd * w;
       d.z = ((dz.z - gm) - (yv.z - mean) * k) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * k) * invstd * w;
@@ -449,7 +462,7 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s) {
   const bool vec = (f.pool ? (f.W % 8 == 0 && f.H % 2 == 0) : (f.W % 4 == 0)) && f.H * f.W >= 64 && pre < 4.0e9;
   if (vec) {
     if (splits > f.B) splits = f.B;
-    KtScope kt("post_backward_a_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);
+    KtScope kt("post_backward_a_vec_kernel", 0.0, 4.0 * ((f.has_bn ? 1.0 : 2.0) * pre + post), s);   // with BN: dz is not stored
     hipLaunchKernelGGL(post_backward_a_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
   } else {
     KtScope kt("post_backward_a_kernel", 0.0, 4.0 * (2.0 * pre + post), s);
@@ -458,7 +471,7 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(post_backward_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a, splits, (double)n);
   if (f.has_bn) {
     if (vec) {
-      KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * 3.0 * pre, s);
+      KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);                      // reads g and y, writes dy
       hipLaunchKernelGGL(post_backward_b_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
     } else {
       KtScope kt("post_backward_b_kernel", 0.0, 4.0 * 3.0 * pre, s);
