@@ -37,6 +37,9 @@ struct ConvArgs {
   ConvEpilogue ep;      // ep.mean != nullptr: evaluate()-mode BatchNorm + activation applied before the store
   const unsigned *amax_in = nullptr, *amax_w = nullptr;   // f16x3 mode: bit patterns of max|in| and max|weights| (device)
   unsigned* amax_out = nullptr;                           // nullable: slot that receives max|out|
+  // nullable: per-channel (sum, sum of squares) of the stored output over this workgroup's pixels, [Cout][stat_tiles][2]
+  // (training-mode BatchNorm statistics without a second pass over y; summed in a fixed order by bn_stats_finalize_tiles)
+  double* stat_part = nullptr; int stat_tiles = 0;
 };
 
 // out = act(((conv + bias - mean) * invstd) * gamma + beta): the per-channel pipeline of an evaluate()-mode stage
@@ -333,6 +336,8 @@ __global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const fl
       v[ci][ky][1] = m.x; v[ci][ky][2] = m.y; v[ci][ky][3] = m.z; v[ci][ky][4] = m.w;
       v[ci][ky][5] = (rin && x + 4 < W) ? rp[4] : 0.f;
     }
+  __shared__ float red[4][256][2];                            // per-wave channel sums for the BatchNorm statistics (Cout <= 256)
+  const bool stats = a.stat_part != nullptr;
   float omax = 0.f;
   for (int o = 0; o < a.Cout; ++o) {
     const float* wp = w_native + (size_t)o * CI * 9;          // uniform address: scalar loads
@@ -354,17 +359,31 @@ __global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const fl
       *reinterpret_cast<float4*>(a.out + (((size_t)b * a.Cout + o) * H + y) * W + x) = r;
       omax = absmax4(omax, r);
     }
+    if (stats) {                                              // training mode: r is the raw output (no epilogue)
+      float sv = pin ? (r.x + r.y) + (r.z + r.w) : 0.f, qv = pin ? (r.x * r.x + r.y * r.y) + (r.z * r.z + r.w * r.w) : 0.f;
+      sv = wave_sum(sv); qv = wave_sum(qv);
+      if ((tid & 63) == 63) { red[tid >> 6][o][0] = sv; red[tid >> 6][o][1] = qv; }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    for (int e = tid; e < 2 * a.Cout; e += 256) {
+      const int o = e >> 1, wh = e & 1;
+      const double t = ((double)red[0][o][wh] + (double)red[1][o][wh]) + ((double)red[2][o][wh] + (double)red[3][o][wh]);
+      a.stat_part[((size_t)o * a.stat_tiles + blockIdx.x) * 2 + wh] = t;
+    }
   }
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 bool conv_fewin_applies(int Cin, int W, bool up) { return Cin <= 3 && !up && W % 4 == 0 && W >= 4; }
 void launch_conv3x3_fewin(const float* in, const float* w_native, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
-                          hipStream_t s, const ConvEpilogue* ep, unsigned* amax_out) {
+                          hipStream_t s, const ConvEpilogue* ep, unsigned* amax_out, double* stat_part, int* stat_tiles) {
   ConvArgs a{};
   if (ep) a.ep = *ep;
   a.in = in; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.amax_out = amax_out;
   a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 31) / 32;
   const int grid = B * a.tiles_x * a.tiles_y;
+  if (stat_tiles) { const bool ok = stat_part && Cout <= 256; a.stat_part = ok ? stat_part : nullptr; a.stat_tiles = grid; *stat_tiles = ok ? grid : 0; }
   const double px = (double)B * H * W;
   const std::string name = "conv3x3_fewin_kernel<" + std::to_string(Cin) + ">";
   KtScope kt(name.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
@@ -830,22 +849,60 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
 #undef GR_BF_LOAD
 #undef GR_BF_STORE
   float omax = 0.f;
+  bool pin[NG]; size_t obase[NG];
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
     const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
     const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
     const int y = y0 + pr, x = x0 + pc;
-    if (y < H && x < W && b + img < a.B) {
+    pin[ng] = y < H && x < W && b + img < a.B;
+    obase[ng] = ((size_t)(b + img) * a.Cout * H + y) * W + x;
+  }
+  // scale back + bias in place
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float bvv = (a.bias && o < a.Cout) ? a.bias[o] : 0.f;
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) acc[mt][ng][r] = (NTERM == 2 ? ldexpf(acc[mt][ng][r], -ktot) : acc[mt][ng][r]) + bvv;
+    }
+  if (a.stat_part) {
+    // BatchNorm batch statistics of what is about to be stored: per channel the 64 pixels of this wave (two per lane, 32
+    // lanes of one half-wave) in fp32, the 8 waves and all workgroups in fp64 and in a fixed order
+    float* red = reinterpret_cast<float*>(smem_raw);             // [8 waves][64 channels][2]; the operand images are dead
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng) { const float v = pin[ng] ? acc[mt][ng][r] : 0.f; sv += v; qv += v * v; }
+        sv = half_wave_sum(sv); qv = half_wave_sum(qv);
+        if (l31 == 16) { const int ch = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; red[(wave * 64 + ch) * 2] = sv; red[(wave * 64 + ch) * 2 + 1] = qv; }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const int ch = tid >> 1, wh = tid & 1;
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += (double)red[(w * 64 + ch) * 2 + wh];
+      const int tile = xcd_remap(blockIdx.x, gridDim.x) / a.n_otiles;
+      if (o0 + ch < a.Cout) a.stat_part[((size_t)(o0 + ch) * a.stat_tiles + tile) * 2 + wh] = t;
+    }
+  }
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    if (pin[ng]) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (o < a.Cout) {
-          const float bvv = a.bias ? a.bias[o] : 0.f;
-          const float v = NTERM == 2 ? ldexpf(acc[mt][ng][r], -ktot) : acc[mt][ng][r];
-          const float res = conv_epilogue(a.ep, v + bvv, o);
-          a.out[(((size_t)(b + img) * a.Cout + o) * H + y) * W + x] = res;
+          const float res = conv_epilogue(a.ep, acc[mt][ng][r], o);
+          a.out[obase[ng] + (size_t)o * H * W] = res;
           omax = fmaxf(omax, fabsf(res));
         }
       }
@@ -1199,6 +1256,7 @@ static void launch_conv_split_wide_db(ConvArgs a, const void* wsplit, hipStream_
   const size_t lds = (DB ? 2 : 1) * 16 * (size_t)(NTERM * 2 * PS + NTERM * 9 * 2 * CT);
   static_assert((DB ? 2 : 1) * 16 * (NTERM * 2 * PS + NTERM * 9 * 2 * CT) <= 160 * 1024, "LDS");
   const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
+  a.stat_tiles = grid / a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_wide_kernel<TW, NI, NTERM, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   // as rocprofv3 prints it: <TW, NI, NTERM (3 = bf16x6, 2 = f16x3), double-buffered>
@@ -1216,32 +1274,40 @@ static void launch_conv_split_wide(const ConvArgs& a, const void* wsplit, hipStr
   else launch_conv_split_wide_db<TW, NI, NTERM, false>(a, wsplit, s);
 }
 
+// returns the number of statistics tiles written per channel (0: the chosen kernel does not produce them)
 template <int NTERM>
-static void launch_conv3x3_split_n(const ConvArgs& a, const void* wsplit, hipStream_t s) {
+static int launch_conv3x3_split_n(ConvArgs a, const void* wsplit, hipStream_t s) {
   const int B = a.B, Cout = a.Cout, H = a.H, W = a.W;
+  const double* want_stats = a.stat_part;
+  a.stat_part = nullptr;
+  ConvArgs aw = a; aw.stat_part = const_cast<double*>(want_stats);      // only the 512-pixel kernels fill it
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("GR_BF16X6_VARIANT"); variant = e ? atoi(e) : 0; }
   const bool wide = round_up(Cout, 32) % 64 == 0 && variant != 1;      // 64 output channels per workgroup (8 waves share one patch)
   if (W <= 8) launch_conv_split_t<8, 1, NTERM>(a, wsplit, s);
   else if (W <= 16) {
     // two stacked 16x16 images per 512-pixel tile (G.convA 799 -> 716 us) when that still leaves a workgroup for every CU
-    if (wide && variant != 4 && H == 16 && W == 16 && (long)((B + 1) / 2) * (round_up(Cout, 32) / 64) >= 256) launch_conv_split_wide<16, 2, NTERM>(a, wsplit, s);
+    if (wide && variant != 4 && H == 16 && W == 16 && (long)((B + 1) / 2) * (round_up(Cout, 32) / 64) >= 256) { launch_conv_split_wide<16, 2, NTERM>(aw, wsplit, s); return want_stats ? ((B + 1) / 2) : 0; }
     else if (wide) launch_conv_split_t<16, 2, NTERM>(a, wsplit, s); else launch_conv_split_t<16, 1, NTERM>(a, wsplit, s);
   }
-  else if (wide && variant != 4 && (long)H * W >= 512 && (long)B * ((H * W + 511) / 512) * (round_up(Cout, 32) / 64) >= 256) launch_conv_split_wide<32, 1, NTERM>(a, wsplit, s);   // measured: -6 % vs the 256-pixel tile
+  else if (wide && variant != 4 && (long)H * W >= 512 && (long)B * ((H * W + 511) / 512) * (round_up(Cout, 32) / 64) >= 256) { launch_conv_split_wide<32, 1, NTERM>(aw, wsplit, s); return want_stats ? B * ((W + 31) / 32) * ((H + 15) / 16) : 0; }   // measured: -6 % vs the 256-pixel tile
   else { if (wide) launch_conv_split_t<32, 2, NTERM>(a, wsplit, s); else launch_conv_split_t<32, 1, NTERM>(a, wsplit, s); }
+  return 0;
 }
 
 // nterm 3: bf16x6 (amax_* unused); nterm 2: f16x3, amax_in / amax_w = device slots holding the bit patterns of max|in|, max|w|
 void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias, float* out,
                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep,
-                          int nterm, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out) {
+                          int nterm, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out,
+                          double* stat_part, int* stat_tiles) {
   ConvArgs a{};
   if (ep) a.ep = *ep;
   a.in = in; a.wt = nullptr; a.bias = bias; a.out = out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
   a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
-  if (nterm == 2) launch_conv3x3_split_n<2>(a, wsplit, s); else launch_conv3x3_split_n<3>(a, wsplit, s);
+  a.stat_part = stat_tiles ? stat_part : nullptr;
+  const int nt = nterm == 2 ? launch_conv3x3_split_n<2>(a, wsplit, s) : launch_conv3x3_split_n<3>(a, wsplit, s);
+  if (stat_tiles) *stat_tiles = nt;
 }
 
 // ---------------------------------------------------------------- weight layout preparation

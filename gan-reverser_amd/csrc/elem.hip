@@ -257,6 +257,32 @@ void launch_bn_stats(const float* y, int B, int C, int HW, double* partials, flo
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partials, C, splits, (double)n,
                      mean, invstd, run_mean, run_var);
 }
+// one workgroup per channel: the conv epilogue's per-tile (sum, sum of squares) added in a fixed order
+__global__ __launch_bounds__(256) void bn_stats_finalize_tiles_kernel(const double* __restrict__ part, int tiles, double n,
+                                                                       float* mean, float* invstd, float* run_mean, float* run_var) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x;
+  double s = 0, q = 0;
+  for (int t = threadIdx.x; t < tiles; t += 256) { s += part[((size_t)c * tiles + t) * 2]; q += part[((size_t)c * tiles + t) * 2 + 1]; }
+  s = block_reduce_sum(s, sh);
+  q = block_reduce_sum(q, sh);
+  if (threadIdx.x == 0) {
+    const double m = s / n;
+    double vs = q - s * m;               // sum (x-mean)^2
+    if (vs < 0) vs = 0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(vs / n + 1e-5));
+    if (run_mean) {
+      run_mean[c] = (float)(0.1 * m + 0.9 * (double)run_mean[c]);
+      run_var[c] = (float)(0.1 * (vs / (n - 1)) + 0.9 * (double)run_var[c]);
+    }
+  }
+}
+void launch_bn_stats_from_tiles(const double* stat_part, int tiles, int C, double n, float* mean, float* invstd,
+                                float* run_mean, float* run_var, hipStream_t s) {
+  KtScope kt("bn_stats_finalize_tiles_kernel", 0.0, 16.0 * tiles * C, s);
+  hipLaunchKernelGGL(bn_stats_finalize_tiles_kernel, dim3(C), dim3(256), 0, s, stat_part, tiles, n, mean, invstd, run_mean, run_var);
+}
 void launch_bn_eval_prepare(const float* rm, const float* rv, float* mean, float* invstd, int C, hipStream_t s) {
   hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, s, rm, rv, mean, invstd, C);
 }

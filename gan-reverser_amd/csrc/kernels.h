@@ -62,6 +62,27 @@ __device__ __forceinline__ unsigned absmax_read(const unsigned* slot) {
   for (int o = AMAX_ENTRIES / 2; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
   return v;
 }
+// Cross-lane sums on the DPP path (full-rate VALU; __shfl_xor goes through ds_bpermute and costs an LDS instruction per step:
+// 13 us per conv launch for the 64 channel sums of the BatchNorm statistics against 1 us this way).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v) {      // lanes outside ROW_MASK receive 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over the 32 lanes of each half-wave: the result is valid in lanes 16-31 and 48-63
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += dpp_take<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+  v += dpp_take<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+  v += dpp_take<0x141, 0xF>(v);     // row_half_mirror: the other quad of the 8-lane half holds the same sums
+  v += dpp_take<0x140, 0xF>(v);     // row_mirror: the other half of the 16-lane row
+  v += dpp_take<0x142, 0xA>(v);     // row_bcast15 into rows 1 and 3: lane 15 of the row before
+  return v;
+}
+// sum over all 64 lanes: valid in lanes 48-63
+__device__ __forceinline__ float wave_sum(float v) {
+  v = half_wave_sum(v);
+  v += dpp_take<0x143, 0xC>(v);     // row_bcast31 into rows 2 and 3: lane 31 holds the sum of the first half-wave
+  return v;
+}
 __device__ __forceinline__ float absmax4(float m, const float4& v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
@@ -81,7 +102,8 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
 // Cin <= 3 forward (R's first layer): HBM-bound VALU kernel on the native weights, any arithmetic mode
 bool conv_fewin_applies(int Cin, int W, bool up);
 void launch_conv3x3_fewin(const float* in, const float* w_native, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
-                          hipStream_t s, const ConvEpilogue* ep = nullptr, unsigned* amax_out = nullptr);
+                          hipStream_t s, const ConvEpilogue* ep = nullptr, unsigned* amax_out = nullptr,
+                          double* stat_part = nullptr, int* stat_tiles = nullptr);
 
 // fp32-accurate convolution on the bf16 MFMA: operands split into 3 bf16 terms, 6 products, fp32 accumulation ("bf16x6").
 // wsplit = image made by launch_conv_weight_split (forward or backward-data flavour, like launch_conv_weight_prep).
@@ -94,7 +116,15 @@ void launch_conv_weight_split(const float* w_native, void* wsplit, int cin, int 
 void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias, float* out,
                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep = nullptr,
                           int nterm = 3, const unsigned* amax_in = nullptr, const unsigned* amax_w = nullptr,
-                          unsigned* amax_out = nullptr /* nullable: max|out| is folded into this slot by the epilogue */);
+                          unsigned* amax_out = nullptr /* nullable: max|out| is folded into this slot by the epilogue */,
+                          // BatchNorm batch statistics from the epilogue: stat_part [Cout][tiles][2] doubles (room for
+                          // conv_stat_tiles_max tiles); *stat_tiles = tiles written per channel, 0 when the kernel chosen
+                          // for this shape does not produce them (then run launch_bn_stats on the output)
+                          double* stat_part = nullptr, int* stat_tiles = nullptr);
+inline size_t conv_stat_tiles_max(int B, int H, int W) { return (size_t)B * ((H + 15) / 16) * ((W + 31) / 32) + 1; }
+// mean / invstd (+ running statistics) from the per-tile (sum, sum of squares) the conv epilogue wrote
+void launch_bn_stats_from_tiles(const double* stat_part, int tiles, int C, double n, float* mean, float* invstd,
+                                float* run_mean, float* run_var, hipStream_t s);
 
 // nearest x2 up-sampling + conv3x3 as four 2x2 convolutions of the source plane (f16x3 arithmetic; forward only):
 // 4 instead of 9 multiply-adds per output.  Shapes: source plane 8x8, 16x16 or at least 17 wide; Cout > 4.

@@ -214,6 +214,8 @@ struct Stage {
   uint64_t amax_x_fwd = 0;                  // forward counter at which amax_x was last taken
   unsigned *amax_x = nullptr, *amax_dy = nullptr, *amax_w = nullptr;   // f16x3: slots (in gr_net::amax) for max|x_in|, max|dy|, max|w|
   float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr;
+  int stat_tiles_last = 0;                  // tiles the last forward's conv epilogue wrote (0: none - run the statistics pass)
+  double* stat_part = nullptr;              // per-tile (sum, sum of squares) written by the conv epilogue in training mode (sized per batch)
   float *run_mean = nullptr, *run_var = nullptr;
   const float* x_in = nullptr;              // input of the last forward
   bool fused_epilogue = false;              // last forward wrote `out` straight from the conv epilogue (y not materialised)
@@ -252,7 +254,7 @@ extern "C" int gr_net_destroy(gr_net* n) {
     if (s.kind != ST_ELEM) (void)hipFree(s.y);
     if (s.has_post) (void)hipFree(s.out);
     (void)hipFree(s.pool_idx); (void)hipFree(s.wt_fwd); (void)hipFree(s.wt_bwd); (void)hipFree(s.ws_fwd); (void)hipFree(s.ws_up); (void)hipFree(s.ws_bwd);
-    (void)hipFree(s.mean); (void)hipFree(s.invstd); (void)hipFree(s.coef); (void)hipFree(s.partials);
+    (void)hipFree(s.mean); (void)hipFree(s.invstd); (void)hipFree(s.coef); (void)hipFree(s.partials); (void)hipFree(s.stat_part);
     (void)hipFree(s.run_mean); (void)hipFree(s.run_var);
   }
   for (auto& m : n->masks) (void)hipFree(m.bits);
@@ -511,6 +513,10 @@ static int ensure_batch(gr_net* n, int B) {
   for (auto& s : n->st) {
     if (s.kind != ST_ELEM) { (void)hipFree(s.y); s.y = nullptr; HIPCHK(c, hipMalloc((void**)&s.y, sizeof(float) * (size_t)B * vol3(s.Cout, s.H, s.W))); }
     if (s.has_post) { (void)hipFree(s.out); s.out = nullptr; HIPCHK(c, hipMalloc((void**)&s.out, sizeof(float) * (size_t)B * vol3(s.outC, s.outH, s.outW))); }
+    if (s.kind == ST_CONV && s.has_bn && !s.fullconv && !s.up) {
+      (void)hipFree(s.stat_part); s.stat_part = nullptr;
+      HIPCHK(c, hipMalloc((void**)&s.stat_part, sizeof(double) * 2 * (size_t)s.Cout * conv_stat_tiles_max(B, s.H, s.W)));
+    }
     if (s.pool) { (void)hipFree(s.pool_idx); s.pool_idx = nullptr; HIPCHK(c, hipMalloc((void**)&s.pool_idx, (size_t)B * vol3(s.outC, s.outH, s.outW))); }
   }
   (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
@@ -617,10 +623,15 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         }
         ep.act = s.act; ep.slope = s.slope; epp = &ep; dst = s.out; s.fused_epilogue = true;
       }
+      // training-mode BatchNorm: the conv epilogue also leaves the per-channel (sum, sum of squares) of what it stores
+      static const bool epi_stats_on = !getenv("GR_NO_EPI_STATS");
+      const bool want_stats = epi_stats_on && n->training && s.has_bn && s.stat_part && !s.fused_epilogue;
+      int stat_tiles = 0;
       static const bool fewin_on = !getenv("GR_NO_FEWIN");
       if (fewin_on && !s.fullconv && conv_fewin_applies(s.Cin, s.W, s.up)) {
         const bool last_writer = s.fused_epilogue || !s.has_post;
-        launch_conv3x3_fewin(x, n->params + s.w_off, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, last_writer ? amax_next : nullptr);
+        launch_conv3x3_fewin(x, n->params + s.w_off, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, last_writer ? amax_next : nullptr,
+                             want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
         if (last_writer && nx) nx->amax_x_fwd = n->fwd_counter;
       } else if (use_bf16x6(n, s)) {
         const int nterm = c->conv_mode == 2 ? 2 : 3;
@@ -633,11 +644,12 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
                                    last_writer ? amax_next : nullptr);
         else
           launch_conv3x3_split(x, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, epp, nterm, s.amax_x, s.amax_w,
-                               last_writer ? amax_next : nullptr);
+                               last_writer ? amax_next : nullptr, want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
         if (last_writer && nx) nx->amax_x_fwd = n->fwd_counter;
       }
       else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off, epp);
       if (s.fused_epilogue) { LAUNCHCHK(c); x = s.out; continue; }
+      s.stat_tiles_last = stat_tiles;
     } else if (s.kind == ST_LINEAR) {
       const size_t wsb = gemm_workspace_bytes(B, s.Cout, s.Cin);
       r = ensure_ws(c, wsb); if (r) return r;
@@ -647,7 +659,9 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     if (!s.has_post) { s.out = s.y; x = s.out; continue; }
     const float* yv = s.kind == ST_ELEM ? x : s.y;
     if (s.has_bn) {
-      if (n->training) launch_bn_stats(yv, B, s.Cout, s.H * s.W, s.partials, s.mean, s.invstd, s.run_mean, s.run_var, 1, c->stream);
+      if (n->training && s.kind == ST_CONV && s.stat_tiles_last > 0)
+        launch_bn_stats_from_tiles(s.stat_part, s.stat_tiles_last, s.Cout, (double)B * s.H * s.W, s.mean, s.invstd, s.run_mean, s.run_var, c->stream);
+      else if (n->training) launch_bn_stats(yv, B, s.Cout, s.H * s.W, s.partials, s.mean, s.invstd, s.run_mean, s.run_var, 1, c->stream);
       else launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream);
     }
     for (int slot : {s.m1, s.m2}) {
