@@ -1085,6 +1085,16 @@ static int conv_split_once(gr_ctx* c, const float* w, int cin, int cout, bool bw
 }
 extern "C" int gr_conv3_forward_dev(gr_ctx* c, const float* in, const float* w, const float* bias, float* out, int B, int cin, int cout, int h, int wd, int up) {
   if (!c || !in || !w || !out) return GR_ERR_INVALID;
+  if (c->conv_mode == 2 && up && conv_up2_supported(cin, cout, h, wd) && !getenv("GR_NO_UP2")) {
+    // the fused up-sampling layer as four 2x2 convolutions (the path a net takes for such a stage in f16x3 mode)
+    void* wup = nullptr;
+    HIPCHK(c, hipMalloc(&wup, conv_weight_up2_bytes(cin, cout)));
+    launch_conv_weight_up2_split(w, wup, cin, cout, c->stream, c->amax + 2 * AMAX_WORDS, true);
+    launch_absmax(in, (long)B * cin * (h / 2) * (wd / 2), c->amax, c->stream);
+    launch_conv3x3_up2_f16x3(in, wup, bias, out, B, cin, cout, h, wd, c->stream, nullptr, c->amax, c->amax + 2 * AMAX_WORDS, nullptr);
+    hipError_t e = hipGetLastError(); (void)hipStreamSynchronize(c->stream); (void)hipFree(wup);
+    return e == hipSuccess ? GR_OK : fail(c, GR_ERR_HIP, "conv launch failed: %s", hipGetErrorString(e));
+  }
   if (c->conv_mode >= 1 && cout > 4) {
     void* ws = nullptr; int r = conv_split_once(c, w, cin, cout, false, &ws); if (r) return r;
     if (c->conv_mode == 2) launch_absmax(in, (long)B * cin * (up ? (h / 2) * (wd / 2) : h * wd), c->amax, c->stream);

@@ -65,9 +65,13 @@ def test_conv3_kernels_vs_oracle(ctx, oracle, conv_mode, B, Cin, Cout, H, W):
         ctx.free(p)
 
 
-def test_conv3_upsample_fused(ctx, oracle, conv_mode):
+# source planes 8x8 (eight stacked images per tile, odd batch -> a partly empty tile), 16x16 (two stacked images), 24x40 (ragged
+# 32-wide tiles, two column tiles), channels not a multiple of the 16-channel chunk / the 32-channel block
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 32, 64, 16, 16), (11, 20, 40, 16, 16), (3, 48, 33, 32, 32), (2, 16, 64, 48, 80)])
+def test_conv3_upsample_fused(ctx, oracle, conv_mode, B, Cin, Cout, H, W):
+    """SpatialUpSamplingNearest(2) + SpatialConvolution (models.lua:121-122,127-128).  In f16x3 mode this is the four-2x2-
+    convolutions kernel; the other modes fold the up-sampling into the 3x3 kernel's input addressing."""
     from ganrev import synth
-    B, Cin, Cout, H, W = 2, 32, 64, 16, 16      # input is 8x8, upsampled x2 while staged
     xs = synth.normal((B, Cin, H // 2, W // 2), 21)
     w = synth.uniform((Cout, Cin, 3, 3), 22, -0.1, 0.1)
     b = synth.uniform((Cout,), 23)
