@@ -15,7 +15,24 @@ struct GemmArgs {
   const float* A; const float* Bm; float* C; float* slab; const float* bias;
   long rsA, ksA, rsB, ksB, ldc;
   int M, N, K, klen, nsplit, accumulate;
+  ConvEpilogue ep;       // optional per-column epilogue (evaluate()-mode BatchNorm over the N features + activation); nsplit == 1 only
+  int has_ep;
+  unsigned* amax_out;    // nullable (nsplit == 1): max|C| folded into this f16x3 scale slot
 };
+
+// out = act(((v - mean[n]) * invstd[n]) * gamma[n] + beta[n]): nn.BatchNormalization in evaluate() mode + activation on the
+// Linear output (G: models.lua:115-117), the same operation order and roundings as the stand-alone pipeline kernel
+__device__ __forceinline__ float gemm_epilogue(const ConvEpilogue& ep, float v, int n) {
+  if (ep.mean) v = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v, ep.mean[n]), ep.invstd[n]), ep.gamma[n]), ep.beta[n]);
+  switch (ep.act) {
+    case ACT_ELU: return v <= 0.f ? (expf(v) - 1.f) : v;
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_LEAKYRELU: return v > 0.f ? v : __fmul_rn(v, ep.slope);
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
 
 // A 64(rows) x 32(k) operand tile is fetched into 8 registers per thread (one float4 pair along k when the operand is
 // K-contiguous and 16-byte aligned, scalars otherwise) while the MFMAs of the previous tile run, then written to LDS as
@@ -95,6 +112,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
     __syncthreads();
   }
   const int n = n0 + wn * 32 + l31;
+  float omax = 0.f;
   if (n < a.N) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -104,12 +122,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
           a.slab[((size_t)blockIdx.z * a.M + m) * a.N + n] = acc[r];
         } else {
           float v = acc[r] + (a.bias ? a.bias[n] : 0.f);
+          if (a.has_ep) v = gemm_epilogue(a.ep, v, n);
           float* c = a.C + (long)m * a.ldc + n;
-          *c = a.accumulate ? *c + v : v;
+          v = a.accumulate ? *c + v : v;
+          *c = v;
+          omax = fmaxf(omax, fabsf(v));
         }
       }
     }
   }
+  if (a.amax_out && a.nsplit == 1) absmax_commit(omax, a.amax_out);
 }
 
 __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ C, const float* __restrict__ bias,
@@ -143,10 +165,14 @@ size_t gemm_workspace_bytes(int M, int N, int K) {
   return ns > 1 ? sizeof(float) * (size_t)ns * M * N : 0;
 }
 
+bool gemm_epilogue_possible(int M, int N, int K) { int ns, kl; gemm_plan(M, N, K, ns, kl); return ns == 1; }
+
 void launch_gemm(const float* A, long rsA, long ksA, const float* Bm, long rsB, long ksB,
                  float* C, long ldc, const float* bias, bool accumulate, int M, int N, int K,
-                 void* workspace, hipStream_t s) {
+                 void* workspace, hipStream_t s, const ConvEpilogue* ep, unsigned* amax_out) {
   GemmArgs a{};
+  if (ep) { a.ep = *ep; a.has_ep = 1; }
+  a.amax_out = amax_out;
   a.A = A; a.Bm = Bm; a.C = C; a.slab = reinterpret_cast<float*>(workspace); a.bias = bias;
   a.rsA = rsA; a.ksA = ksA; a.rsB = rsB; a.ksB = ksB; a.ldc = ldc;
   a.M = M; a.N = N; a.K = K; a.accumulate = accumulate ? 1 : 0;

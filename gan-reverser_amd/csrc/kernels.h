@@ -155,9 +155,11 @@ inline bool conv_wgrad_is_split(int mode, int Cin, int W) { return mode >= 1 && 
 // ---------------------------------------------------------------- GEMM (Linear) on fp32 MFMA
 // C[m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]);  A(m,k) = A[m*rsA + k*ksA], B(n,k) = Bm[n*rsB + k*ksB]
 size_t gemm_workspace_bytes(int M, int N, int K);
+// ep (nullable; only when gemm_epilogue_possible, i.e. no split-K): per-column evaluate()-mode BatchNorm + activation
+bool gemm_epilogue_possible(int M, int N, int K);
 void launch_gemm(const float* A, long rsA, long ksA, const float* Bm, long rsB, long ksB,
                  float* C, long ldc, const float* bias, bool accumulate, int M, int N, int K,
-                 void* workspace, hipStream_t s);
+                 void* workspace, hipStream_t s, const ConvEpilogue* ep = nullptr, unsigned* amax_out = nullptr);
 
 // ---------------------------------------------------------------- per-channel pipelines (BN / act / dropout / pool)
 enum Act { ACT_NONE = 0, ACT_ELU = 3, ACT_RELU = 4, ACT_LEAKYRELU = 5, ACT_SIGMOID = 6, ACT_TANH = 7 };

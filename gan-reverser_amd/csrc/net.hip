@@ -653,6 +653,24 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     } else if (s.kind == ST_LINEAR) {
       const size_t wsb = gemm_workspace_bytes(B, s.Cout, s.Cin);
       r = ensure_ws(c, wsb); if (r) return r;
+      // evaluate() mode: per-feature BatchNorm + activation ride in the GEMM epilogue (G's first stage, models.lua:115-117:
+      // the raw Linear output - 268 MB at cfg3 - is never written)
+      bool nb1 = false, nb2 = false;
+      const MaskRef r1 = mask_ref(n, s.m1, nb1), r2 = mask_ref(n, s.m2, nb2);
+      if (!n->training && s.has_post && !s.pool && r1.kind == MASK_NONE && r2.kind == MASK_NONE && s.H == 1 && s.W == 1 &&
+          gemm_epilogue_possible(B, s.Cout, s.Cin)) {
+        ConvEpilogue ep;
+        if (s.has_bn) {
+          launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream);
+          ep.mean = s.mean; ep.invstd = s.invstd; ep.gamma = n->params + s.g_off; ep.beta = n->params + s.be_off;
+        }
+        ep.act = s.act; ep.slope = s.slope;
+        launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.out, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream, &ep, amax_next);
+        if (nx) nx->amax_x_fwd = n->fwd_counter;
+        s.fused_epilogue = true;
+        LAUNCHCHK(c);
+        x = s.out; continue;
+      }
       launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.y, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream);
     }
     LAUNCHCHK(c);
