@@ -2103,7 +2103,9 @@ static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a,
   long want = (wgrad_use_vec(W) ? 256 : 512) / (a.n_ob * a.n_cb);   // vec kernel: one software-pipelined workgroup per CU
   if (wgrad_use_small(Cin, W)) want = 1024 / a.n_ob;
   // measured (B=256): 32-wide planes 512 splits (two workgroups per CU overlap convert/store with MFMAs), 16-wide planes 256
-  else if (split) { const char* e = getenv("GR_WGRAD_SPLITS"); want = (e ? atoi(e) : (TW == 32 ? 512 : 256)) / (a.n_ob * a.n_cb); }
+  // measured (f16x3): 512 partial blocks pay off on 32-wide planes once there are many row steps per block (cfg3: 1.75 vs 1.93 ms),
+  // 256 otherwise (cfg2: the slab round trip of the extra blocks costs more than the overlap gains, -0.02 ms)
+  else if (split) { const char* e = getenv("GR_WGRAD_SPLITS"); want = (e ? atoi(e) : ((TW == 32 && (long)B * H * a.tiles_x >= 16384) ? 512 : 256)) / (a.n_ob * a.n_cb); }
   if (want < 1) want = 1;
   if (want > a.tiles_total) want = a.tiles_total;
   a.nsplit = (int)want;
