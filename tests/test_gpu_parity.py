@@ -65,6 +65,62 @@ def test_conv3_kernels_vs_oracle(ctx, oracle, conv_mode, B, Cin, Cout, H, W):
         ctx.free(p)
 
 
+def test_f16x3_scale_tracking_is_exact_and_range_safe(ctx, oracle):
+    """f16x3 puts every operand tensor into fp16 range with a power-of-two scale taken from its device-tracked maximum and
+    scales the result back with ldexp.  Consequences checked here, on forward / backward-data / backward-weight and on the
+    up-sampling kernel: (1) multiplying the inputs by powers of two - 2^-60, 2^40: far outside fp16's exponent range -
+    changes the output by exactly that power of two, bit for bit; (2) one element 2^20 times larger than the rest (every other
+    element's low term goes subnormal) keeps fp32-level accuracy relative to the largest output, and 1e-4 absolute away from it."""
+    from ganrev import synth
+    prev = ctx.conv_mode()
+    ctx.set_conv_mode("f16x3")
+    try:
+        B, Cin, Cout, H, W = 4, 64, 64, 16, 16
+        x = synth.normal((B, Cin, H, W), 91)
+        w = synth.uniform((Cout, Cin, 3, 3), 92, -1, 1) / np.float32(np.sqrt(Cin * 9))
+        gy = synth.normal((B, Cout, H, W), 93)
+        xs = synth.normal((B, Cin, H // 2, W // 2), 94)
+        lib = ctx.lib
+
+        def run(xv, wv, gv, xsv):
+            dx, dw, dg, dxs = _dev(ctx, xv), _dev(ctx, wv), _dev(ctx, gv), _dev(ctx, xsv)
+            dout, dgin = ctx.malloc(4 * B * Cout * H * W), ctx.malloc(4 * B * Cin * H * W)
+            dgw = _dev(ctx, np.zeros((Cout, Cin, 3, 3), np.float32))
+            ctx.check(lib.gr_conv3_forward_dev(ctx.h, dx, dw, None, dout, B, Cin, Cout, H, W, 0), "fwd")
+            y = ctx.download(dout, (B, Cout, H, W))
+            ctx.check(lib.gr_conv3_forward_dev(ctx.h, dxs, dw, None, dout, B, Cin, Cout, H, W, 1), "fwd-up")
+            yu = ctx.download(dout, (B, Cout, H, W))
+            ctx.check(lib.gr_conv3_backward_data_dev(ctx.h, dg, dw, dgin, B, Cin, Cout, H, W), "bwd-data")
+            gin = ctx.download(dgin, (B, Cin, H, W))
+            ctx.check(lib.gr_conv3_backward_weight_dev(ctx.h, dx, dg, dgw, B, Cin, Cout, H, W), "bwd-weight")
+            ctx.synchronize()
+            gw = ctx.download(dgw, (Cout, Cin, 3, 3))
+            for q in (dx, dw, dg, dxs, dout, dgin, dgw):
+                ctx.free(q)
+            return y, yu, gin, gw
+
+        base = run(x, w, gy, xs)
+        for kx, kw, kg in ((-60, 20, 30), (40, -50, -45)):
+            sx, sw, sg = np.float32(2.0) ** kx, np.float32(2.0) ** kw, np.float32(2.0) ** kg
+            y, yu, gin, gw = run(x * sx, w * sw, gy * sg, xs * sx)
+            assert np.array_equal(y, base[0] * (sx * sw)), "forward is not exactly scale-equivariant"
+            assert np.array_equal(yu, base[1] * (sx * sw)), "up-sampling forward is not exactly scale-equivariant"
+            assert np.array_equal(gin, base[2] * (sg * sw)), "backward-data is not exactly scale-equivariant"
+            assert np.array_equal(gw, base[3] * (sx * sg)), "backward-weight is not exactly scale-equivariant"
+        xo = x.copy(); xo[1, 3, 5, 7] = np.float32(2.0 ** 20)
+        y = run(xo, w, gy, xs)[0]
+        import torch
+        ref = torch.nn.functional.conv2d(torch.from_numpy(xo).double(), torch.from_numpy(w).double(), padding=1).numpy()
+        top = float(np.abs(ref).max())
+        # fp32 accumulation next to a 4e4 term rounds at ulp(4e4) = 4e-3 per add (the fp32 oracle is off by as much):
+        # the bar is fp32-level error relative to the largest output, and outputs away from the outlier keep their own accuracy
+        assert maxdiff(y, ref) <= 1e-5 * top
+        far = np.ones_like(ref, bool); far[1, :, 3:8, 5:10] = False
+        assert maxdiff(y[far], ref[far]) <= 1e-4
+    finally:
+        ctx.set_conv_mode(prev)
+
+
 # source planes 8x8 (eight stacked images per tile, odd batch -> a partly empty tile), 16x16 (two stacked images), 24x40 (ragged
 # 32-wide tiles, two column tiles), channels not a multiple of the 16-channel chunk / the 32-channel block
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 32, 64, 16, 16), (11, 20, 40, 16, 16), (3, 48, 33, 32, 32), (2, 16, 64, 48, 80)])
