@@ -38,6 +38,10 @@ int gr_adam_step(gr_net*, const gr_hyper*, int t);
 int gr_cosine_topk_host(gr_ctx*, const float* emb, int64_t n, int d, const int64_t* rows, int q, int k,
                         int64_t* idx, float* score, int accumulate_in_float);
 int gr_cosine_similarity_host(gr_ctx*, const float* a, const float* b, int d, float* out);
+int gr_l2_distance_rows_host(gr_ctx*, const float* a, const float* b, int64_t n, int64_t d, double* out);
+int gr_kmeans_host(gr_ctx*, const float* x, int64_t n, int d, int k, int niter, float* centroids_inout, float* total_counts, int32_t* labels);
+int gr_cosine_assign_host(gr_ctx*, const float* x, int64_t n, int d, const float* centroids, int k, int take_min, int32_t* labels, float* sims);
+int gr_set_conv_mode(gr_ctx*, int mode);   /* 0 exact fp32 MFMA, 1 bf16x6, 2 f16x3 (default) */
 ]]
 local C = ffi.load('ganrev')          -- libganrev.so on LD_LIBRARY_PATH
 local hipnn = {}
@@ -170,6 +174,27 @@ function hipnn.cosineTopK(attributes, needles, k)
    check(C.gr_cosine_topk_host(context(), attributes:contiguous():data(), N, d, rows, Q, k,
                                ffi.cast('int64_t*', idx:data()), sc:data(), 0), 'gr_cosine_topk_host')
    return idx:add(1), sc
+end
+
+-- apply_r.lua:198 replacement: unsup.kmeans(attributes, nbClusters, nbIterations) -> centroids, totalcounts
+-- (initial centroids drawn here exactly as unsup does: normal() rows divided by their norm, from Torch's RNG)
+function hipnn.kmeans(attributes, k, niter)
+   local N, d = attributes:size(1), attributes:size(2)
+   local centroids = torch.FloatTensor(k, d):normal()
+   for i = 1, k do centroids[i]:div(centroids[i]:norm()) end
+   local counts = torch.FloatTensor(k)
+   check(C.gr_kmeans_host(context(), attributes:contiguous():data(), N, d, k, niter, centroids:data(), counts:data(), nil), 'gr_kmeans_host')
+   return centroids, counts
+end
+
+-- apply_r.lua:205-217 replacement: per row the (1-based) cluster with the MINIMUM cosine similarity, as the reference's loop
+-- keeps it, and that similarity
+function hipnn.assignClusters(attributes, centroids)
+   local N, d, k = attributes:size(1), attributes:size(2), centroids:size(1)
+   local labels = torch.IntTensor(N); local sims = torch.FloatTensor(N)
+   check(C.gr_cosine_assign_host(context(), attributes:contiguous():data(), N, d, centroids:contiguous():data(), k, 1,
+                                 labels:data(), sims:data()), 'gr_cosine_assign_host')
+   return labels:add(1), sims
 end
 
 return hipnn
