@@ -32,6 +32,9 @@ class LocalCommunicator:
     def allreduce_scalar(self, x):
         return x
 
+    def allgather(self, arr):
+        return [arr]
+
 
 class TorchDistCommunicator:
     """torch.distributed (gloo on CPU, or any initialised backend) all-reduce of host arrays: test / control plane."""
@@ -52,6 +55,14 @@ class TorchDistCommunicator:
         t = torch.tensor([x], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
+
+    def allgather(self, arr):
+        """Equal-shaped host arrays from every rank, in rank order."""
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.numpy() for o in out]
 
 
 class RcclCommunicator:
@@ -146,3 +157,55 @@ def host_allreduce_grads(dist):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         rnet.set_grads(t.numpy())
     return fn
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sharded similarity search: the corpus rows are independent and top-k merges associatively, so the N rows are
+# split over the ranks, every rank scores ITS rows against the needles and keeps its k best, and the P*k candidates are
+# merged with the order the single-GPU search defines (score descending, global row index ascending).  A (needle, row)
+# score does not depend on which rank computes it, so the merged lists are bit-identical to an unsharded search.
+# The only exchanges are the needle vectors (Q x d floats) and the candidates (Q x k x 12 bytes per rank).
+
+def gather_needles(emb_shard, row_offset, needle_rows, comm):
+    """The needle vectors emb[needle_rows] on every rank: each needle is contributed by the rank that owns its row, zeros
+    elsewhere, and summed (x + 0 is exact)."""
+    emb_shard = np.asarray(emb_shard, np.float32)
+    out = np.zeros((len(needle_rows), emb_shard.shape[1]), np.float32)
+    for i, r in enumerate(needle_rows):
+        if row_offset <= r < row_offset + len(emb_shard):
+            out[i] = emb_shard[r - row_offset]
+    return comm.allreduce_sum(out)
+
+
+def merge_candidates(idx_lists, score_lists, k):
+    """Candidates [P][Q, k'] -> the k best per needle, ordered by (score descending, row index ascending)."""
+    idx = np.concatenate(idx_lists, axis=1)
+    sc = np.concatenate(score_lists, axis=1)
+    Q = idx.shape[0]
+    out_i = np.empty((Q, min(k, idx.shape[1])), np.int64)
+    out_s = np.empty(out_i.shape, np.float32)
+    for q in range(Q):
+        order = np.lexsort((idx[q], -sc[q].astype(np.float64)))       # primary: score desc; ties: index asc
+        order = order[sc[q][order] > -np.inf][:out_i.shape[1]]
+        out_i[q, :len(order)] = idx[q][order]; out_s[q, :len(order)] = sc[q][order]
+        out_i[q, len(order):] = -1; out_s[q, len(order):] = -np.inf
+    return out_i, out_s
+
+
+def sharded_cosine_topk(local_topk, emb_shard, row_offset, needle_rows, k, comm):
+    """apply_r.lua:266-282 over a corpus whose rows [row_offset, row_offset + len(emb_shard)) live on this rank.
+    local_topk(emb, query_rows, k) -> (idx, scores) is the single-device search (Context.cosine_topk).  The needle vectors
+    are put in front of the shard so that they are rows of the searched matrix; their own hits are dropped afterwards."""
+    emb_shard = np.asarray(emb_shard, np.float32)
+    needles = gather_needles(emb_shard, row_offset, needle_rows, comm)
+    Q = len(needle_rows)
+    aug = np.concatenate([needles, emb_shard])
+    kk = min(k + Q, len(aug))
+    idx, sc = local_topk(aug, np.arange(Q, dtype=np.int64), kk)
+    cand_i = np.full((Q, k), -1, np.int64); cand_s = np.full((Q, k), -np.inf, np.float32)
+    for q in range(Q):
+        keep = idx[q] >= Q                                          # rows of the shard proper
+        ii, ss = idx[q][keep][:k], sc[q][keep][:k]
+        cand_i[q, :len(ii)] = ii - Q + row_offset; cand_s[q, :len(ii)] = ss
+    gi, gs = comm.allgather(cand_i), comm.allgather(cand_s)
+    return merge_candidates(gi, gs, k)

@@ -109,3 +109,46 @@ def test_two_rank_step_equals_grouped_single_process_oracle():
     well = np.abs(oR.grads) > 1e-4
     assert np.max(np.abs(p0[well] - oR.params[well])) < 1e-5
     assert np.max(np.abs(p0 - oR.params)) < 4.1e-3
+
+
+def _search_worker(rank, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    for p in (os.path.join(ROOT, "gan-reverser_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ganrev import synth
+    from ganrev.parallel import TorchDistCommunicator, sharded_cosine_topk
+    from oracle import oracle
+    N, d, k = 4001, 32, 50
+    emb = synth.normal((N, d), 77)
+    emb[1234] = emb[99]                                     # a duplicate row: a score tie across the two shards
+    lo = 0 if rank == 0 else 2000
+    hi = 2000 if rank == 0 else N
+    idx, sc = sharded_cosine_topk(oracle.cosine_topk, emb[lo:hi], lo, [99, 199, 2999, 4000], k, TorchDistCommunicator())
+    q.put((rank, idx, sc))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_sharded_search_two_ranks_equals_unsharded():
+    """corpus rows split over 2 ranks (unequal shards), local top-k, candidate all-gather, merge: the lists must be
+    bit-identical to the unsharded search (oracle as the local search: the HIP library needs a GPU), ties included."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_search_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(WORLD)]
+    for p in procs:
+        p.join(60)
+    for p in (os.path.join(ROOT, "gan-reverser_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ganrev import synth
+    from oracle import oracle
+    emb = synth.normal((4001, 32), 77); emb[1234] = emb[99]
+    ridx, rsc = oracle.cosine_topk(emb, [99, 199, 2999, 4000], 50)
+    for _, idx, sc in res:
+        assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)

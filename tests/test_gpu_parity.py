@@ -711,3 +711,35 @@ def test_create_cluster_images_mirror(ctx, oracle):
         assert [r for r, _ in members] == list(ref)
         if len(ref):
             assert maxdiff(faces[j], images[ref].mean(0)) <= 1e-6
+
+
+def test_sharded_search_merge_equals_unsharded(ctx):
+    """ganrev.parallel.sharded_cosine_topk with the HIP search as the local search: three unequal shards merged in one process
+    (a list-backed communicator) give the unsharded device result bit for bit."""
+    from ganrev import synth
+    from ganrev.parallel import sharded_cosine_topk
+    N, d, k = 30011, 100, 50
+    emb = synth.normal((N, d), 88); emb[20000] = emb[150]
+    needles = [100, 150, 29999]
+    bounds = [(0, 9000), (9000, 21000), (21000, N)]
+
+    shards = [emb[lo:hi] for lo, hi in bounds]
+    nd = emb[needles]
+
+    class Comm:
+        def __init__(self, r, box): self.rank, self.world, self.box = r, 3, box
+        def allreduce_sum(self, arr): return nd.copy()      # what the sum of the three contributions is
+        def allgather(self, arr):
+            self.box.setdefault(id(self), []).append(arr); return [arr]
+    # two phases: collect every rank's candidates, then merge
+    from ganrev.parallel import merge_candidates
+    cand_i, cand_s = [], []
+    for r, (lo, hi) in enumerate(bounds):
+        box = {}
+        c = Comm(r, box)
+        sharded_cosine_topk(ctx.cosine_topk, shards[r], lo, needles, k, c)
+        ci, cs = box[id(c)]
+        cand_i.append(ci); cand_s.append(cs)
+    idx, sc = merge_candidates(cand_i, cand_s, k)
+    ridx, rsc = ctx.cosine_topk(emb, needles, k)
+    assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
