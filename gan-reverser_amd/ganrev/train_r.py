@@ -66,11 +66,23 @@ def main(argv=None):
     dims = (OPT.channels, OPT.height, OPT.width)
     ctx = L.Context(OPT.gpu) if OPT.gpu != int(__import__("os").environ.get("LOCAL_RANK", "0")) else L.default_context()
     ctx.set_conv_mode(OPT.conv_mode)
-    MODEL_G = models.create_G(dims, OPT.noiseDim, seed=OPT.seed)
-    if OPT.G:
-        load_params(OPT.G, MODEL_G)                                      # train_r.lua:68-75
+    if OPT.G and OPT.G.endswith((".net", ".t7")):
+        # a checkpoint in Torch7's own format (train.lua:256 {G=..., opt=...}): train_r.lua:68-75 takes G and the image
+        # geometry / noise settings from it
+        from . import t7
+        ck = t7.load_checkpoint(OPT.G)
+        MODEL_G = ck["G"]
+        o = ck.get("opt", {})
+        OPT.noiseDim, OPT.noiseMethod = int(o.get("noiseDim", OPT.noiseDim)), o.get("noiseMethod", OPT.noiseMethod)
+        OPT.height, OPT.width = int(o.get("height", OPT.height)), int(o.get("width", OPT.width))
+        OPT.channels = 1 if o.get("colorSpace", "rgb") == "y" else 3
+        dims = (OPT.channels, OPT.height, OPT.width)
     else:
-        synth.init_params(MODEL_G, OPT.seed)
+        MODEL_G = models.create_G(dims, OPT.noiseDim, seed=OPT.seed)
+        if OPT.G:
+            load_params(OPT.G, MODEL_G)                                  # train_r.lua:68-75 (this package's npz form)
+        else:
+            synth.init_params(MODEL_G, OPT.seed)
     MODEL_G.evaluate()                                                   # train_r.lua:70
     MODEL_R = models.create_R(dims, OPT.noiseDim, OPT.noiseMethod, OPT.fixer, seed=OPT.seed)   # train_r.lua:106
     MODEL_G._ctx = MODEL_R._ctx = ctx
@@ -116,6 +128,14 @@ def main(argv=None):
         if not OPT.quiet:
             print("<trainer> Last batch reached. %.1f images/s" % (OPT.batchSize * OPT.nbBatches / (time.perf_counter() - t0)))
         MODEL_R.pull_params()
+    if OPT.save:
+        # train_r.lua:227-235: {R=MODEL_R, opt=OPT}; ".net" -> Torch7 serialisation (ganrev/t7.py), otherwise this package's npz
+        opt_table = {k: v for k, v in vars(OPT).items() if isinstance(v, (int, float, str, bool))}
+        if str(OPT.save).endswith((".net", ".t7")):
+            from . import t7
+            t7.save_checkpoint(OPT.save, R=MODEL_R, opt=opt_table)
+        elif str(OPT.save).endswith(".npz"):
+            save_model(OPT.save, MODEL_R, opt_table)
     return MODEL_G, MODEL_R, losses
 
 

@@ -743,3 +743,20 @@ def test_sharded_search_merge_equals_unsharded(ctx):
     idx, sc = merge_candidates(cand_i, cand_s, k)
     ridx, rsc = ctx.cosine_topk(emb, needles, k)
     assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
+
+
+def test_train_r_reads_and_writes_torch7_checkpoints(ctx, tmp_path):
+    """train_r.lua:68-75 (G and the geometry come from a Torch7 checkpoint {G=..., opt=...}) and :227-235 (torch.save {R=..., opt=...})
+    through ganrev/t7.py: G's images from the loaded model equal the original's, and the saved R reloads to the trained parameters."""
+    from ganrev import models, synth, t7, train_r
+    G = models.create_G((1, 16, 16), 8); synth.init_params(G, 3)
+    gpath, rpath = str(tmp_path / "g.net"), str(tmp_path / "r.net")
+    t7.save_checkpoint(gpath, G=G, opt={"noiseDim": 8, "noiseMethod": "normal", "height": 16, "width": 16, "colorSpace": "y"})
+    G2, R, losses = train_r.main(["--G", gpath, "--save", rpath, "--nbBatches", "3", "--batchSize", "8", "--quiet", "--height", "99"])
+    z = synth.normal((4, 8), 5)
+    G.evaluate(); G2.evaluate()
+    assert np.array_equal(G.forward(z), G2.forward(z))                    # same weights, same kernels; --height was overridden by opt
+    back = t7.load_checkpoint(rpath)
+    assert back["opt"]["noiseDim"] == 8 and back["opt"]["height"] == 16
+    assert np.array_equal(back["R"]._flat_host(), R._flat_host())
+    assert len(losses) == 3 and all(np.isfinite(losses))

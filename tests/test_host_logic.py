@@ -116,3 +116,48 @@ def test_shard_bounds():
     assert [shard_bounds(4096, 8, r) for r in (0, 7)] == [(0, 512), (3584, 4096)]
     with pytest.raises(ValueError):
         shard_bounds(10, 4, 0)
+
+
+def test_t7_reader_on_hand_assembled_bytes():
+    """Torch7 binary serialisation (train_r.lua:68 torch.load; format restated from memory in ganrev/t7.py): a byte string put
+    together here field by field - number, string, boolean, nested array table, a 2x3 FloatTensor view with a storage offset
+    and non-trivial strides, a repeated reference, an nn object - must read back as the values it encodes."""
+    import struct
+    from ganrev import t7
+    i32 = lambda v: struct.pack("<i", v)
+    i64 = lambda v: struct.pack("<q", v)
+    num = lambda v: i32(1) + struct.pack("<d", v)
+    st = lambda s: i32(2) + i32(len(s)) + s.encode()
+    raw = lambda s: i32(len(s)) + s.encode()
+    storage = np.arange(10, dtype=np.float32)
+    # tensor: 2x3 view of the storage, offset 2 (1-based 3), strides (1, 2): element [i][j] = storage[2 + i + 2j]
+    tensor = (i32(4) + i32(5) + raw("V 1") + raw("torch.FloatTensor") + i32(2) + i64(2) + i64(3) + i64(1) + i64(2) + i64(3) +
+              i32(4) + i32(6) + raw("V 1") + raw("torch.FloatStorage") + i64(10) + storage.tobytes())
+    inner = i32(3) + i32(2) + i32(3) + num(1) + num(10) + num(2) + num(20) + num(3) + num(30)
+    module = i32(4) + i32(7) + raw("V 1") + raw("nn.ReLU") + i32(3) + i32(8) + i32(1) + st("inplace") + i32(5) + i32(0)
+    blob = (i32(3) + i32(1) + i32(7) +
+            st("a") + num(1.5) + st("b") + st("xy") + st("flag") + i32(5) + i32(1) + st("arr") + inner +
+            st("t") + tensor + st("again") + i32(4) + i32(5) + st("m") + module)
+    o = t7.load(blob)
+    assert o["a"] == 1.5 and o["b"] == "xy" and o["flag"] is True and o["arr"] == [10, 20, 30]
+    assert o["t"].dtype == np.float32 and np.array_equal(o["t"], [[2, 4, 6], [3, 5, 7]])
+    assert o["again"] is o["t"]
+    assert o["m"].typename == "nn.ReLU" and o["m"].fields == {"inplace": False}
+
+
+def test_t7_checkpoint_round_trip():
+    """train_r.lua:234 / :68: {R=MODEL_R, opt=OPT} written by ganrev.t7.save_checkpoint and read back: same layers, parameters,
+    running statistics, the fixer's always-on dropout, and the opt table; G with its cudnn-free layer set likewise."""
+    from ganrev import models, synth, t7
+    for make, dims in ((lambda: models.create_R((3, 16, 16), 10, "uniform", True), (3, 16, 16)), (lambda: models.create_G((1, 16, 16), 8), (8, 1, 1))):
+        m = make(); synth.init_params(m, 9)
+        for j, bn in enumerate([x for x in m.leaves() if hasattr(x, "running_mean")]):
+            bn.running_mean[...] = synth.normal(bn.running_mean.shape, 30 + j); bn.running_var[...] = synth.uniform(bn.running_var.shape, 60 + j, 0.5, 2)
+        blob = t7.dumps({"R": t7.from_model(m), "opt": {"noiseDim": 10, "noiseMethod": "uniform", "height": 16, "width": 16, "colorSpace": "rgb"}})
+        back = t7.load(blob)
+        assert back["opt"] == {"noiseDim": 10, "noiseMethod": "uniform", "height": 16, "width": 16, "colorSpace": "rgb"}
+        m2 = t7.to_model(back["R"])
+        assert m2._descs(dims)[0] == m._descs(dims)[0]                       # same layer descriptors (kinds, sizes, dropout flags)
+        assert np.array_equal(m2._flat_host(), m._flat_host())
+        for a, b in zip([x for x in m.leaves() if hasattr(x, "running_mean")], [x for x in m2.leaves() if hasattr(x, "running_mean")]):
+            assert np.array_equal(a.running_mean, b.running_mean) and np.array_equal(a.running_var, b.running_var)
