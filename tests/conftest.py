@@ -28,8 +28,8 @@ def ctx():
 
 @pytest.fixture(params=["f32", "bf16x6", "f16x3"])
 def conv_mode(request):
-    """Run the test once per convolution arithmetic: exact fp32 MFMA, and the fp32-accurate 3-term bf16 split (bf16x6) that
-    bench.py uses by default.  Same tolerances for both."""
+    """Run the test once per convolution arithmetic: exact fp32 MFMA, the fp32-accurate 3-term bf16 split (bf16x6) and the
+    fp32-accurate 2-term fp16 split of scaled operands (f16x3) that bench.py uses by default.  Same tolerances for all three."""
     import ganrev._lib as L
     c = L.default_context()
     prev = c.conv_mode()
