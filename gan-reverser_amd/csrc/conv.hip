@@ -869,27 +869,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
       for (int ng = 0; ng < NG; ++ng) acc[mt][ng][r] = (NTERM == 2 ? ldexpf(acc[mt][ng][r], -ktot) : acc[mt][ng][r]) + bvv;
     }
   if (a.stat_part) {
-    // BatchNorm batch statistics of what is about to be stored: per channel the 64 pixels of this wave (two per lane, 32
-    // lanes of one half-wave) in fp32, the 8 waves and all workgroups in fp64 and in a fixed order
-    float* red = reinterpret_cast<float*>(smem_raw);             // [8 waves][64 channels][2]; the operand images are dead
+    // BatchNorm batch statistics of what is about to be stored.  Per (wave, channel) the 64 pixels are two per lane over 32
+    // lanes: the per-lane sums go through LDS transposed ([wave][quantity][channel][lane], row stride 33), one thread adds a
+    // row in lane order, then the 8 waves are added in fp64 - everything in a fixed order.  (640 DPP adds per wave did the
+    // same at four times the cost; the operand images in LDS are dead by now.)
+    float* red = reinterpret_cast<float*>(smem_raw);             // [8 waves][2][32 channels][33]  = 67.6 KB per channel block
+    float* rowsum = red + 8 * 2 * 32 * 33;                       // [512]
+    const int tile = xcd_remap(blockIdx.x, gridDim.x) / a.n_otiles;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float sv = 0.f, qv = 0.f;
 #pragma unroll
         for (int ng = 0; ng < NG; ++ng) { const float v = pin[ng] ? acc[mt][ng][r] : 0.f; sv += v; qv += v * v; }
-        sv = half_wave_sum(sv); qv = half_wave_sum(qv);
-        if (l31 == 16) { const int ch = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; red[(wave * 64 + ch) * 2] = sv; red[(wave * 64 + ch) * 2 + 1] = qv; }
+        const int chl = (r & 3) + 8 * (r >> 2) + 4 * h;            // channel within this 32-channel block
+        red[((wave * 2 + 0) * 32 + chl) * 33 + l31] = sv;
+        red[((wave * 2 + 1) * 32 + chl) * 33 + l31] = qv;
       }
-    __syncthreads();
-    if (tid < 128) {
-      const int ch = tid >> 1, wh = tid & 1;
-      double t = 0.0;
+      __syncthreads();
+      {
+        const float* row = red + tid * 33;                         // row tid = (wave, quantity, channel)
+        float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) t += (double)red[(w * 64 + ch) * 2 + wh];
-      const int tile = xcd_remap(blockIdx.x, gridDim.x) / a.n_otiles;
-      if (o0 + ch < a.Cout) a.stat_part[((size_t)(o0 + ch) * a.stat_tiles + tile) * 2 + wh] = t;
+        for (int i = 0; i < 32; ++i) t += row[i];
+        rowsum[tid] = t;
+      }
+      __syncthreads();
+      if (tid < 64) {                                              // (quantity, channel): the 8 waves in order
+        const int wh = tid >> 5, chl = tid & 31;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += (double)rowsum[(w * 2 + wh) * 32 + chl];
+        const int o = o0 + mt * 32 + chl;
+        if (o < a.Cout) a.stat_part[((size_t)o * a.stat_tiles + tile) * 2 + wh] = t;
+      }
+      __syncthreads();
     }
   }
 #pragma unroll
