@@ -114,11 +114,30 @@ def main():
     rnet.set_seed(1 + rank)                                              # independent dropout noise per rank
     rnet.adam_reset()
     shared_gpu = bool(os.environ.get("GANREV_ALL_RANKS_ON_DEVICE0")) and world > 1
-    if world > 1 and not shared_gpu:
+    host_reduce, rccl_error = shared_gpu, None
+    # GANREV_TEST_RCCL_INIT: with the shared-GPU hook, attempt the RCCL bootstrap anyway (it is refused: duplicate device) to
+    # exercise the fallback below on a 1-GPU box
+    if world > 1 and (not shared_gpu or os.environ.get("GANREV_TEST_RCCL_INIT")):
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], world, rank)                                # RCCL over xGMI, inside libganrev.so
-        rnet.broadcast_params(0)
+        try:
+            ctx.comm_init(uid[0], world, rank)                            # RCCL over xGMI, inside libganrev.so
+            ok = 1
+        except Exception as e:                                            # noqa: BLE001 - reported below, never silent
+            ok, rccl_error = 0, str(e)
+        t_ok = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok.item()) == 1:
+            rnet.broadcast_params(0)
+        else:
+            # Safety net so that a communicator problem on one node type does not lose the whole scaling run: the gradients go
+            # through the gloo control group on the host instead (correct, slow); the JSON line says so in config.parallelism.
+            if ok:
+                ctx.comm_destroy()
+            host_reduce = True
+            errs = [None] * world
+            dist.all_gather_object(errs, rccl_error)
+            rccl_error = next((e for e in errs if e), "unknown")
     hyper = L.Hyper()
     GB = B * world
     from ganrev.parallel import DeviceTrainer, host_allreduce_grads
@@ -135,7 +154,7 @@ def main():
         nonlocal t_adam
         t_adam += 1
         trainer.new_noise((t_adam << 8) + rank)                          # createNoiseInputs (utils/nn_utils.lua:39-51), on device
-        if shared_gpu:   # test hook only: ranks share GPU 0, RCCL refuses duplicate devices -> reduce through gloo
+        if host_reduce:  # test hook (ranks share GPU 0: RCCL refuses duplicate devices) or the RCCL-init fallback: reduce through gloo
             return trainer.step_decomposed(host_allreduce_grads(dist))
         return trainer.step(want_loss=want_loss)
 
@@ -218,7 +237,8 @@ def main():
                       "f16x3": "f32 via f16x3 (2-term fp16 split of power-of-two-scaled operands, 3 MFMA products, fp32 accumulate)"}[ctx.conv_mode()],
             "data": "synthetic",
             "config": {"workload": wl["name"], "global_batch": GB, "per_gpu_batch": B,
-                       "parallelism": f"dp{world}" + (" (RCCL all-reduce of R's flat gradient)" if world > 1 else ""),
+                       "parallelism": f"dp{world}" + ("" if world == 1 else (" (RCCL all-reduce of R's flat gradient)" if not host_reduce else
+                                                      f" (gradients reduced through gloo on the host: {'ranks share one GPU' if shared_gpu else 'RCCL init FAILED: ' + str(rccl_error)})")),
                        "bn": "per-rank batch statistics"},
             "step_tflops": round(fl_img * GB * args.steps / dt / 1e12 / world, 2),
             "step_frac_of_fp32_mfma_peak": round(fl_img * GB * args.steps / dt / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -236,7 +256,7 @@ def main():
             out["cpu_baseline"] = None
     if world > 1:
         dist.barrier()
-        if not shared_gpu:
+        if not host_reduce:
             ctx.comm_destroy()
         dist.destroy_process_group()
     if out is not None:
