@@ -400,13 +400,30 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
   if (threadIdx.x == 0) { a.partials[((long)c * STAT_SPLITS + sp) * 2] = s; a.partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
 }
 
-__global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a, int splits) {
+// BatchNorm-backward coefficients of channel c from pass A's partial sums (what post_backward_finalize_kernel computes, same
+// summation order): every pass-B workgroup derives them itself - 2 x `splits` doubles - instead of a launch in between; the
+// workgroup of split 0 also accumulates the gamma / beta gradients.
+__device__ __forceinline__ void post_bwd_coef(const PostBwdArgs& a, int c, int sp, int splits, double n, float* sh_coef) {
+  if (threadIdx.x == 0) {
+    double s = 0, q = 0;
+    for (int k = 0; k < splits; ++k) { s += a.partials[((long)c * STAT_SPLITS + k) * 2]; q += a.partials[((long)c * STAT_SPLITS + k) * 2 + 1]; }
+    const double invstd = a.f.invstd[c];
+    sh_coef[0] = (float)(s / n);
+    sh_coef[1] = (float)(q * invstd * invstd / n);
+    if (sp == 0) { a.ggamma[c] += (float)(q * invstd); a.gbeta[c] += (float)s; }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a, int splits, double n) {
   __shared__ double sh[8];
+  __shared__ float sh_coef[2];
   const PostArgs& f = a.f;
   const int c = blockIdx.x, sp = blockIdx.y;
+  post_bwd_coef(a, c, sp, splits, n, sh_coef);
   const unsigned H = f.H, W = f.W, Wo = f.pool ? W >> 1 : W, HW = H * W, HWo = f.pool ? (H >> 1) * Wo : HW, q4 = HW >> 2, wq = W >> 2;
   const int per = (f.B + splits - 1) / splits, b0 = sp * per, b1 = min(f.B, b0 + per);
-  const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], bt = f.beta[c], gm = a.coef[2 * c], k = a.coef[2 * c + 1];
+  const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], bt = f.beta[c], gm = sh_coef[0], k = sh_coef[1];
   double s = 0;
   float dmax = 0.f;
   const unsigned tot = (unsigned)(b1 - b0) * q4;
@@ -428,7 +445,7 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
   }
   if (a.amax_dy) absmax_commit(dmax, a.amax_dy);
   s = block_reduce_sum(s, sh);
-  if (threadIdx.x == 0) a.partials[((long)c * STAT_SPLITS + sp) * 2] = s;
+  if (threadIdx.x == 0) a.partials_b[(long)c * STAT_SPLITS + sp] = s;
 }
 
 __global__ void post_backward_finalize_kernel(PostBwdArgs a, int splits, double n) {
@@ -449,14 +466,16 @@ __global__ void post_backward_finalize_kernel(PostBwdArgs a, int splits, double 
 }
 
 // pass B (BN only): dy = ((dz - gm) - (y-mean)*k) * invstd * gamma ; per-channel sum of dy for the bias gradient
-__global__ __launch_bounds__(256) void post_backward_b_kernel(PostBwdArgs a, int splits) {
+__global__ __launch_bounds__(256) void post_backward_b_kernel(PostBwdArgs a, int splits, double nn) {
   __shared__ double sh[8];
+  __shared__ float sh_coef[2];
   const PostArgs& f = a.f;
   const int c = blockIdx.x, sp = blockIdx.y;
+  post_bwd_coef(a, c, sp, splits, nn, sh_coef);
   const long HW = (long)f.H * f.W;
   const long n = (long)f.B * HW, chunk = (n + splits - 1) / splits;
   const long j0 = sp * chunk, j1 = min(n, j0 + chunk);
-  const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], gm = a.coef[2 * c], k = a.coef[2 * c + 1];
+  const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], gm = sh_coef[0], k = sh_coef[1];
   double s = 0;
   float dmax = 0.f;
   for (long j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
@@ -469,18 +488,28 @@ __global__ __launch_bounds__(256) void post_backward_b_kernel(PostBwdArgs a, int
   }
   if (a.amax_dy) absmax_commit(dmax, a.amax_dy);
   s = block_reduce_sum(s, sh);
-  if (threadIdx.x == 0) a.partials[((long)c * STAT_SPLITS + sp) * 2] = s;
+  if (threadIdx.x == 0) a.partials_b[(long)c * STAT_SPLITS + sp] = s;
 }
 
-__global__ void bias_grad_finalize_kernel(const double* __restrict__ partials, float* gbias, int C, int splits) {
+// conv / linear bias gradients of several stages in one launch (blockIdx.y = stage): sums of pass B's per-split sums of dy
+__global__ void bias_grad_batch_kernel(BiasJobs jobs) {
+  const BiasJob j = jobs.job[blockIdx.y];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  if (c >= j.C) return;
   double s = 0;
-  for (int k = 0; k < splits; ++k) s += partials[((long)c * STAT_SPLITS + k) * 2];
-  gbias[c] += (float)s;
+  for (int k = 0; k < j.splits; ++k) s += j.partials[(long)c * STAT_SPLITS + k];
+  j.gbias[c] += (float)s;
+}
+void launch_bias_grad_batch(BiasJobs& jobs, hipStream_t s) {
+  if (jobs.n <= 0) return;
+  int maxc = 1;
+  for (int i = 0; i < jobs.n; ++i) if (jobs.job[i].C > maxc) maxc = jobs.job[i].C;
+  KtScope kt("bias_grad_batch_kernel", 0.0, 0.0, s);
+  hipLaunchKernelGGL(bias_grad_batch_kernel, dim3((maxc + 255) / 256, jobs.n), dim3(256), 0, s, jobs);
+  jobs.n = 0;
 }
 
-void launch_post_backward(const PostBwdArgs& a, hipStream_t s) {
+void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) {
   const PostArgs& f = a.f;
   const long n = (long)f.B * f.H * f.W;
   int splits = stat_splits(n);
@@ -494,17 +523,23 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s) {
     KtScope kt("post_backward_a_kernel", 0.0, 4.0 * (2.0 * pre + post), s);
     hipLaunchKernelGGL(post_backward_a_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
   }
-  hipLaunchKernelGGL(post_backward_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a, splits, (double)n);
-  if (f.has_bn) {
-    if (vec) {
-      KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);                      // reads g and y, writes dy
-      hipLaunchKernelGGL(post_backward_b_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
-    } else {
-      KtScope kt("post_backward_b_kernel", 0.0, 4.0 * 3.0 * pre, s);
-      hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
-    }
-    if (a.gbias)
-      hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a.partials, a.gbias, f.C, splits);
+  if (!f.has_bn) {      // no BatchNorm: pass A's dz is dy; only the bias gradient is left to sum
+    hipLaunchKernelGGL(post_backward_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a, splits, (double)n);
+    return;
+  }
+  if (vec) {
+    KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);                      // reads g and y, writes dy
+    hipLaunchKernelGGL(post_backward_b_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits, (double)n);
+  } else {
+    KtScope kt("post_backward_b_kernel", 0.0, 4.0 * 3.0 * pre, s);
+    hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits, (double)n);
+  }
+  if (a.gbias) {
+    BiasJobs one{}; one.n = 0;
+    BiasJobs* q = defer ? defer : &one;
+    if (q->n == 16) launch_bias_grad_batch(*q, s);
+    q->job[q->n++] = BiasJob{a.partials_b, a.gbias, f.C, splits};
+    if (!defer) launch_bias_grad_batch(one, s);
   }
 }
 
@@ -584,6 +619,41 @@ __global__ void gen_mask_kernel(uint32_t* words, long nwords, uint32_t thresh, i
     }
     words[i] = w;
   }
+}
+// every Dropout / SpatialDropout mask of one forward in ONE launch (blockIdx.y = job): the masks depend on (seed, forward
+// counter, layer, element) only, so they can all be drawn before the first layer runs.  Same Philox indexing as gen_mask_kernel.
+__global__ void gen_mask_batch_kernel(MaskJobs jobs, uint32_t s0, uint32_t s1, uint32_t c0, uint32_t c1) {
+  const MaskJob j = jobs.job[blockIdx.y];
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (j.half) {
+    if (i * 4 >= j.nwords) return;
+    const u4 r = philox4x32(u4{(uint32_t)i, j.layer, c0, c1}, s0, s1);
+    const uint32_t o[4] = {r.x, r.y, r.z, r.w};
+    for (int k = 0; k < 4; ++k) if (i * 4 + k < j.nwords) j.words[i * 4 + k] = o[k];
+  } else {
+    if (i >= j.nwords) return;
+    uint32_t w = 0;
+    for (int jj = 0; jj < 8; ++jj) {
+      const u4 r = philox4x32(u4{(uint32_t)i, (uint32_t)jj | (j.layer << 8), c0, c1}, s0, s1);
+      const uint32_t o[4] = {r.x, r.y, r.z, r.w};
+      for (int k = 0; k < 4; ++k) w |= (o[k] >= j.thresh ? 1u : 0u) << (jj * 4 + k);
+    }
+    j.words[i] = w;
+  }
+}
+MaskJob make_mask_job(uint32_t* words, long n_elems, float p_drop, uint32_t layer) {
+  MaskJob j{};
+  j.words = words; j.nwords = (n_elems + 31) / 32; j.half = p_drop == 0.5f ? 1 : 0; j.layer = layer;
+  j.thresh = (uint32_t)fmin(4294967295.0, (double)p_drop * 4294967296.0);
+  return j;
+}
+void launch_gen_mask_batch(const MaskJobs& jobs, uint64_t seed, uint64_t counter, hipStream_t s) {
+  if (jobs.n <= 0) return;
+  long threads = 1;
+  for (int i = 0; i < jobs.n; ++i) { const long t = jobs.job[i].half ? (jobs.job[i].nwords + 3) / 4 : jobs.job[i].nwords; if (t > threads) threads = t; }
+  KtScope kt("gen_mask_batch_kernel", 0.0, 0.0, s);
+  hipLaunchKernelGGL(gen_mask_batch_kernel, dim3((unsigned)((threads + 255) / 256), jobs.n), dim3(256), 0, s, jobs,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)counter, (uint32_t)(counter >> 32));
 }
 void launch_gen_mask(uint32_t* words, long n_elems, float p_drop, uint64_t seed, uint64_t counter, uint32_t layer, hipStream_t s) {
   const long nwords = (n_elems + 31) / 32;

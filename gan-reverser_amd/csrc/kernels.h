@@ -196,14 +196,26 @@ struct PostBwdArgs {
   float* ggamma; float* gbeta;   // += (BN)
   float* gbias;            // += sum dy per channel (conv / linear bias), nullable
   unsigned* amax_dy;       // nullable: max|dy| is folded into this slot (f16x3 scale of the weight / data gradients)
+  double* partials_b;      // [C][STAT_SPLITS] pass B's per-channel sums of dy (bias gradient); separate from `partials`,
+                           // which every pass-B workgroup of the channel still reads (BN coefficients are derived in pass B)
 };
-void launch_post_backward(const PostBwdArgs& a, hipStream_t s);
+// Bias gradients are summed from partials_b by one batched launch for several stages (launch_bias_grad_batch) when
+// `defer` is given; otherwise inside the call.
+struct BiasJob { const double* partials; float* gbias; int C, splits; };
+struct BiasJobs { BiasJob job[16]; int n; };
+void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer = nullptr);
+void launch_bias_grad_batch(BiasJobs& jobs, hipStream_t s);    // runs and empties the list
 
 // ---------------------------------------------------------------- criterion / optimiser / misc
 void launch_mse(const float* x, const float* t, long n, long n_global, double* loss_dev, float* grad, hipStream_t s);
 struct AdamConsts { float b1, b2, c1, c2, eps, step, l1, l2, clamp; int use_penalty, use_clamp; };
 void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long n, const AdamConsts& c, hipStream_t s);
 void launch_gen_mask(uint32_t* words, long n_elems, float p_drop, uint64_t seed, uint64_t counter, uint32_t layer, hipStream_t s);
+// all masks of one forward in one launch (jobs travel in the kernel argument block)
+struct MaskJob { uint32_t* words; long nwords; uint32_t thresh; int half; uint32_t layer; };
+struct MaskJobs { MaskJob job[24]; int n; };
+MaskJob make_mask_job(uint32_t* words, long n_elems, float p_drop, uint32_t layer);
+void launch_gen_mask_batch(const MaskJobs& jobs, uint64_t seed, uint64_t counter, hipStream_t s);
 void launch_pack_mask(const uint8_t* keep, uint32_t* words, long n, hipStream_t s);
 void launch_unpack_mask(const uint32_t* words, uint8_t* keep, long n, hipStream_t s);
 void launch_fill_normal(float* dst, long n, uint64_t seed, hipStream_t s);

@@ -213,10 +213,11 @@ struct Stage {
   void* ws_up = nullptr; uint64_t ws_up_version = 0;   // f16x3 image of the fused up-sampling kernel (four 2x2 convolutions)
   uint64_t amax_x_fwd = 0;                  // forward counter at which amax_x was last taken
   unsigned *amax_x = nullptr, *amax_dy = nullptr, *amax_w = nullptr;   // f16x3: slots (in gr_net::amax) for max|x_in|, max|dy|, max|w|
-  float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr;
+  float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr; double* partials_b = nullptr;
   int stat_tiles_last = 0;                  // tiles the last forward's conv epilogue wrote (0: none - run the statistics pass)
   double* stat_part = nullptr;              // per-tile (sum, sum of squares) written by the conv epilogue in training mode (sized per batch)
   float *run_mean = nullptr, *run_var = nullptr;
+  bool eval_ready = false;                  // mean / invstd hold the evaluate()-mode values of the current running statistics
   const float* x_in = nullptr;              // input of the last forward
   bool fused_epilogue = false;              // last forward wrote `out` straight from the conv epilogue (y not materialised)
 };
@@ -254,7 +255,7 @@ extern "C" int gr_net_destroy(gr_net* n) {
     if (s.kind != ST_ELEM) (void)hipFree(s.y);
     if (s.has_post) (void)hipFree(s.out);
     (void)hipFree(s.pool_idx); (void)hipFree(s.wt_fwd); (void)hipFree(s.wt_bwd); (void)hipFree(s.ws_fwd); (void)hipFree(s.ws_up); (void)hipFree(s.ws_bwd);
-    (void)hipFree(s.mean); (void)hipFree(s.invstd); (void)hipFree(s.coef); (void)hipFree(s.partials); (void)hipFree(s.stat_part);
+    (void)hipFree(s.mean); (void)hipFree(s.invstd); (void)hipFree(s.coef); (void)hipFree(s.partials); (void)hipFree(s.partials_b); (void)hipFree(s.stat_part);
     (void)hipFree(s.run_mean); (void)hipFree(s.run_var);
   }
   for (auto& m : n->masks) (void)hipFree(m.bits);
@@ -366,7 +367,8 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
       (void)hipMemcpy(s.run_var, ones.data(), sizeof(float) * C, hipMemcpyHostToDevice);
     }
     if (hipMalloc((void**)&s.mean, sizeof(float) * C) || hipMalloc((void**)&s.invstd, sizeof(float) * C) ||
-        hipMalloc((void**)&s.coef, sizeof(float) * 2 * C) || hipMalloc((void**)&s.partials, sizeof(double) * 2 * STAT_SPLITS * C)) {
+        hipMalloc((void**)&s.coef, sizeof(float) * 2 * C) || hipMalloc((void**)&s.partials, sizeof(double) * 2 * STAT_SPLITS * C) ||
+        hipMalloc((void**)&s.partials_b, sizeof(double) * STAT_SPLITS * C)) {
       gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed");
     }
     if (s.kind == ST_CONV) {
@@ -458,6 +460,7 @@ extern "C" int gr_net_set_bn_running(gr_net* n, int i, const float* m, const flo
   if (m) HIPCHK(c, hipMemcpyAsync(s.run_mean, m, sizeof(float) * s.Cout, hipMemcpyHostToDevice, c->stream));
   if (v) HIPCHK(c, hipMemcpyAsync(s.run_var, v, sizeof(float) * s.Cout, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  s.eval_ready = false;
   return GR_OK;
 }
 extern "C" int gr_net_set_training(gr_net* n, int t) { if (!n) return GR_ERR_INVALID; n->training = t != 0; return GR_OK; }
@@ -603,6 +606,29 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
   const bool f16 = c->conv_mode == 2;
   const size_t nst = n->st.size();
   if (f16) HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst, c->stream));     // the x slots; producers fold maxima in
+  {
+    // Dropout noise of every stage, drawn in one launch (injected masks - tests - are consumed instead)
+    MaskJobs jobs{}; jobs.n = 0;
+    for (auto& s : n->st)
+      for (int slot : {s.m1, s.m2}) {
+        if (slot < 0 || !s.has_post) continue;
+        bool need; (void)mask_ref(n, slot, need);
+        if (!need) continue;
+        MaskSlot& m = n->masks[slot];
+        const int64_t elems = mask_elems(m, B);
+        if (m.injected) {
+          if (m.n_last != elems) return fail(c, GR_ERR_INVALID, "injected noise for layer %d has %lld elements, forward needs %lld", m.layer, (long long)m.n_last, (long long)elems);
+          m.injected = false;
+        } else {
+          r = ensure_mask_bits(n, m, elems); if (r) return r;
+          if (jobs.n == 24) { launch_gen_mask_batch(jobs, n->seed, n->fwd_counter, c->stream); jobs.n = 0; }
+          jobs.job[jobs.n++] = make_mask_job(m.bits, elems, m.p, (uint32_t)m.layer);
+          m.n_last = elems;
+        }
+      }
+    launch_gen_mask_batch(jobs, n->seed, n->fwd_counter, c->stream);
+    LAUNCHCHK(c);
+  }
   for (size_t si = 0; si < nst; ++si) {
     Stage& s = n->st[si];
     // f16x3: the kernel that writes this stage's output also tracks its max|.| for the convolution that consumes it
@@ -618,7 +644,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
       const MaskRef r1 = mask_ref(n, s.m1, nb1), r2 = mask_ref(n, s.m2, nb2);
       if (!n->training && s.has_post && !s.pool && !s.fullconv && r1.kind == MASK_NONE && r2.kind == MASK_NONE) {
         if (s.has_bn) {
-          launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream);
+          if (!s.eval_ready) { launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream); s.eval_ready = true; }
           ep.mean = s.mean; ep.invstd = s.invstd; ep.gamma = n->params + s.g_off; ep.beta = n->params + s.be_off;
         }
         ep.act = s.act; ep.slope = s.slope; epp = &ep; dst = s.out; s.fused_epilogue = true;
@@ -661,7 +687,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
           gemm_epilogue_possible(B, s.Cout, s.Cin)) {
         ConvEpilogue ep;
         if (s.has_bn) {
-          launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream);
+          if (!s.eval_ready) { launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream); s.eval_ready = true; }
           ep.mean = s.mean; ep.invstd = s.invstd; ep.gamma = n->params + s.g_off; ep.beta = n->params + s.be_off;
         }
         ep.act = s.act; ep.slope = s.slope;
@@ -677,25 +703,11 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     if (!s.has_post) { s.out = s.y; x = s.out; continue; }
     const float* yv = s.kind == ST_ELEM ? x : s.y;
     if (s.has_bn) {
+      if (n->training) s.eval_ready = false;          // mean / invstd become batch statistics, the running statistics move
       if (n->training && s.kind == ST_CONV && s.stat_tiles_last > 0)
         launch_bn_stats_from_tiles(s.stat_part, s.stat_tiles_last, s.Cout, (double)B * s.H * s.W, s.mean, s.invstd, s.run_mean, s.run_var, c->stream);
       else if (n->training) launch_bn_stats(yv, B, s.Cout, s.H * s.W, s.partials, s.mean, s.invstd, s.run_mean, s.run_var, 1, c->stream);
-      else launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream);
-    }
-    for (int slot : {s.m1, s.m2}) {
-      if (slot < 0) continue;
-      bool need; (void)mask_ref(n, slot, need);
-      if (!need) continue;
-      MaskSlot& m = n->masks[slot];
-      const int64_t elems = mask_elems(m, B);
-      if (m.injected) {
-        if (m.n_last != elems) return fail(c, GR_ERR_INVALID, "injected noise for layer %d has %lld elements, forward needs %lld", m.layer, (long long)m.n_last, (long long)elems);
-        m.injected = false;
-      } else {
-        r = ensure_mask_bits(n, m, elems); if (r) return r;
-        launch_gen_mask(m.bits, elems, m.p, n->seed, n->fwd_counter, (uint32_t)m.layer, c->stream);
-        m.n_last = elems;
-      }
+      else if (!s.eval_ready) { launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream); s.eval_ready = true; }
     }
     PostArgs pa = post_args(n, s, B);
     pa.amax_out = amax_next;
@@ -765,6 +777,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
   if (B != n->lastB) return fail(c, GR_ERR_STATE, "backward batch %d does not match the last forward (%d)", B, n->lastB);
   reduce = reduce && c->comm != nullptr;
   int64_t bucket_hi = n->n_params;            // everything in [stage first offset, bucket_hi) is final but not yet reduced
+  BiasJobs bias_jobs{}; bias_jobs.n = 0;
   { int r = prep_weights(n); if (r) return r; }   // no-op unless the arithmetic mode changed since the forward
   const bool f16 = c->conv_mode == 2;
   if (f16) HIPCHK(c, hipMemsetAsync(n->amax + AMAX_WORDS * n->st.size(), 0, sizeof(unsigned) * AMAX_WORDS * n->st.size(), c->stream));   // the dy slots
@@ -781,11 +794,11 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     if (!s.has_post) { pb.f.out = nullptr; }
     pb.gout = g;
     pb.dy = s.kind == ST_ELEM ? gin : n->dy_buf;
-    pb.partials = s.partials; pb.coef = s.coef;
+    pb.partials = s.partials; pb.partials_b = s.partials_b; pb.coef = s.coef;
     pb.ggamma = s.has_bn ? n->grads + s.g_off : nullptr; pb.gbeta = s.has_bn ? n->grads + s.be_off : nullptr;
     pb.gbias = s.kind == ST_ELEM ? nullptr : n->grads + s.b_off;
     pb.amax_dy = (f16 && s.kind == ST_CONV && !s.up && !s.fullconv) ? s.amax_dy : nullptr;
-    launch_post_backward(pb, c->stream);
+    launch_post_backward(pb, c->stream, &bias_jobs);       // bias gradients of several stages are summed by one launch
     LAUNCHCHK(c);
     if (s.kind == ST_CONV) {
       if (s.up) return fail(c, GR_ERR_UNSUPPORTED, "backward through the fused UpSamplingNearest is not implemented (G is forward-only on this path)");
@@ -820,11 +833,14 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       int64_t lo = -1;
       if (s.w_off >= 0) lo = s.w_off; else if (s.g_off >= 0) lo = s.g_off;
       if (lo >= 0 && (bucket_hi - lo >= BUCKET_MIN_ELEMS || si == 0)) {
+        launch_bias_grad_batch(bias_jobs, c->stream);             // the bucket must hold final bias gradients
         int r = reduce_bucket(n, lo, bucket_hi); if (r) return r;
         bucket_hi = lo;
       }
     }
   }
+  launch_bias_grad_batch(bias_jobs, c->stream);
+  LAUNCHCHK(c);
   if (reduce) {
     int r = reduce_bucket(n, 0, bucket_hi); if (r) return r;
     // Adam (compute stream) must see every reduced bucket
