@@ -41,7 +41,7 @@ def step_flops_per_image(dims, nd):
     return g + 3 * r, g, r
 
 
-def cpu_baseline(dims, nd, sample_batch, threads):
+def cpu_baseline(dims, nd, sample_batch, threads, ctx=None):
     """The oracle (CPU restatement of the Torch7 nn path) timed on this box's host cores on a bounded sample."""
     import numpy as np
     from ganrev import models, synth
@@ -64,8 +64,20 @@ def cpu_baseline(dims, nd, sample_batch, threads):
         dt = time.perf_counter() - t0
         if dt > 8.0 or n >= 20:
             break
-    return dict(value=round(sample_batch * n / dt, 2), unit="images/sec", cores=threads, kind="port",
-                sample=f"{n} steps of the same step at batch {sample_batch} ({dt:.1f} s); oracle = C restatement of the Torch7 nn CPU path, OpenMP")
+    out = dict(value=round(sample_batch * n / dt, 2), unit="images/sec", cores=threads, kind="port",
+               sample=f"{n} steps of the same step at batch {sample_batch} ({dt:.1f} s); oracle = C restatement of the Torch7 nn CPU path, OpenMP")
+    if ctx is not None:
+        # second half of BASELINE.json's metric - "cosine top-50 exact-match vs ref" - at the size north_star names (10k x 32-d
+        # embeddings, apply_r.lua:266-282): the HIP search against the oracle's, index lists compared element by element,
+        # both timed (the oracle on the same host threads)
+        N, d, k, needles = 10000, 32, 50, [99, 199, 299, 399, 499]
+        emb = synth.normal((N, d), 77)
+        t0 = time.perf_counter(); ridx, rsc = oracle.cosine_topk(emb, needles, k); t_cpu = time.perf_counter() - t0
+        ctx.cosine_topk(emb, needles, k)                                          # warm-up (workspace allocation)
+        t0 = time.perf_counter(); idx, sc = ctx.cosine_topk(emb, needles, k); t_gpu = time.perf_counter() - t0
+        out["search_top50"] = dict(n=N, d=d, k=k, needles=len(needles), exact_match=bool(np.array_equal(idx, ridx) and np.array_equal(sc, rsc)),
+                                   gpu_ms_incl_h2d=round(t_gpu * 1e3, 3), cpu_ms=round(t_cpu * 1e3, 3))
+    return out
 
 
 def main():
@@ -251,7 +263,7 @@ def main():
             # 16-32 OpenMP threads measured fastest for the oracle on the 2x64-core box (tools/cpu_baseline_sweep.py:
             # 74 img/s at 16-32 threads, 51-62 at 64, 28-37 at 128-256); the reference's own default is 8 (train_r.lua:21)
             threads = min(32, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(dims, nd, args.cpu_sample_batch, threads)
+            out["cpu_baseline"] = cpu_baseline(dims, nd, args.cpu_sample_batch, threads, ctx)
         else:
             out["cpu_baseline"] = None
     if world > 1:
