@@ -484,24 +484,6 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_a
 // puts its largest magnitude into [2^14, 2^15) (exact; elements more than 2^17 below the maximum lose relative but not
 // absolute precision: their error stays below 2^-39 of the maximum); the result is scaled back with one v_ldexp_f32.
 // The maxima are tracked on the device (producer kernels or absmax_kernel), never read by the host.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ int f16_scale_exp(unsigned amax_bits) {      // k such that max|x| * 2^k lies in [2^14, 2^15)
-  const int e = (int)((amax_bits >> 23) & 0xffu);
-  return e == 0 ? 0 : min(141 - e, 126);
-}
-__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }   // k in [-126, 127]
-// split 8 scaled floats into the two fp16 term vectors (round-to-nearest both times; x - x0 is exact in fp32)
-__device__ __forceinline__ void split8_f16(const float* x, float sc, uint4& t0, uint4& t1) {
-  unsigned short a[8], b[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = x[j] * sc;
-    const _Float16 h0 = (_Float16)v; const float r = v - (float)h0; const _Float16 h1 = (_Float16)r;
-    a[j] = __builtin_bit_cast(unsigned short, h0); b[j] = __builtin_bit_cast(unsigned short, h1);
-  }
-  t0 = make_uint4(a[0] | (unsigned)a[1] << 16, a[2] | (unsigned)a[3] << 16, a[4] | (unsigned)a[5] << 16, a[6] | (unsigned)a[7] << 16);
-  t1 = make_uint4(b[0] | (unsigned)b[1] << 16, b[2] | (unsigned)b[3] << 16, b[4] | (unsigned)b[5] << 16, b[6] | (unsigned)b[7] << 16);
-}
 __device__ __forceinline__ void split8_bf16(const float* x, uint4& r0, uint4& r1, uint4& r2) {
   unsigned short t0[8], t1[8], t2[8];
 #pragma unroll
@@ -1358,6 +1340,7 @@ void launch_conv_weight_prep(const float* w_native, float* wt, int cin, int cout
 // One launch prepares every convolution of a net (forward + backward-data images, either flavour): blockIdx.y = job.
 __global__ void conv_weight_prep_batch_kernel(const PrepJob* __restrict__ jobs, const float* __restrict__ params) {
   const PrepJob j = jobs[blockIdx.y];
+  if (j.split == 5) return;      // nn.Linear weights of the f16x3 GEMM: only their maximum is taken (the GEMM splits while staging)
   const float* w = params + j.w_off;
   if (j.split) {
     unsigned short* dst = reinterpret_cast<unsigned short*>(j.dst);
@@ -1393,9 +1376,9 @@ __global__ void conv_weight_prep_batch_kernel(const PrepJob* __restrict__ jobs, 
 // max|w| of every f16x3 job's weight tensor (blockIdx.y = job), slots zeroed by the launcher
 __global__ __launch_bounds__(256) void conv_weight_absmax_batch_kernel(const PrepJob* __restrict__ jobs, const float* __restrict__ params) {
   const PrepJob j = jobs[blockIdx.y];
-  if (j.split != 2 || j.bwd) return;                 // the backward-data image shares the forward image's slot
+  if ((j.split != 2 && j.split != 5) || j.bwd) return;   // the backward-data image shares the forward image's slot; 5 = maximum only
   const float* w = params + j.w_off;
-  const long n = (long)j.cin * j.cout * 9;
+  const long n = (long)j.cin * j.cout * (j.split == 5 ? 1 : 9);     // nn.Linear weight [cout][cin] / conv weight [cout][cin][3][3]
   float m = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
   absmax_commit(m, j.amax);

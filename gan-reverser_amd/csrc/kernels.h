@@ -83,6 +83,25 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_take<0x143, 0xC>(v);     // row_bcast31 into rows 2 and 3: lane 31 holds the sum of the first half-wave
   return v;
 }
+// f16x3 operand handling shared by the convolution and GEMM kernels (see conv.hip for the arithmetic)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int f16_scale_exp(unsigned amax_bits) {      // k such that max|x| * 2^k lies in [2^14, 2^15)
+  const int e = (int)((amax_bits >> 23) & 0xffu);
+  return e == 0 ? 0 : min(141 - e, 126);
+}
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }   // k in [-126, 127]
+// split 8 scaled floats into the two fp16 term vectors (round-to-nearest both times; x - x0 is exact in fp32)
+__device__ __forceinline__ void split8_f16(const float* x, float sc, uint4& t0, uint4& t1) {
+  unsigned short a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = x[j] * sc;
+    const _Float16 h0 = (_Float16)v; const float r = v - (float)h0; const _Float16 h1 = (_Float16)r;
+    a[j] = __builtin_bit_cast(unsigned short, h0); b[j] = __builtin_bit_cast(unsigned short, h1);
+  }
+  t0 = make_uint4(a[0] | (unsigned)a[1] << 16, a[2] | (unsigned)a[3] << 16, a[4] | (unsigned)a[5] << 16, a[6] | (unsigned)a[7] << 16);
+  t1 = make_uint4(b[0] | (unsigned)b[1] << 16, b[2] | (unsigned)b[3] << 16, b[4] | (unsigned)b[5] << 16, b[6] | (unsigned)b[7] << 16);
+}
 __device__ __forceinline__ float absmax4(float m, const float4& v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
@@ -159,7 +178,9 @@ size_t gemm_workspace_bytes(int M, int N, int K);
 bool gemm_epilogue_possible(int M, int N, int K);
 void launch_gemm(const float* A, long rsA, long ksA, const float* Bm, long rsB, long ksB,
                  float* C, long ldc, const float* bias, bool accumulate, int M, int N, int K,
-                 void* workspace, hipStream_t s, const ConvEpilogue* ep = nullptr, unsigned* amax_out = nullptr);
+                 void* workspace, hipStream_t s, const ConvEpilogue* ep = nullptr, unsigned* amax_out = nullptr,
+                 // both non-null: the f16x3 kernel (operands scaled by their tracked maxima and split in two fp16 terms while staged)
+                 const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr);
 
 // ---------------------------------------------------------------- per-channel pipelines (BN / act / dropout / pool)
 enum Act { ACT_NONE = 0, ACT_ELU = 3, ACT_RELU = 4, ACT_LEAKYRELU = 5, ACT_SIGMOID = 6, ACT_TANH = 7 };

@@ -403,6 +403,8 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
         jf.push_back(make_prep_job(s.w_off, s.wt_bwd, s.Cout, s.Cin, false, 0));
       }
     }
+    for (auto& s : n->st)          // nn.Linear weights: only their maximum (f16x3 GEMM scales)
+      if (s.kind == ST_LINEAR && (int64_t)s.Cin * s.Cout >= (1 << 20)) jh.push_back(make_prep_job(s.w_off, nullptr, s.Cin, s.Cout, false, 5, s.amax_w));
     for (int m = 0; m < 3; ++m) {
       std::vector<PrepJob>& v = m == 0 ? jf : (m == 1 ? js : jh);
       n->njobs[m] = (int)v.size();
@@ -536,6 +538,11 @@ static int ensure_batch(gr_net* n, int B) {
 // bf16x6 mode: every plain convolution runs on the split kernel except few-output-channel layers the HBM-bound VALU
 // kernel covers (same predicate as launch_conv3x3); only the split images are kept current in that mode.
 static bool fewout_applies(const Stage& s) { return s.Cout <= 4 && !s.up && s.W % 4 == 0 && s.W >= 16; }
+// f16x3 GEMM for the large nn.Linear layers (R.fc1: 90-97 % of R's parameters); small ones stay on the fp32 MFMA kernel
+static bool use_f16_gemm(gr_net* n, const Stage& s) {
+  static const bool on = !getenv("GR_NO_F16_GEMM");
+  return on && n->ctx->conv_mode == 2 && s.kind == ST_LINEAR && (int64_t)s.Cin * s.Cout >= (1 << 20);
+}
 static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode >= 1 && s.kind == ST_CONV && !s.fullconv && !fewout_applies(s); }   // either split flavour
 // Re-lay every convolution's weights (one launch) when the parameters changed since the last time.  bf16x6 mode needs the
 // split images; the fp32 k-major images are still needed there by SpatialFullConvolution stages (no split kernel).
@@ -632,7 +639,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
   for (size_t si = 0; si < nst; ++si) {
     Stage& s = n->st[si];
     // f16x3: the kernel that writes this stage's output also tracks its max|.| for the convolution that consumes it
-    Stage* nx = (f16 && si + 1 < nst && use_bf16x6(n, n->st[si + 1])) ? &n->st[si + 1] : nullptr;
+    Stage* nx = (f16 && si + 1 < nst && (use_bf16x6(n, n->st[si + 1]) || use_f16_gemm(n, n->st[si + 1]))) ? &n->st[si + 1] : nullptr;
     unsigned* amax_next = nx ? nx->amax_x : nullptr;
     s.x_in = x;
     s.fused_epilogue = false;
@@ -697,6 +704,11 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         LAUNCHCHK(c);
         x = s.out; continue;
       }
+      if (use_f16_gemm(n, s)) {
+        if (s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream); s.amax_x_fwd = n->fwd_counter; }
+        launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.y, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream,
+                    nullptr, nullptr, s.amax_x, s.amax_w);
+      } else
       launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.y, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream);
     }
     LAUNCHCHK(c);
@@ -797,7 +809,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     pb.partials = s.partials; pb.partials_b = s.partials_b; pb.coef = s.coef;
     pb.ggamma = s.has_bn ? n->grads + s.g_off : nullptr; pb.gbeta = s.has_bn ? n->grads + s.be_off : nullptr;
     pb.gbias = s.kind == ST_ELEM ? nullptr : n->grads + s.b_off;
-    pb.amax_dy = (f16 && s.kind == ST_CONV && !s.up && !s.fullconv) ? s.amax_dy : nullptr;
+    pb.amax_dy = (f16 && ((s.kind == ST_CONV && !s.up && !s.fullconv) || use_f16_gemm(n, s))) ? s.amax_dy : nullptr;
     launch_post_backward(pb, c->stream, &bias_jobs);       // bias gradients of several stages are summed by one launch
     LAUNCHCHK(c);
     if (s.kind == ST_CONV) {
@@ -821,10 +833,14 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       const size_t wsb2 = gemm_workspace_bytes(B, s.Cin, s.Cout);
       if (wsb2 > wsb) wsb = wsb2;
       int r = ensure_ws(c, wsb); if (r) return r;
+      const bool f16g = use_f16_gemm(n, s);
+      if (f16g && s.amax_x_fwd != n->fwd_counter) launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream);   // (mode switched since the forward)
       // gW[o][i] += sum_b dy[b][o] x[b][i]
-      launch_gemm(n->dy_buf, 1, s.Cout, x, 1, s.Cin, n->grads + s.w_off, s.Cin, nullptr, true, s.Cout, s.Cin, B, c->ws, c->stream);
+      launch_gemm(n->dy_buf, 1, s.Cout, x, 1, s.Cin, n->grads + s.w_off, s.Cin, nullptr, true, s.Cout, s.Cin, B, c->ws, c->stream,
+                  nullptr, nullptr, f16g ? s.amax_dy : nullptr, f16g ? s.amax_x : nullptr);
       // gx[b][i] = sum_o dy[b][o] W[o][i]
-      if (need_gin) launch_gemm(n->dy_buf, s.Cout, 1, n->params + s.w_off, 1, s.Cin, gin, s.Cin, nullptr, false, B, s.Cin, s.Cout, c->ws, c->stream);
+      if (need_gin) launch_gemm(n->dy_buf, s.Cout, 1, n->params + s.w_off, 1, s.Cin, gin, s.Cin, nullptr, false, B, s.Cin, s.Cout, c->ws, c->stream,
+                                nullptr, nullptr, f16g ? s.amax_dy : nullptr, f16g ? s.amax_w : nullptr);
       LAUNCHCHK(c);
     }
     g = gin;
