@@ -23,8 +23,7 @@ struct GemmArgs {
 
 // out = act(((v - mean[n]) * invstd[n]) * gamma[n] + beta[n]): nn.BatchNormalization in evaluate() mode + activation on the
 // Linear output (G: models.lua:115-117), the same operation order and roundings as the stand-alone pipeline kernel
-__device__ __forceinline__ float gemm_epilogue(const ConvEpilogue& ep, float v, int n) {
-  if (ep.mean) v = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v, ep.mean[n]), ep.invstd[n]), ep.gamma[n]), ep.beta[n]);
+__device__ __forceinline__ float gemm_activation(const ConvEpilogue& ep, float v) {
   switch (ep.act) {
     case ACT_ELU: return v <= 0.f ? (expf(v) - 1.f) : v;
     case ACT_RELU: return v > 0.f ? v : 0.f;
@@ -32,6 +31,65 @@ __device__ __forceinline__ float gemm_epilogue(const ConvEpilogue& ep, float v, 
     case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     case ACT_TANH: return tanhf(v);
     default: return v;
+  }
+}
+
+// Store one 32 x 32 accumulator block (MFMA layout: lane -> column n, register r -> row mb + (r & 3) + 8 (r >> 2)).
+// The per-column parameters and, when accumulating, the 16 old values are fetched BEFORE the first store: loads and stores
+// share one in-order counter on this hardware, so a load issued after a store waits for that store to reach memory, and the
+// plain "load, add, store" per element loop serialises 16 memory round trips (measured: 244 us of a 330 us launch).
+__device__ __forceinline__ void gemm_store_block(const GemmArgs& a, const f32x16& acc, int mb, int n, int shift, float& omax) {
+  if (n >= a.N) return;
+  const bool full = mb + 27 < a.M;          // every row of the block inside the matrix: no per-row tests
+  if (a.nsplit > 1) {
+    float* sl = a.slab + ((size_t)blockIdx.z * a.M + mb) * a.N + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      if (full || mb + dm < a.M) sl[(size_t)dm * a.N] = ldexpf(acc[r], shift);
+    }
+    return;
+  }
+  float v[16];
+  const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = ldexpf(acc[r], shift) + bias;
+  if (a.has_ep) {
+    if (a.ep.mean) {
+      const float mean = a.ep.mean[n], invstd = a.ep.invstd[n], gamma = a.ep.gamma[n], beta = a.ep.beta[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v[r], mean), invstd), gamma), beta);
+    }
+    switch (a.ep.act) {                     // one uniform branch per block, not per element
+      case ACT_RELU:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        break;
+      case ACT_LEAKYRELU:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : __fmul_rn(v[r], a.ep.slope);
+        break;
+      case ACT_NONE: break;
+      default:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = gemm_activation(a.ep, v[r]);
+    }
+  }
+  float* c0 = a.C + (long)mb * a.ldc + n;
+  if (a.accumulate) {
+    float old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dm = (r & 3) + 8 * (r >> 2);
+      old[r] = (full || mb + dm < a.M) ? c0[(long)dm * a.ldc] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = old[r] + v[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int dm = (r & 3) + 8 * (r >> 2);
+    if (full || mb + dm < a.M) { c0[(long)dm * a.ldc] = v[r]; omax = fmaxf(omax, fabsf(v[r])); }
   }
 }
 
@@ -112,26 +170,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs a) {
     }
     __syncthreads();
   }
-  const int n = n0 + wn * 32 + l31;
   float omax = 0.f;
-  if (n < a.N) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m < a.M) {
-        if (a.nsplit > 1) {
-          a.slab[((size_t)blockIdx.z * a.M + m) * a.N + n] = acc[r];
-        } else {
-          float v = acc[r] + (a.bias ? a.bias[n] : 0.f);
-          if (a.has_ep) v = gemm_epilogue(a.ep, v, n);
-          float* c = a.C + (long)m * a.ldc + n;
-          v = a.accumulate ? *c + v : v;
-          *c = v;
-          omax = fmaxf(omax, fabsf(v));
-        }
-      }
-    }
-  }
+  gemm_store_block(a, acc, m0 + wm * 32 + 4 * h, n0 + wn * 32 + l31, 0, omax);
   if (a.amax_out && a.nsplit == 1) absmax_commit(omax, a.amax_out);
 }
 
@@ -167,13 +207,13 @@ __device__ __forceinline__ void tile_store8(uint4* T, float sc, const float (&v)
   const int r = KCONTIG ? tid >> 2 : tid & 63, g = KCONTIG ? tid & 3 : tid >> 6;
   uint4 t0, t1;
   split8_f16(v, sc, t0, t1);
-  T[(0 * 4 + g) * 64 + r] = t0; T[(1 * 4 + g) * 64 + r] = t1;
+  T[(0 * 4 + g) * 68 + r] = t0; T[(1 * 4 + g) * 68 + r] = t1;       // 68: the four k-groups of a row land in distinct banks
 }
 
 template <bool AK, bool BK>
 __global__ __launch_bounds__(256) void gemm_f16x3_kernel(GemmArgs a) {
-  __shared__ uint4 As[2 * 4 * 64];
-  __shared__ uint4 Bs[2 * 4 * 64];
+  __shared__ uint4 As[2 * 4 * 68];
+  __shared__ uint4 Bs[2 * 4 * 68];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -201,34 +241,153 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(GemmArgs a) {
     for (int kk = 0; kk < 2; ++kk) {                    // two 16-wide k steps: lanes 0-31 take k-group 2kk, lanes 32-63 k-group 2kk+1
       uint4 x[2], y[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) { x[t] = As[(t * 4 + 2 * kk + h) * 64 + wm * 32 + l31]; y[t] = Bs[(t * 4 + 2 * kk + h) * 64 + wn * 32 + l31]; }
+      for (int t = 0; t < 2; ++t) { x[t] = As[(t * 4 + 2 * kk + h) * 68 + wm * 32 + l31]; y[t] = Bs[(t * 4 + 2 * kk + h) * 68 + wn * 32 + l31]; }
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[1]), __builtin_bit_cast(f16x8, y[0]), acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[0]), __builtin_bit_cast(f16x8, y[1]), acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[0]), __builtin_bit_cast(f16x8, y[0]), acc, 0, 0, 0);
     }
     __syncthreads();
   }
-  const int n = n0 + wn * 32 + l31;
   float omax = 0.f;
-  if (n < a.N) {
+  gemm_store_block(a, acc, m0 + wm * 32 + 4 * h, n0 + wn * 32 + l31, -(ka + kb), omax);
+  if (a.amax_out && a.nsplit == 1) absmax_commit(omax, a.amax_out);
+}
+
+// 128 x 128 tile: every wave owns a 64 x 64 quadrant (2 x 2 accumulators), so an operand vector read from LDS feeds two MFMAs and
+// the staging work per MFMA halves.  Used when the output has at least two such tiles per dimension pair to spare (see gemm_plan).
+// Operand tile loads through a buffer descriptor based at the tile's first element: rows outside the matrix and k beyond
+// the split's end are parked past the descriptor's range (the hardware returns 0), so the loop holds no exec-masked
+// branches and no 64-bit address arithmetic; the chunk advance rides in the scalar offset.
+template <bool KCONTIG>
+struct BigTileLoader {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff[2], kg[2], kstep;
+  bool vec;
+  static constexpr int PARK = (int)0x80000000;
+  __device__ __forceinline__ void init(const float* P, long rs, long ks, int row0, int nrows, int K, int kbeg, bool vec_, int tid) {
+    const size_t total = ((size_t)(nrows - 1) * rs + (size_t)(K - 1) * ks + 1) * sizeof(float);
+    const size_t used = ((size_t)row0 * rs + (size_t)kbeg * ks) * sizeof(float);
+    const size_t left = total - used;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P + (size_t)row0 * rs + (size_t)kbeg * ks), 0,
+                                             (int)(left < 0x7FFFF000ul ? left : 0x7FFFF000ul), 0x00020000);
+    kstep = (int)(ks * 4); vec = vec_;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m < a.M) {
-        const float res = ldexpf(acc[r], -(ka + kb));
-        if (a.nsplit > 1) {
-          a.slab[((size_t)blockIdx.z * a.M + m) * a.N + n] = res;
-        } else {
-          float v = res + (a.bias ? a.bias[n] : 0.f);
-          if (a.has_ep) v = gemm_epilogue(a.ep, v, n);
-          float* c = a.C + (long)m * a.ldc + n;
-          v = a.accumulate ? *c + v : v;
-          *c = v;
-          omax = fmaxf(omax, fabsf(v));
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 256 * u;
+      const int r = KCONTIG ? e >> 2 : e & 127, g = KCONTIG ? e & 3 : e >> 7;
+      kg[u] = 8 * g;
+      voff[u] = row0 + r < nrows ? (int)((long)r * rs * 4 + (long)(8 * g) * ks * 4) : PARK;
+    }
+  }
+  // kc = k0 - kbeg (first k of the chunk relative to the descriptor base), kleft = kend - k0
+  __device__ __forceinline__ void load(int kc, int kleft, float (&v)[2][8]) const {
+    const int soff = kc * kstep;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (KCONTIG && vec) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int off = kg[u] + 4 * i < kleft ? voff[u] + 16 * i : PARK;
+          const uint4 t = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff, 0));
+          v[u][4 * i] = __uint_as_float(t.x); v[u][4 * i + 1] = __uint_as_float(t.y);
+          v[u][4 * i + 2] = __uint_as_float(t.z); v[u][4 * i + 3] = __uint_as_float(t.w);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int off = kg[u] + i < kleft ? voff[u] + i * kstep : PARK;
+          v[u][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, soff, 0));
         }
       }
     }
   }
+};
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_store8_big(uint4* T, float sc, const float (&v)[2][8], int tid) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u;
+    const int r = KCONTIG ? e >> 2 : e & 127, g = KCONTIG ? e & 3 : e >> 7;
+    uint4 t0, t1;
+    split8_f16(v[u], sc, t0, t1);
+    T[(0 * 4 + g) * 132 + r] = t0; T[(1 * 4 + g) * 132 + r] = t1;   // 132: the four k-groups of a row land in distinct banks
+  }
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_big_kernel(GemmArgs a) {
+  __shared__ uint4 As[2 * 2 * 4 * 132];
+  __shared__ uint4 Bs[2 * 2 * 4 * 132];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int kbeg = blockIdx.z * a.klen;
+  const int kend = min(a.K, kbeg + a.klen);
+  const bool avec = AK && (a.rsA & 3) == 0 && (kbeg & 3) == 0 && (a.K & 3) == 0 && ((uintptr_t)a.A & 15) == 0;
+  const bool bvec = BK && (a.rsB & 3) == 0 && (kbeg & 3) == 0 && (a.K & 3) == 0 && ((uintptr_t)a.Bm & 15) == 0;
+  const int ka = f16_scale_exp(absmax_read(a.amax_a)), kb = f16_scale_exp(absmax_read(a.amax_b));
+  const float sa = pow2f(ka), sb = pow2f(kb);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // Two LDS images: chunk k + 1 is split and stored while chunk k is multiplied, one barrier per chunk; the global loads of
+  // chunk k + 2 are in flight across that whole period.
+  float av[2][8], bv[2][8];
+  BigTileLoader<AK> la; la.init(a.A, a.rsA, a.ksA, m0, a.M, a.K, kbeg, avec, tid);
+  BigTileLoader<BK> lb; lb.init(a.Bm, a.rsB, a.ksB, n0, a.N, a.K, kbeg, bvec, tid);
+  la.load(0, kend - kbeg, av); lb.load(0, kend - kbeg, bv);
+  tile_store8_big<AK>(As, sa, av, tid);
+  tile_store8_big<BK>(Bs, sb, bv, tid);
+  if (kbeg + 32 < kend) { la.load(32, kend - kbeg - 32, av); lb.load(32, kend - kbeg - 32, bv); }
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += 32, cur ^= 1) {
+    const uint4* Ac = As + cur * (2 * 4 * 132);
+    const uint4* Bc = Bs + cur * (2 * 4 * 132);
+    if (k0 + 32 < kend) {
+      tile_store8_big<AK>(As + (cur ^ 1) * (2 * 4 * 132), sa, av, tid);
+      tile_store8_big<BK>(Bs + (cur ^ 1) * (2 * 4 * 132), sb, bv, tid);
+      if (k0 + 64 < kend) { la.load(k0 + 64 - kbeg, kend - k0 - 64, av); lb.load(k0 + 64 - kbeg, kend - k0 - 64, bv); }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 x[2][2], y[2][2];                          // [block][term]
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          x[i][t] = Ac[(t * 4 + 2 * kk + h) * 132 + wm * 64 + i * 32 + l31];
+          y[i][t] = Bc[(t * 4 + 2 * kk + h) * 132 + wn * 64 + i * 32 + l31];
+        }
+      // term-major: consecutive MFMAs go to different accumulators (the per-accumulator order lo*hi, hi*lo, hi*hi is the 64-tile kernel's)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[i][1]), __builtin_bit_cast(f16x8, y[j][0]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[i][0]), __builtin_bit_cast(f16x8, y[j][1]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x[i][0]), __builtin_bit_cast(f16x8, y[j][0]), acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float omax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      gemm_store_block(a, acc[i][j], m0 + wm * 64 + i * 32 + 4 * h, n0 + wn * 64 + j * 32 + l31, -(ka + kb), omax);
   if (a.amax_out && a.nsplit == 1) absmax_commit(omax, a.amax_out);
 }
 
@@ -244,8 +403,8 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, float*
   *c = accumulate ? *c + s : s;
 }
 
-static void gemm_plan(int M, int N, int K, int& nsplit, int& klen) {
-  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+static void gemm_plan(int M, int N, int K, int& nsplit, int& klen, int tile = 64) {
+  const long tiles = (long)((M + tile - 1) / tile) * ((N + tile - 1) / tile);
   nsplit = 1;
   if (tiles < 256 && K >= 256) {
     long want = (512 + tiles - 1) / tiles;
@@ -259,7 +418,9 @@ static void gemm_plan(int M, int N, int K, int& nsplit, int& klen) {
 }
 
 size_t gemm_workspace_bytes(int M, int N, int K) {
-  int ns, kl; gemm_plan(M, N, K, ns, kl);
+  // the larger of the two tilings' split counts (launch_gemm picks the tiling from the operand mode)
+  int ns, kl, nb, kb; gemm_plan(M, N, K, ns, kl); gemm_plan(M, N, K, nb, kb, 128);
+  if (nb > ns) ns = nb;
   return ns > 1 ? sizeof(float) * (size_t)ns * M * N : 0;
 }
 
@@ -273,15 +434,34 @@ void launch_gemm(const float* A, long rsA, long ksA, const float* Bm, long rsB, 
   if (ep) { a.ep = *ep; a.has_ep = 1; }
   a.amax_out = amax_out; a.amax_a = amax_a; a.amax_b = amax_b;
   const bool f16 = amax_a != nullptr && amax_b != nullptr;
+  static const bool big_on = !getenv("GR_GEMM_SMALL_TILES");
+  bool big = f16 && big_on && M >= 128 && N >= 128;
   a.A = A; a.Bm = Bm; a.C = C; a.slab = reinterpret_cast<float*>(workspace); a.bias = bias;
   a.rsA = rsA; a.ksA = ksA; a.rsB = rsB; a.ksB = ksB; a.ldc = ldc;
   a.M = M; a.N = N; a.K = K; a.accumulate = accumulate ? 1 : 0;
-  gemm_plan(M, N, K, a.nsplit, a.klen);
-  dim3 grid((N + 63) / 64, (M + 63) / 64, a.nsplit);
+  gemm_plan(M, N, K, a.nsplit, a.klen, big ? 128 : 64);
+  // the 128-tile kernel addresses a tile with 32-bit offsets from its first element
+  if (big && ((127.0 * rsA + (a.klen + 32.0) * ksA) * 4 >= 0x7FFFF000 || (127.0 * rsB + (a.klen + 32.0) * ksB) * 4 >= 0x7FFFF000)) {
+    big = false;
+    gemm_plan(M, N, K, a.nsplit, a.klen, 64);
+  }
+  if (big && a.nsplit > 1 && gemm_epilogue_possible(M, N, K)) {
+    // callers fuse epilogues whenever the 64-tile plan keeps K whole: stay on that plan then
+    big = false;
+    gemm_plan(M, N, K, a.nsplit, a.klen, 64);
+  }
+  const int T = big ? 128 : 64;
+  dim3 grid((N + T - 1) / T, (M + T - 1) / T, a.nsplit);
   const bool ak = ksA == 1, bk = ksB == 1;
   {
-  KtScope kt(f16 ? "gemm_f16x3_kernel" : "gemm_mfma_kernel", 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), s);
-  if (f16) {
+  KtScope kt(big ? "gemm_f16x3_big_kernel" : (f16 ? "gemm_f16x3_kernel" : "gemm_mfma_kernel"), 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), s);
+  if (big) {
+    if (ak && bk) hipLaunchKernelGGL((gemm_f16x3_big_kernel<true, true>), grid, dim3(256), 0, s, a);
+    else if (ak && !bk) hipLaunchKernelGGL((gemm_f16x3_big_kernel<true, false>), grid, dim3(256), 0, s, a);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_f16x3_big_kernel<false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_f16x3_big_kernel<false, false>), grid, dim3(256), 0, s, a);
+  }
+  else if (f16) {
     if (ak && bk) hipLaunchKernelGGL((gemm_f16x3_kernel<true, true>), grid, dim3(256), 0, s, a);
     else if (ak && !bk) hipLaunchKernelGGL((gemm_f16x3_kernel<true, false>), grid, dim3(256), 0, s, a);
     else if (!ak && bk) hipLaunchKernelGGL((gemm_f16x3_kernel<false, true>), grid, dim3(256), 0, s, a);

@@ -698,7 +698,10 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
           ep.mean = s.mean; ep.invstd = s.invstd; ep.gamma = n->params + s.g_off; ep.beta = n->params + s.be_off;
         }
         ep.act = s.act; ep.slope = s.slope;
-        launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.out, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream, &ep, amax_next);
+        const bool f16g = use_f16_gemm(n, s);
+        if (f16g && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream); s.amax_x_fwd = n->fwd_counter; }
+        launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.out, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream, &ep, amax_next,
+                    f16g ? s.amax_x : nullptr, f16g ? s.amax_w : nullptr);
         if (nx) nx->amax_x_fwd = n->fwd_counter;
         s.fused_epilogue = true;
         LAUNCHCHK(c);

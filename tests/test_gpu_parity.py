@@ -364,7 +364,7 @@ def test_full_size_cfg2_step_vs_oracle(ctx, oracle, conv_mode):
 FULL_SIZES = [pytest.param((1, 32, 32), 32, 256, id="cfg2"), pytest.param((3, 64, 64), 100, 512, id="cfg3")]
 
 
-@pytest.mark.parametrize("dims,nd,B", FULL_SIZES)
+@pytest.mark.parametrize("dims,nd,B", FULL_SIZES + [pytest.param((1, 32, 32), 32, 200, id="cfg2-ragged-batch")])
 def test_full_size_backward_is_linear(ctx, conv_mode, dims, nd, B):
     """Size-independent property at the full sizes of BASELINE.json configs[1] and configs[2]: with the forward state fixed (batch statistics,
     dropout masks, pool argmax) nn.Sequential:backward is linear in gradOutput, for gradInput and for every gradParameter
@@ -397,7 +397,7 @@ def test_full_size_backward_is_linear(ctx, conv_mode, dims, nd, B):
     assert np.array_equal(gi_u, gi_u2) and np.array_equal(gp_u, gp_u2)
 
 
-@pytest.mark.parametrize("dims,nd,B", FULL_SIZES)
+@pytest.mark.parametrize("dims,nd,B", FULL_SIZES + [pytest.param((1, 32, 32), 32, 200, id="cfg2-ragged-batch")])   # 200: a partial 128-row GEMM tile
 def test_full_size_forward_is_batch_consistent(ctx, oracle, conv_mode, dims, nd, B):
     """In evaluate() mode every sample is independent (running statistics, no dropout), so rows of a full-size batch must
     equal the same rows pushed through as a small batch - bit for bit through the conv stack, whose per-pixel accumulation
