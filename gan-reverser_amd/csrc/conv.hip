@@ -1379,9 +1379,18 @@ __global__ __launch_bounds__(256) void conv_weight_absmax_batch_kernel(const Pre
   if ((j.split != 2 && j.split != 5) || j.bwd) return;   // the backward-data image shares the forward image's slot; 5 = maximum only
   const float* w = params + j.w_off;
   const long n = (long)j.cin * j.cout * (j.split == 5 ? 1 : 9);     // nn.Linear weight [cout][cin] / conv weight [cout][cin][3][3]
+  // 16-byte vectors over the aligned body, scalars for the ragged ends (an nn.Linear weight is 17 M floats at cfg3: with the
+  // 16 scalar-loading workgroups this kernel started with it took 1 ms of a 17 ms step)
+  const long head = min(n, (long)((16 - (reinterpret_cast<uintptr_t>(w) & 15)) & 15) / 4);
+  const long nv = (n - head) >> 2, tail = head + 4 * nv;
+  const float4* wv = reinterpret_cast<const float4*>(w + head);
   float m = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
-  absmax_commit(m, j.amax);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) m = absmax4(m, wv[i]);
+  if (blockIdx.x == 0) {
+    if ((long)threadIdx.x < head) m = fmaxf(m, fabsf(w[threadIdx.x]));
+    if (tail + threadIdx.x < n) m = fmaxf(m, fabsf(w[tail + threadIdx.x]));
+  }
+  if (blockIdx.x * (long)blockDim.x < nv || blockIdx.x == 0) absmax_commit(m, j.amax);
 }
 
 PrepJob make_prep_job(long w_off, void* dst, int cin, int cout, bool bwd, int split, unsigned* amax) {
@@ -1397,7 +1406,7 @@ void launch_conv_weight_prep_batch(const PrepJob* jobs_dev, int njobs, const flo
   if (amax_slots) {                                   // f16x3 images: weight maxima first
     (void)hipMemsetAsync(amax_slots, 0, sizeof(unsigned) * AMAX_WORDS * n_slots, s);
     KtScope kt("conv_weight_absmax_batch_kernel", 0.0, 0.0, s);
-    hipLaunchKernelGGL(conv_weight_absmax_batch_kernel, dim3(16, njobs), dim3(256), 0, s, jobs_dev, params);
+    hipLaunchKernelGGL(conv_weight_absmax_batch_kernel, dim3(256, njobs), dim3(256), 0, s, jobs_dev, params);
   }
   KtScope kt("conv_weight_prep_batch_kernel", 0.0, 0.0, s);
   hipLaunchKernelGGL(conv_weight_prep_batch_kernel, dim3(96, njobs), dim3(256), 0, s, jobs_dev, params);
