@@ -229,7 +229,12 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const f
   constexpr int TW = 32, TRr = 32, CK = 8, PR = TRr + 2, PCS = 40, PS = PR * PCS;   // interior columns at [4, 36), halo at 3 and 36
   constexpr int NV = (CK * PR * (TW / 4) + 255) / 256;     // float4 loads per thread per chunk (interior)
   constexpr int NHL = (CK * PR * 2 + 255) / 256;           // scalar loads per thread per chunk (halo columns)
+  // the chunk's weights sit in LDS next to the patch ([ci][o][tap], rows padded to float4s) and are read back as broadcast
+  // vectors: scalar-cache loads share the LDS counter and return out of order, so every use of one drained the whole
+  // LDS queue (128 -> 1 at cfg2: 77 -> 57 us; 128 -> 3 at cfg3, VALU-bound: 531 -> 507 us)
+  constexpr int WS = (CO * 9 + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float patch[CK * PS];
+  __shared__ __attribute__((aligned(16))) float wsh[CK * WS];
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
@@ -238,6 +243,9 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const f
   const size_t HW = (size_t)H * W;
   const float* in_base = a.in + (size_t)b * a.Cin * HW;
   const int row = tid >> 3, strip = tid & 7;               // this thread's 4 output pixels: (y0+row, x0+4*strip ..+3)
+  static_assert(CK * WS <= 512, "two weight words per thread");
+  const int wl_c = tid / WS, wl_e = tid % WS, wl_c2 = (tid + 256) / WS, wl_e2 = (tid + 256) % WS;
+  float wreg[2];
   float acc[CO][4];
 #pragma unroll
   for (int o = 0; o < CO; ++o)
@@ -259,6 +267,11 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const f
       hv[i] = (cil < CK && ci < a.Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)                 \
                   ? in_base[(size_t)ci * HW + (size_t)yy * W + xx] : 0.f;                        \
     }                                                                                            \
+    {                                                                                            \
+      const int ci = (ch_) * CK + wl_c, ci2 = (ch_) * CK + wl_c2;                                \
+      wreg[0] = (wl_c < CK && wl_e < CO * 9 && ci < a.Cin) ? w_native[((size_t)(wl_e / 9) * a.Cin + ci) * 9 + wl_e % 9] : 0.f;      \
+      wreg[1] = (wl_c2 < CK && wl_e2 < CO * 9 && ci2 < a.Cin) ? w_native[((size_t)(wl_e2 / 9) * a.Cin + ci2) * 9 + wl_e2 % 9] : 0.f; \
+    }                                                                                            \
   }
   GR_FO_LOAD(0)
   for (int ch = 0; ch < a.nchunks; ++ch) {
@@ -272,12 +285,20 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const f
       const int e = tid + 256 * i, side = e & 1, rr = (e >> 1) % PR, cil = (e >> 1) / PR;
       if (cil < CK) patch[cil * PS + rr * PCS + (side ? 36 : 3)] = hv[i];
     }
+    if (wl_c < CK) wsh[wl_c * WS + wl_e] = wreg[0];
+    if (wl_c2 < CK) wsh[wl_c2 * WS + wl_e2] = wreg[1];
     __syncthreads();
     if (ch + 1 < a.nchunks) GR_FO_LOAD(ch + 1)
 #pragma unroll
     for (int cil = 0; cil < CK; ++cil) {
       const int ci = ch * CK + cil;
       if (ci < a.Cin) {
+        float wr[WS];
+#pragma unroll
+        for (int q = 0; q < WS / 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(wsh + cil * WS + 4 * q);
+          wr[4 * q] = t.x; wr[4 * q + 1] = t.y; wr[4 * q + 2] = t.z; wr[4 * q + 3] = t.w;
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const float* pr = patch + cil * PS + (row + ky) * PCS + 4 * strip;
@@ -285,8 +306,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const f
           const float v[6] = {pr[3], m.x, m.y, m.z, m.w, pr[8]};
 #pragma unroll
           for (int o = 0; o < CO; ++o) {
-            const float* wp = w_native + ((size_t)o * a.Cin + ci) * 9 + ky * 3;
-            const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const float w0 = wr[o * 9 + ky * 3], w1 = wr[o * 9 + ky * 3 + 1], w2 = wr[o * 9 + ky * 3 + 2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[o][j] += w0 * v[j] + w1 * v[j + 1] + w2 * v[j + 2];
           }
