@@ -183,6 +183,36 @@ def test_R_forward_backward_vs_oracle(oracle, conv_mode, dims, nd, B, method, fi
     assert_close(grads, onet.grads, 2 * TOL * max(1.0, gmax), f"R flat gradient (max |g| = {gmax:.3g})")
 
 
+@pytest.mark.parametrize("B,nin,nmid,nout", [(130, 1030, 1100, 37), (257, 2052, 640, 129), (128, 1024, 1024, 128)])
+def test_large_linear_ragged_shapes_vs_oracle(oracle, conv_mode, B, nin, nmid, nout):
+    """nn.Linear layers big enough for the f16x3 GEMM (>= 2^20 weights) at sizes that are not multiples of anything: partial
+    128-row tiles in M and N, a K tail (1030 = 32 * 32 + 6, not a multiple of 4: scalar tile loads), split-K and unsplit
+    plans, training-mode BatchNormalization after the first layer (models.lua:447-451 pattern), evaluate()-mode epilogue
+    (models.lua:115-117 pattern).  Forward, gradInput and the flat gradient against the oracle."""
+    from ganrev import nn, synth
+    net = nn.Sequential()
+    net.add(nn.Linear(nin, nmid)); net.add(nn.BatchNormalization(nmid)); net.add(nn.ReLU())
+    net.add(nn.Linear(nmid, nout))
+    synth.init_params(net, 17)
+    flat, grads = net.getParameters()
+    onet = oracle.from_model(net, (nin, 1, 1))
+    x = synth.normal((B, nin), 5)
+    net.training(); onet.set_training(True)
+    ref = onet.forward(x)
+    out = net.forward(x)
+    assert_close(out, ref, TOL * max(1.0, float(np.abs(ref).max())), "forward (training)")
+    gy = synth.normal(ref.shape, 9) * np.float32(0.1)
+    grads[...] = 0; onet.zero_grads()
+    gin = net.backward(x, gy)
+    ref_gin = onet.backward(x, gy)
+    gmax = float(np.abs(onet.grads).max())
+    assert_close(gin, ref_gin, TOL * max(1.0, float(np.abs(ref_gin).max())), "gradInput")
+    assert_close(grads, onet.grads, 2 * TOL * max(1.0, gmax), "flat gradient")
+    net.evaluate(); onet.set_training(False)
+    ref_e = onet.forward(x)
+    assert_close(net.forward(x), ref_e, TOL * max(1.0, float(np.abs(ref_e).max())), "forward (evaluate)")
+
+
 def test_R_eval_forward_and_running_stats(oracle, conv_mode):
     from ganrev import models, synth
     dims, nd, B = (1, 16, 16), 8, 6
