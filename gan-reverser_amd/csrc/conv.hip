@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 // this is a VALU kernel: one thread = 4 consecutive output pixels x all CO channels; input channels stream through LDS in
 // chunks of 8 (register-prefetched float4 rows + scalar halo columns), weights come in through the scalar cache.
 template <int CO>
-__global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const float* __restrict__ w_native) {
+__global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, const float* __restrict__ w_native) {
   constexpr int TW = 32, TRr = 32, CK = 8, PR = TRr + 2, PCS = 40, PS = PR * PCS;   // interior columns at [4, 36), halo at 3 and 36
   constexpr int NV = (CK * PR * (TW / 4) + 255) / 256;     // float4 loads per thread per chunk (interior)
   constexpr int NHL = (CK * PR * 2 + 255) / 256;           // scalar loads per thread per chunk (halo columns)
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout_kernel(ConvArgs a, const f
     if (wl_c2 < CK) wsh[wl_c2 * WS + wl_e2] = wreg[1];
     __syncthreads();
     if (ch + 1 < a.nchunks) GR_FO_LOAD(ch + 1)
-#pragma unroll
+#pragma unroll 2
     for (int cil = 0; cil < CK; ++cil) {
       const int ci = ch * CK + cil;
       if (ci < a.Cin) {
