@@ -34,6 +34,7 @@ struct ConvArgs {
   const float* in; const float* wt; const float* bias; float* out;
   int B, Cin, Cout, H, W;
   int up, nchunks, cout_pad, tiles_x, tiles_y, n_otiles;
+  int n_tiles = 0;      // wide kernel: logical tiles (a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...)
   ConvEpilogue ep;      // ep.mean != nullptr: evaluate()-mode BatchNorm + activation applied before the store
   const unsigned *amax_in = nullptr, *amax_w = nullptr;   // f16x3 mode: bit patterns of max|in| and max|weights| (device)
   unsigned* amax_out = nullptr;                           // nullable: slot that receives max|out|
@@ -694,52 +695,70 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
   uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [NTERM][2][PS]   (one uint4 = 8 bf16 / f16)
   uint4* wts = patch + NTERM * 2 * PS;                            // [NTERM][9][2][CT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y; const int b = (bid / a.tiles_y) * NI;
-  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * CT;
   const int H = a.H, W = a.W;
   const int Hs = a.up ? H >> 1 : H, Ws = a.up ? W >> 1 : W;
   const size_t HWs = (size_t)Hs * Ws;
+  // Persistent workgroups: with two operand images in LDS only one workgroup fits a CU, so the chip would run in lock-step
+  // rounds - every CU loading, then multiplying, then storing at the same time, HBM idle two thirds of a round (PMC: waves
+  // alive 34 us of which 12 us MFMA on R.conv2 at cfg2).  A workgroup walks tiles L, L + gridDim.x, ...: the first chunk of
+  // the next tile is requested BEFORE the epilogue of the current one, so its stores drain behind the next tile's MFMAs.
+  struct Geo { int y0, x0, o0, b, tile; };
+  auto tile_geo = [&](int L) {
+    int bid = xcd_remap(L, a.n_tiles);
+    Geo g; g.tile = bid / a.n_otiles;
+    const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; g.b = (bid / a.tiles_y) * NI;
+    g.y0 = ty * TR; g.x0 = tx * TW; g.o0 = ot * CT;
+    return g;
+  };
   // Staging loads go through buffer descriptors: one 32-bit byte offset per staged (pixel, half) pair, the channel /
   // chunk part of the address in the scalar offset, and padding / out-of-image positions parked past the descriptor's
   // range (the hardware returns 0 for them) - no 64-bit pointers, no exec-masked branches around the loads.
-  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
-  const size_t in_left = (size_t)(a.B - b) * a.Cin * HWs * sizeof(float);
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
-      (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
+  auto in_rsrc = [&](const Geo& g) {
+    const float* in_base = a.in + (size_t)g.b * a.Cin * HWs;
+    const size_t in_left = (size_t)(a.B - g.b) * a.Cin * HWs * sizeof(float);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0, (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
+  };
   const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
   const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wsplit), 0,
       (int)((size_t)nchunks * WROWS * a.cout_pad * 16), 0x00020000);
   int kin = 0, ktot = 0;
   if (NTERM == 2) { kin = f16_scale_exp(absmax_read(a.amax_in)); ktot = kin + f16_scale_exp(absmax_read(a.amax_w)); }
   const float sc_in = pow2f(kin);
-  int voff[NSL], clim[NSL];
+  int clim[NSL];
 #pragma unroll
-  for (int s = 0; s < NSL; ++s) {
-    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
-    const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
-    const int yy = y0 + r - 1, xx = x0 + c - 1;
-    const bool inb = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W && b + img < a.B;
-    const int so = (a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx) + (img * a.Cin + 8 * hh) * (int)HWs;
-    voff[s] = inb ? so * 4 : (int)0x7FFFF000;
-    clim[s] = a.Cin - 8 * hh;                                      // channel j of chunk ch is real iff ch*16 + j < clim
-  }
-  const int wvoff = ((tid >> 6) * a.cout_pad + o0 + (tid & 63)) * 16;   // weight vector f = tid + NT*i: row (tid>>6) + 8i
+  for (int s = 0; s < NSL; ++s) clim[s] = a.Cin - 8 * ((tid + NT * s) >= PS ? 1 : 0);   // channel j of chunk ch is real iff ch*16 + j < clim
+  auto stage_offsets = [&](const Geo& g, int (&voff_)[NSL]) {
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+      const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
+      const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
+      const int yy = g.y0 + r - 1, xx = g.x0 + c - 1;
+      const bool inb = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W && g.b + img < a.B;
+      const int so = (a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx) + (img * a.Cin + 8 * hh) * (int)HWs;
+      voff_[s] = inb ? so * 4 : (int)0x7FFFF000;
+    }
+  };
+  int L = blockIdx.x;
+  Geo g = tile_geo(L);
+  __amdgpu_buffer_rsrc_t rin = in_rsrc(g);
+  int voff[NSL];
+  stage_offsets(g, voff);
+  int wvoff = ((tid >> 6) * a.cout_pad + g.o0 + (tid & 63)) * 16;   // weight vector f = tid + NT*i: row (tid>>6) + 8i
   float pv[NSL][8];
   uint4 wv[NWV];
   static_assert(CT == 64 && NT % CT == 0, "weight rows advance by NT / CT per staging slot");
-#define GR_BF_LOAD(ch_)                                                                                   \
+#define GR_BF_LOAD(ch_, rin_, voff_, wvoff_)                                                              \
   {                                                                                                       \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
       const int soff_ = (int)(((ch_) * BF_CK + j) * HWs * 4);                                             \
       _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
-        pv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
+        pv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin_, voff_[s], soff_, 0)); \
     }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
       const int soff_ = (((ch_) * WROWS + (NT / CT) * i) * a.cout_pad) * 16;                              \
-      wv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rwt, wvoff, soff_, 0));     \
+      wv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rwt, wvoff_, soff_, 0));    \
     }                                                                                                     \
   }
 #define GR_BF_STORE(patch, wts, ch_)                                                                      \
@@ -765,12 +784,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
   }
 
   f32x16 acc[MT][NG];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][ng][r] = 0.f;
   int pix[NG];
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
@@ -791,10 +804,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
     _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) acc[mt][ng] = split_mma<NTERM>(av_[mt], bv_[ng], acc[mt][ng]);
   // one tap's worth: (MT + NG) * NTERM LDS reads (for the next tap) first, then MT * NG * (NTERM == 3 ? 6 : 3) MFMAs
 #define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, (MT + NG) * NTERM, 0); __builtin_amdgcn_sched_group_barrier(0x008, MT * NG * (NTERM == 3 ? 6 : 3), 0);
-  GR_BF_LOAD(0)
+  float omax = 0.f;
+  GR_BF_LOAD(0, rin, voff, wvoff)
+  for (;;) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][ng][r] = 0.f;
   if (DB) {
     GR_BF_STORE(patch, wts, 0)
-    if (nchunks > 1) GR_BF_LOAD(1)
+    if (nchunks > 1) GR_BF_LOAD(1, rin, voff, wvoff)
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
       uint4* pc_ = patch + (ch & 1) * LBUF; uint4* wc_ = wts + (ch & 1) * LBUF;
@@ -809,7 +830,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
       // the other image is free since the last barrier: convert + store chunk ch+1 while the matrix pipe drains the taps
       // above (the partner wave on this SIMD keeps it busy meanwhile), then fetch chunk ch+2 behind the remaining taps
       if (ch + 1 < nchunks) GR_BF_STORE(pn_, wn_, ch + 1)
-      if (ch + 2 < nchunks) GR_BF_LOAD(ch + 2)
+      if (ch + 2 < nchunks) GR_BF_LOAD(ch + 2, rin, voff, wvoff)
       GR_BF_OPS(pc_, wc_, 5, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
       GR_BF_OPS(pc_, wc_, 6, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
       GR_BF_OPS(pc_, wc_, 7, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
@@ -821,7 +842,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
     for (int ch = 0; ch < nchunks; ++ch) {
       GR_BF_STORE(patch, wts, ch)
       __syncthreads();
-      if (ch + 1 < nchunks) GR_BF_LOAD(ch + 1)
+      if (ch + 1 < nchunks) GR_BF_LOAD(ch + 1, rin, voff, wvoff)
       if (NTERM == 3) {
         // one operand set: a second set (tap t+1 fetched behind tap t's MFMAs) measured no faster on bf16x6 - on random data
         // those kernels run at the clock the chip holds under MFMA load, not at an issue or latency limit
@@ -845,12 +866,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
       __syncthreads();
     }
   }
-#undef GR_BF_OPS
-#undef GR_BF_MMA
-#undef GR_BF_PIN
-#undef GR_BF_LOAD
-#undef GR_BF_STORE
-  float omax = 0.f;
+  // first chunk of the next tile: requested now, so that the stores below drain behind its arrival and the next tile's MFMAs
+  const int Ln = L + (int)gridDim.x;
+  const bool more = Ln < a.n_tiles;
+  Geo gn = g; __amdgpu_buffer_rsrc_t rinn = rin; int voffn[NSL]; int wvoffn = wvoff;
+  if (more) {
+    gn = tile_geo(Ln); rinn = in_rsrc(gn); stage_offsets(gn, voffn);
+    wvoffn = ((tid >> 6) * a.cout_pad + gn.o0 + (tid & 63)) * 16;
+    GR_BF_LOAD(0, rinn, voffn, wvoffn)
+  }
+  const int y0 = g.y0, x0 = g.x0, o0 = g.o0, b = g.b;
   bool pin[NG]; size_t obase[NG];
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
@@ -877,7 +902,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
     // same at four times the cost; the operand images in LDS are dead by now.)
     float* red = reinterpret_cast<float*>(smem_raw);             // [8 waves][2][32 channels][33]  = 67.6 KB per channel block
     float* rowsum = red + 8 * 2 * 32 * 33;                       // [512]
-    const int tile = xcd_remap(blockIdx.x, gridDim.x) / a.n_otiles;
+    const int tile = g.tile;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -925,6 +950,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
       }
     }
   }
+  if (!more) break;
+  L = Ln; g = gn; rin = rinn; wvoff = wvoffn;
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) voff[s] = voffn[s];
+  // (every wave is past the operand images: the chunk loop and the statistics block both end with a barrier)
+  }
+#undef GR_BF_OPS
+#undef GR_BF_MMA
+#undef GR_BF_PIN
+#undef GR_BF_LOAD
+#undef GR_BF_STORE
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
@@ -1272,8 +1308,14 @@ static void launch_conv_split_wide_db(ConvArgs a, const void* wsplit, hipStream_
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
   const size_t lds = (DB ? 2 : 1) * 16 * (size_t)(NTERM * 2 * PS + NTERM * 9 * 2 * CT);
   static_assert((DB ? 2 : 1) * 16 * (NTERM * 2 * PS + NTERM * 9 * 2 * CT) <= 160 * 1024, "LDS");
-  const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
-  a.stat_tiles = grid / a.n_otiles;
+  a.n_tiles = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
+  a.stat_tiles = a.n_tiles / a.n_otiles;
+  // persistent workgroups: one per CU with two LDS images, two with one (a multiple of 8 so that a workgroup's tiles stay
+  // on its XCD); GR_CONV_PERSIST=0 launches one workgroup per tile
+  static int persist = -1;
+  if (persist < 0) { const char* e = getenv("GR_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
+  const int resident = 256 * (DB ? 1 : 2);
+  const int grid = (persist && a.n_tiles > resident) ? resident : a.n_tiles;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_wide_kernel<TW, NI, NTERM, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   // as rocprofv3 prints it: <TW, NI, NTERM (3 = bf16x6, 2 = f16x3), double-buffered>
