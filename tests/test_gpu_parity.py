@@ -32,6 +32,8 @@ CONV_SHAPES = [
     (257, 16, 128, 16, 16),  # enough workgroups for the stacked two-image 512-pixel tile; odd batch -> half-empty last tile
     (64, 8, 128, 32, 32),    # enough workgroups for the 512-pixel tile on 32-wide planes
     (32, 8, 64, 64, 64),     # 512-pixel tiles, two column tiles per row (cfg3 geometry)
+    (150, 16, 64, 32, 32),   # 300 tiles on 256 persistent workgroups: 44 of them walk two tiles
+    (37, 8, 128, 64, 64),    # 592 tiles (two channel blocks per pixel tile): two or three tiles per workgroup
 ]
 
 
