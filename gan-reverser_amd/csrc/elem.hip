@@ -404,9 +404,12 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
 // summation order): every pass-B workgroup derives them itself - 2 x `splits` doubles - instead of a launch in between; the
 // workgroup of split 0 also accumulates the gamma / beta gradients.
 __device__ __forceinline__ void post_bwd_coef(const PostBwdArgs& a, int c, int sp, int splits, double n, float* sh_coef) {
+  __shared__ double sh_part[2 * STAT_SPLITS];      // fetched by 2 * splits threads at once, added by one in split order
+  if ((int)threadIdx.x < 2 * splits) sh_part[threadIdx.x] = a.partials[(long)c * STAT_SPLITS * 2 + threadIdx.x];
+  __syncthreads();
   if (threadIdx.x == 0) {
     double s = 0, q = 0;
-    for (int k = 0; k < splits; ++k) { s += a.partials[((long)c * STAT_SPLITS + k) * 2]; q += a.partials[((long)c * STAT_SPLITS + k) * 2 + 1]; }
+    for (int k = 0; k < splits; ++k) { s += sh_part[2 * k]; q += sh_part[2 * k + 1]; }
     const double invstd = a.f.invstd[c];
     sh_coef[0] = (float)(s / n);
     sh_coef[1] = (float)(q * invstd * invstd / n);
