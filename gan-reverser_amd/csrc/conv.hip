@@ -2130,7 +2130,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce8_kernel(const float*
     const size_t stride = (size_t)9 * coutp * cinp;
     const float* p = slab + ((size_t)tap * coutp + o) * cinp + ci;
     const int per = (nsplit + 7) / 8, k0 = grp * per, k1 = min(nsplit, k0 + per);
-    for (int k = k0; k < k1; ++k) s += p[(size_t)k * stride];
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {            // eight loads in flight per lane, added in split order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < k1; ++k) s += p[(size_t)k * stride];
   }
   part[grp][lane] = s;
   __syncthreads();

@@ -397,7 +397,15 @@ __global__ void gemm_splitk_reduce_kernel(const float* __restrict__ slab, float*
   if (i >= (long)M * N) return;
   const int n = (int)(i % N); const int m = (int)(i / N);
   float s = 0.f;
-  for (int z = 0; z < nsplit; ++z) s += slab[(size_t)z * M * N + i];
+  int z = 0;
+  for (; z + 8 <= nsplit; z += 8) {          // eight loads in flight per thread, added in split order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(z + u) * M * N + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; z < nsplit; ++z) s += slab[(size_t)z * M * N + i];
   s += bias ? bias[n] : 0.f;
   float* c = C + (long)m * ldc + n;
   *c = accumulate ? *c + s : s;
