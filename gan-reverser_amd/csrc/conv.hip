@@ -360,7 +360,10 @@ __global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const fl
   __shared__ float red[4][256][2];                            // per-wave channel sums for the BatchNorm statistics (Cout <= 256)
   const bool stats = a.stat_part != nullptr;
   float omax = 0.f;
-  for (int o = 0; o < a.Cout; ++o) {
+  // blockIdx.y: slice of the output channels (small grids only: B * tiles workgroups of four waves leave the CUs at one wave
+  // per SIMD, nothing to hide the scalar weight loads behind - cfg2: 256 workgroups, 50 us for a 20 us store stream)
+  const int o_per = (a.Cout + (int)gridDim.y - 1) / (int)gridDim.y, o_beg = blockIdx.y * o_per, o_end = min(a.Cout, o_beg + o_per);
+  for (int o = o_beg; o < o_end; ++o) {
     const float* wp = w_native + (size_t)o * CI * 9;          // uniform address: scalar loads
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const fl
   }
   if (stats) {
     __syncthreads();
-    for (int e = tid; e < 2 * a.Cout; e += 256) {
+    for (int e = 2 * o_beg + tid; e < 2 * o_end; e += 256) {
       const int o = e >> 1, wh = e & 1;
       const double t = ((double)red[0][o][wh] + (double)red[1][o][wh]) + ((double)red[2][o][wh] + (double)red[3][o][wh]);
       a.stat_part[((size_t)o * a.stat_tiles + blockIdx.x) * 2 + wh] = t;
@@ -408,10 +411,12 @@ void launch_conv3x3_fewin(const float* in, const float* w_native, const float* b
   const double px = (double)B * H * W;
   const std::string name = "conv3x3_fewin_kernel<" + std::to_string(Cin) + ">";
   KtScope kt(name.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
+  int og = 1;                                                  // output-channel slices: aim at >= 1024 workgroups, >= 8 channels each
+  while (grid * og < 1024 && Cout / (2 * og) >= 8) og *= 2;
   switch (Cin) {
-    case 1: hipLaunchKernelGGL(conv3x3_fewin_kernel<1>, dim3(grid), dim3(256), 0, s, a, w_native); break;
-    case 2: hipLaunchKernelGGL(conv3x3_fewin_kernel<2>, dim3(grid), dim3(256), 0, s, a, w_native); break;
-    default: hipLaunchKernelGGL(conv3x3_fewin_kernel<3>, dim3(grid), dim3(256), 0, s, a, w_native); break;
+    case 1: hipLaunchKernelGGL(conv3x3_fewin_kernel<1>, dim3(grid, og), dim3(256), 0, s, a, w_native); break;
+    case 2: hipLaunchKernelGGL(conv3x3_fewin_kernel<2>, dim3(grid, og), dim3(256), 0, s, a, w_native); break;
+    default: hipLaunchKernelGGL(conv3x3_fewin_kernel<3>, dim3(grid, og), dim3(256), 0, s, a, w_native); break;
   }
 }
 
