@@ -982,7 +982,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
 // (a, dy, b, dx) - one patch conversion serves 96 MFMAs per wave.  f16x3 arithmetic only.
 //   LDS patch   [2 terms][2 halves][PS] (zero-padded source patch, 1-pixel halo; NI whole images stacked)
 //   LDS weights [2 terms][2 a][8 slots = (dy, b, dx)][2 halves][32 o]
-template <int TW, int NI>
+template <int TW, int NI, bool DB>
 __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, const uint4* __restrict__ wup) {
   constexpr int NT = 512, NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
     _Pragma("unroll") for (int i = 0; i < NWV; ++i)                                                       \
       wv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rwt, wvoff, ((ch_) * 64 + 16 * i) * a.cout_pad * 16, 0)); \
   }
-#define GR_UP_STORE(ch_)                                                                                  \
+#define GR_UP_STORE(patch, wts, ch_)                                                                      \
   {                                                                                                       \
     if (((ch_) + 1) * BF_CK > a.Cin) {                                                                    \
       _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
@@ -1068,9 +1068,96 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
     const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;
     pix[ng] = h * PS + pr * PC + pc;                               // patch row pr = source row y - 1
   }
+  constexpr int LBUF = 2 * 2 * PS + WV;                           // uint4s of one (patch, weights) image
   GR_UP_LOAD(0)
+  if (DB) {
+    // two LDS images (TW >= 16: 144-148 KB): chunk ch+1 is converted and stored after the first source row of chunk ch, one
+    // barrier per chunk - as in conv3x3_split_wide_kernel
+    GR_UP_STORE(patch, wts, 0)
+    if (nchunks > 1) GR_UP_LOAD(1)
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const uint4* pc_ = patch + (ch & 1) * LBUF; const uint4* wc_ = wts + (ch & 1) * LBUF;
+      uint4* pn_ = patch + ((ch + 1) & 1) * LBUF; uint4* wn_ = wts + ((ch + 1) & 1) * LBUF;
+    {
+      uint4 bv[3][NG][2];                                          // source columns x-1, x, x+1
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3)
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bv[c3][ng][t] = pc_[t * 2 * PS + pix[ng] + 0 * PC + c3];
+#pragma unroll
+      for (int pa = 0; pa < 2; ++pa) {
+        const int dy = 0 - pa;                                    // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
+        if (dy < 0 || dy > 1) continue;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            uint4 av[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = wc_[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[pb + dx][ng], acc[pa][pb][ng]);
+          }
+      }
+    }
+      if (ch + 1 < nchunks) GR_UP_STORE(pn_, wn_, ch + 1)
+      if (ch + 2 < nchunks) GR_UP_LOAD(ch + 2)
+    {
+      uint4 bv[3][NG][2];                                          // source columns x-1, x, x+1
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3)
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bv[c3][ng][t] = pc_[t * 2 * PS + pix[ng] + 1 * PC + c3];
+#pragma unroll
+      for (int pa = 0; pa < 2; ++pa) {
+        const int dy = 1 - pa;                                    // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
+        if (dy < 0 || dy > 1) continue;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            uint4 av[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = wc_[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[pb + dx][ng], acc[pa][pb][ng]);
+          }
+      }
+    }
+    {
+      uint4 bv[3][NG][2];                                          // source columns x-1, x, x+1
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3)
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bv[c3][ng][t] = pc_[t * 2 * PS + pix[ng] + 2 * PC + c3];
+#pragma unroll
+      for (int pa = 0; pa < 2; ++pa) {
+        const int dy = 2 - pa;                                    // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
+        if (dy < 0 || dy > 1) continue;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            uint4 av[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = wc_[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[pb + dx][ng], acc[pa][pb][ng]);
+          }
+      }
+    }
+      __syncthreads();
+    }
+  } else {
   for (int ch = 0; ch < nchunks; ++ch) {
-    GR_UP_STORE(ch)
+    GR_UP_STORE(patch, wts, ch)
     __syncthreads();
     if (ch + 1 < nchunks) GR_UP_LOAD(ch + 1)
 #pragma unroll
@@ -1099,6 +1186,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
       }
     }
     __syncthreads();
+  }
   }
 #undef GR_UP_LOAD
 #undef GR_UP_STORE
@@ -1195,21 +1283,30 @@ void launch_conv_weight_up2_split(const float* w_native, void* dst, int cin, int
   hipLaunchKernelGGL(conv_weight_up2_split_kernel, dim3(512), dim3(256), 0, s, w_native, reinterpret_cast<unsigned short*>(dst), cin, cout,
                      round_up(cin, BF_CK), round_up(cout, 32), amax_w);
 }
-template <int TW, int NI>
-static void launch_conv_up2_t(ConvArgs a, const void* wup, hipStream_t s) {
+template <int TW, int NI, bool DB>
+static void launch_conv_up2_db(ConvArgs a, const void* wup, hipStream_t s) {
   constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2);
   const int Hs = a.H / 2, Ws = a.W / 2;
   a.tiles_x = (Ws + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (Hs + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / 32;
-  const size_t lds = 16 * (size_t)(2 * 2 * PS + 2 * 2 * 8 * 2 * 32);
+  const size_t lds = (DB ? 2 : 1) * 16 * (size_t)(2 * 2 * PS + 2 * 2 * 8 * 2 * 32);
   const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_f16x3_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  static const std::string name = "conv3x3_up2_f16x3_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_f16x3_kernel<TW, NI, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = "conv3x3_up2_f16x3_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + (DB ? ", true>" : ", false>");   // as rocprofv3 prints it
   const double px = (double)a.B * a.H * a.W;
   // FLOPs reported = those of the layer as the reference defines it (9 taps per output); the kernel issues 4/9 of them
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_up2_f16x3_kernel<TW, NI>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wup));
+  hipLaunchKernelGGL((conv3x3_up2_f16x3_kernel<TW, NI, DB>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wup));
+}
+template <int TW, int NI>
+static void launch_conv_up2_t(const ConvArgs& a, const void* wup, hipStream_t s) {
+  constexpr int IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2);
+  constexpr bool FITS = 2 * 16 * (2 * 2 * PS + 2 * 2 * 8 * 2 * 32) <= 160 * 1024;    // two LDS images where they fit (not the 8-wide tile)
+  static int db = -1;
+  if (db < 0) { const char* e = getenv("GR_UP2_DB"); db = e ? atoi(e) : 1; }
+  if (FITS && db) launch_conv_up2_db<TW, NI, FITS>(a, wup, s);
+  else launch_conv_up2_db<TW, NI, false>(a, wup, s);
 }
 // in: [B, Cin, H/2, W/2]; out: [B, Cout, H, W] = conv3x3(nearest-upsample x2 (in)); wup from launch_conv_weight_up2_split
 void launch_conv3x3_up2_f16x3(const float* in, const void* wup, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
