@@ -1334,8 +1334,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
   absmax_commit(m, slot);
 }
-void launch_absmax(const float* x, long n, unsigned* slot, hipStream_t s) {
-  (void)hipMemsetAsync(slot, 0, sizeof(unsigned) * AMAX_WORDS, s);
+void launch_absmax(const float* x, long n, unsigned* slot, hipStream_t s, bool slot_is_zero) {
+  if (!slot_is_zero) (void)hipMemsetAsync(slot, 0, sizeof(unsigned) * AMAX_WORDS, s);
   long blocks = (n / 4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
   KtScope kt("absmax_kernel", 0.0, 4.0 * (double)n, s);
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, slot);

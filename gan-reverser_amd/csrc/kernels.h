@@ -129,7 +129,7 @@ void launch_conv3x3_fewin(const float* in, const float* w_native, const float* b
 size_t conv_weight_split_bytes(int cin, int cout, bool for_backward_data);
 // nterm 3 = bf16x6; nterm 2 = "f16x3": two fp16 terms of the power-of-two-scaled operands, 3 products.  The scales come from
 // device slots holding the bit pattern of max|tensor| (amax_*), filled by launch_absmax or by the producing kernel.
-void launch_absmax(const float* x, long n, unsigned* slot, hipStream_t s);       // zeroes the slot, then max|x| -> slot
+void launch_absmax(const float* x, long n, unsigned* slot, hipStream_t s, bool slot_is_zero = false);   // slot_is_zero: the caller has just filled the slot with 0       // zeroes the slot, then max|x| -> slot
 void launch_conv_weight_split(const float* w_native, void* wsplit, int cin, int cout, bool for_backward_data, hipStream_t s,
                               int nterm = 3, unsigned* amax_w = nullptr);        // nterm 2: also computes amax_w
 void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias, float* out,

@@ -241,6 +241,7 @@ struct gr_net {
   PrepJob* jobs_dev[3] = {nullptr, nullptr, nullptr}; int njobs[3] = {0, 0, 0};   // [0] fp32 k-major images, [1] bf16x6, [2] f16x3 split images
   uint64_t prepped_version[3] = {0, 0, 0};
   unsigned* amax = nullptr;          // f16x3 scale tracking: [nst] x slots, [nst] dy slots, [nst] weight slots
+  bool dy_slots_zeroed = false, w_slots_zeroed = false;   // set by forward_impl's single fill, consumed by backward / weight prep
 };
 
 static int64_t vol3(int c, int h, int w) { return (int64_t)c * h * w; }
@@ -555,7 +556,8 @@ static int prep_weights(gr_net* n) {
     if (!(m == mode || (m == 0 && any_full))) continue;
     if (n->prepped_version[m] == n->params_version) continue;
     // the bf16 and f16 images share their buffers: switching the mode invalidates the other flavour
-    if (m == 2) launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream, n->amax + AMAX_WORDS * 2 * n->st.size(), (int)n->st.size());
+    if (m == 2) launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream, n->amax + AMAX_WORDS * 2 * n->st.size(),
+                                              n->w_slots_zeroed ? 0 : (int)n->st.size());     // 0: the caller has just zeroed the slots
     else launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream);
     LAUNCHCHK(c);
     n->prepped_version[m] = n->params_version;
@@ -609,10 +611,20 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
   int r = ensure_batch(n, B); if (r) return r;
   const float* x = in_dev;
   n->fwd_counter++;
-  r = prep_weights(n); if (r) return r;
   const bool f16 = c->conv_mode == 2;
   const size_t nst = n->st.size();
-  if (f16) HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst, c->stream));     // the x slots; producers fold maxima in
+  // f16x3 scale slots [x | dy | w] x stages: ONE fill per forward (each hipMemsetAsync is a 5 us kernel of its own) - the x slots
+  // (producers fold maxima in), in training mode the dy slots of the backward that follows, and the w slots when the weight
+  // prep below is about to recompute the weight maxima
+  n->w_slots_zeroed = false;
+  if (f16) {
+    const bool w_too = n->training && n->prepped_version[2] != n->params_version;
+    const size_t groups = w_too ? 3 : (n->training ? 2 : 1);
+    HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst * groups, c->stream));
+    n->dy_slots_zeroed = groups >= 2;
+    n->w_slots_zeroed = groups == 3;
+  }
+  r = prep_weights(n); if (r) return r;
   {
     // Dropout noise of every stage, drawn in one launch (injected masks - tests - are consumed instead)
     MaskJobs jobs{}; jobs.n = 0;
@@ -669,7 +681,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
       } else if (use_bf16x6(n, s)) {
         const int nterm = c->conv_mode == 2 ? 2 : 3;
         // input not produced by a tracking kernel (the net's own input, a GEMM, a VALU conv): take its maximum now
-        if (nterm == 2 && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream); s.amax_x_fwd = n->fwd_counter; }
+        if (nterm == 2 && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream, true); s.amax_x_fwd = n->fwd_counter; }
         const bool last_writer = s.fused_epilogue || !s.has_post;
         static const bool up2_on = !getenv("GR_NO_UP2");
         if (nterm == 2 && s.up && s.ws_up && up2_on)
@@ -699,7 +711,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         }
         ep.act = s.act; ep.slope = s.slope;
         const bool f16g = use_f16_gemm(n, s);
-        if (f16g && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream); s.amax_x_fwd = n->fwd_counter; }
+        if (f16g && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream, true); s.amax_x_fwd = n->fwd_counter; }
         launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.out, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream, &ep, amax_next,
                     f16g ? s.amax_x : nullptr, f16g ? s.amax_w : nullptr);
         if (nx) nx->amax_x_fwd = n->fwd_counter;
@@ -708,7 +720,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         x = s.out; continue;
       }
       if (use_f16_gemm(n, s)) {
-        if (s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream); s.amax_x_fwd = n->fwd_counter; }
+        if (s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream, true); s.amax_x_fwd = n->fwd_counter; }
         launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.y, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream,
                     nullptr, nullptr, s.amax_x, s.amax_w);
       } else
@@ -795,7 +807,9 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
   BiasJobs bias_jobs{}; bias_jobs.n = 0;
   { int r = prep_weights(n); if (r) return r; }   // no-op unless the arithmetic mode changed since the forward
   const bool f16 = c->conv_mode == 2;
-  if (f16) HIPCHK(c, hipMemsetAsync(n->amax + AMAX_WORDS * n->st.size(), 0, sizeof(unsigned) * AMAX_WORDS * n->st.size(), c->stream));   // the dy slots
+  if (f16 && !n->dy_slots_zeroed)   // the dy slots (already zero when this is the first backward after a training-mode forward)
+    HIPCHK(c, hipMemsetAsync(n->amax + AMAX_WORDS * n->st.size(), 0, sizeof(unsigned) * AMAX_WORDS * n->st.size(), c->stream));
+  n->dy_slots_zeroed = false;
   const float* g = gout_dev;
   for (int si = (int)n->st.size() - 1; si >= 0; --si) {
     Stage& s = n->st[si];
