@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_tiles_kernel(const doub
   __shared__ double sh[8];
   const int c = blockIdx.x;
   double s = 0, q = 0;
+#pragma unroll 4
   for (int t = threadIdx.x; t < tiles; t += 256) { s += part[((size_t)c * tiles + t) * 2]; q += part[((size_t)c * tiles + t) * 2 + 1]; }
   s = block_reduce_sum(s, sh);
   q = block_reduce_sum(q, sh);
@@ -500,6 +501,7 @@ __global__ void bias_grad_batch_kernel(BiasJobs jobs) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= j.C) return;
   double s = 0;
+#pragma unroll 8
   for (int k = 0; k < j.splits; ++k) s += j.partials[(long)c * STAT_SPLITS + k];
   j.gbias[c] += (float)s;
 }
