@@ -985,7 +985,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
 template <int TW, int NI, bool DB>
 __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, const uint4* __restrict__ wup) {
   constexpr int NT = 512, NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
-  constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;
+  // NI > 1: the tile is NI whole images, so every halo slot of the patch is zero padding for every chunk.  Those slots are
+  // zeroed once and the per-chunk staging walks only the 512 real pixels x 2 channel halves (2 per thread instead of
+  // 3 (16-wide) or 4 (8-wide) slots: a third / half of the loads, conversions and LDS stores).
+  constexpr bool COMPACT = NI > 1;
+  constexpr int NEH = 2 * PS, NSL = COMPACT ? 2 : (NEH + NT - 1) / NT;
   constexpr int WV = 2 * 2 * 8 * 2 * 32, NWV = WV / NT;           // 2048 weight vectors per chunk: 4 per thread
   static_assert(NI == 1 || IH * NI * TW == PT, "tile must hold whole images");
   static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2) || (TW == 8 && NI == 8), "tile_pixel assumes these tilings");
@@ -1011,16 +1015,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
   const int kin = f16_scale_exp(absmax_read(a.amax_in));
   const int ktot = kin + f16_scale_exp(absmax_read(a.amax_w)) - 2;   // summed weights: up to 4 max|w|
   const float sc_in = pow2f(kin);
-  int voff[NSL], clim[NSL];
+  int voff[NSL], clim[NSL], eoff[NSL];                             // eoff: slot index in the term-0 patch image ((half) * PS + position)
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
-    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
-    const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
-    const int yy = y0 + r - 1, xx = x0 + c - 1;
-    const bool inb = eh < NEH && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws && b + img < a.B;
-    const int so = yy * Ws + xx + (img * a.Cin + 8 * hh) * (int)HWs;
-    voff[s] = inb ? so * 4 : (int)0x7FFFF000;
-    clim[s] = a.Cin - 8 * hh;
+    if (COMPACT) {
+      const int q = tid + NT * s, hh = q >> 9, p = q & 511, prr = p / TW, pc = p - prr * TW, img = prr / IH, r = prr - img * IH;
+      const int yy = y0 + r, xx = x0 + pc;
+      const bool inb = yy < Hs && xx < Ws && b + img < a.B;
+      const int so = yy * Ws + xx + (img * a.Cin + 8 * hh) * (int)HWs;
+      voff[s] = inb ? so * 4 : (int)0x7FFFF000;
+      clim[s] = a.Cin - 8 * hh;
+      eoff[s] = hh * PS + (img * (IH + 2) + r + 1) * PC + pc + 1;
+    } else {
+      const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
+      const int yy = y0 + rr - 1, xx = x0 + c - 1;
+      const bool inb = eh < NEH && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws && b < a.B;
+      const int so = yy * Ws + xx + (8 * hh) * (int)HWs;
+      voff[s] = inb ? so * 4 : (int)0x7FFFF000;
+      clim[s] = a.Cin - 8 * hh;
+      eoff[s] = eh < NEH ? eh : -1;
+    }
   }
   const int wvoff = ((tid >> 5) * a.cout_pad + o0 + (tid & 31)) * 16;   // weight vector f = tid + NT*i: row (tid>>5) + 16i
   float pv[NSL][8];
@@ -1042,12 +1056,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
         _Pragma("unroll") for (int j = 0; j < 8; ++j) if ((ch_) * BF_CK + j >= clim[s]) pv[s][j] = 0.f;   \
     }                                                                                                     \
     _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
-      const int eh = tid + NT * s;                                                                        \
-      if (eh < NEH) {                                                                                     \
-        const int hh = eh >= PS ? 1 : 0, e = eh - hh * PS;                                                \
+      if (COMPACT || eoff[s] >= 0) {                                                                      \
         uint4 t0, t1;                                                                                     \
         split8_f16(pv[s], sc_in, t0, t1);                                                                 \
-        patch[(0 * 2 + hh) * PS + e] = t0; patch[(1 * 2 + hh) * PS + e] = t1;                             \
+        patch[eoff[s]] = t0; patch[2 * PS + eoff[s]] = t1;                                                \
       }                                                                                                   \
     }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) wts[tid + NT * i] = wv[i];                            \
@@ -1070,6 +1082,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
   }
   constexpr int LBUF = 2 * 2 * PS + WV;                           // uint4s of one (patch, weights) image
   GR_UP_LOAD(0)
+  if (COMPACT) {                                                   // the padding slots, once (both images when double-buffered)
+    for (int i = tid; i < (DB ? 2 : 1) * LBUF; i += NT) if (i % LBUF < 2 * 2 * PS) patch[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+  }
   if (DB) {
     // two LDS images (TW >= 16: 144-148 KB): chunk ch+1 is converted and stored after the first source row of chunk ch, one
     // barrier per chunk - as in conv3x3_split_wide_kernel
