@@ -691,7 +691,10 @@ template <int TW, int NI, int NTERM, bool DB>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
   constexpr int NT = 512, MT = 2;
   constexpr int NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
-  constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
+  // NI > 1 (whole images per tile): every halo slot is zero padding for every chunk and tile - zeroed once, and the staging
+  // walks only the 512 real pixels x 2 channel halves (2 slots per thread instead of 3)
+  constexpr bool COMPACT = NI > 1;
+  constexpr int NEH = 2 * PS, NSL = COMPACT ? 2 : (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
   constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
   static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2), "tile_pixel assumes these tilings");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -731,12 +734,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
   int kin = 0, ktot = 0;
   if (NTERM == 2) { kin = f16_scale_exp(absmax_read(a.amax_in)); ktot = kin + f16_scale_exp(absmax_read(a.amax_w)); }
   const float sc_in = pow2f(kin);
-  int clim[NSL];
+  int clim[NSL], eoff[NSL];                                       // eoff: slot in the term-0 patch image (half * PS + position), -1 = none
 #pragma unroll
-  for (int s = 0; s < NSL; ++s) clim[s] = a.Cin - 8 * ((tid + NT * s) >= PS ? 1 : 0);   // channel j of chunk ch is real iff ch*16 + j < clim
+  for (int s = 0; s < NSL; ++s) {
+    if (COMPACT) {
+      const int q = tid + NT * s, hh = q >> 9, p = q & 511, prr = p / TW, pc = p - prr * TW, img = prr / IH, r = prr - img * IH;
+      clim[s] = a.Cin - 8 * hh;                                    // channel j of chunk ch is real iff ch*16 + j < clim
+      eoff[s] = hh * PS + (img * (IH + 2) + r + 1) * PC + pc + 1;
+    } else {
+      const int eh = tid + NT * s;
+      clim[s] = a.Cin - 8 * (eh >= PS ? 1 : 0);
+      eoff[s] = eh < NEH ? eh : -1;
+    }
+  }
   auto stage_offsets = [&](const Geo& g, int (&voff_)[NSL]) {
 #pragma unroll
     for (int s = 0; s < NSL; ++s) {
+      if (COMPACT) {
+        const int q = tid + NT * s, hh = q >> 9, p = q & 511, prr = p / TW, pc = p - prr * TW, img = prr / IH, r = prr - img * IH;
+        const int yy = g.y0 + r, xx = g.x0 + pc;
+        const bool inb = yy < H && xx < W && g.b + img < a.B;
+        const int so = (a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx) + (img * a.Cin + 8 * hh) * (int)HWs;
+        voff_[s] = inb ? so * 4 : (int)0x7FFFF000;
+        continue;
+      }
       const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
       const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
       const int yy = g.y0 + r - 1, xx = g.x0 + c - 1;
@@ -773,13 +794,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
         _Pragma("unroll") for (int j = 0; j < 8; ++j) if ((ch_) * BF_CK + j >= clim[s]) pv[s][j] = 0.f;   \
     }                                                                                                     \
     _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
-      const int eh = tid + NT * s;                                                                        \
-      if (eh < NEH) {                                                                                     \
-        const int hh = eh >= PS ? 1 : 0, e = eh - hh * PS;                                                \
+      if (COMPACT || eoff[s] >= 0) {                                                                      \
         uint4 t0, t1, t2;                                                                                 \
-        if (NTERM == 3) { split8_bf16(pv[s], t0, t1, t2); patch[(2 * 2 + hh) * PS + e] = t2; }            \
+        if (NTERM == 3) { split8_bf16(pv[s], t0, t1, t2); patch[4 * PS + eoff[s]] = t2; }                 \
         else split8_f16(pv[s], sc_in, t0, t1);                                                            \
-        patch[(0 * 2 + hh) * PS + e] = t0; patch[(1 * 2 + hh) * PS + e] = t1;                             \
+        patch[eoff[s]] = t0; patch[2 * PS + eoff[s]] = t1;                                                \
       }                                                                                                   \
     }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) {                                                     \
@@ -811,6 +830,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
 #define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, (MT + NG) * NTERM, 0); __builtin_amdgcn_sched_group_barrier(0x008, MT * NG * (NTERM == 3 ? 6 : 3), 0);
   float omax = 0.f;
   GR_BF_LOAD(0, rin, voff, wvoff)
+  if (COMPACT) {                                                   // the padding slots, once (both images when double-buffered)
+    for (int i = tid; i < (DB ? 2 : 1) * LBUF; i += NT) if (i % LBUF < NTERM * 2 * PS) patch[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+  }
   for (;;) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -956,6 +979,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
     }
   }
   if (!more) break;
+  if (COMPACT && a.stat_part) {                                    // the statistics block used the first image as scratch: padding slots again
+    for (int i = tid; i < NTERM * 2 * PS; i += NT) patch[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+  }
   L = Ln; g = gn; rin = rinn; wvoff = wvoffn;
 #pragma unroll
   for (int s = 0; s < NSL; ++s) voff[s] = voffn[s];
