@@ -3,12 +3,17 @@
    noise -> G forward (evaluate) -> R forward/backward (training) -> [RCCL all-reduce] -> L2+clamp+Adam
    (reference train_r.lua:138-170) at BASELINE.json configs[1]: 32x32 grayscale, noise=32, batch=256 per GPU.
 
-python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run, one rank per GPU)
-Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+python bench.py --gpus N --steps K --warmup W
+  N > 1 without a torch.distributed.run environment: this process (which never touches a GPU) starts the N ranks itself
+  (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>) and exits with their code.
+  N > 1 under torch.distributed.run (RANK / WORLD_SIZE set): one rank per GPU, gradients over RCCL.
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline`, `cpu_baseline`, and per arithmetic mode
+(`modes`: f16x3 = headline, bf16x6, f32) the same timed loop with its own roofline.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,54 +27,121 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (the 5
 BF16X6_PASSES = 6                  # bf16x6 mode: six bf16 MFMA products per fp32-accurate product
 F16X3_PASSES = 3                   # f16x3 mode: three f16 MFMA products per fp32-accurate product
 PEAK_HBM_GBS = 8000.0
+MODES = ("f16x3", "bf16x6", "f32")
+DTYPE = {"f32": "f32", "bf16x6": "f32 via bf16x6 (3-term bf16 split, 6 MFMA products, fp32 accumulate)",
+         "f16x3": "f32 via f16x3 (2-term fp16 split of power-of-two-scaled operands, 3 MFMA products, fp32 accumulate)"}
 
 WORKLOADS = {
     # BASELINE.json configs[1] / configs[2]
     "cfg2": dict(dims=(1, 32, 32), nd=32, batch=256, name="32x32 grayscale, noise=32, batch=256/GPU: G fwd + R fwd/bwd + Adam"),
     "cfg3": dict(dims=(3, 64, 64), nd=100, batch=512, name="64x64 RGB, noise=100, batch=512/GPU: G fwd + R fwd/bwd + Adam"),
 }
+ELEMENTWISE = ("post_forward", "post_backward", "bn_stats", "bias_grad", "gen_mask", "absmax_kernel")
 
 
 def step_flops_per_image(dims, nd):
-    """Algorithmic FLOPs (multiply-add = 2) of one image through the step: G fwd + 3 x R fwd."""
+    """Algorithmic FLOPs (multiply-add = 2) of one image through the step: G fwd + 3 x R fwd.
+    Also returns R's 3x3 convolutions alone (forward): the "R's 3x3 convs at bs256" figure of north_star is 3 x that x batch."""
     c, h, w = dims
     h4, w4 = h // 4, w // 4
     conv = lambda ci, co, hh, ww: 2.0 * 9 * ci * co * hh * ww
     g = 2.0 * nd * 512 * h4 * w4 + conv(512, 256, h // 2, w // 2) + conv(256, 128, h, w) + conv(128, c, h, w)
-    r = (conv(c, 64, h, w) + 2 * conv(64, 64, h, w) + conv(64, 128, h // 2, w // 2) + 2 * conv(128, 128, h // 2, w // 2)
-         + 2.0 * 128 * h4 * w4 * 512 + 2.0 * 512 * nd)
-    return g + 3 * r, g, r
+    r_conv = conv(c, 64, h, w) + 2 * conv(64, 64, h, w) + conv(64, 128, h // 2, w // 2) + 2 * conv(128, 128, h // 2, w // 2)
+    r = r_conv + 2.0 * 128 * h4 * w4 * 512 + 2.0 * 512 * nd
+    return g + 3 * r, g, r, r_conv
 
 
-def cpu_baseline(dims, nd, sample_batch, threads, ctx=None):
-    """The oracle (CPU restatement of the Torch7 nn path) timed on this box's host cores on a bounded sample."""
+# ----------------------------------------------------------------------------------------------------------------------
+# launch: `python bench.py --gpus N` starts its own ranks
+def spawn_ranks(args):
+    """Called before anything in this process has touched a GPU (no torch.cuda / HIP call has run): start N ranks as CHILD
+    processes through torch.distributed.run and relay their output; never re-exec a process that has initialised the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the dominant kernel, measured in this run: two rocprofv3 --pmc children (FETCH_SIZE / WRITE_SIZE in separate
+# passes, MI355X_MICROARCH.md section HBM), each a short run of this same script.  They are started BEFORE this process
+# initialises the GPU.
+def measure_traffic(args):
+    import csv, glob, shutil, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    out, base = {}, tempfile.mkdtemp(prefix="ganrev_pmc_")
+    child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "2", "--warmup", "1", "--conv-mode", args.conv_mode,
+             "--modes", args.conv_mode, "--traffic", "off", "--no-cpu-baseline", "--no-search", "--quiet-child"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(base, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
+            agg = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter:
+                    continue
+                k = row["Kernel_Name"].replace("void ", "").replace("gr::", "").split("(")[0]
+                a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(row["Counter_Value"])
+            out[counter] = {k: v / n for k, (n, v) in agg.items()}
+    except Exception as e:  # noqa: BLE001 - reported in the line, never silent
+        return None, f"traffic measurement failed: {e}"
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    # KiB -> bytes; gfx950: FETCH_SIZE reports half the bytes of a wide streaming read -> doubled (the guide's correction)
+    kernels = set(out["FETCH_SIZE"]) | set(out["WRITE_SIZE"])
+    return {k: round(2 * 1024 * out["FETCH_SIZE"].get(k, 0.0) + 1024 * out["WRITE_SIZE"].get(k, 0.0)) for k in kernels}, \
+        "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 3 steps of this script; per launch, 2 x FETCH + WRITE"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(dims, nd, ctx=None):
+    """The oracle (CPU restatement of the Torch7 nn path, OpenMP) timed on this box's host cores at BASELINE.json configs[0]
+    (32x32 grayscale, noise 32, batch 16 - train_r.lua's own CPU case) on a bounded sample: with the reference's default thread
+    count (8, train_r.lua:21) and with the thread count that measured fastest on this box class."""
     import numpy as np
     from ganrev import models, synth
     from oracle import oracle
-    threads = oracle.set_threads(threads)      # libgomp is already initialised (torch): the env var would be ignored
+    B = 16
     G = models.create_G(dims, nd); synth.init_params(G, 1)
     R = models.create_R(dims, nd); synth.init_params(R, 2)
     oG, oR = oracle.from_model(G, (nd, 1, 1)), oracle.from_model(R, dims)
     for m in R.leaves():
         if m.typename in ("nn.Dropout", "nn.SpatialDropout"):
             li = oR.layer_index[id(m)]
-            oR.set_mask(li, synth.bernoulli_keep((oR.mask_size(li, sample_batch),), 7 + li, m.p))
+            oR.set_mask(li, synth.bernoulli_keep((oR.mask_size(li, B),), 7 + li, m.p))
     mm = np.zeros(oR.n_params, np.float32); vv = np.zeros_like(mm)
-    noise = synth.normal((sample_batch, nd), 9)
-    oracle.train_r_step(oG, oR, noise, oracle.GoHyper(), mm, vv, 1)          # warm-up (page-in, thread pool)
-    t0 = time.perf_counter(); n = 0
-    while True:
-        oracle.train_r_step(oG, oR, noise, oracle.GoHyper(), mm, vv, 2 + n)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > 8.0 or n >= 20:
-            break
-    out = dict(value=round(sample_batch * n / dt, 2), unit="images/sec", cores=threads, kind="port",
-               sample=f"{n} steps of the same step at batch {sample_batch} ({dt:.1f} s); oracle = C restatement of the Torch7 nn CPU path, OpenMP")
+    noise = synth.normal((B, nd), 9)
+
+    def run(threads, budget):
+        threads = oracle.set_threads(threads)      # libgomp is already initialised (torch): the env var would be ignored
+        oracle.train_r_step(oG, oR, noise, oracle.GoHyper(), mm, vv, 1)          # warm-up (page-in, thread pool)
+        t0 = time.perf_counter(); n = 0
+        while True:
+            oracle.train_r_step(oG, oR, noise, oracle.GoHyper(), mm, vv, 2 + n)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or n >= 40:
+                break
+        return threads, n, dt
+    t8, n8, dt8 = run(8, 6.0)
+    # 16-32 OpenMP threads measured fastest for the oracle on the 2x64-core box (tools/cpu_baseline_sweep.py)
+    tb, nb, dtb = run(min(32, os.cpu_count() or 1), 6.0)
+    out = dict(value=round(B * nb / dtb, 2), unit="images/sec", cores=tb, kind="port",
+               sample=f"{nb} steps of the same step at batch {B} = BASELINE configs[0] ({dtb:.1f} s); oracle = C restatement of the Torch7 nn CPU "
+                      "path (direct-loop convolutions, OpenMP), not Torch7 itself",
+               reference_default_threads=dict(value=round(B * n8 / dt8, 2), cores=t8, sample=f"{n8} steps ({dt8:.1f} s), --threads 8 = train_r.lua:21"))
     if ctx is not None:
         # second half of BASELINE.json's metric - "cosine top-50 exact-match vs ref" - at the size north_star names (10k x 32-d
-        # embeddings, apply_r.lua:266-282): the HIP search against the oracle's, index lists compared element by element,
-        # both timed (the oracle on the same host threads)
+        # embeddings, apply_r.lua:266-282): the HIP search against the oracle's, index lists compared element by element
         N, d, k, needles = 10000, 32, 50, [99, 199, 299, 399, 499]
         emb = synth.normal((N, d), 77)
         t0 = time.perf_counter(); ridx, rsc = oracle.cosine_topk(emb, needles, k); t_cpu = time.perf_counter() - t0
@@ -80,6 +152,96 @@ def cpu_baseline(dims, nd, sample_batch, threads, ctx=None):
     return out
 
 
+def search_cfg5(ctx):
+    """BASELINE.json configs[4]: 1M x 100-d embeddings (generated on the device), top-50 for the five needles of apply_r.lua:267,
+    timed with HIP events on the library's stream, checked element by element against the oracle's search of the same corpus."""
+    import numpy as np
+    from oracle import oracle
+    N, d, k = 1_000_000, 100, 50
+    needles = np.array([100, 200, 300, 400, 500], dtype=np.int64)
+    dev = ctx.malloc(4 * N * d)
+    ctx.fill_normal(dev, N * d, 4242)
+    ctx.cosine_topk(None, needles, k, emb_dev=dev, n=N, d=d)                  # warm-up
+    reps = 5
+    ctx.event_record(60000)
+    for _ in range(reps):
+        idx, sc = ctx.cosine_topk(None, needles, k, emb_dev=dev, n=N, d=d)
+    ctx.event_record(60001)
+    ms = ctx.event_elapsed_ms(60000, 60001) / reps
+    emb = ctx.download(dev, (N, d)); ctx.free(dev)
+    oracle.set_threads(min(32, os.cpu_count() or 1))
+    t0 = time.perf_counter(); ridx, rsc = oracle.cosine_topk(emb, needles, k); t_cpu = time.perf_counter() - t0
+    return dict(n=N, d=d, k=k, needles=int(needles.size), ms=round(ms, 4), hbm_gbs=round(N * d * 4 / ms / 1e6, 1),
+                hbm_frac=round(N * d * 4 / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                exact_match=bool(np.array_equal(idx, ridx) and np.array_equal(sc, rsc)), cpu_ms=round(t_cpu * 1e3, 1),
+                note="ms includes the D2H copy of the 5 x 50 results and one host sync per search (gr_cosine_topk_dev)")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def kernel_report(kt, nprof, dims, nd, B, traffic=None):
+    """Per-kernel table + the roofline object of the dominant MFMA kernel + R's convolutions / element-wise shares."""
+    by_name = {}
+    for k in kt:
+        a = by_name.setdefault(k["kernel"], dict(kernel=k["kernel"], launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+        for f in ("launches", "total_ms", "flops", "bytes"):
+            a[f] += k[f]
+    rows = list(by_name.values())
+    mfma = [k for k in rows if k["kernel"].startswith("conv3x3_") and k["flops"] > 1e9 and "reduce" not in k["kernel"]
+            and "fewout" not in k["kernel"] and "fewin" not in k["kernel"] and "small" not in k["kernel"]]
+    dom = max(mfma, key=lambda k: k["total_ms"])
+    avg_ms = dom["total_ms"] / dom["launches"]
+    achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+    # kernel names are the symbols rocprofv3 prints; the split kernels carry their number of terms as a template argument
+    # (conv3x3_split_wide_kernel<TW, NI, NTERM, DB>, conv3x3_split_kernel<TW, MT, NTERM>, conv3x3_wgrad_split_*<..., NTERM>)
+    kname = dom["kernel"]
+    passes = 0
+    if "_split_" in kname or "_pre_" in kname:
+        targs = [t.strip() for t in kname[kname.index("<") + 1:kname.rindex(">")].split(",")]
+        nterm = int(targs[2]) if ("split_wide" in kname or kname.startswith("conv3x3_split_kernel")) else int(targs[-1])
+        passes = {3: BF16X6_PASSES, 2: F16X3_PASSES}[nterm]
+    elif "f16x3" in kname:
+        passes = F16X3_PASSES
+    split = passes > 0
+    # split modes: the kernel issues `passes` 16-bit MFMA products per algorithmic multiply-add; its ceiling for ALGORITHMIC
+    # flops is the dense 16-bit MFMA peak / passes
+    peak = PEAK_BF16_MFMA_TFLOPS / passes if split else PEAK_FP32_MFMA_TFLOPS
+    up2 = "up2" in kname
+    if up2:     # fused up-sampling layer: the reference's 9 taps per output collapse to 4 (conv.hip), so the ceiling for the
+        peak *= 9.0 / 4.0   # reference-algorithm FLOPs this line is quoted in is 9/4 of the issued-FLOP ceiling
+    roofline = dict(bound="mfma", kernel=kname, achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
+                    frac=round(achieved / peak, 4), traffic=(traffic or {}).get(kname),
+                    peak_note=(f"dense bf16/f16 MFMA 2500 TFLOP/s / {passes} products per fp32-accurate multiply-add "
+                               f"({'f16x3' if passes == 3 else 'bf16x6'} split); issued MFMA rate = {passes} x achieved"
+                               + (" x 4/9 (up-sampling taps pre-summed: four 2x2 convolutions)" if up2 else "")) if split else "fp32 MFMA v_mfma_f32_32x32x2_f32",
+                    frac_of_fp32_mfma_peak=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                    avg_launch_ms=round(avg_ms, 4), launches_per_step=dom["launches"] / nprof,
+                    algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3))
+    kernels = {k["kernel"]: dict(ms_per_step=round(k["total_ms"] / nprof, 4), launches_per_step=round(k["launches"] / nprof, 2),
+                                 tflops=round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 2) if k["flops"] else None,
+                                 gbs=round(k["bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1) if k["bytes"] else None)
+               for k in sorted(rows, key=lambda k: -k["total_ms"])}
+    total_ms = sum(k["total_ms"] for k in rows) / nprof
+    # north_star: ">= 40 % of MFMA roofline on R's 3x3 convs at bs256" - every conv3x3_* launch of R's forward and backward
+    # (forward, data gradient, weight gradient incl. its slab reductions) against 3 x R's forward conv FLOPs x batch
+    r_ms = sum(k["total_ms"] for k in kt if k["kernel"].startswith("conv3x3_") and k.get("phase") in ("R forward", "R backward")) / nprof
+    r_gflop = 3 * step_flops_per_image(dims, nd)[3] * B / 1e9
+    r_convs = dict(ms_per_step=round(r_ms, 4), algorithmic_gflop=round(r_gflop, 1), tflops=round(r_gflop / max(r_ms, 1e-9), 2),
+                   frac_of_fp32_mfma_peak=round(r_gflop / max(r_ms, 1e-9) / PEAK_FP32_MFMA_TFLOPS, 4))
+    ew_ms = sum(k["total_ms"] for k in rows if k["kernel"].startswith(ELEMENTWISE)) / nprof
+    conv_ms = sum(k["total_ms"] for k in mfma) / nprof
+    conv_fl = sum(k["flops"] for k in mfma) / nprof
+    extra = dict(conv_kernels_tflops=round(conv_fl / max(conv_ms * 1e-3, 1e-12) / 1e12, 2), r_convs=r_convs,
+                 elementwise=dict(ms_per_step=round(ew_ms, 4), share_of_kernel_time=round(ew_ms / max(total_ms, 1e-9), 4)),
+                 kernel_ms_per_step=round(total_ms, 4))
+    return roofline, kernels, extra
+
+
+def percentiles(ms):
+    s = sorted(ms)
+    q = lambda f: round(s[min(len(s) - 1, max(0, int(round(f * (len(s) - 1)))))], 4)
+    return dict(p10=q(0.10), p50=q(0.50), p90=q(0.90), min=round(s[0], 4), max=round(s[-1], 4))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,19 +249,57 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "f16x3"), choices=["f32", "bf16x6", "f16x3"],
-                    help="convolution arithmetic (all meet the 1e-4 parity bar; see DESIGN.md)")
-    ap.add_argument("--cpu-sample-batch", type=int, default=32)
+    ap.add_argument("--no-search", action="store_true", help="skip the cfg5 (1M x 100, top-50) search leg")
+    ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "f16x3"), choices=list(MODES),
+                    help="arithmetic of the headline line (all meet the 1e-4 parity bar; see DESIGN.md)")
+    ap.add_argument("--modes", default=",".join(MODES), help="arithmetic modes timed in this invocation (the headline mode is always run)")
+    ap.add_argument("--traffic", default="live", choices=["live", "file", "off"],
+                    help="roofline.traffic: measured in this run by rocprofv3 --pmc children (N = 1), read from profiles/traffic.json, or omitted")
+    ap.add_argument("--quiet-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))                       # this process has not touched a GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("GANREV_ALL_RANKS_ON_DEVICE0"):     # test hook: exercise the N>1 code path on a 1-GPU box
+    shared_gpu = bool(os.environ.get("GANREV_ALL_RANKS_ON_DEVICE0")) and world > 1   # test hook: the N>1 control flow on a 1-GPU box
+    if shared_gpu:
         local_rank = 0
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a different job size")
 
+    if os.environ.get("GANREV_BENCH_DRY_RUN"):
+        # launcher rehearsal for boxes without a GPU (tests/test_host_logic.py): the ranks rendezvous over gloo, rank 0 reports
+        # who showed up, nothing touches a device
+        import torch.distributed as dist
+        seen = [(rank, local_rank)]
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            seen = [None] * world
+            dist.all_gather_object(seen, (rank, local_rank))
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": sorted(seen)}))
+        return
+
+    traffic, traffic_from = None, None
+    if world == 1 and args.traffic == "live":
+        traffic, traffic_from = measure_traffic(args)     # children first: this process has not initialised the GPU yet
+    if traffic is None and args.traffic != "off":
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        note = traffic_from
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload)
+                traffic_from = "profiles/traffic.json (committed rocprofv3 --pmc summary of an earlier run, NOT measured in this run)" + (f"; live: {note}" if note else "")
+            except Exception:  # noqa: BLE001
+                traffic = None
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import ganrev._lib as L
@@ -116,40 +316,23 @@ def main():
     ctx.set_conv_mode(args.conv_mode)
     G = models.create_G(dims, nd); synth.init_params(G, 1)               # random-init weights of the named architecture
     R = models.create_R(dims, nd); synth.init_params(R, 2)
-    dnoise = ctx.malloc(4 * B * nd)
     G._ctx = R._ctx = ctx
     # compile the nets with one small forward each (allocation happens at the first full-size step, in warm-up)
-    import numpy as np
     G.evaluate(); G.forward(synth.normal((2, nd), 1))
     R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
     gnet, rnet = G._net, R._net
     rnet.set_seed(1 + rank)                                              # independent dropout noise per rank
     rnet.adam_reset()
-    shared_gpu = bool(os.environ.get("GANREV_ALL_RANKS_ON_DEVICE0")) and world > 1
-    host_reduce, rccl_error = shared_gpu, None
-    # GANREV_TEST_RCCL_INIT: with the shared-GPU hook, attempt the RCCL bootstrap anyway (it is refused: duplicate device) to
-    # exercise the fallback below on a 1-GPU box
-    if world > 1 and (not shared_gpu or os.environ.get("GANREV_TEST_RCCL_INIT")):
+    theta0 = rnet.get_params()
+    host_reduce, rccl_ranks = shared_gpu, 1
+    if world > 1 and not shared_gpu:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        try:
-            ctx.comm_init(uid[0], world, rank)                            # RCCL over xGMI, inside libganrev.so
-            ok = 1
-        except Exception as e:                                            # noqa: BLE001 - reported below, never silent
-            ok, rccl_error = 0, str(e)
-        t_ok = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-        if int(t_ok.item()) == 1:
-            rnet.broadcast_params(0)
-        else:
-            # Safety net so that a communicator problem on one node type does not lose the whole scaling run: the gradients go
-            # through the gloo control group on the host instead (correct, slow); the JSON line says so in config.parallelism.
-            if ok:
-                ctx.comm_destroy()
-            host_reduce = True
-            errs = [None] * world
-            dist.all_gather_object(errs, rccl_error)
-            rccl_error = next((e for e in errs if e), "unknown")
+        ctx.comm_init(uid[0], world, rank)                                # RCCL over xGMI, inside libganrev.so; raises on failure
+        rccl_ranks, rccl_rank = ctx.comm_ranks()
+        if rccl_ranks != world or rccl_rank != rank:
+            raise SystemExit(f"bench.py: RCCL communicator has {rccl_ranks} ranks (this is {rccl_rank}), expected {world} / {rank}")
+        rnet.broadcast_params(0)
     hyper = L.Hyper()
     GB = B * world
     from ganrev.parallel import DeviceTrainer, host_allreduce_grads
@@ -158,6 +341,7 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+        ctx.synchronize()
         torch.cuda.synchronize()
 
     t_adam = 0
@@ -166,104 +350,88 @@ def main():
         nonlocal t_adam
         t_adam += 1
         trainer.new_noise((t_adam << 8) + rank)                          # createNoiseInputs (utils/nn_utils.lua:39-51), on device
-        if host_reduce:  # test hook (ranks share GPU 0: RCCL refuses duplicate devices) or the RCCL-init fallback: reduce through gloo
+        if host_reduce:  # test hook only (ranks share GPU 0: RCCL refuses duplicate devices): reduce through gloo
             return trainer.step_decomposed(host_allreduce_grads(dist))
         return trainer.step(want_loss=want_loss)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    loss = step(want_loss=True)
+    def timed(mode):
+        """W untimed steps, then EXACTLY K steps between barrier + device sync on both sides (max over ranks); one HIP event per
+        step on the library's stream for the percentiles; then 3 instrumented steps for the per-kernel table."""
+        nonlocal t_adam
+        ctx.set_conv_mode(mode)
+        rnet.set_params(theta0); rnet.adam_reset(); t_adam = 0            # every mode starts from the same state
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.event_record(0)
+        for i in range(args.steps):
+            step()
+            ctx.event_record(i + 1)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        per_step = [ctx.event_elapsed_ms(i, i + 1) for i in range(args.steps)]
+        loss = step(want_loss=True)
+        # roofline leg: per-kernel HIP events (on the launch stream) over extra steps of the same workload.  Every rank runs
+        # these steps (they contain the collective); only rank 0 instruments and reports.
+        nprof = 3
+        if rank == 0:
+            ctx.set_timing(2)
+        for _ in range(nprof):
+            step()
+        barrier()
+        rep = None
+        if rank == 0:
+            kt = ctx.kernel_times()
+            ctx.set_timing(0)
+            rep = kernel_report(kt, nprof, dims, nd, B, traffic if mode == args.conv_mode else None)
+        return dt, per_step, loss, rep
 
-    # ---- roofline leg: per-kernel HIP events (on the launch stream) over extra steps of the same workload.
-    # Every rank runs these steps (they contain the collective); only rank 0 instruments and reports.
-    nprof = 3
-    if rank == 0:
-        ctx.set_timing(2)
-    for _ in range(nprof):
-        step()
-    barrier()
+    modes = [args.conv_mode] + [m for m in args.modes.split(",") if m in MODES and m != args.conv_mode]
+    results = {m: timed(m) for m in modes}
+    ctx.set_conv_mode(args.conv_mode)
+
     out = None
     if rank == 0:
-        kt = ctx.kernel_times()
-        ctx.set_timing(0)
-        fl_img, g_fl, r_fl = step_flops_per_image(dims, nd)
-        mfma = [k for k in kt if k["kernel"].startswith("conv3x3_") and k["flops"] > 1e9 and "reduce" not in k["kernel"]
-                and "fewout" not in k["kernel"] and "fewin" not in k["kernel"] and "small" not in k["kernel"]]
-        dom = max(mfma, key=lambda k: k["total_ms"])
-        avg_ms = dom["total_ms"] / dom["launches"]
-        achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-        # kernel names are the symbols rocprofv3 prints; the split kernels carry their number of terms as a template argument
-        # (conv3x3_split_wide_kernel<TW, NI, NTERM, DB>, conv3x3_split_kernel<TW, MT, NTERM>, conv3x3_wgrad_split_*<..., NTERM>)
-        kname = dom["kernel"]
-        passes = 0
-        if "_split_" in kname:
-            targs = [t.strip() for t in kname[kname.index("<") + 1:kname.rindex(">")].split(",")]
-            nterm = int(targs[2]) if ("split_wide" in kname or kname.startswith("conv3x3_split_kernel")) else int(targs[-1])
-            passes = {3: BF16X6_PASSES, 2: F16X3_PASSES}[nterm]
-        elif "f16x3" in kname:
-            passes = F16X3_PASSES
-        split = passes > 0
-        # split modes: the kernel issues `passes` 16-bit MFMA products per algorithmic multiply-add; its ceiling for
-        # ALGORITHMIC flops is the dense 16-bit MFMA peak / passes
-        peak = PEAK_BF16_MFMA_TFLOPS / passes if split else PEAK_FP32_MFMA_TFLOPS
-        up2 = "up2" in kname
-        if up2:     # fused up-sampling layer: the reference's 9 taps per output collapse to 4 (conv.hip), so the ceiling for the
-            peak *= 9.0 / 4.0   # reference-algorithm FLOPs this line is quoted in is 9/4 of the issued-FLOP ceiling
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get(dom["kernel"])
-            except Exception:
-                traffic = None
-        roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
-                        frac=round(achieved / peak, 4), traffic=traffic,
-                        peak_note=(f"dense bf16/f16 MFMA 2500 TFLOP/s / {passes} products per fp32-accurate multiply-add "
-                                   f"({'f16x3' if passes == 3 else 'bf16x6'} split); issued MFMA rate = {passes} x achieved"
-                                   + (" x 4/9 (up-sampling taps pre-summed: four 2x2 convolutions)" if up2 else "")) if split else "fp32 MFMA v_mfma_f32_32x32x2_f32",
-                        frac_of_fp32_mfma_peak=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                        avg_launch_ms=round(avg_ms, 4), launches_per_step=dom["launches"] / nprof,
-                        algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3))
-        conv_ms = sum(k["total_ms"] for k in mfma) / nprof
-        conv_fl = sum(k["flops"] for k in mfma) / nprof
-        kernels = {k["kernel"]: dict(ms_per_step=round(k["total_ms"] / nprof, 4), launches_per_step=round(k["launches"] / nprof, 2),
-                                     tflops=round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 2) if k["flops"] else None,
-                                     gbs=round(k["bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1) if k["bytes"] else None)
-                   for k in sorted(kt, key=lambda k: -k["total_ms"])}
+        fl_img = step_flops_per_image(dims, nd)[0]
+        dt, per_step, loss, (roofline, kernels, extra) = results[args.conv_mode]
+        if roofline.get("traffic") is not None or traffic_from:
+            roofline["traffic_from"] = traffic_from
         ms_step = dt / args.steps * 1e3
+        mode_rows = {}
+        for m, (mdt, mps, mloss, (mroof, _, mextra)) in results.items():
+            mode_rows[m] = dict(images_per_sec=round(GB * args.steps / mdt, 1), ms_per_step=round(mdt / args.steps * 1e3, 4), dtype=DTYPE[m],
+                                step_ms_events=percentiles(mps), last_loss=mloss,
+                                roofline={k: mroof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_of_fp32_mfma_peak", "avg_launch_ms")},
+                                r_convs=mextra["r_convs"], elementwise=mextra["elementwise"])
         out = {
             "metric": "images/sec G+R fwd/bwd", "value": round(GB * args.steps / dt, 1), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x6": "f32 via bf16x6 (3-term bf16 split, 6 MFMA products, fp32 accumulate)",
-                      "f16x3": "f32 via f16x3 (2-term fp16 split of power-of-two-scaled operands, 3 MFMA products, fp32 accumulate)"}[ctx.conv_mode()],
+            "dtype": DTYPE[args.conv_mode],
             "data": "synthetic",
             "config": {"workload": wl["name"], "global_batch": GB, "per_gpu_batch": B,
                        "parallelism": f"dp{world}" + ("" if world == 1 else (" (RCCL all-reduce of R's flat gradient)" if not host_reduce else
-                                                      f" (gradients reduced through gloo on the host: {'ranks share one GPU' if shared_gpu else 'RCCL init FAILED: ' + str(rccl_error)})")),
+                                                      " (TEST HOOK: ranks share one GPU, gradients reduced through gloo on the host)")),
                        "bn": "per-rank batch statistics"},
+            "rccl_ranks": rccl_ranks,
+            "step_ms_events": percentiles(per_step),
             "step_tflops": round(fl_img * GB * args.steps / dt / 1e12 / world, 2),
             "step_frac_of_fp32_mfma_peak": round(fl_img * GB * args.steps / dt / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
-            "conv_kernels_tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
             "last_loss": loss,
             "roofline": roofline,
+            **extra,
+            "modes": mode_rows,
             "kernels": kernels,
         }
+        if world == 1 and not args.no_search:
+            out["search_cfg5"] = search_cfg5(ctx)
         if world == 1 and not args.no_cpu_baseline:
-            # 16-32 OpenMP threads measured fastest for the oracle on the 2x64-core box (tools/cpu_baseline_sweep.py:
-            # 74 img/s at 16-32 threads, 51-62 at 64, 28-37 at 128-256); the reference's own default is 8 (train_r.lua:21)
-            threads = min(32, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(dims, nd, args.cpu_sample_batch, threads, ctx)
+            out["cpu_baseline"] = cpu_baseline(WORKLOADS["cfg2"]["dims"], WORKLOADS["cfg2"]["nd"], ctx)
         else:
             out["cpu_baseline"] = None
     if world > 1:
@@ -271,7 +439,7 @@ def main():
         if not host_reduce:
             ctx.comm_destroy()
         dist.destroy_process_group()
-    if out is not None:
+    if out is not None and not args.quiet_child:
         print(json.dumps(out))
 
 

@@ -179,6 +179,15 @@ static inline int stat_splits(long n) {
   if (s > STAT_SPLITS) s = STAT_SPLITS;
   return (int)s;
 }
+// The float4 kernels split the BATCH: block sp owns images [sp*per, min(B, (sp+1)*per)), per = ceil(B / splits).  With
+// splits = min(stat_splits, B) alone the last blocks can start past B (B = 29, per = 2: blocks 15.. own nothing), so the
+// split count is re-derived from `per`: every block owns at least one image.  (The kernels also guard b0 >= b1.)
+static inline int batch_splits(long n, int B) {
+  int s = stat_splits(n);
+  if (s > B) s = B;
+  const int per = (B + s - 1) / s;
+  return (B + per - 1) / per;
+}
 
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, int B, int C, int HW, int splits,
                                                                double* __restrict__ partials) {
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_vec_kernel(const float* 
   const int c = blockIdx.x, sp = blockIdx.y;
   const int per = (B + splits - 1) / splits, b0 = sp * per, b1 = min(B, b0 + per), q4 = HW >> 2;
   double s = 0, q = 0;
-  const unsigned tot = (unsigned)(b1 - b0) * q4;
+  const unsigned tot = b1 > b0 ? (unsigned)(b1 - b0) * q4 : 0u;     // an empty slice contributes zeros
   for (unsigned j = threadIdx.x; j < tot; j += 256) {
     const unsigned bb = j / (unsigned)q4, i = j - bb * q4;
     const float4 v = reinterpret_cast<const float4*>(y + ((size_t)(b0 + bb) * C + c) * HW)[i];
@@ -246,7 +255,7 @@ void launch_bn_stats(const float* y, int B, int C, int HW, double* partials, flo
   const long n = (long)B * HW;
   int splits = stat_splits(n);
   if (HW % 4 == 0 && HW >= 64) {
-    if (splits > B) splits = B;
+    splits = batch_splits(n, B);
     KtScope kt("bn_stats_partial_vec_kernel", 0.0, 4.0 * (double)n * C, s);
     hipLaunchKernelGGL(bn_stats_partial_vec_kernel, dim3(C, splits), dim3(256), 0, s, y, B, C, HW, splits, partials);
   } else {
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
   if (f.has_bn) { mean = f.mean[c]; invstd = f.invstd[c]; gm = f.gamma[c]; bt = f.beta[c]; }
   double s = 0, q = 0;
   float dmax = 0.f;
-  const unsigned tot = (unsigned)(b1 - b0) * q4;
+  const unsigned tot = b1 > b0 ? (unsigned)(b1 - b0) * q4 : 0u;     // an empty slice contributes zeros
   {
     for (unsigned j = threadIdx.x; j < tot; j += 256) {
       const unsigned bb = j / q4, i = j - bb * q4;
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
   const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], bt = f.beta[c], gm = sh_coef[0], k = sh_coef[1];
   double s = 0;
   float dmax = 0.f;
-  const unsigned tot = (unsigned)(b1 - b0) * q4;
+  const unsigned tot = b1 > b0 ? (unsigned)(b1 - b0) * q4 : 0u;     // an empty slice contributes zeros
   {
     for (unsigned j = threadIdx.x; j < tot; j += 256) {
       const unsigned bb = j / q4, i = j - bb * q4;
@@ -521,7 +530,7 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
   const double pre = (double)n * f.C, post = f.pool ? pre / 4 : pre;
   const bool vec = (f.pool ? (f.W % 8 == 0 && f.H % 2 == 0) : (f.W % 4 == 0)) && f.H * f.W >= 64 && pre < 4.0e9;
   if (vec) {
-    if (splits > f.B) splits = f.B;
+    splits = batch_splits(n, f.B);
     KtScope kt("post_backward_a_vec_kernel", 0.0, 4.0 * ((f.has_bn ? 1.0 : 2.0) * pre + post), s);   // with BN: dz is not stored
     hipLaunchKernelGGL(post_backward_a_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
   } else {
@@ -702,6 +711,19 @@ __global__ void fill_normal_kernel(float* dst, long n, uint32_t s0, uint32_t s1)
 void launch_fill_normal(float* dst, long n, uint64_t seed, hipStream_t s) {
   const long t = (n + 3) / 4;
   hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, dst, n, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// uniform(lo, hi): the other createNoiseInputs method (utils/nn_utils.lua:44-45 uniform(-1.0, 1.0)); 24-bit mantissa draws
+__global__ void fill_uniform_kernel(float* dst, long n, float lo, float hi, uint32_t s0, uint32_t s1) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i * 4 >= n) return;
+  const u4 r = philox4x32(u4{(uint32_t)i, (uint32_t)(i >> 32), 0x756e6966u, 0u}, s0, s1);
+  const uint32_t o[4] = {r.x, r.y, r.z, r.w};
+  for (int k = 0; k < 4; ++k) if (i * 4 + k < n) dst[i * 4 + k] = lo + (hi - lo) * ((float)(o[k] >> 8) * (1.f / 16777216.f));
+}
+void launch_fill_uniform(float* dst, long n, float lo, float hi, uint64_t seed, hipStream_t s) {
+  const long t = (n + 3) / 4;
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, dst, n, lo, hi, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 // torch.dist(a_i, b_i) per row (apply_r.lua:369: 1 - torch.dist(images[i], fixedImage)): sqrt(sum (a-b)^2), fp32 difference and

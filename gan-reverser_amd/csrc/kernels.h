@@ -240,6 +240,7 @@ void launch_gen_mask_batch(const MaskJobs& jobs, uint64_t seed, uint64_t counter
 void launch_pack_mask(const uint8_t* keep, uint32_t* words, long n, hipStream_t s);
 void launch_unpack_mask(const uint32_t* words, uint8_t* keep, long n, hipStream_t s);
 void launch_fill_normal(float* dst, long n, uint64_t seed, hipStream_t s);
+void launch_fill_uniform(float* dst, long n, float lo, float hi, uint64_t seed, hipStream_t s);
 void launch_l2_distance_rows(const float* a, const float* b, long n, long d, double* out, hipStream_t s);
 void launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s);
 

@@ -34,28 +34,30 @@ struct gr_ctx {
   int conv_mode = 2;            // 2 = f16x3 split (fp32-accurate, f16 MFMA; default), 1 = bf16x6 split (fp32-accurate, bf16 MFMA), 0 = exact fp32 MFMA
   unsigned* amax = nullptr;     // 4 scratch slots for the single-kernel entry points (f16x3 scales)
   hipEvent_t ev[7] = {};
+  std::vector<hipEvent_t> marks;  // gr_event_record slots (bench: per-step times on THIS stream)
   float times[6] = {0, 0, 0, 0, 0, 0};
 };
 
 // ---- per-kernel event timer (gr_set_timing(ctx, 2)) -------------------------------------------------------------
 namespace gr { KernelTimer* g_ktimer = nullptr; }
+static int g_kphase = 0;      // which part of gr_train_r_step is launching: 0 outside, 1 G forward, 2 R forward, 3 loss, 4 R backward, 5 Adam
 struct EventTimer : gr::KernelTimer {
-  struct Rec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
+  struct Rec { std::string name; int phase; double flops, bytes; hipEvent_t e0, e1; };
   std::vector<hipEvent_t> pool; size_t next = 0;
   std::vector<Rec> open_, recs;
   struct Agg { long launches = 0; double ms = 0, flops = 0, bytes = 0; };
-  std::vector<std::pair<std::string, Agg>> agg;
+  std::vector<std::pair<std::pair<std::string, int>, Agg>> agg;      // keyed by (kernel, phase)
   hipEvent_t get() { if (next == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); } return pool[next++]; }
   void begin(const char* name, double flops, double bytes, hipStream_t s) override {
-    Rec r{name, flops, bytes, get(), get()}; (void)hipEventRecord(r.e0, s); open_.push_back(r);
+    Rec r{name, g_kphase, flops, bytes, get(), get()}; (void)hipEventRecord(r.e0, s); open_.push_back(r);
   }
   void end(hipStream_t s) override { Rec r = open_.back(); open_.pop_back(); (void)hipEventRecord(r.e1, s); recs.push_back(r); }
   void collect() {   // caller has synchronised the stream
     for (auto& r : recs) {
       float ms = 0; (void)hipEventElapsedTime(&ms, r.e0, r.e1);
       Agg* a = nullptr;
-      for (auto& kv : agg) if (kv.first == r.name) a = &kv.second;
-      if (!a) { agg.push_back({r.name, Agg()}); a = &agg.back().second; }
+      for (auto& kv : agg) if (kv.first.first == r.name && kv.first.second == r.phase) a = &kv.second;
+      if (!a) { agg.push_back({{r.name, r.phase}, Agg()}); a = &agg.back().second; }
       a->launches++; a->ms += ms; a->flops += r.flops; a->bytes += r.bytes;
     }
     recs.clear(); next = 0;
@@ -124,6 +126,7 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   if (c->ws) (void)hipFree(c->ws);
   (void)hipFree(c->d_loss); (void)hipFree(c->amax); (void)hipHostFree(c->h_loss);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : c->marks) if (e) (void)hipEventDestroy(e);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
   if (c->comm_stream) { (void)hipStreamSynchronize(c->comm_stream); (void)hipStreamDestroy(c->comm_stream); }
@@ -169,13 +172,27 @@ extern "C" int gr_kernel_times(gr_ctx* c, char* buf, int buflen) {
   for (size_t i = 0; i < g_evtimer->agg.size(); ++i) {
     const auto& kv = g_evtimer->agg[i];
     char line[512];
-    snprintf(line, sizeof line, "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
-             i ? ", " : "", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes);
+    static const char* phase_names[] = {"", "G forward", "R forward", "loss", "R backward", "adam"};
+    snprintf(line, sizeof line, "%s{\"kernel\": \"%s\", \"phase\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+             i ? ", " : "", kv.first.first.c_str(), phase_names[kv.first.second], kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes);
     out += line;
   }
   out += "]";
   if ((int)out.size() + 1 > buflen) return fail(c, GR_ERR_INVALID, "gr_kernel_times: buffer too small (%zu needed)", out.size() + 1);
   memcpy(buf, out.c_str(), out.size() + 1);
+  return GR_OK;
+}
+extern "C" int gr_event_record(gr_ctx* c, int slot) {
+  if (!c || slot < 0 || slot >= (1 << 16)) return GR_ERR_INVALID;
+  if ((size_t)slot >= c->marks.size()) c->marks.resize((size_t)slot + 1, nullptr);
+  if (!c->marks[slot]) HIPCHK(c, hipEventCreate(&c->marks[slot]));
+  HIPCHK(c, hipEventRecord(c->marks[slot], c->stream));
+  return GR_OK;
+}
+extern "C" int gr_event_elapsed_ms(gr_ctx* c, int a, int b, float* ms) {
+  if (!c || !ms || a < 0 || b < 0 || (size_t)a >= c->marks.size() || (size_t)b >= c->marks.size() || !c->marks[a] || !c->marks[b]) return GR_ERR_INVALID;
+  HIPCHK(c, hipEventSynchronize(c->marks[b]));
+  HIPCHK(c, hipEventElapsedTime(ms, c->marks[a], c->marks[b]));
   return GR_OK;
 }
 extern "C" int gr_last_step_times(gr_ctx* c, float* ms6) { if (!c || !ms6) return GR_ERR_INVALID; memcpy(ms6, c->times, sizeof c->times); return GR_OK; }
@@ -185,6 +202,8 @@ extern "C" int gr_free(gr_ctx* c, void* p) { if (!c) return GR_ERR_INVALID; HIPC
 extern "C" int gr_memcpy_h2d(gr_ctx* c, void* d, const void* h, int64_t b) { if (!c) return GR_ERR_INVALID; HIPCHK(c, hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return GR_OK; }
 extern "C" int gr_memcpy_d2h(gr_ctx* c, void* h, const void* d, int64_t b) { if (!c) return GR_ERR_INVALID; HIPCHK(c, hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return GR_OK; }
 extern "C" int gr_fill_normal_dev(gr_ctx* c, float* d, int64_t n, uint64_t seed) { if (!c || !d) return GR_ERR_INVALID; launch_fill_normal(d, n, seed, c->stream); LAUNCHCHK(c); return GR_OK; }
+
+extern "C" int gr_fill_uniform_dev(gr_ctx* c, float* d, int64_t n, float lo, float hi, uint64_t seed) { if (!c || !d) return GR_ERR_INVALID; launch_fill_uniform(d, n, lo, hi, seed, c->stream); LAUNCHCHK(c); return GR_OK; }
 
 // ------------------------------------------------------------------ net
 enum { ST_CONV = 1, ST_LINEAR = 2, ST_ELEM = 3 };
@@ -211,7 +230,7 @@ struct Stage {
   float *wt_fwd = nullptr, *wt_bwd = nullptr; uint64_t wt_version = 0;
   void *ws_fwd = nullptr, *ws_bwd = nullptr; uint64_t ws_version = 0;     // bf16x6 / f16x3 split images
   void* ws_up = nullptr; uint64_t ws_up_version = 0;   // f16x3 image of the fused up-sampling kernel (four 2x2 convolutions)
-  uint64_t amax_x_fwd = 0;                  // forward counter at which amax_x was last taken
+  uint64_t amax_x_fwd = 0;                  // gr_net::amax_gen at which amax_x was last taken
   unsigned *amax_x = nullptr, *amax_dy = nullptr, *amax_w = nullptr;   // f16x3: slots (in gr_net::amax) for max|x_in|, max|dy|, max|w|
   float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr; double* partials_b = nullptr;
   int stat_tiles_last = 0;                  // tiles the last forward's conv epilogue wrote (0: none - run the statistics pass)
@@ -233,7 +252,8 @@ struct gr_net {
   float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
   uint64_t params_version = 1;
   bool training = true;
-  uint64_t seed = 1, fwd_counter = 0;
+  uint64_t seed = 1, fwd_counter = 0;   // fwd_counter: Philox counter of the dropout noise (gr_net_set_seed restarts it)
+  uint64_t amax_gen = 0;                // generation of the f16x3 scale slots: one per forward, never restarted, so a reseed cannot make a stale slot look fresh
   int capB = 0, lastB = 0;
   float *in_buf = nullptr, *gout_buf = nullptr, *dy_buf = nullptr, *g_buf[2] = {nullptr, nullptr};
   size_t max_y = 0, max_in = 0;      // per-sample element counts
@@ -611,6 +631,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
   int r = ensure_batch(n, B); if (r) return r;
   const float* x = in_dev;
   n->fwd_counter++;
+  n->amax_gen++;
   const bool f16 = c->conv_mode == 2;
   const size_t nst = n->st.size();
   // f16x3 scale slots [x | dy | w] x stages: ONE fill per forward (each hipMemsetAsync is a 5 us kernel of its own) - the x slots
@@ -677,11 +698,11 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         const bool last_writer = s.fused_epilogue || !s.has_post;
         launch_conv3x3_fewin(x, n->params + s.w_off, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, last_writer ? amax_next : nullptr,
                              want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
-        if (last_writer && nx) nx->amax_x_fwd = n->fwd_counter;
+        if (last_writer && nx) nx->amax_x_fwd = n->amax_gen;
       } else if (use_bf16x6(n, s)) {
         const int nterm = c->conv_mode == 2 ? 2 : 3;
         // input not produced by a tracking kernel (the net's own input, a GEMM, a VALU conv): take its maximum now
-        if (nterm == 2 && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream, true); s.amax_x_fwd = n->fwd_counter; }
+        if (nterm == 2 && s.amax_x_fwd != n->amax_gen) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream, true); s.amax_x_fwd = n->amax_gen; }
         const bool last_writer = s.fused_epilogue || !s.has_post;
         static const bool up2_on = !getenv("GR_NO_UP2");
         if (nterm == 2 && s.up && s.ws_up && up2_on)
@@ -690,7 +711,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         else
           launch_conv3x3_split(x, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, epp, nterm, s.amax_x, s.amax_w,
                                last_writer ? amax_next : nullptr, want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
-        if (last_writer && nx) nx->amax_x_fwd = n->fwd_counter;
+        if (last_writer && nx) nx->amax_x_fwd = n->amax_gen;
       }
       else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off, epp);
       if (s.fused_epilogue) { LAUNCHCHK(c); x = s.out; continue; }
@@ -711,16 +732,16 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
         }
         ep.act = s.act; ep.slope = s.slope;
         const bool f16g = use_f16_gemm(n, s);
-        if (f16g && s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream, true); s.amax_x_fwd = n->fwd_counter; }
+        if (f16g && s.amax_x_fwd != n->amax_gen) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream, true); s.amax_x_fwd = n->amax_gen; }
         launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.out, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream, &ep, amax_next,
                     f16g ? s.amax_x : nullptr, f16g ? s.amax_w : nullptr);
-        if (nx) nx->amax_x_fwd = n->fwd_counter;
+        if (nx) nx->amax_x_fwd = n->amax_gen;
         s.fused_epilogue = true;
         LAUNCHCHK(c);
         x = s.out; continue;
       }
       if (use_f16_gemm(n, s)) {
-        if (s.amax_x_fwd != n->fwd_counter) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream, true); s.amax_x_fwd = n->fwd_counter; }
+        if (s.amax_x_fwd != n->amax_gen) { launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream, true); s.amax_x_fwd = n->amax_gen; }
         launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.y, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream,
                     nullptr, nullptr, s.amax_x, s.amax_w);
       } else
@@ -739,7 +760,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     PostArgs pa = post_args(n, s, B);
     pa.amax_out = amax_next;
     launch_post_forward(pa, c->stream);
-    if (nx) nx->amax_x_fwd = n->fwd_counter;
+    if (nx) nx->amax_x_fwd = n->amax_gen;
     LAUNCHCHK(c);
     x = s.out;
   }
@@ -783,6 +804,25 @@ extern "C" int gr_net_layer_output(gr_net* n, int layer, float* host, int64_t cn
     }
   }
   return fail(c, GR_ERR_UNSUPPORTED, "layer %d is fused into its stage; its output is never materialised", layer);
+}
+
+// nn.SpatialMaxPooling's `indices` of the last forward (models.lua:422,440), one byte per output element: 0..3 = position in the
+// 2x2 window in scan order (dy, dx).  Lets a parity test tell an argmax that differs between two correct fp32 implementations
+// (a window whose two largest inputs differ by rounding noise) from a wrong gradient.
+extern "C" int gr_net_get_pool_index(gr_net* n, int layer, uint8_t* host, int64_t cnt) {
+  if (!n || !host || n->lastB <= 0) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx;
+  if (layer < 0 || layer >= (int)n->layers.size() || n->layers[layer].kind != GR_MAXPOOL2) return fail(c, GR_ERR_INVALID, "layer %d is not a SpatialMaxPooling", layer);
+  for (auto& s : n->st) {
+    if (!s.pool || layer < s.first || layer > s.last) continue;
+    const int64_t e = (int64_t)n->lastB * vol3(s.outC, s.outH, s.outW);
+    if (cnt != e) return fail(c, GR_ERR_INVALID, "layer %d has %lld pooling windows", layer, (long long)e);
+    if (!s.pool_idx) return fail(c, GR_ERR_STATE, "no forward recorded");
+    HIPCHK(c, hipMemcpyAsync(host, s.pool_idx, (size_t)e, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GR_OK;
+  }
+  return fail(c, GR_ERR_STATE, "layer %d: pooling stage not found", layer);
 }
 
 // Gradient bucket [lo, hi) of the flat vector is final: reduce it over RCCL on the comm stream while the compute stream
@@ -836,7 +876,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       if (c->conv_mode == 2) {
         // max|dy| was folded into s.amax_dy by the pipeline-backward kernel that wrote dy_buf
         // x's maximum is current when this stage's forward ran on the f16x3 kernel; otherwise (few-channel input, mode switched) take it now
-        if (conv_wgrad_is_split(2, s.Cin, s.W) && s.amax_x_fwd != n->fwd_counter) launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream);
+        if (conv_wgrad_is_split(2, s.Cin, s.W) && s.amax_x_fwd != n->amax_gen) launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream);
       }
       launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode, s.amax_x, s.amax_dy);
       if (need_gin) {
@@ -851,7 +891,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       if (wsb2 > wsb) wsb = wsb2;
       int r = ensure_ws(c, wsb); if (r) return r;
       const bool f16g = use_f16_gemm(n, s);
-      if (f16g && s.amax_x_fwd != n->fwd_counter) launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream);   // (mode switched since the forward)
+      if (f16g && s.amax_x_fwd != n->amax_gen) launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream);   // (mode switched since the forward)
       // gW[o][i] += sum_b dy[b][o] x[b][i]
       launch_gemm(n->dy_buf, 1, s.Cout, x, 1, s.Cin, n->grads + s.w_off, s.Cin, nullptr, true, s.Cout, s.Cin, B, c->ws, c->stream,
                   nullptr, nullptr, f16g ? s.amax_dy : nullptr, f16g ? s.amax_x : nullptr);
@@ -985,6 +1025,7 @@ extern "C" int gr_broadcast_params(gr_net* n, int root) {
   for (auto& s : n->st) if (s.has_bn) {
     NCCLCHK(c, ncclBroadcast(s.run_mean, s.run_mean, (size_t)s.Cout, ncclFloat, root, c->comm, c->stream));
     NCCLCHK(c, ncclBroadcast(s.run_var, s.run_var, (size_t)s.Cout, ncclFloat, root, c->comm, c->stream));
+    s.eval_ready = false;        // the evaluate()-mode constants cached from the old running statistics are stale
   }
   n->params_version++;
   return GR_OK;
@@ -1002,13 +1043,16 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   int r;
   if (tm) (void)hipEventRecord(c->ev[0], c->stream);
   g->training = false;                                         // train_r.lua:70  MODEL_G:evaluate()
+  g_kphase = 1;
   r = forward_impl(g, noise_dev, B); if (r) return r;          // train_r.lua:139
   const float* images = g->st.back().out;
   if (tm) (void)hipEventRecord(c->ev[1], c->stream);
   rn->training = true;
+  g_kphase = 2;
   r = gr_net_zero_grads(rn); if (r) return r;                  // :143
   r = forward_impl(rn, images, B); if (r) return r;            // :146
   if (tm) (void)hipEventRecord(c->ev[2], c->stream);
+  g_kphase = 3;
   launch_mse(rn->st.back().out, noise_dev, (long)B * nd, (long)GB * nd, c->d_loss, rn->gout_buf, c->stream);  // :147,150
   LAUNCHCHK(c);
   if (c->comm) {   // global MSE = sum of the ranks' partial means (same communicator, same stream as the gradient buckets)
@@ -1019,11 +1063,13 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   if (tm) (void)hipEventRecord(c->ev[3], c->stream);
   // the penalty and the clamp are non-linear in g (train_r.lua:154-165): the SUM over ranks comes first.  It is issued
   // bucket by bucket from inside backward on the comm stream; the compute stream waits for it only here.
+  g_kphase = 4;
   r = backward_impl(rn, images, rn->gout_buf, B, nullptr, /*reduce=*/true); if (r) return r;   // :151
   if (tm) (void)hipEventRecord(c->ev[4], c->stream);
 
   if (tm) (void)hipEventRecord(c->ev[5], c->stream);
-  r = gr_adam_step(rn, h, t); if (r) return r;                 // :153-170
+  g_kphase = 5;
+  r = gr_adam_step(rn, h, t); g_kphase = 0; if (r) return r;   // :153-170
   if (tm) (void)hipEventRecord(c->ev[6], c->stream);
   if (loss_out || tm) {
     HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -83,6 +83,7 @@ _SIGS = {
     "gr_net_backward_host": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "gr_net_backward_dev": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "gr_net_layer_output": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
+    "gr_net_get_pool_index": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "gr_mse_host": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),
     "gr_mse_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P, _P]),
     "gr_adam_step": (C.c_int, [_P, C.POINTER(Hyper), C.c_int]),
@@ -101,6 +102,8 @@ _SIGS = {
     "gr_get_conv_mode": (C.c_int, [_P]),
     "gr_set_timing": (C.c_int, [_P, C.c_int]),
     "gr_last_step_times": (C.c_int, [_P, _P]),
+    "gr_event_record": (C.c_int, [_P, C.c_int]),
+    "gr_event_elapsed_ms": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "gr_kernel_times": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "gr_cosine_topk_host": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "gr_cosine_topk_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
@@ -113,6 +116,7 @@ _SIGS = {
     "gr_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_int64]),
     "gr_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_int64]),
     "gr_fill_normal_dev": (C.c_int, [_P, _P, C.c_int64, C.c_uint64]),
+    "gr_fill_uniform_dev": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, C.c_uint64]),
     "gr_conv3_forward_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gr_conv3_backward_data_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gr_conv3_backward_weight_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -209,6 +213,9 @@ class Context:
     def fill_normal(self, dptr, n, seed):
         self.check(self.lib.gr_fill_normal_dev(self.h, _ptr(dptr), int(n), int(seed)), "gr_fill_normal_dev")
 
+    def fill_uniform(self, dptr, n, seed, lo=-1.0, hi=1.0):
+        self.check(self.lib.gr_fill_uniform_dev(self.h, _ptr(dptr), int(n), float(lo), float(hi), int(seed)), "gr_fill_uniform_dev")
+
     # ---- criterion / search
     def mse(self, x, t, n_global=None, want_grad=True):
         x, t = f32(x), f32(t)
@@ -297,9 +304,22 @@ class Context:
 
     def kernel_times(self):
         import json
-        buf = C.create_string_buffer(1 << 16)
-        self.check(self.lib.gr_kernel_times(self.h, buf, 1 << 16), "gr_kernel_times")
+        buf = C.create_string_buffer(1 << 18)
+        self.check(self.lib.gr_kernel_times(self.h, buf, 1 << 18), "gr_kernel_times")
         return json.loads(buf.value.decode())
+
+    def event_record(self, slot):
+        self.check(self.lib.gr_event_record(self.h, int(slot)), "gr_event_record")
+
+    def event_elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self.check(self.lib.gr_event_elapsed_ms(self.h, int(a), int(b), C.byref(ms)), "gr_event_elapsed_ms")
+        return ms.value
+
+    def comm_ranks(self):
+        n, r = C.c_int(), C.c_int()
+        self.check(self.lib.gr_comm_ranks(self.h, C.byref(n), C.byref(r)), "gr_comm_ranks")
+        return n.value, r.value
 
     def last_step_times(self):
         t = np.zeros(6, dtype=np.float32)
@@ -425,6 +445,12 @@ class Net:
     def layer_output(self, layer, shape):
         a = np.empty(shape, dtype=np.float32)
         self._c(self.lib.gr_net_layer_output(self.h, layer, _ptr(a), a.size), "gr_net_layer_output")
+        return a
+
+    def pool_index(self, layer, n):
+        """nn.SpatialMaxPooling.indices of the last forward: n bytes, 0..3 = (dy, dx) scan position in the window"""
+        a = np.empty(n, dtype=np.uint8)
+        self._c(self.lib.gr_net_get_pool_index(self.h, int(layer), _ptr(a), a.size), "gr_net_get_pool_index")
         return a
 
     def adam_step(self, hyper, t):

@@ -14,6 +14,7 @@ class _CudnnReLU(nn.ReLU):
 
 def create_G3(dimensions, noiseDim, cuda=True, seed=0):
     """models.lua:104-143.  dimensions = (channels, height, width)."""
+    nn.manualSeed(seed)          # the cudnn.* convolutions and the BatchNorm gammas keep their constructor draw (weight-init.lua:54-67)
     model = nn.Sequential()
     if cuda:
         model.add(nn.Copy("torch.FloatTensor", "torch.CudaTensor", True, True))
@@ -46,6 +47,7 @@ def create_G(dimensions, noiseDim, cuda=True, seed=0):
 def create_R_default(dimensions, noiseDim, noiseMethod="normal", fixer=False, cuda=True, seed=0):
     """models.lua:389-464."""
     assert noiseMethod in ("normal", "uniform")                # models.lua:390
+    nn.manualSeed(seed)
     conv = nn.Sequential()
     if cuda:
         conv.add(nn.Copy("torch.FloatTensor", "torch.CudaTensor", True, True))

@@ -19,6 +19,20 @@ import numpy as np
 
 from . import _lib as L
 
+# Torch7 draws every module's initial parameters from ONE process-wide generator (torch.manualSeed, train_r.lua:38-39), so two
+# modules of equal shape never start out identical.  Constructors and reset() without an explicit rng draw from this one.
+_RNG = np.random.default_rng(0)
+
+
+def manualSeed(seed):
+    """torch.manualSeed for parameter initialisation: restart the generator the constructors draw from."""
+    global _RNG
+    _RNG = np.random.default_rng(int(seed))
+
+
+def _rng(rng=None):
+    return rng if rng is not None else _RNG
+
 
 class Module:
     __typename = "nn.Module"
@@ -326,7 +340,7 @@ class SpatialConvolution(_Param):
 
     def reset(self, stdv=None, rng=None):
         """nn.SpatialConvolution:reset — uniform(-stdv, stdv); a given stdv is scaled by sqrt(3) (upstream)."""
-        rng = rng or np.random.default_rng(0)
+        rng = _rng(rng)
         stdv = stdv * math.sqrt(3) if stdv is not None else 1.0 / math.sqrt(self.kW * self.kH * self.nInputPlane)
         self.weight[...] = rng.uniform(-stdv, stdv, self.weight.shape)
         self.bias[...] = rng.uniform(-stdv, stdv, self.bias.shape)
@@ -359,7 +373,7 @@ class Linear(_Param):
         self.reset()
 
     def reset(self, stdv=None, rng=None):
-        rng = rng or np.random.default_rng(0)
+        rng = _rng(rng)
         stdv = stdv * math.sqrt(3) if stdv is not None else 1.0 / math.sqrt(self.weight.shape[1])
         self.weight[...] = rng.uniform(-stdv, stdv, self.weight.shape)
         self.bias[...] = rng.uniform(-stdv, stdv, self.bias.shape)
@@ -387,7 +401,7 @@ class BatchNormalization(_Param):
         self.reset()
 
     def reset(self, rng=None):
-        rng = rng or np.random.default_rng(0)
+        rng = _rng(rng)
         self.weight[...] = rng.uniform(0, 1, self.weight.shape)   # upstream: weight:uniform(), bias:zero()
         self.bias[...] = 0
         self.running_mean[...] = 0

@@ -111,17 +111,25 @@ class DeviceTrainer:
                          (several ranks on one GPU).
     """
 
-    def __init__(self, ctx, gnet, rnet, hyper, per_gpu_batch, world=1, rank=0):
+    def __init__(self, ctx, gnet, rnet, hyper, per_gpu_batch, world=1, rank=0, noise_method="normal"):
         from . import _lib as L
         self.L, self.ctx, self.gnet, self.rnet, self.hyper = L, ctx, gnet, rnet, hyper
         self.B, self.world, self.rank, self.t = int(per_gpu_batch), int(world), int(rank), 0
+        if noise_method not in ("normal", "uniform"):
+            raise ValueError(f"Unknown noise method '{noise_method}'")        # utils/nn_utils.lua:48
+        self.noise_method = noise_method
         self.nd = int(np.prod(rnet.out_dims))
         self.noise = ctx.malloc(4 * self.B * self.nd)
         self.dfdo = ctx.malloc(4 * self.B * self.nd)
         self.loss_dev = ctx.malloc(64)
 
     def new_noise(self, seed):
-        self.ctx.fill_normal(self.noise, self.B * self.nd, seed)      # createNoiseInputs, on device
+        # createNoiseInputs on device (utils/nn_utils.lua:39-51): normal(0, 1) or uniform(-1, 1) - with the uniform method R ends
+        # in a Tanh (models.lua:452-454) and can only reach targets in (-1, 1)
+        if self.noise_method == "uniform":
+            self.ctx.fill_uniform(self.noise, self.B * self.nd, seed, -1.0, 1.0)
+        else:
+            self.ctx.fill_normal(self.noise, self.B * self.nd, seed)
 
     def step(self, want_loss=False):
         self.t += 1

@@ -39,9 +39,10 @@ def load_params(path, model):
 def parse(argv=None):
     p = argparse.ArgumentParser(description="train_r.lua options (train_r.lua:12-29)")
     p.add_argument("--batchSize", type=int, default=32)
-    p.add_argument("--nbBatches", type=int, default=2000)          # README.md:103
-    p.add_argument("--save", default="logs")
-    p.add_argument("--saveFreq", type=int, default=100)
+    p.add_argument("--nbBatches", type=int, default=2000)          # README.md:103 (train_r.lua:15 default -1: "<0 is infinite")
+    p.add_argument("--save", default="logs")                       # a directory (train_r.lua:13,231) - or one explicit .net/.t7/.npz file
+    p.add_argument("--saveFreq", type=int, default=2000)           # train_r.lua:19
+    p.add_argument("--continue", dest="continue_", default="")     # train_r.lua:26,101-104
     p.add_argument("--G", default="")
     p.add_argument("--seed", type=int, default=1)
     p.add_argument("--threads", type=int, default=8)
@@ -84,15 +85,53 @@ def main(argv=None):
         else:
             synth.init_params(MODEL_G, OPT.seed)
     MODEL_G.evaluate()                                                   # train_r.lua:70
-    MODEL_R = models.create_R(dims, OPT.noiseDim, OPT.noiseMethod, OPT.fixer, seed=OPT.seed)   # train_r.lua:106
+    if OPT.continue_:                                                    # train_r.lua:101-104  MODEL_R = torch.load(OPT.continue).R
+        if OPT.continue_.endswith((".net", ".t7")):
+            from . import t7
+            MODEL_R = t7.load_checkpoint(OPT.continue_)["R"]
+        else:
+            MODEL_R = models.create_R(dims, OPT.noiseDim, OPT.noiseMethod, OPT.fixer, seed=OPT.seed)
+            load_params(OPT.continue_, MODEL_R)
+            if MODEL_R._flat is not None:                                # module arrays are views of the loaded flat storage
+                MODEL_R._flat = None
+    else:
+        MODEL_R = models.create_R(dims, OPT.noiseDim, OPT.noiseMethod, OPT.fixer, seed=OPT.seed)   # train_r.lua:106
     MODEL_G._ctx = MODEL_R._ctx = ctx
     losses = []
+    opt_table = {k.rstrip("_"): v for k, v in vars(OPT).items() if isinstance(v, (int, float, str, bool))}
+
+    def save():
+        """train_r.lua:227-235: torch.save(<OPT.save>/r_CxHxW_ndN_<method>[_fixer].net, {R=MODEL_R, opt=OPT}).  An --save that names a
+        .net/.t7/.npz file is written as that file instead."""
+        if not OPT.save:
+            return None
+        MODEL_R.pull_params()                   # parameters AND BatchNorm running statistics live on the device
+        target = str(OPT.save)
+        if not target.endswith((".net", ".t7", ".npz")):
+            import os
+            os.makedirs(target, exist_ok=True)
+            target = os.path.join(target, "r_%dx%dx%d_nd%d_%s%s.net" % (dims[0], dims[1], dims[2], OPT.noiseDim, OPT.noiseMethod,
+                                                                        "_fixer" if OPT.fixer else ""))
+        if target.endswith(".npz"):
+            save_model(target, MODEL_R, opt_table)
+        else:
+            from . import t7
+            t7.save_checkpoint(target, R=MODEL_R, opt=opt_table)
+        if not OPT.quiet:
+            print("Saving networks...", target)
+        return target
+
+    def batches():
+        i = 1
+        while OPT.nbBatches < 0 or i <= OPT.nbBatches:                   # train_r.lua:131-135: "<0 is infinite"
+            yield i
+            i += 1
     if OPT.compat:
         CRITERION_R = nn.MSECriterion()                                  # :119
         PARAMETERS_R, GRAD_PARAMETERS_R = MODEL_R.getParameters()        # :122
         state = {}                                                       # OPTSTATE = {adam={R={}}}  :125
         MODEL_R.manualSeed(OPT.seed)
-        for batchIdx in range(1, OPT.nbBatches + 1):
+        for batchIdx in batches():
             noise = nn_utils.createNoiseInputs(OPT.batchSize, OPT.noiseDim, OPT.noiseMethod, seed=OPT.seed * 100003 + batchIdx)
             images = MODEL_G.forward(noise).copy()                       # :139
 
@@ -113,29 +152,28 @@ def main(argv=None):
             losses.append(CRITERION_R.output)
             if not OPT.quiet:
                 print("[batch %d of %d (%.2f%%)] loss R=%.4f" % (batchIdx, OPT.nbBatches, 100 * batchIdx / OPT.nbBatches, CRITERION_R.output))
+            if batchIdx % OPT.saveFreq == 0:                             # :185-187
+                save()
     else:
         MODEL_G.forward(synth.normal((2, OPT.noiseDim), 1))              # compile both nets
         MODEL_R.training(); MODEL_R.forward(synth.uniform((2,) + dims, 2, 0, 1)); MODEL_R.push_params()
         MODEL_R._net.set_seed(OPT.seed); MODEL_R._net.adam_reset()
-        tr = DeviceTrainer(ctx, MODEL_G._net, MODEL_R._net, L.Hyper(l1=OPT.R_L1, l2=OPT.R_L2, clamp=OPT.R_clamp), OPT.batchSize)
+        tr = DeviceTrainer(ctx, MODEL_G._net, MODEL_R._net, L.Hyper(l1=OPT.R_L1, l2=OPT.R_L2, clamp=OPT.R_clamp), OPT.batchSize,
+                           noise_method=OPT.noiseMethod)
         t0 = time.perf_counter()
-        for batchIdx in range(1, OPT.nbBatches + 1):
+        nb = 0
+        for batchIdx in batches():
+            nb = batchIdx
             tr.new_noise(OPT.seed * 100003 + batchIdx)
             loss = tr.step(want_loss=True)
             losses.append(loss)
             if not OPT.quiet:
                 print("[batch %d of %d (%.2f%%)] loss R=%.4f" % (batchIdx, OPT.nbBatches, 100 * batchIdx / OPT.nbBatches, loss))
+            if batchIdx % OPT.saveFreq == 0:                             # :185-187
+                save()
         if not OPT.quiet:
-            print("<trainer> Last batch reached. %.1f images/s" % (OPT.batchSize * OPT.nbBatches / (time.perf_counter() - t0)))
-        MODEL_R.pull_params()
-    if OPT.save:
-        # train_r.lua:227-235: {R=MODEL_R, opt=OPT}; ".net" -> Torch7 serialisation (ganrev/t7.py), otherwise this package's npz
-        opt_table = {k: v for k, v in vars(OPT).items() if isinstance(v, (int, float, str, bool))}
-        if str(OPT.save).endswith((".net", ".t7")):
-            from . import t7
-            t7.save_checkpoint(OPT.save, R=MODEL_R, opt=opt_table)
-        elif str(OPT.save).endswith(".npz"):
-            save_model(OPT.save, MODEL_R, opt_table)
+            print("<trainer> Last batch reached. %.1f images/s" % (OPT.batchSize * nb / (time.perf_counter() - t0)))
+    save()                                                               # :136 "Last batch reached" -> save()
     return MODEL_G, MODEL_R, losses
 
 

@@ -27,8 +27,9 @@ def w_init(net, arg, seed=0):
     """weight-init.lua:40-75.  Only typenames 'nn.SpatialConvolution' and 'nn.Linear' are re-initialised — the
     reference's G is built from cudnn.SpatialConvolution, which the typename test does not match (weight-init.lua:54-67),
     so G's convolutions keep their constructor init and only get their bias zeroed (weight-init.lua:70-72)."""
+    from . import nn
     method = _METHODS[arg]
-    rng = np.random.default_rng(seed)
+    rng = nn._rng()              # the same process-wide stream the constructors drew from (seeded by models.create_*)
     for m in getattr(net, "modules", []):
         tn = m.typename
         if tn == "nn.SpatialConvolution":

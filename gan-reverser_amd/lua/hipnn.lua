@@ -42,6 +42,17 @@ int gr_l2_distance_rows_host(gr_ctx*, const float* a, const float* b, int64_t n,
 int gr_kmeans_host(gr_ctx*, const float* x, int64_t n, int d, int k, int niter, float* centroids_inout, float* total_counts, int32_t* labels);
 int gr_cosine_assign_host(gr_ctx*, const float* x, int64_t n, int d, const float* centroids, int k, int take_min, int32_t* labels, float* sims);
 int gr_set_conv_mode(gr_ctx*, int mode);   /* 0 exact fp32 MFMA, 1 bf16x6, 2 f16x3 (default) */
+/* fast mode: everything resident on the GPU (INTEGRATION.md section 2) */
+int gr_malloc(gr_ctx*, int64_t bytes, void** out_dev);  int gr_free(gr_ctx*, void* dev);
+int gr_memcpy_h2d(gr_ctx*, void* dst_dev, const void* src_host, int64_t bytes);
+int gr_memcpy_d2h(gr_ctx*, void* dst_host, const void* src_dev, int64_t bytes);
+int gr_fill_normal_dev(gr_ctx*, float* dst_dev, int64_t n, uint64_t seed);
+int gr_fill_uniform_dev(gr_ctx*, float* dst_dev, int64_t n, float lo, float hi, uint64_t seed);
+int gr_net_forward_dev(gr_net*, const float* in_dev, int batch, float* out_dev);
+float* gr_net_output_dev(gr_net*);
+int gr_adam_reset(gr_net*);
+int gr_train_r_step(gr_net* gnet, gr_net* rnet, const float* noise_dev, int batch, int global_batch,
+                    const gr_hyper* h, int t, double* loss_out);
 ]]
 local C = ffi.load('ganrev')          -- libganrev.so on LD_LIBRARY_PATH
 local hipnn = {}
@@ -127,6 +138,27 @@ function Wrapped:pushParams()
    end
 end
 
+-- BatchNorm running statistics live on the device and move with every training-mode forward; the nn modules inside
+-- `inner` are what torch.save writes (train_r.lua:228-235) and what :evaluate() forwards of a reloaded net use, so they
+-- are refreshed from the device after each such forward (2 x nFeature floats per BN layer).
+function Wrapped:pullRunningStats()
+   local bi = 0
+   for _, m in ipairs(self.leaves) do
+      if m.running_mean then
+         local rm, rv = m.running_mean:float(), m.running_var:float()
+         check(C.gr_net_get_bn_running(self.net, bi, rm:data(), rv:data()), 'gr_net_get_bn_running')
+         m.running_mean:copy(rm); m.running_var:copy(rv)
+         bi = bi + 1
+      end
+   end
+end
+
+-- device parameters -> the host flat storage the nn modules view (needed after fast-mode steps, before torch.save)
+function Wrapped:pullParams()
+   check(C.gr_net_get_params(self.net, self.flat:data()), 'gr_net_get_params')
+   self:pullRunningStats()
+end
+
 function Wrapped:updateOutput(input)
    input = input:contiguous()
    self:compile(input)
@@ -138,6 +170,7 @@ function Wrapped:updateOutput(input)
    C.gr_net_out_dim(self.net, out, out + 1, out + 2)
    if out[1] == 1 and out[2] == 1 then self.output:resize(B, out[0]) else self.output:resize(B, out[0], out[1], out[2]) end
    check(C.gr_net_forward_host(self.net, input:data(), B, self.output:data()), 'gr_net_forward_host')
+   if self.train then self:pullRunningStats() end
    return self.output
 end
 
@@ -158,6 +191,30 @@ function Wrapped:float() return self end
 function Wrapped:listModules() return self.inner:listModules() end
 
 function hipnn.wrap(model) return hipnn.Sequential(model) end
+
+-- Fast mode: train_r.lua:138-170 as ONE call with noise, images, parameters and the Adam state resident on the GPU.
+--   local step = hipnn.trainer(MODEL_G, MODEL_R, OPT.batchSize, {l1=OPT.R_L1, l2=OPT.R_L2, clamp=OPT.R_clamp}, noiseMethod)
+--   for batchIdx = 1, n do local loss = step(batchIdx) ... end ;  MODEL_R:pullParams() before save()
+-- Both models must have been compiled by one forward each (so that the nets exist and hold the current parameters).
+function hipnn.trainer(G, R, batchSize, pen, noiseMethod)
+   assert(G.net and R.net, 'hipnn.trainer: run one forward through G and R first')
+   local nd = R.output:size(2)
+   local pnoise = ffi.new('void*[1]')
+   check(C.gr_malloc(context(), 4 * batchSize * nd, pnoise), 'gr_malloc')
+   local noise = ffi.cast('float*', pnoise[0])
+   local h = ffi.new('gr_hyper', {1e-3, 0.9, 0.999, 1e-8, pen.l1 or 0, pen.l2 or 1e-4, pen.clamp or 1})   -- optim.adam defaults, train_r.lua:22-24
+   local loss = ffi.new('double[1]')
+   check(C.gr_net_set_params(R.net, R.flat:data()), 'gr_net_set_params')
+   check(C.gr_adam_reset(R.net), 'gr_adam_reset')                  -- OPTSTATE = {adam={R={}}}  train_r.lua:125
+   local t = 0
+   return function(seed)
+      t = t + 1
+      if noiseMethod == 'uniform' then check(C.gr_fill_uniform_dev(context(), noise, batchSize * nd, -1, 1, seed), 'fill')
+      else check(C.gr_fill_normal_dev(context(), noise, batchSize * nd, seed), 'fill') end
+      check(C.gr_train_r_step(G.net, R.net, noise, batchSize, batchSize, h, t, loss), 'gr_train_r_step')
+      return loss[0]
+   end
+end
 
 -- apply_r.lua:396-400 replacement
 function hipnn.cosineSimilarity(v1, v2)

@@ -99,6 +99,9 @@ float* gr_net_output_dev(gr_net* net);                     /* m.output (device),
 /* m:backward(input, gradOutput) -> m.gradInput ; accumulates into the flat gradient  (train_r.lua:151) */
 int gr_net_backward_host(gr_net* net, const float* in_host, const float* grad_out_host, int batch, float* grad_in_host /*nullable*/);
 int gr_net_backward_dev(gr_net* net, const float* in_dev, const float* grad_out_dev, int batch, float* grad_in_dev /*nullable*/);
+/* nn.SpatialMaxPooling.indices of the last forward (models.lua:422,440): one byte per output element, 0..3 = position in the
+ * 2x2 window in scan order (dy, dx); n must be batch * C * Ho * Wo of that layer */
+int gr_net_get_pool_index(gr_net* net, int layer_index, uint8_t* host, int64_t n);
 /* debugging / layer-by-layer parity: copy out the output of module `layer_index` of the last forward */
 int gr_net_layer_output(gr_net* net, int layer_index, float* host, int64_t n);
 
@@ -142,9 +145,14 @@ int gr_train_r_step(gr_net* gnet, gr_net* rnet, const float* noise_dev, int batc
 int gr_set_conv_mode(gr_ctx* ctx, int mode);
 int gr_get_conv_mode(gr_ctx* ctx);
 int gr_set_timing(gr_ctx* ctx, int mode /*0 off, 1 per-phase events in gr_train_r_step, 2 per-kernel events*/);
-/* mode 2: JSON array of {kernel, launches, total_ms, flops, bytes} (algorithmic flops/bytes) accumulated since it was enabled */
+/* mode 2: JSON array of {kernel, phase, launches, total_ms, flops, bytes} (algorithmic flops/bytes) accumulated since it was
+ * enabled; phase = the part of gr_train_r_step that launched it ("G forward", "R forward", "loss", "R backward", "adam") or "" */
 int gr_kernel_times(gr_ctx* ctx, char* buf, int buflen);
 int gr_last_step_times(gr_ctx* ctx, float* ms6);
+/* HIP events on the ctx's own stream (a host timer or a torch.cuda.Event on another stream does not see this work):
+ * gr_event_record marks slot (0..65535) at the current point of the stream; gr_event_elapsed_ms waits for slot b. */
+int gr_event_record(gr_ctx* ctx, int slot);
+int gr_event_elapsed_ms(gr_ctx* ctx, int slot_a, int slot_b, float* ms);
 
 /* ---- apply_r.lua:265-282 search loop + apply_r.lua:396-400 cosineSimilarity (nn.CosineDistance) ----
  * For each query row q: score every row j of emb[N x d] (self included) with
@@ -179,6 +187,8 @@ int gr_memcpy_h2d(gr_ctx* ctx, void* dst_dev, const void* src_host, int64_t byte
 int gr_memcpy_d2h(gr_ctx* ctx, void* dst_host, const void* src_dev, int64_t bytes);
 /* fill a device buffer with N(0,1) (Philox + Box-Muller): synthetic createNoiseInputs (utils/nn_utils.lua:39-51) for benches */
 int gr_fill_normal_dev(gr_ctx* ctx, float* dst_dev, int64_t n, uint64_t seed);
+/* the other noise method of createNoiseInputs (utils/nn_utils.lua:44-45): uniform(lo, hi), lo = -1, hi = 1 in the reference */
+int gr_fill_uniform_dev(gr_ctx* ctx, float* dst_dev, int64_t n, float lo, float hi, uint64_t seed);
 
 /* ---- single-kernel entry points used by bench.py's roofline leg and by kernel-level parity tests ---- */
 int gr_conv3_forward_dev(gr_ctx* ctx, const float* in_dev, const float* w_dev, const float* bias_dev, float* out_dev,

@@ -82,8 +82,13 @@ void go_net_set_bn_groups(go_net*, int groups);    /* data-parallel emulation: p
 int go_net_set_mask(go_net*, int layer_index, const uint8_t* keep, int64_t n);
 int64_t go_net_mask_size(const go_net*, int layer_index, int B);
 void go_net_zero_grads(go_net*);
+void go_net_set_lean(go_net*, int lean);   /* backward frees each buffer once consumed (memory of full-size runs); layer outputs are gone afterwards */
 int go_net_forward(go_net*, const float* in, int B, float* out);
 int go_net_backward(go_net*, const float* in, const float* gout, int B, float* gin /*nullable*/);
+/* nn.SpatialMaxPooling argmax (0..3 = (dy,dx) scan position) of the last forward: read it / force the next forwards to use a
+ * given one (NULL: compute it again).  Parity-test hooks: see oracle_net.c. */
+int64_t go_net_get_pool_index(const go_net*, int layer_index, uint8_t* out /*nullable: returns the count*/, int64_t cap);
+int go_net_force_pool_index(go_net*, int layer_index, const uint8_t* idx /*nullable*/, int64_t n);
 /* intermediate module outputs, for layer-by-layer debugging of the HIP path */
 const float* go_net_layer_output(const go_net*, int layer_index, int64_t* n);
 

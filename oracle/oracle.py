@@ -56,10 +56,14 @@ def lib():
         L.go_net_mask_size.restype = C.c_int64
         L.go_net_mask_size.argtypes = [_P, C.c_int, C.c_int]
         L.go_net_zero_grads.argtypes = [_P]
+        L.go_net_set_lean.argtypes = [_P, C.c_int]
         L.go_net_forward.argtypes = [_P, _P, C.c_int, _P]
         L.go_net_backward.argtypes = [_P, _P, _P, C.c_int, _P]
         L.go_net_layer_output.restype = C.POINTER(C.c_float)
         L.go_net_layer_output.argtypes = [_P, C.c_int, C.POINTER(C.c_int64)]
+        L.go_net_get_pool_index.restype = C.c_int64
+        L.go_net_get_pool_index.argtypes = [_P, C.c_int, _P, C.c_int64]
+        L.go_net_force_pool_index.argtypes = [_P, C.c_int, _P, C.c_int64]
         L.go_mse.restype = C.c_double
         L.go_mse.argtypes = [_P, _P, C.c_int64, _P]
         L.go_mse_scaled.restype = C.c_double
@@ -143,6 +147,10 @@ class Net:
     def zero_grads(self):
         self.L.go_net_zero_grads(self.h)
 
+    def set_lean(self, lean=True):
+        """backward frees every buffer it has consumed: layer outputs are unavailable after a backward"""
+        self.L.go_net_set_lean(self.h, int(bool(lean)))
+
     @staticmethod
     def _shape(d):
         c, h, w = d
@@ -161,6 +169,23 @@ class Net:
         rc = self.L.go_net_backward(self.h, _p(x), _p(gout), x.shape[0], _p(gin))
         assert rc == 0, f"oracle backward rc={rc}"
         return gin
+
+    def pool_index(self, layer):
+        """argmax (0..3) nn.SpatialMaxPooling `layer` took in the last forward"""
+        n = int(self.L.go_net_get_pool_index(self.h, layer, None, 0))
+        assert n > 0, f"layer {layer} is not a max-pool with a recorded forward"
+        out = np.empty(n, np.uint8)
+        assert self.L.go_net_get_pool_index(self.h, layer, _p(out), n) == n
+        return out
+
+    def force_pool_index(self, layer, idx):
+        """use `idx` instead of computing the argmax in the following forwards (None: compute again)"""
+        if idx is None:
+            rc = self.L.go_net_force_pool_index(self.h, layer, None, 0)
+        else:
+            idx = np.ascontiguousarray(idx, dtype=np.uint8)
+            rc = self.L.go_net_force_pool_index(self.h, layer, _p(idx), idx.size)
+        assert rc == 0, rc
 
     def layer_output(self, layer):
         n = C.c_int64()

@@ -120,6 +120,7 @@ typedef struct {
   float *save_mean, *save_invstd;  /* BN train cache, [groups][C] */
   uint8_t* keep; int64_t keep_n;   /* dropout keep flags set by the test */
   uint8_t* pool_idx;               /* maxpool argmax 0..3 */
+  uint8_t* forced_idx; int64_t forced_n;  /* test hook: argmax to USE instead of computing it (go_net_force_pool_index) */
   float* out; int64_t out_cap;     /* module.output */
   int alias;                       /* nn.View: output shares the input's storage */
   float* gin; int64_t gin_cap;     /* module.gradInput */
@@ -131,6 +132,7 @@ struct go_net {
   int64_t n_params;
   float *params, *grads;
   int training, groups, n_bn, lastB;
+  int lean;                        /* backward releases every buffer it has consumed (full-size parity runs: 10 instead of 21 GB at cfg3) */
 };
 
 static int64_t vol(int c, int h, int w) { return (int64_t)c * h * w; }
@@ -183,7 +185,7 @@ void go_net_destroy(go_net* net) {
   for (int i = 0; i < net->n; ++i) {
     olayer* l = &net->L[i];
     free(l->run_mean); free(l->run_var); free(l->save_mean); free(l->save_invstd);
-    free(l->keep); free(l->pool_idx); if (!l->alias) free(l->out); free(l->gin);
+    free(l->keep); free(l->pool_idx); free(l->forced_idx); if (!l->alias) free(l->out); free(l->gin);
   }
   free(net->L); free(net->params); free(net->grads); free(net);
 }
@@ -203,6 +205,7 @@ float* go_net_bn_running_mean(go_net* n, int idx, int* cnt) { olayer* l = find_b
 float* go_net_bn_running_var(go_net* n, int idx, int* cnt) { olayer* l = find_bn(n, idx); if (!l) return NULL; if (cnt) *cnt = l->inC; return l->run_var; }
 void go_net_set_training(go_net* n, int t) { n->training = t; }
 void go_net_set_bn_groups(go_net* n, int g) { n->groups = g < 1 ? 1 : g; }
+void go_net_set_lean(go_net* n, int lean) { n->lean = lean; }
 void go_net_zero_grads(go_net* n) { memset(n->grads, 0, sizeof(float) * n->n_params); }
 
 int64_t go_net_mask_size(const go_net* n, int li, int B) {
@@ -223,6 +226,23 @@ const float* go_net_layer_output(const go_net* n, int li, int64_t* cnt) {
   if (li < 0 || li >= n->n) return NULL;
   if (cnt) *cnt = (int64_t)n->lastB * vol(n->L[li].outC, n->L[li].outH, n->L[li].outW);
   return n->L[li].out;
+}
+
+/* Parity-test hooks for nn.SpatialMaxPooling's argmax.  Two correct fp32 implementations may pick different elements of a
+ * window whose two largest inputs differ by rounding noise; a test reads the argmax the oracle took, compares it with the
+ * device's, and re-runs the oracle with the device's argmax forced so that every gradient can be held to the strict bar. */
+int64_t go_net_get_pool_index(const go_net* n, int li, uint8_t* out, int64_t cap) {
+  if (li < 0 || li >= n->n || n->L[li].d.kind != GO_MAXPOOL2 || !n->L[li].pool_idx) return -1;
+  const int64_t cnt = (int64_t)n->lastB * vol(n->L[li].outC, n->L[li].outH, n->L[li].outW);
+  if (out) { if (cap < cnt) return -2; memcpy(out, n->L[li].pool_idx, cnt); }
+  return cnt;
+}
+int go_net_force_pool_index(go_net* n, int li, const uint8_t* idx, int64_t cnt) {   /* idx == NULL: back to computing it */
+  if (li < 0 || li >= n->n || n->L[li].d.kind != GO_MAXPOOL2) return -1;
+  olayer* l = &n->L[li];
+  free(l->forced_idx); l->forced_idx = NULL; l->forced_n = 0;
+  if (idx) { l->forced_idx = (uint8_t*)malloc(cnt); memcpy(l->forced_idx, idx, cnt); l->forced_n = cnt; }
+  return 0;
 }
 
 static float* ensure(float** p, int64_t* cap, int64_t n) {
@@ -312,7 +332,8 @@ int go_net_forward(go_net* net, const float* in, int B, float* out_host) {
           for (int yy = 0; yy < oh; ++yy) for (int xx = 0; xx < ow; ++xx) {
             const float* s = x + bc * ih * iw + (2 * yy) * iw + 2 * xx;
             float m = -INFINITY; int mi = 0;
-            for (int t = 0; t < 4; ++t) { const float v = s[(t >> 1) * iw + (t & 1)]; if (v > m) { m = v; mi = t; } }
+            if (l->forced_idx && l->forced_n == nout) { mi = l->forced_idx[bc * oh * ow + yy * ow + xx] & 3; m = s[(mi >> 1) * iw + (mi & 1)]; }
+            else for (int t = 0; t < 4; ++t) { const float v = s[(t >> 1) * iw + (t & 1)]; if (v > m) { m = v; mi = t; } }
             y[bc * oh * ow + yy * ow + xx] = m; l->pool_idx[bc * oh * ow + yy * ow + xx] = (uint8_t)mi;
           }
         break; }
@@ -333,6 +354,7 @@ int go_net_forward(go_net* net, const float* in, int B, float* out_host) {
 /* nn.Sequential:backward — reverse walk, gradInput then accGradParameters(scale=1) per module */
 int go_net_backward(go_net* net, const float* in, const float* gout, int B, float* gin_host) {
   const float* g = gout;
+  int g_owner = -1;                                             /* layer whose gin buffer `g` points into */
   for (int i = net->n - 1; i >= 0; --i) {
     olayer* l = &net->L[i];
     const float* x = (i == 0) ? in : net->L[i - 1].out;          /* this module's input */
@@ -410,6 +432,11 @@ int go_net_backward(go_net* net, const float* in, const float* gout, int B, floa
       default: return -1;
     }
     g = gi;
+    if (net->lean) {   /* the consumed gradOutput and this module's own output are dead from here on */
+      if (g_owner >= 0) { free(net->L[g_owner].gin); net->L[g_owner].gin = NULL; net->L[g_owner].gin_cap = 0; }
+      if (!l->alias && i + 1 < net->n && net->L[i + 1].d.kind != GO_VIEW) { free(l->out); l->out = NULL; l->out_cap = 0; }
+    }
+    g_owner = i;
   }
   if (gin_host) memcpy(gin_host, g, sizeof(float) * B * vol(net->C, net->H, net->W));
   return 0;

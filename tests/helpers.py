@@ -66,3 +66,64 @@ def pools_well_conditioned(model, onet, B, gap=2e-6):
         if np.any((g > 0) & (g < gap)):
             return False
     return True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Strict gradient parity around nn.SpatialMaxPooling.  A window whose two largest inputs differ by less than the forward
+# error of a correct fp32 implementation (2-3e-6 here) may legitimately get a different argmax on the two sides; the gradient
+# element it routes then lands elsewhere, which no element-wise tolerance can express.  Instead of budgeting for that, the
+# tests (1) read the argmax both sides took (gr_net_get_pool_index / go_net_get_pool_index), (2) require the windows where
+# they differ to be FEW and each to be a genuine near-tie in the oracle's own forward, and (3) re-run the oracle with the
+# device's argmax forced, after which every gradient tensor is held to the strict bar.
+NEAR_TIE = 1e-5
+
+
+def pool_layers(model, onet):
+    """[(max-pool module, its layer index, per-sample input dims)] of a ganrev model / oracle twin pair."""
+    return [(m, onet.layer_index[id(m)], onet.pool_in_dims[onet.layer_index[id(m)]])
+            for m in model.leaves() if m.typename == "nn.SpatialMaxPooling"]
+
+
+def adopt_device_argmax(model, onet, B, max_flips):
+    """Compare the pool argmax of the device's and the oracle's last forward, assert the differences are few genuine
+    near-ties, force the device's argmax onto the oracle.  Returns the number of differing windows per pool layer."""
+    flips = []
+    for m, li, (c, h, w) in pool_layers(model, onet):
+        n = B * c * (h // 2) * (w // 2)
+        dev = model._net.pool_index(li, n)
+        ora = onet.pool_index(li)
+        assert dev.max() <= 3
+        diff = np.nonzero(dev != ora)[0]
+        if diff.size:
+            x = onet.layer_output(li - 1).reshape(B * c, h // 2, 2, w // 2, 2).transpose(0, 1, 3, 2, 4).reshape(-1, 4)
+            gap = x[diff, ora[diff]].astype(np.float64) - x[diff, dev[diff]].astype(np.float64)
+            assert np.all(gap >= 0), "the oracle's argmax is not the maximum of its own window"
+            assert gap.max() < NEAR_TIE, (f"pool layer {li}: {diff.size} windows with a different argmax, largest gap "
+                                          f"{gap.max():.3e}: not a rounding-level near-tie")
+        assert diff.size <= max_flips, f"pool layer {li}: {diff.size} of {n} windows differ in argmax (allowed {max_flips})"
+        onet.force_pool_index(li, dev)
+        flips.append(int(diff.size))
+    return flips
+
+
+def release_argmax(model, onet):
+    for m, li, _ in pool_layers(model, onet):
+        onet.force_pool_index(li, None)
+
+
+def param_segments(model):
+    segs, off = [], 0
+    for mod in model.leaves():
+        for nm, arr in zip(("weight", "bias"), mod.param_arrays()):
+            segs.append((mod, nm, off, off + arr.size)); off += arr.size
+    return segs
+
+
+def assert_grads_close(model, got, ref, rtol=1e-4, floor=1e-3, what=""):
+    """every parameter tensor's gradient within rtol of that tensor's largest reference entry (floor: tensors whose true
+    gradient is zero - conv biases under BatchNorm - hold rounding noise only)"""
+    for mod, nm, lo, hi in param_segments(model):
+        r, g = ref[lo:hi], got[lo:hi]
+        gmax = max(float(np.abs(r).max()), floor)
+        d = maxdiff(g, r)
+        assert d <= rtol * gmax, f"{what} {mod.typename}.{nm} [{lo}:{hi}]: max |diff| {d:.3e} vs max |g| {gmax:.3e}"

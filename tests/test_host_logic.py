@@ -161,3 +161,74 @@ def test_t7_checkpoint_round_trip():
         assert np.array_equal(m2._flat_host(), m._flat_host())
         for a, b in zip([x for x in m.leaves() if hasattr(x, "running_mean")], [x for x in m2.leaves() if hasattr(x, "running_mean")]):
             assert np.array_equal(a.running_mean, b.running_mean) and np.array_equal(a.running_var, b.running_var)
+
+
+def test_module_initialisation_draws_from_one_stream():
+    """Torch draws every module's initial parameters from one process-wide generator: equal-shaped modules must not start
+    out identical, create_*(seed=...) must reach the modules weight-init.lua does not touch (BatchNorm gammas, G's
+    cudnn.SpatialConvolution), and the same seed must reproduce the same model."""
+    R = models.create_R((1, 32, 32), 32, seed=3)
+    bns = [m for m in R.leaves() if isinstance(m, nn.BatchNormalization) and m.nFeature == 64]
+    assert len(bns) == 3 and not np.array_equal(bns[0].weight, bns[1].weight) and not np.array_equal(bns[1].weight, bns[2].weight)
+    convs = [m for m in R.leaves() if m.typename == "nn.SpatialConvolution" and m.weight.shape == (64, 64, 3, 3)]
+    assert not np.array_equal(convs[0].weight, convs[1].weight)
+    G1, G2, G3 = models.create_G((1, 32, 32), 32, seed=1), models.create_G((1, 32, 32), 32, seed=1), models.create_G((1, 32, 32), 32, seed=2)
+    c1, c2, c3 = ([m for m in g.leaves() if m.typename == "cudnn.SpatialConvolution"][0].weight for g in (G1, G2, G3))
+    assert np.array_equal(c1, c2) and not np.array_equal(c1, c3)
+
+
+def test_oracle_argmax_hooks_and_lean_backward(oracle):
+    """The parity tests' hooks on the oracle: the recorded pool argmax, forcing it (its own argmax reproduces the same
+    forward and gradients bit for bit; a re-routed window changes exactly that window's output), and the memory-lean backward
+    (same gradients)."""
+    from helpers import inject_noise, pool_layers
+    dims, nd, B = (1, 16, 16), 8, 5
+    R = models.create_R(dims, nd); synth.init_params(R, 3)
+    onet = oracle.from_model(R, dims)
+    onet.set_training(True)
+    x = synth.uniform((B,) + dims, 5, 0, 1)
+    gy = synth.normal((B, nd), 9)
+    inject_noise(R, onet, B, 7)
+    out0 = onet.forward(x)
+    onet.zero_grads(); gin0 = onet.backward(x, gy); g0 = onet.grads.copy()
+    pools = pool_layers(R, onet)
+    assert len(pools) == 2
+    idx = [onet.pool_index(li) for _, li, _ in pools]
+    assert idx[0].size == B * 64 * 8 * 8 and idx[0].max() <= 3
+    for (_, li, _), ix in zip(pools, idx):
+        onet.force_pool_index(li, ix)
+    onet.set_lean(True)
+    assert np.array_equal(onet.forward(x), out0)
+    onet.zero_grads(); gin1 = onet.backward(x, gy)
+    assert np.array_equal(gin1, gin0) and np.array_equal(onet.grads, g0)
+    # re-route one window of the first pool: its output becomes another element of the window
+    li = pools[0][1]
+    before = onet.forward(x) is not None and onet.layer_output(li).copy()
+    pin = onet.layer_output(li - 1).reshape(B, 64, 8, 2, 8, 2)
+    forced = idx[0].copy(); forced[0] = (forced[0] + 1) % 4
+    onet.force_pool_index(li, forced)
+    onet.forward(x)
+    after = onet.layer_output(li)
+    assert after[0] == pin[0, 0, 0, forced[0] >> 1, 0, forced[0] & 1] and np.array_equal(after[1:], before[1:])
+    for _, li, _ in pools:
+        onet.force_pool_index(li, None)
+    onet.set_lean(False)
+    assert np.array_equal(onet.forward(x), out0)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run environment must start two ranks itself (one child process per
+    rank, this parent never touching a GPU) and relay rank 0's line with n_gpus = 2; with a WORLD_SIZE that contradicts --gpus it
+    must refuse.  GANREV_BENCH_DRY_RUN stops each rank after the gloo rendezvous (this box has no GPU)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GANREV_BENCH_DRY_RUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == [[0, 0], [1, 1]]
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
