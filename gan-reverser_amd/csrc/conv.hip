@@ -996,6 +996,234 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
+// ---------------------------------------------------------------- f16x3 convolution on OPERAND-READY activations ("P16")
+// The kernel above re-loads fp32 activations one dword per lane and re-splits them to fp16 hi/lo on the VALU for every
+// 16-channel chunk in every workgroup (PMC, R.conv2 at cfg2: 4.5 VALU instructions per MFMA, matrix pipe busy 30 %).  Here
+// the PRODUCER of the activation (post_forward_g8_kernel / post_backward_b_g8_kernel, elem.hip) has already written the
+// operand image:   p16[b][g = channel / 8][t = term][pixel] = 16 bytes = the 8 fp16 halves of term t (hi, lo) of channels
+// 8g .. 8g+7 at that pixel, scaled by the power of two that the tensor's scale slot defines - the same 4 bytes per value as
+// fp32.  A chunk's patch image [term][half][position] is then a pure gather of 16-byte vectors: it goes HBM -> LDS by
+// LDS-DMA (buffer_load_dwordx4 ... lds: 64 consecutive LDS slots per wave-instruction, per-lane source address; positions
+// outside the image are parked past the descriptor's range and arrive as zeros = the padding), the weight slab likewise.
+// No staging registers, no VALU work, no ds_write: per chunk a wave issues ~10 DMA instructions next to its 108 MFMAs.
+// Two LDS images; the DMA of the next chunk IN THE STREAM (tiles are walked persistently, so that is the next tile's first
+// chunk at a tile's end) is issued at the top of a chunk and waited for (vmcnt(0) + barrier) at its bottom.
+constexpr int P16_PAD = 64;          // LDS regions are multiples of one wave-instruction's 64 vectors
+template <int TW, int NI>
+__global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
+  constexpr int NT = 512, MT = 2, NTERM = 2;
+  constexpr int NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
+  constexpr int PV = NTERM * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;      // patch vectors (padded to whole instructions)
+  constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT;                                 // weight vectors: one instruction per row
+  constexpr int LBUF = PVP + WV;
+  constexpr int NPI = PVP / 64, NPS = (NPI + 7) / 8, NWS = (WROWS + 7) / 8;            // DMA instructions per chunk / per wave
+  static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2), "tile_pixel assumes these tilings");
+  static_assert(CT == 64, "one weight row = one wave-instruction");
+  static_assert(2 * LBUF * 16 <= 160 * 1024, "LDS");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* lds = reinterpret_cast<uint4*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int G = a.Cin >> 3;                                        // 8-channel groups (Cin % 16 == 0 on this path)
+  struct Geo { int y0, x0, o0, b, tile; };
+  auto tile_geo = [&](int L) {
+    int bid = xcd_remap(L, a.n_tiles);
+    Geo g; g.tile = bid / a.n_otiles;
+    const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; g.b = (bid / a.tiles_y) * NI;
+    g.y0 = ty * TR; g.x0 = tx * TW; g.o0 = ot * CT;
+    return g;
+  };
+  const int nchunks = a.Cin / BF_CK;
+  // one descriptor for the whole activation tensor (< 2 GB), one for the weight image
+  const size_t xbytes = (size_t)a.B * G * 2 * HW * 16;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(xin), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wsplit), 0,
+      (int)((size_t)nchunks * WROWS * a.cout_pad * 16), 0x00020000);
+  const int ktot = f16_scale_exp(absmax_read(a.amax_in)) + f16_scale_exp(absmax_read(a.amax_w));
+  // byte offset (chunk 0) of the source vector of patch slot e = 64 * (wave + 8 j) + lane, for this tile; parked when the
+  // slot is padding, outside the image, or past the batch
+  auto stage_offsets = [&](const Geo& g, int (&voff_)[NPS]) {
+#pragma unroll
+    for (int j = 0; j < NPS; ++j) {
+      const int e = 64 * (wave + 8 * j) + lane;
+      const int q = e / PS, pos = e - q * PS, t = q >> 1, hh = q & 1;     // plane q = term * 2 + half
+      const int rr = pos / PC, c = pos - rr * PC;
+      const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
+      const int yy = g.y0 + r - 1, xx = g.x0 + c - 1;
+      const bool inb = e < PV && yy >= 0 && yy < H && xx >= 0 && xx < W && g.b + img < a.B;
+      voff_[j] = inb ? ((((g.b + img) * G + hh) * 2 + t) * HW + yy * W + xx) * 16 : (int)0x7FFFF000;
+    }
+  };
+  int woff[NWS];                                                     // weight row r = wave + 8 j of the chunk's slab
+  auto weight_offsets = [&](const Geo& g) {
+#pragma unroll
+    for (int j = 0; j < NWS; ++j) { const int r = wave + 8 * j; woff[j] = r < WROWS ? (r * a.cout_pad + g.o0 + lane) * 16 : (int)0x7FFFF000; }
+  };
+  // LDS-DMA of chunk ch of the tile described by (voff_, woff) into image buf_
+#define GR_P16_DMA(buf_, ch_, voff_)                                                                      \
+  {                                                                                                       \
+    uint4* img_ = lds + (buf_) * LBUF;                                                                    \
+    const int psoff_ = (ch_) * HW * 64;                               /* 2 groups x 2 terms x HW x 16 B per chunk */ \
+    _Pragma("unroll") for (int j = 0; j < NPS; ++j) {                                                     \
+      const int i_ = wave + 8 * j;                                                                        \
+      if (i_ < NPI) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(img_ + 64 * i_), 16, voff_[j], psoff_, 0, 0); \
+    }                                                                                                     \
+    const int wsoff_ = (ch_) * WROWS * a.cout_pad * 16;                                                   \
+    _Pragma("unroll") for (int j = 0; j < NWS; ++j) {                                                     \
+      const int r_ = wave + 8 * j;                                                                        \
+      if (r_ < WROWS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (__attribute__((address_space(3))) void*)(img_ + PVP + 64 * r_), 16, woff[j], wsoff_, 0, 0); \
+    }                                                                                                     \
+  }
+  f32x16 acc[MT][NG];
+  int pix[NG];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;                   // skip the padding rows between stacked images
+    pix[ng] = h * PS + pr * PC + pc;
+  }
+#define GR_BF_OPS(patch, wts, tap_, av_, bv_)                                                            \
+    {                                                                                                     \
+      const int toff_ = ((tap_) / 3) * PC + ((tap_) % 3);                                                 \
+      _Pragma("unroll") for (int s = 0; s < NTERM; ++s) {                                                 \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) av_[mt][s] = wts[((s * 9 + (tap_)) * 2 + h) * CT + mt * 32 + l31]; \
+        _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) bv_[ng][s] = patch[s * 2 * PS + pix[ng] + toff_]; \
+      }                                                                                                   \
+    }
+#define GR_BF_MMA(av_, bv_)                                                                               \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                     \
+    _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) acc[mt][ng] = split_mma<NTERM>(av_[mt], bv_[ng], acc[mt][ng]);
+#define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, (MT + NG) * NTERM, 0); __builtin_amdgcn_sched_group_barrier(0x008, MT * NG * 3, 0);
+  float omax = 0.f;
+  int L = blockIdx.x;
+  Geo g = tile_geo(L);
+  int voff[NPS];
+  stage_offsets(g, voff);
+  weight_offsets(g);
+  int cc = 0;                                                        // chunks consumed so far: image cc & 1 holds the current one
+  GR_P16_DMA(0, 0, voff)
+  __syncthreads();                                                   // (vmcnt(0) for the DMA just issued, then the barrier)
+  for (;;) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][ng][r] = 0.f;
+    const int Ln = L + (int)gridDim.x;
+    const bool more = Ln < a.n_tiles;
+    Geo gn = g; int voffn[NPS];
+#pragma unroll
+    for (int j = 0; j < NPS; ++j) voffn[j] = voff[j];
+    for (int ch = 0; ch < nchunks; ++ch, ++cc) {
+      // the other image is free since the barrier that ended the previous chunk: fetch the next chunk of the stream into it
+      if (ch + 1 < nchunks) GR_P16_DMA((cc + 1) & 1, ch + 1, voff)
+      else if (more) {                                               // last chunk of this tile: the next tile's first chunk
+        gn = tile_geo(Ln); stage_offsets(gn, voffn); weight_offsets(gn);
+        GR_P16_DMA((cc + 1) & 1, 0, voffn)
+      }
+      const uint4* pc_ = lds + (cc & 1) * LBUF; const uint4* wc_ = pc_ + PVP;
+      uint4 avA[MT][NTERM], bvA[NG][NTERM], avB[MT][NTERM], bvB[NG][NTERM];
+      GR_BF_OPS(pc_, wc_, 0, avA, bvA)
+      GR_BF_OPS(pc_, wc_, 1, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 2, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 3, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 4, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 5, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 6, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 7, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+      GR_BF_OPS(pc_, wc_, 8, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+      GR_BF_MMA(avA, bvA)
+      __syncthreads();                                               // vmcnt(0): the DMA issued above has landed; every wave is past image cc & 1
+    }
+    const int y0 = g.y0, x0 = g.x0, o0 = g.o0, b = g.b;
+    bool pin[NG]; size_t obase[NG];
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) {
+      const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+      const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
+      const int y = y0 + pr, x = x0 + pc;
+      pin[ng] = y < H && x < W && b + img < a.B;
+      obase[ng] = ((size_t)(b + img) * a.Cout * H + y) * W + x;
+    }
+    // scale back + bias in place
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float bvv = (a.bias && o < a.Cout) ? a.bias[o] : 0.f;
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng) acc[mt][ng][r] = ldexpf(acc[mt][ng][r], -ktot) + bvv;
+      }
+    if (a.stat_part) {
+      // BatchNorm batch statistics of what is about to be stored (as in conv3x3_split_wide_kernel).  Scratch = the image the
+      // last chunk was read from (cc - 1): the other one already holds the next tile's first chunk.
+      float* red = reinterpret_cast<float*>(lds + ((cc - 1) & 1) * LBUF);   // [8 waves][2][32 channels][33]
+      float* rowsum = red + 8 * 2 * 32 * 33;                       // [512]
+      static_assert((8 * 2 * 32 * 33 + 512) * 4 <= LBUF * 16, "statistics scratch fits one image");
+      const int tile = g.tile;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float sv = 0.f, qv = 0.f;
+#pragma unroll
+          for (int ng = 0; ng < NG; ++ng) { const float v = pin[ng] ? acc[mt][ng][r] : 0.f; sv += v; qv += v * v; }
+          const int chl = (r & 3) + 8 * (r >> 2) + 4 * h;            // channel within this 32-channel block
+          red[((wave * 2 + 0) * 32 + chl) * 33 + l31] = sv;
+          red[((wave * 2 + 1) * 32 + chl) * 33 + l31] = qv;
+        }
+        __syncthreads();
+        {
+          const float* row = red + tid * 33;                         // row tid = (wave, quantity, channel)
+          float t = 0.f;
+#pragma unroll
+          for (int i = 0; i < 32; ++i) t += row[i];
+          rowsum[tid] = t;
+        }
+        __syncthreads();
+        if (tid < 64) {                                              // (quantity, channel): the 8 waves in order
+          const int wh = tid >> 5, chl = tid & 31;
+          double t = 0.0;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) t += (double)rowsum[(w * 2 + wh) * 32 + chl];
+          const int o = o0 + mt * 32 + chl;
+          if (o < a.Cout) a.stat_part[((size_t)o * a.stat_tiles + tile) * 2 + wh] = t;
+        }
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) {
+      if (pin[ng]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (o < a.Cout) {
+            const float res = conv_epilogue(a.ep, acc[mt][ng][r], o);
+            a.out[obase[ng] + (size_t)o * H * W] = res;
+            omax = fmaxf(omax, fabsf(res));
+          }
+        }
+      }
+    }
+    if (!more) break;
+    L = Ln; g = gn;
+#pragma unroll
+    for (int j = 0; j < NPS; ++j) voff[j] = voffn[j];
+  }
+#undef GR_BF_OPS
+#undef GR_BF_MMA
+#undef GR_BF_PIN
+#undef GR_P16_DMA
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+
 // ---------------------------------------------------------------- nearest x2 up-sampling + 3x3 convolution as four 2x2 convolutions
 // nn.SpatialUpSamplingNearest(2) followed by the 3x3 convolution (G: models.lua:121-122,127-128) reads every source pixel
 // through several taps: for output pixel (2y+a, 2x+b) the three tap rows 2y+a-1 .. 2y+a+1 of the up-sampled plane are only
@@ -1512,6 +1740,46 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
   a.stat_part = stat_tiles ? stat_part : nullptr;
   const int nt = nterm == 2 ? launch_conv3x3_split_n<2>(a, wsplit, s) : launch_conv3x3_split_n<3>(a, wsplit, s);
   if (stat_tiles) *stat_tiles = nt;
+}
+
+// f16x3 convolution on an operand-ready (P16) activation: see conv3x3_p16_wide_kernel
+bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("GR_NO_P16"); on = e ? 0 : 1; }
+  if (!on || Cin % 16 != 0 || round_up(Cout, 32) % 64 != 0 || (size_t)B * Cin * H * W * 4 >= 0x7FFFF000ul) return false;
+  const long otiles = round_up(Cout, 32) / 64;
+  if (H == 16 && W == 16) return (long)((B + 1) / 2) * otiles >= 256;
+  return W >= 32 && W % 32 == 0 && H % 16 == 0 && (long)B * (H / 16) * (W / 32) * otiles >= 256;
+}
+template <int TW, int NI>
+static int launch_conv_p16_t(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {
+  constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
+  constexpr int PVP = (4 * PS + P16_PAD - 1) / P16_PAD * P16_PAD, LBUF = PVP + 36 * CT;
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;
+  a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
+  const size_t lds = 2 * 16 * (size_t)LBUF;
+  a.n_tiles = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
+  a.stat_tiles = a.n_tiles / a.n_otiles;
+  const int grid = a.n_tiles > 256 ? 256 : a.n_tiles;                 // persistent: one workgroup per CU walks the tiles
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_wide_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = "conv3x3_p16_wide_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";   // as rocprofv3 prints it
+  const double px = (double)a.B * a.H * a.W;
+  KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+  hipLaunchKernelGGL((conv3x3_p16_wide_kernel<TW, NI>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
+  return a.stat_tiles;
+}
+void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                        hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out,
+                        double* stat_part, int* stat_tiles) {
+  ConvArgs a{};
+  if (ep) a.ep = *ep;
+  a.in = nullptr; a.wt = nullptr; a.bias = bias; a.out = out;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = 0;
+  a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
+  a.stat_part = stat_tiles ? stat_part : nullptr;
+  const int nt = (H == 16 && W == 16) ? launch_conv_p16_t<16, 2>(a, wsplit, x_p16, s) : launch_conv_p16_t<32, 1>(a, wsplit, x_p16, s);
+  if (stat_tiles) *stat_tiles = stat_part ? nt : 0;
 }
 
 // ---------------------------------------------------------------- weight layout preparation

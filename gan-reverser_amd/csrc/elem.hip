@@ -157,8 +157,79 @@ __global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
+// Operand-ready variant: one thread = 4 consecutive OUTPUT pixels of a row x the 8 channels of group g = c / 8.  Besides the
+// fp32 tensor it writes the consumer's image p16[b][g][term][pixel] (16 bytes = the 8 channels' fp16 halves of one term),
+// scaled by the power of two that the consumer's slot - an upper bound of max|out| fixed before this launch - defines: a wave's
+// stores per term are 4 KB contiguous.  Same arithmetic per element as post_forward_vec_kernel.
+bool post_g8_supported(int C, int H, int W, bool pool) {
+  const int Ho = pool ? H >> 1 : H, Wo = pool ? W >> 1 : W;
+  return C % 8 == 0 && (pool ? (W % 8 == 0 && H % 2 == 0) : (W % 4 == 0)) && (Ho * Wo) % 256 == 0;   // a wave stays inside one (b, g) plane
+}
+__global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
+  const unsigned H = a.H, W = a.W, Ho = a.pool ? H >> 1 : H, Wo = a.pool ? W >> 1 : W;
+  const unsigned HW = H * W, HWo = Ho * Wo, q_per_plane = HWo >> 2, wq = Wo >> 2, G = (unsigned)a.C >> 3;
+  const unsigned n4 = (unsigned)a.B * G * q_per_plane;
+  const float sc = pow2f(f16_scale_exp(absmax_read(a.p16_scale)));
+  uint4* p16 = reinterpret_cast<uint4*>(a.p16);
+  for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
+    const unsigned bg = __builtin_amdgcn_readfirstlane(i4 / q_per_plane);      // wave-uniform: (Ho * Wo) % 256 == 0
+    const unsigned within = i4 - bg * q_per_plane, b = bg / G, g = bg - b * G;
+    float vals[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned c = 8 * g + j, bc = b * (unsigned)a.C + c;
+      float mean = 0.f, invstd = 1.f, gm = 1.f, bt = 0.f;
+      if (a.has_bn) { mean = a.mean[c]; invstd = a.invstd[c]; gm = a.gamma[c]; bt = a.beta[c]; }
+      const unsigned eo = bc * HWo + within * 4;
+      float4 r;
+      if (a.pool) {
+        const unsigned yo = within / wq, xo = (within - yo * wq) * 4;
+        const unsigned e0 = bc * HW + (2 * yo) * W + 2 * xo, e1 = e0 + W;
+        const float4 t0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0), mean, invstd, gm, bt), mask4(a.m1, e0, bc));
+        const float4 t1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0 + 4), mean, invstd, gm, bt), mask4(a.m1, e0 + 4, bc));
+        const float4 b0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1), mean, invstd, gm, bt), mask4(a.m1, e1, bc));
+        const float4 b1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1 + 4), mean, invstd, gm, bt), mask4(a.m1, e1 + 4, bc));
+        const float top[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        const float bot[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[4]; uint32_t idx = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float best = -INFINITY; uint32_t bi = 0;      // scan order (0,0) (0,1) (1,0) (1,1); first strictly greater wins
+          if (top[2 * k] > best) { best = top[2 * k]; bi = 0; }
+          if (top[2 * k + 1] > best) { best = top[2 * k + 1]; bi = 1; }
+          if (bot[2 * k] > best) { best = bot[2 * k]; bi = 2; }
+          if (bot[2 * k + 1] > best) { best = bot[2 * k + 1]; bi = 3; }
+          o[k] = best; idx |= bi << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(a.pool_idx + eo) = idx;
+        r = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        r = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + eo), mean, invstd, gm, bt), mask4(a.m1, eo, bc));
+      }
+      const float4 res = mul4(r, mask4(a.m2, eo, bc));
+      *reinterpret_cast<float4*>(a.out + eo) = res;
+      vals[j][0] = res.x; vals[j][1] = res.y; vals[j][2] = res.z; vals[j][3] = res.w;
+    }
+    uint4* dst = p16 + (size_t)bg * 2 * HWo + within * 4;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const float x8[8] = {vals[0][px], vals[1][px], vals[2][px], vals[3][px], vals[4][px], vals[5][px], vals[6][px], vals[7][px]};
+      uint4 t0, t1;
+      split8_f16(x8, sc, t0, t1);
+      dst[px] = t0; dst[HWo + px] = t1;
+    }
+  }
+}
+
 void launch_post_forward(const PostArgs& a, hipStream_t s) {
   const long n = (long)a.B * a.C * (a.pool ? (a.H >> 1) * (a.W >> 1) : a.H * a.W);
+  if (a.p16) {      // caller checked post_g8_supported
+    long blocks = (n / 32 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    KtScope kt("post_forward_g8_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + 2.0 * (double)n), s);
+    hipLaunchKernelGGL(post_forward_g8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return;
+  }
   const bool vec = (a.pool ? (a.W % 8 == 0 && a.H % 2 == 0) : (a.W % 4 == 0)) && (long)a.B * a.C * a.H * a.W < (1l << 32);
   long blocks = ((vec ? n / 4 : n) + 255) / 256;
   if (blocks > 16384) blocks = 16384;
@@ -267,10 +338,15 @@ void launch_bn_stats(const float* y, int B, int C, int HW, double* partials, flo
                      mean, invstd, run_mean, run_var);
 }
 // one workgroup per channel: the conv epilogue's per-tile (sum, sum of squares) added in a fixed order
+__device__ __forceinline__ void amax_fold(unsigned* slot, int entry, float v) {
+  unsigned* e = slot + (entry % AMAX_ENTRIES) * AMAX_STRIDE;
+  atomicMax(e, __float_as_uint(v));
+}
 __global__ __launch_bounds__(256) void bn_stats_finalize_tiles_kernel(const double* __restrict__ part, int tiles, double n,
-                                                                       float* mean, float* invstd, float* run_mean, float* run_var) {
+                                                                       float* mean, float* invstd, float* run_mean, float* run_var, BnBounds bd) {
   __shared__ double sh[8];
   const int c = blockIdx.x;
+  const unsigned ymax_bits = bd.amax_y ? absmax_read(bd.amax_y) : 0u;
   double s = 0, q = 0;
 #pragma unroll 4
   for (int t = threadIdx.x; t < tiles; t += 256) { s += part[((size_t)c * tiles + t) * 2]; q += part[((size_t)c * tiles + t) * 2 + 1]; }
@@ -286,12 +362,24 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_tiles_kernel(const doub
       run_mean[c] = (float)(0.1 * m + 0.9 * (double)run_mean[c]);
       run_var[c] = (float)(0.1 * (vs / (n - 1)) + 0.9 * (double)run_var[c]);
     }
+    if (bd.amax_y) {
+      // |y - mean| <= max|y| + |mean| for every element of the channel; every activation on this path has |act(z)| <= |z|
+      // (ELU: |e^z - 1| <= |z| for z <= 0), Sigmoid / Tanh additionally <= 1; masks multiply by at most mask_scale
+      const float ymax = __uint_as_float(ymax_bits), is = invstd[c], dev = (ymax + fabsf(mean[c])) * is;
+      float zb = dev * fabsf(bd.gamma[c]) + fabsf(bd.beta[c]);
+      if (bd.act == ACT_SIGMOID || bd.act == ACT_TANH) zb = fminf(zb, 1.f);
+      if (bd.bound_out) amax_fold(bd.bound_out, c, zb * bd.mask_scale * 1.0001f);
+      // backward: dy = ((dz - mean(dz)) - yhat * mean(yhat dz)) * invstd * gamma, |mean(dz)| <= max|dz|,
+      // |mean(yhat dz)| <= sqrt(mean yhat^2) * max|dz| <= max|dz|  =>  |dy| <= (2 + max|yhat|) * invstd * |gamma| * max|dz|
+      if (bd.kb_out) amax_fold(bd.kb_out, c, (2.f + dev) * is * fabsf(bd.gamma[c]) * 1.0001f);
+    }
   }
 }
 void launch_bn_stats_from_tiles(const double* stat_part, int tiles, int C, double n, float* mean, float* invstd,
-                                float* run_mean, float* run_var, hipStream_t s) {
+                                float* run_mean, float* run_var, hipStream_t s, const BnBounds* bounds) {
   KtScope kt("bn_stats_finalize_tiles_kernel", 0.0, 16.0 * tiles * C, s);
-  hipLaunchKernelGGL(bn_stats_finalize_tiles_kernel, dim3(C), dim3(256), 0, s, stat_part, tiles, n, mean, invstd, run_mean, run_var);
+  BnBounds bd{}; if (bounds) bd = *bounds;
+  hipLaunchKernelGGL(bn_stats_finalize_tiles_kernel, dim3(C), dim3(256), 0, s, stat_part, tiles, n, mean, invstd, run_mean, run_var, bd);
 }
 void launch_bn_eval_prepare(const float* rm, const float* rv, float* mean, float* invstd, int C, hipStream_t s) {
   hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, s, rm, rv, mean, invstd, C);
@@ -405,6 +493,7 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
     }
   }
   if (a.amax_dy && !f.has_bn) absmax_commit(dmax, a.amax_dy);      // without BN pass A's dz is the final dy
+  if (a.amax_dz) absmax_commit(dmax, a.amax_dz);                    // max|dz|: pass B's a-priori bound of max|dy| (operand-ready dy)
   s = block_reduce_sum(s, sh);
   q = block_reduce_sum(q, sh);
   if (threadIdx.x == 0) { a.partials[((long)c * STAT_SPLITS + sp) * 2] = s; a.partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
@@ -459,6 +548,66 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
   if (a.amax_dy) absmax_commit(dmax, a.amax_dy);
   s = block_reduce_sum(s, sh);
   if (threadIdx.x == 0) a.partials_b[(long)c * STAT_SPLITS + sp] = s;
+}
+
+// Operand-ready pass B: block (8-channel group, batch slice); thread = 4 consecutive pre-pool pixels x the group's 8 channels.
+// Writes dy as fp32 (weight gradient) AND as the data-gradient convolution's image dy_p16[b][g][term][pixel], scaled by the
+// power of two of the bound K * max|dz| (K from the forward's statistics, max|dz| from pass A) that it also leaves in amax_dy.
+__global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, int splits, double n) {
+  __shared__ double sh[8];
+  __shared__ float par[8][6];          // mean, invstd, gamma, beta, gm, k
+  const PostArgs& f = a.f;
+  const int g = blockIdx.x, sp = blockIdx.y;
+  const float bound = __uint_as_float(absmax_read(a.amax_dz)) * __uint_as_float(absmax_read(a.kb));
+  if (threadIdx.x < 8) {
+    const int c = 8 * g + threadIdx.x;
+    double s = 0, q = 0;
+    for (int k = 0; k < splits; ++k) { s += a.partials[((long)c * STAT_SPLITS + k) * 2]; q += a.partials[((long)c * STAT_SPLITS + k) * 2 + 1]; }
+    const double invstd = f.invstd[c];
+    par[threadIdx.x][0] = f.mean[c]; par[threadIdx.x][1] = f.invstd[c]; par[threadIdx.x][2] = f.gamma[c]; par[threadIdx.x][3] = f.beta[c];
+    par[threadIdx.x][4] = (float)(s / n);
+    par[threadIdx.x][5] = (float)(q * invstd * invstd / n);
+    if (sp == 0) { a.ggamma[c] += (float)(q * invstd); a.gbeta[c] += (float)s; }
+  }
+  if (threadIdx.x == 0) a.amax_dy[((blockIdx.x + blockIdx.y * gridDim.x) % AMAX_ENTRIES) * AMAX_STRIDE] = __float_as_uint(bound);   // the same value from every block
+  __syncthreads();
+  const float sc = pow2f(f16_scale_exp(__float_as_uint(bound)));
+  const unsigned H = f.H, W = f.W, Wo = f.pool ? W >> 1 : W, HW = H * W, HWo = f.pool ? (H >> 1) * Wo : HW, q4 = HW >> 2, wq = W >> 2;
+  const unsigned G = (unsigned)f.C >> 3;
+  const int per = (f.B + splits - 1) / splits, b0 = sp * per, b1 = min(f.B, b0 + per);
+  uint4* p16 = reinterpret_cast<uint4*>(a.dy_p16);
+  double sums[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned tot = b1 > b0 ? (unsigned)(b1 - b0) * q4 : 0u;
+  for (unsigned j = threadIdx.x; j < tot; j += 256) {
+    const unsigned bb = j / q4, i = j - bb * q4, b = (unsigned)b0 + bb;
+    float vals[8][4];
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc) {
+      const unsigned c = 8 * g + jc, bc = b * f.C + c;
+      const float mean = par[jc][0], invstd = par[jc][1], w = par[jc][2], bt = par[jc][3], gm = par[jc][4], k = par[jc][5];
+      float4 yv;
+      const float4 dz = post_bwd_dz4(a, bc, bc * HW + i * 4, i, bc * HWo, wq, Wo, mean, invstd, w, bt, yv);   // as pass A computed it
+      float4 d;
+      d.x = ((dz.x - gm) - (yv.x - mean) * k) * invstd * w; d.y = ((dz.y - gm) - (yv.y - mean) * k) * invstd * w;
+      d.z = ((dz.z - gm) - (yv.z - mean) * k) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * k) * invstd * w;
+      reinterpret_cast<float4*>(a.dy + (size_t)bc * HW)[i] = d;
+      sums[jc] += (double)d.x + (double)d.y + (double)d.z + (double)d.w;
+      vals[jc][0] = d.x; vals[jc][1] = d.y; vals[jc][2] = d.z; vals[jc][3] = d.w;
+    }
+    uint4* dst = p16 + ((size_t)b * G + g) * 2 * HW + i * 4;
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const float x8[8] = {vals[0][px], vals[1][px], vals[2][px], vals[3][px], vals[4][px], vals[5][px], vals[6][px], vals[7][px]};
+      uint4 t0, t1;
+      split8_f16(x8, sc, t0, t1);
+      dst[px] = t0; dst[HW + px] = t1;
+    }
+  }
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc) {
+    const double t = block_reduce_sum(sums[jc], sh);
+    if (threadIdx.x == 0) a.partials_b[(long)(8 * g + jc) * STAT_SPLITS + sp] = t;
+  }
 }
 
 __global__ void post_backward_finalize_kernel(PostBwdArgs a, int splits, double n) {
@@ -541,7 +690,10 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
     hipLaunchKernelGGL(post_backward_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a, splits, (double)n);
     return;
   }
-  if (vec) {
+  if (vec && a.dy_p16) {      // caller checked post_g8_supported
+    KtScope kt("post_backward_b_g8_kernel", 0.0, 4.0 * (3.0 * pre + post), s);                       // reads g and y, writes dy twice (fp32 + operand-ready)
+    hipLaunchKernelGGL(post_backward_b_g8_kernel, dim3(f.C / 8, splits), dim3(256), 0, s, a, splits, (double)n);
+  } else if (vec) {
     KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);                      // reads g and y, writes dy
     hipLaunchKernelGGL(post_backward_b_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits, (double)n);
   } else {

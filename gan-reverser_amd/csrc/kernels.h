@@ -140,10 +140,21 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
                           // conv_stat_tiles_max tiles); *stat_tiles = tiles written per channel, 0 when the kernel chosen
                           // for this shape does not produce them (then run launch_bn_stats on the output)
                           double* stat_part = nullptr, int* stat_tiles = nullptr);
+// Operand-ready activations ("P16"): p16[b][c / 8][term][pixel] = 16 bytes = the 8 fp16 halves of term `term` (hi, lo) of
+// channels 8(c/8) .. +7 at that pixel, scaled by the power of two the tensor's scale slot defines (f16_scale_exp of its
+// bits).  Same bytes as the fp32 tensor.  Written by the pipeline kernels (elem.hip), read by LDS-DMA in conv3x3_p16_wide_kernel.
+bool conv_p16_supported(int B, int Cin, int Cout, int H, int W);
+void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                        hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out,
+                        double* stat_part, int* stat_tiles);
 inline size_t conv_stat_tiles_max(int B, int H, int W) { return (size_t)B * ((H + 15) / 16) * ((W + 31) / 32) + 1; }
 // mean / invstd (+ running statistics) from the per-tile (sum, sum of squares) the conv epilogue wrote
+// bounds (nullable): from max|y| (slot amax_y) and the fresh statistics, an upper bound of max|pipeline output| is folded into
+// bound_out (the consuming convolution's scale slot) and the factor K with max|dy| <= K * max|dz| of the stage's backward
+// into kb_out - both known BEFORE the kernels that write those tensors run, so they can write them operand-ready
+struct BnBounds { const unsigned* amax_y; const float *gamma, *beta; int act; float mask_scale; unsigned* bound_out; unsigned* kb_out; };
 void launch_bn_stats_from_tiles(const double* stat_part, int tiles, int C, double n, float* mean, float* invstd,
-                                float* run_mean, float* run_var, hipStream_t s);
+                                float* run_mean, float* run_var, hipStream_t s, const BnBounds* bounds = nullptr);
 
 // nearest x2 up-sampling + conv3x3 as four 2x2 convolutions of the source plane (f16x3 arithmetic; forward only):
 // 4 instead of 9 multiply-adds per output.  Shapes: source plane 8x8, 16x16 or at least 17 wide; Cout > 4.
@@ -199,6 +210,10 @@ struct PostArgs {
   uint8_t* pool_idx;       // [B,C,Ho,Wo] argmax 0..3
   MaskRef m2;              // applied after the pool, indexed at [B,C,Ho,Wo] / [B,C]
   unsigned* amax_out;      // nullable: max|out| is folded into this slot (f16x3 scale of the consuming convolution)
+  // operand-ready copy of `out` for the convolution that consumes it (see conv_p16_supported): p16 != null selects the
+  // 8-channel-group kernel; p16_scale = the consumer's scale slot, which already holds an UPPER BOUND of max|out| (written by
+  // launch_bn_stats_from_tiles from the batch statistics and max|y|) - amax_out must then be null
+  void* p16; const unsigned* p16_scale;
 };
 void launch_post_forward(const PostArgs& a, hipStream_t s);
 
@@ -219,7 +234,12 @@ struct PostBwdArgs {
   unsigned* amax_dy;       // nullable: max|dy| is folded into this slot (f16x3 scale of the weight / data gradients)
   double* partials_b;      // [C][STAT_SPLITS] pass B's per-channel sums of dy (bias gradient); separate from `partials`,
                            // which every pass-B workgroup of the channel still reads (BN coefficients are derived in pass B)
+  // operand-ready copy of dy for the data-gradient convolution: dy_p16 != null selects the 8-channel-group pass B.  amax_dz
+  // receives max|dz| from pass A; kb holds the forward's factor K (BnBounds); pass B writes the bound K * max|dz| into amax_dy
+  // (which then must not be accumulated into) and scales by it.
+  void* dy_p16; unsigned* amax_dz; const unsigned* kb;
 };
+bool post_g8_supported(int C, int H, int W, bool pool);
 // Bias gradients are summed from partials_b by one batched launch for several stages (launch_bias_grad_batch) when
 // `defer` is given; otherwise inside the call.
 struct BiasJob { const double* partials; float* gbias; int C, splits; };

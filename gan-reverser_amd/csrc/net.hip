@@ -232,6 +232,10 @@ struct Stage {
   void* ws_up = nullptr; uint64_t ws_up_version = 0;   // f16x3 image of the fused up-sampling kernel (four 2x2 convolutions)
   uint64_t amax_x_fwd = 0;                  // gr_net::amax_gen at which amax_x was last taken
   unsigned *amax_x = nullptr, *amax_dy = nullptr, *amax_w = nullptr;   // f16x3: slots (in gr_net::amax) for max|x_in|, max|dy|, max|w|
+  unsigned *amax_y = nullptr, *amax_kb = nullptr, *amax_dz = nullptr;  // max|y| (raw main-op output), the backward bound factor K (BnBounds), max|dz|
+  void* x_p16 = nullptr; size_t x_p16_cap = 0;   // operand-ready copy of this stage's INPUT, written by the previous stage's pipeline kernel
+  uint64_t x_p16_gen = 0;                         // gr_net::amax_gen at which x_p16 (and the bound in amax_x) was written
+  uint64_t kb_gen = 0;                            // ... at which amax_kb / amax_y were written (operand-ready dy possible in the backward)
   float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr; double* partials_b = nullptr;
   int stat_tiles_last = 0;                  // tiles the last forward's conv epilogue wrote (0: none - run the statistics pass)
   double* stat_part = nullptr;              // per-tile (sum, sum of squares) written by the conv epilogue in training mode (sized per batch)
@@ -256,14 +260,16 @@ struct gr_net {
   uint64_t amax_gen = 0;                // generation of the f16x3 scale slots: one per forward, never restarted, so a reseed cannot make a stale slot look fresh
   int capB = 0, lastB = 0;
   float *in_buf = nullptr, *gout_buf = nullptr, *dy_buf = nullptr, *g_buf[2] = {nullptr, nullptr};
+  void* dy_p16 = nullptr;            // operand-ready copy of dy_buf for the data-gradient convolution
   size_t max_y = 0, max_in = 0;      // per-sample element counts
   uint8_t* mask_stage = nullptr; size_t mask_stage_cap = 0;
   PrepJob* jobs_dev[3] = {nullptr, nullptr, nullptr}; int njobs[3] = {0, 0, 0};   // [0] fp32 k-major images, [1] bf16x6, [2] f16x3 split images
   uint64_t prepped_version[3] = {0, 0, 0};
-  unsigned* amax = nullptr;          // f16x3 scale tracking: [nst] x slots, [nst] dy slots, [nst] weight slots
+  unsigned* amax = nullptr;          // f16x3 scale tracking, groups of [nst] slots: x | y | kb | dy | dz | w  (AMAX_GROUPS)
   bool dy_slots_zeroed = false, w_slots_zeroed = false;   // set by forward_impl's single fill, consumed by backward / weight prep
 };
 
+enum { AG_X = 0, AG_Y = 1, AG_KB = 2, AG_DY = 3, AG_DZ = 4, AG_W = 5, AMAX_GROUPS = 6 };
 static int64_t vol3(int c, int h, int w) { return (int64_t)c * h * w; }
 static bool is_act(int k) { return k == GR_ELU || k == GR_RELU || k == GR_LEAKYRELU || k == GR_SIGMOID || k == GR_TANH; }
 
@@ -277,12 +283,12 @@ extern "C" int gr_net_destroy(gr_net* n) {
     if (s.has_post) (void)hipFree(s.out);
     (void)hipFree(s.pool_idx); (void)hipFree(s.wt_fwd); (void)hipFree(s.wt_bwd); (void)hipFree(s.ws_fwd); (void)hipFree(s.ws_up); (void)hipFree(s.ws_bwd);
     (void)hipFree(s.mean); (void)hipFree(s.invstd); (void)hipFree(s.coef); (void)hipFree(s.partials); (void)hipFree(s.partials_b); (void)hipFree(s.stat_part);
-    (void)hipFree(s.run_mean); (void)hipFree(s.run_var);
+    (void)hipFree(s.run_mean); (void)hipFree(s.run_var); (void)hipFree(s.x_p16);
   }
   for (auto& m : n->masks) (void)hipFree(m.bits);
   (void)hipFree(n->params); (void)hipFree(n->grads); (void)hipFree(n->adam_m); (void)hipFree(n->adam_v);
   (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
-  (void)hipFree(n->mask_stage); (void)hipFree(n->jobs_dev[0]); (void)hipFree(n->jobs_dev[1]); (void)hipFree(n->jobs_dev[2]); (void)hipFree(n->amax);
+  (void)hipFree(n->dy_p16); (void)hipFree(n->mask_stage); (void)hipFree(n->jobs_dev[0]); (void)hipFree(n->jobs_dev[1]); (void)hipFree(n->jobs_dev[2]); (void)hipFree(n->amax);
   delete n;
   return GR_OK;
 }
@@ -406,9 +412,13 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
   }
   {
     std::vector<PrepJob> jf, js, jh;
-    HIPCHK(c, hipMalloc((void**)&n->amax, sizeof(unsigned) * AMAX_WORDS * 3 * n->st.size()));
-    HIPCHK(c, hipMemset(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * 3 * n->st.size()));
-    for (size_t si = 0, ns = n->st.size(); si < ns; ++si) { Stage& s = n->st[si]; s.amax_x = n->amax + AMAX_WORDS * si; s.amax_dy = n->amax + AMAX_WORDS * (ns + si); s.amax_w = n->amax + AMAX_WORDS * (2 * ns + si); }
+    HIPCHK(c, hipMalloc((void**)&n->amax, sizeof(unsigned) * AMAX_WORDS * AMAX_GROUPS * n->st.size()));
+    HIPCHK(c, hipMemset(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * AMAX_GROUPS * n->st.size()));
+    for (size_t si = 0, ns = n->st.size(); si < ns; ++si) {
+      Stage& s = n->st[si];
+      auto slot = [&](int grp) { return n->amax + AMAX_WORDS * (grp * ns + si); };
+      s.amax_x = slot(AG_X); s.amax_y = slot(AG_Y); s.amax_kb = slot(AG_KB); s.amax_dy = slot(AG_DY); s.amax_dz = slot(AG_DZ); s.amax_w = slot(AG_W);
+    }
     for (auto& s : n->st) {
       if (s.kind != ST_CONV) continue;
       if (!s.fullconv) {
@@ -544,7 +554,13 @@ static int ensure_batch(gr_net* n, int B) {
       HIPCHK(c, hipMalloc((void**)&s.stat_part, sizeof(double) * 2 * (size_t)s.Cout * conv_stat_tiles_max(B, s.H, s.W)));
     }
     if (s.pool) { (void)hipFree(s.pool_idx); s.pool_idx = nullptr; HIPCHK(c, hipMalloc((void**)&s.pool_idx, (size_t)B * vol3(s.outC, s.outH, s.outW))); }
+    if (s.kind == ST_CONV && !s.up && !s.fullconv && s.Cin % 16 == 0) {       // operand-ready input image (same bytes as the fp32 input)
+      (void)hipFree(s.x_p16); s.x_p16 = nullptr; s.x_p16_gen = 0;
+      HIPCHK(c, hipMalloc(&s.x_p16, sizeof(float) * (size_t)B * vol3(s.inC, s.inH, s.inW)));
+    }
   }
+  (void)hipFree(n->dy_p16); n->dy_p16 = nullptr;
+  HIPCHK(c, hipMalloc(&n->dy_p16, sizeof(float) * (size_t)B * n->max_y));
   (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
   n->in_buf = n->gout_buf = n->dy_buf = n->g_buf[0] = n->g_buf[1] = nullptr;
   HIPCHK(c, hipMalloc((void**)&n->in_buf, sizeof(float) * (size_t)B * vol3(n->inC, n->inH, n->inW)));
@@ -576,7 +592,7 @@ static int prep_weights(gr_net* n) {
     if (!(m == mode || (m == 0 && any_full))) continue;
     if (n->prepped_version[m] == n->params_version) continue;
     // the bf16 and f16 images share their buffers: switching the mode invalidates the other flavour
-    if (m == 2) launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream, n->amax + AMAX_WORDS * 2 * n->st.size(),
+    if (m == 2) launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream, n->amax + AMAX_WORDS * AG_W * n->st.size(),
                                               n->w_slots_zeroed ? 0 : (int)n->st.size());     // 0: the caller has just zeroed the slots
     else launch_conv_weight_prep_batch(n->jobs_dev[m], n->njobs[m], n->params, c->stream);
     LAUNCHCHK(c);
@@ -640,10 +656,10 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
   n->w_slots_zeroed = false;
   if (f16) {
     const bool w_too = n->training && n->prepped_version[2] != n->params_version;
-    const size_t groups = w_too ? 3 : (n->training ? 2 : 1);
+    const size_t groups = w_too ? AMAX_GROUPS : (n->training ? AG_W : 1);      // x | y kb dy dz | w
     HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst * groups, c->stream));
-    n->dy_slots_zeroed = groups >= 2;
-    n->w_slots_zeroed = groups == 3;
+    n->dy_slots_zeroed = groups >= (size_t)AG_W;
+    n->w_slots_zeroed = groups == (size_t)AMAX_GROUPS;
   }
   r = prep_weights(n); if (r) return r;
   {
@@ -693,24 +709,34 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
       static const bool epi_stats_on = !getenv("GR_NO_EPI_STATS");
       const bool want_stats = epi_stats_on && n->training && s.has_bn && s.stat_part && !s.fused_epilogue;
       int stat_tiles = 0;
+      // f16x3 training: max|y| of the raw output rides along (slot amax_y): with the batch statistics it bounds max|pipeline
+      // output| and max|dy| BEFORE the kernels that write those tensors run, so they can write them operand-ready (P16)
+      const bool track_y = f16 && want_stats;
+      const bool last_writer = s.fused_epilogue || !s.has_post;
+      unsigned* conv_amax_out = last_writer ? amax_next : (track_y ? s.amax_y : nullptr);
       static const bool fewin_on = !getenv("GR_NO_FEWIN");
       if (fewin_on && !s.fullconv && conv_fewin_applies(s.Cin, s.W, s.up)) {
-        const bool last_writer = s.fused_epilogue || !s.has_post;
-        launch_conv3x3_fewin(x, n->params + s.w_off, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, last_writer ? amax_next : nullptr,
+        launch_conv3x3_fewin(x, n->params + s.w_off, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, conv_amax_out,
                              want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
         if (last_writer && nx) nx->amax_x_fwd = n->amax_gen;
       } else if (use_bf16x6(n, s)) {
         const int nterm = c->conv_mode == 2 ? 2 : 3;
-        // input not produced by a tracking kernel (the net's own input, a GEMM, a VALU conv): take its maximum now
-        if (nterm == 2 && s.amax_x_fwd != n->amax_gen) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream, true); s.amax_x_fwd = n->amax_gen; }
-        const bool last_writer = s.fused_epilogue || !s.has_post;
         static const bool up2_on = !getenv("GR_NO_UP2");
-        if (nterm == 2 && s.up && s.ws_up && up2_on)
-          launch_conv3x3_up2_f16x3(x, s.ws_up, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, s.amax_x, s.amax_w,
-                                   last_writer ? amax_next : nullptr);
-        else
-          launch_conv3x3_split(x, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, epp, nterm, s.amax_x, s.amax_w,
-                               last_writer ? amax_next : nullptr, want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
+        if (nterm == 2 && !s.up && s.x_p16 && s.x_p16_gen == n->amax_gen) {
+          // the previous stage's pipeline kernel left this stage's input operand-ready, scaled by the bound in amax_x
+          launch_conv3x3_p16(s.x_p16, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, s.amax_x, s.amax_w, conv_amax_out,
+                             want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
+        } else {
+          // input not produced by a tracking kernel (the net's own input, a GEMM, a VALU conv): take its maximum now
+          if (nterm == 2 && s.amax_x_fwd != n->amax_gen) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream, true); s.amax_x_fwd = n->amax_gen; }
+          if (nterm == 2 && s.up && s.ws_up && up2_on)
+            launch_conv3x3_up2_f16x3(x, s.ws_up, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, s.amax_x, s.amax_w,
+                                     last_writer ? amax_next : nullptr);
+          else
+            launch_conv3x3_split(x, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, epp, nterm, s.amax_x, s.amax_w,
+                                 (nterm == 2 && !s.up) ? conv_amax_out : (last_writer ? amax_next : nullptr),
+                                 want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
+        }
         if (last_writer && nx) nx->amax_x_fwd = n->amax_gen;
       }
       else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off, epp);
@@ -750,16 +776,31 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     LAUNCHCHK(c);
     if (!s.has_post) { s.out = s.y; x = s.out; continue; }
     const float* yv = s.kind == ST_ELEM ? x : s.y;
+    PostArgs pa = post_args(n, s, B);
+    bool p16_out = false;
     if (s.has_bn) {
       if (n->training) s.eval_ready = false;          // mean / invstd become batch statistics, the running statistics move
-      if (n->training && s.kind == ST_CONV && s.stat_tiles_last > 0)
-        launch_bn_stats_from_tiles(s.stat_part, s.stat_tiles_last, s.Cout, (double)B * s.H * s.W, s.mean, s.invstd, s.run_mean, s.run_var, c->stream);
+      if (n->training && s.kind == ST_CONV && s.stat_tiles_last > 0) {
+        // f16x3: the statistics kernel also folds the a-priori bounds (BnBounds) - into the NEXT convolution's scale slot when
+        // this stage's pipeline kernel can write that convolution's input operand-ready, and into this stage's backward factor
+        BnBounds bd{}; const BnBounds* bdp = nullptr;
+        if (f16 && !s.up && !s.fullconv) {
+          p16_out = nx && nx->kind == ST_CONV && nx->x_p16 && !nx->up && !nx->fullconv && use_bf16x6(n, *nx) &&
+                    post_g8_supported(s.Cout, s.H, s.W, s.pool) && conv_p16_supported(B, nx->Cin, nx->Cout, nx->H, nx->W);
+          bd.amax_y = s.amax_y; bd.gamma = pa.gamma; bd.beta = pa.beta; bd.act = s.act;
+          bd.mask_scale = fmaxf(1.f, pa.m1.scale) * fmaxf(1.f, pa.m2.scale);
+          bd.bound_out = p16_out ? nx->amax_x : nullptr; bd.kb_out = s.amax_kb;
+          bdp = &bd; s.kb_gen = n->amax_gen;
+        }
+        launch_bn_stats_from_tiles(s.stat_part, s.stat_tiles_last, s.Cout, (double)B * s.H * s.W, s.mean, s.invstd, s.run_mean, s.run_var, c->stream, bdp);
+      }
       else if (n->training) launch_bn_stats(yv, B, s.Cout, s.H * s.W, s.partials, s.mean, s.invstd, s.run_mean, s.run_var, 1, c->stream);
       else if (!s.eval_ready) { launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream); s.eval_ready = true; }
     }
-    PostArgs pa = post_args(n, s, B);
-    pa.amax_out = amax_next;
+    pa.amax_out = p16_out ? nullptr : amax_next;      // operand-ready: the slot already holds the bound and must not move
+    pa.p16 = p16_out ? nx->x_p16 : nullptr; pa.p16_scale = p16_out ? nx->amax_x : nullptr;
     launch_post_forward(pa, c->stream);
+    if (p16_out) nx->x_p16_gen = n->amax_gen;
     if (nx) nx->amax_x_fwd = n->amax_gen;
     LAUNCHCHK(c);
     x = s.out;
@@ -848,7 +889,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
   { int r = prep_weights(n); if (r) return r; }   // no-op unless the arithmetic mode changed since the forward
   const bool f16 = c->conv_mode == 2;
   if (f16 && !n->dy_slots_zeroed)   // the dy slots (already zero when this is the first backward after a training-mode forward)
-    HIPCHK(c, hipMemsetAsync(n->amax + AMAX_WORDS * n->st.size(), 0, sizeof(unsigned) * AMAX_WORDS * n->st.size(), c->stream));
+    HIPCHK(c, hipMemsetAsync(n->amax + AMAX_WORDS * AG_DY * n->st.size(), 0, sizeof(unsigned) * AMAX_WORDS * 2 * n->st.size(), c->stream));   // dy and dz groups
   n->dy_slots_zeroed = false;
   const float* g = gout_dev;
   for (int si = (int)n->st.size() - 1; si >= 0; --si) {
@@ -867,6 +908,10 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     pb.ggamma = s.has_bn ? n->grads + s.g_off : nullptr; pb.gbeta = s.has_bn ? n->grads + s.be_off : nullptr;
     pb.gbias = s.kind == ST_ELEM ? nullptr : n->grads + s.b_off;
     pb.amax_dy = (f16 && ((s.kind == ST_CONV && !s.up && !s.fullconv) || use_f16_gemm(n, s))) ? s.amax_dy : nullptr;
+    // operand-ready dy for the data-gradient convolution: needs the forward's bound factor of THIS forward (kb_gen)
+    const bool dy_p16 = f16 && s.kind == ST_CONV && !s.up && !s.fullconv && s.has_bn && need_gin && n->dy_p16 && s.kb_gen == n->amax_gen &&
+                        post_g8_supported(s.Cout, s.H, s.W, s.pool) && conv_p16_supported(B, s.Cout, s.Cin, s.H, s.W);
+    pb.dy_p16 = dy_p16 ? n->dy_p16 : nullptr; pb.amax_dz = dy_p16 ? s.amax_dz : nullptr; pb.kb = s.amax_kb;
     launch_post_backward(pb, c->stream, &bias_jobs);       // bias gradients of several stages are summed by one launch
     LAUNCHCHK(c);
     if (s.kind == ST_CONV) {
@@ -881,7 +926,8 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode, s.amax_x, s.amax_dy);
       if (need_gin) {
         // backward-data = the same convolution on the transposed + flipped weights (Cout -> Cin)
-        if (c->conv_mode >= 1) launch_conv3x3_split(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
+        if (dy_p16) launch_conv3x3_p16(n->dy_p16, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, c->stream, nullptr, s.amax_dy, s.amax_w, nullptr, nullptr, nullptr);
+        else if (c->conv_mode >= 1) launch_conv3x3_split(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
         else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
       }
       LAUNCHCHK(c);

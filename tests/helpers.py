@@ -75,7 +75,7 @@ def pools_well_conditioned(model, onet, B, gap=2e-6):
 # tests (1) read the argmax both sides took (gr_net_get_pool_index / go_net_get_pool_index), (2) require the windows where
 # they differ to be FEW and each to be a genuine near-tie in the oracle's own forward, and (3) re-run the oracle with the
 # device's argmax forced, after which every gradient tensor is held to the strict bar.
-NEAR_TIE = 1e-5
+NEAR_TIE = 3e-5      # activations are O(1) and correct to about 3-5e-6 on either side (TOL is 1e-4): a gap below this can swap
 
 
 def pool_layers(model, onet):
@@ -120,10 +120,24 @@ def param_segments(model):
 
 
 def assert_grads_close(model, got, ref, rtol=1e-4, floor=1e-3, what=""):
-    """every parameter tensor's gradient within rtol of that tensor's largest reference entry (floor: tensors whose true
-    gradient is zero - conv biases under BatchNorm - hold rounding noise only)"""
-    for mod, nm, lo, hi in param_segments(model):
+    """Every parameter tensor's gradient within rtol of the largest reference gradient entry of ITS MODULE (weight and bias
+    together).  Exception: a convolution / Linear bias directly in front of a BatchNorm has an exactly-zero true gradient
+    (BatchNorm's backward makes sum(dy) vanish per channel): what both sides hold there is the rounding residue of a sum of
+    B*H*W terms, not a quantity with digits to compare - it is required to BE residue on both sides (below 1e-3 of the
+    module's weight gradient), which is what a wrong bias-gradient kernel would violate."""
+    segs = param_segments(model)
+    leaves = model.leaves()
+    mod_max = {}
+    for mod, nm, lo, hi in segs:
+        mod_max[id(mod)] = max(mod_max.get(id(mod), 0.0), float(np.abs(ref[lo:hi]).max()))
+    for mod, nm, lo, hi in segs:
         r, g = ref[lo:hi], got[lo:hi]
-        gmax = max(float(np.abs(r).max()), floor)
+        gmax = max(mod_max[id(mod)], floor)
+        li = leaves.index(mod)
+        before_bn = li + 1 < len(leaves) and leaves[li + 1].typename.endswith("BatchNormalization") and not mod.typename.endswith("BatchNormalization")
+        if nm == "bias" and before_bn:
+            assert float(np.abs(g).max()) <= 1e-3 * gmax and float(np.abs(r).max()) <= 1e-3 * gmax, \
+                f"{what} {mod.typename}.bias [{lo}:{hi}] in front of BatchNorm: |g| {np.abs(g).max():.3e} (oracle {np.abs(r).max():.3e}) is not rounding residue of {gmax:.3e}"
+            continue
         d = maxdiff(g, r)
-        assert d <= rtol * gmax, f"{what} {mod.typename}.{nm} [{lo}:{hi}]: max |diff| {d:.3e} vs max |g| {gmax:.3e}"
+        assert d <= rtol * gmax, f"{what} {mod.typename}.{nm} [{lo}:{hi}]: max |diff| {d:.3e} vs module max |g| {gmax:.3e}"
