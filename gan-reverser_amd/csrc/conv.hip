@@ -1009,9 +1009,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
 // Two LDS images; the DMA of the next chunk IN THE STREAM (tiles are walked persistently, so that is the next tile's first
 // chunk at a tile's end) is issued at the top of a chunk and waited for (vmcnt(0) + barrier) at its bottom.
 constexpr int P16_PAD = 64;          // LDS regions are multiples of one wave-instruction's 64 vectors
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes land at lds_dst + 16 * lane, lane l fetching rsrc[voff_l + soff]
+// (out-of-range lanes write zeros - verified on gfx950 by tools/probe/dma_probe.hip).  The builtin only exists in the device
+// pass; hipcc drops the kernel's host stub if the host pass meets it, hence the guard.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, uint4* lds_dst, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#else
+  (void)rsrc; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
 template <int TW, int NI>
 __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
-  constexpr int NT = 512, MT = 2, NTERM = 2;
+  constexpr int MT = 2, NTERM = 2;
   constexpr int NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int PV = NTERM * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;      // patch vectors (padded to whole instructions)
   constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT;                                 // weight vectors: one instruction per row
@@ -1053,7 +1063,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
       const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
       const int yy = g.y0 + r - 1, xx = g.x0 + c - 1;
       const bool inb = e < PV && yy >= 0 && yy < H && xx >= 0 && xx < W && g.b + img < a.B;
-      voff_[j] = inb ? ((((g.b + img) * G + hh) * 2 + t) * HW + yy * W + xx) * 16 : (int)0x7FFFF000;
+      voff_[j] = inb ? ((((g.b + img) * G + hh) * 2 + t) * HW + (int)p16_pos((unsigned)(yy * W + xx))) * 16 : (int)0x7FFFF000;
     }
   };
   int woff[NWS];                                                     // weight row r = wave + 8 j of the chunk's slab
@@ -1068,12 +1078,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
     const int psoff_ = (ch_) * HW * 64;                               /* 2 groups x 2 terms x HW x 16 B per chunk */ \
     _Pragma("unroll") for (int j = 0; j < NPS; ++j) {                                                     \
       const int i_ = wave + 8 * j;                                                                        \
-      if (i_ < NPI) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(img_ + 64 * i_), 16, voff_[j], psoff_, 0, 0); \
+      if (i_ < NPI) lds_dma16(rin, img_ + 64 * i_, voff_[j], psoff_);                                     \
     }                                                                                                     \
     const int wsoff_ = (ch_) * WROWS * a.cout_pad * 16;                                                   \
     _Pragma("unroll") for (int j = 0; j < NWS; ++j) {                                                     \
       const int r_ = wave + 8 * j;                                                                        \
-      if (r_ < WROWS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwt, (__attribute__((address_space(3))) void*)(img_ + PVP + 64 * r_), 16, woff[j], wsoff_, 0, 0); \
+      if (r_ < WROWS) lds_dma16(rwt, img_ + PVP + 64 * r_, woff[j], wsoff_);                              \
     }                                                                                                     \
   }
   f32x16 acc[MT][NG];
@@ -1097,6 +1107,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
     _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) acc[mt][ng] = split_mma<NTERM>(av_[mt], bv_[ng], acc[mt][ng]);
 #define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, (MT + NG) * NTERM, 0); __builtin_amdgcn_sched_group_barrier(0x008, MT * NG * 3, 0);
   float omax = 0.f;
+  const int dbg = a.up;                                              // diagnostic bit mask (0 in production): see g_p16_debug
   int L = blockIdx.x;
   Geo g = tile_geo(L);
   int voff[NPS];
@@ -1119,12 +1130,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
     for (int j = 0; j < NPS; ++j) voffn[j] = voff[j];
     for (int ch = 0; ch < nchunks; ++ch, ++cc) {
       // the other image is free since the barrier that ended the previous chunk: fetch the next chunk of the stream into it
-      if (ch + 1 < nchunks) GR_P16_DMA((cc + 1) & 1, ch + 1, voff)
+      if (ch + 1 < nchunks) { if (!(dbg & 4)) GR_P16_DMA((cc + 1) & 1, ch + 1, voff) }
       else if (more) {                                               // last chunk of this tile: the next tile's first chunk
         gn = tile_geo(Ln); stage_offsets(gn, voffn); weight_offsets(gn);
-        GR_P16_DMA((cc + 1) & 1, 0, voffn)
+        if (!(dbg & 4)) GR_P16_DMA((cc + 1) & 1, 0, voffn)
       }
       const uint4* pc_ = lds + (cc & 1) * LBUF; const uint4* wc_ = pc_ + PVP;
+      if (!(dbg & 8)) {
       uint4 avA[MT][NTERM], bvA[NG][NTERM], avB[MT][NTERM], bvB[NG][NTERM];
       GR_BF_OPS(pc_, wc_, 0, avA, bvA)
       GR_BF_OPS(pc_, wc_, 1, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
@@ -1136,6 +1148,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
       GR_BF_OPS(pc_, wc_, 7, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
       GR_BF_OPS(pc_, wc_, 8, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
       GR_BF_MMA(avA, bvA)
+      }
       __syncthreads();                                               // vmcnt(0): the DMA issued above has landed; every wave is past image cc & 1
     }
     const int y0 = g.y0, x0 = g.x0, o0 = g.o0, b = g.b;
@@ -1158,7 +1171,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
 #pragma unroll
         for (int ng = 0; ng < NG; ++ng) acc[mt][ng][r] = ldexpf(acc[mt][ng][r], -ktot) + bvv;
       }
-    if (a.stat_part) {
+    if (a.stat_part && !(dbg & 2)) {
       // BatchNorm batch statistics of what is about to be stored (as in conv3x3_split_wide_kernel).  Scratch = the image the
       // last chunk was read from (cc - 1): the other one already holds the next tile's first chunk.
       float* red = reinterpret_cast<float*>(lds + ((cc - 1) & 1) * LBUF);   // [8 waves][2][32 channels][33]
@@ -1198,7 +1211,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
     }
 #pragma unroll
     for (int ng = 0; ng < NG; ++ng) {
-      if (pin[ng]) {
+      if (pin[ng] && !(dbg & 1)) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1221,6 +1234,243 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
 #undef GR_BF_MMA
 #undef GR_BF_PIN
 #undef GR_P16_DMA
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+
+// ---------------------------------------------------------------- the same, as TWO independent workgroups per CU
+// Ablation of conv3x3_p16_wide_kernel on R.conv2 at cfg2 (tools/ablate_p16.py): skeleton 10.7 us + MFMA and LDS reads 35.5 +
+// output stores 22 + DMA 9 = the 76 us it takes - its eight waves move through DMA issue, multiply and epilogue in lock-step and
+// nothing overlaps.  Here a workgroup is FOUR waves (one per SIMD) that own the same 512-pixel x 64-channel tile, 128 pixels x
+// 64 channels = 8 accumulator blocks per wave, with ONE operand image (76.8 KB): two workgroups are resident per CU and run
+// out of phase by themselves, so while one waits for its DMA or stores its tile the other one has the matrix pipe.  An operand
+// vector feeds more MFMAs than before (12 reads per 24 MFMAs per tap); staging and compute of ONE workgroup are serial
+// (DMA -> barrier -> 216 MFMAs per wave -> barrier).
+template <int TW, int NI>
+__global__ __launch_bounds__(256, 2) void conv3x3_p16_quad_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
+  constexpr int MT = 2, NTERM = 2, NW = 4;
+  constexpr int NG = 4, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
+  constexpr int PV = NTERM * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;
+  constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT;
+  constexpr int LBUF = PVP + WV;
+  constexpr int NPI = PVP / 64, NPS = (NPI + NW - 1) / NW, NWS = (WROWS + NW - 1) / NW;
+  static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2), "tile_pixel assumes these tilings");
+  static_assert(2 * LBUF * 16 <= 160 * 1024, "two workgroups per CU");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* lds = reinterpret_cast<uint4*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int G = a.Cin >> 3;
+  const int dbg = a.up;
+  int bid = xcd_remap(blockIdx.x, a.n_tiles);
+  const int tile = bid / a.n_otiles;
+  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = (bid / a.tiles_y) * NI;
+  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * CT;
+  const int nchunks = a.Cin / BF_CK;
+  const size_t xbytes = (size_t)a.B * G * 2 * HW * 16;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(xin), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wsplit), 0,
+      (int)((size_t)nchunks * WROWS * a.cout_pad * 16), 0x00020000);
+  const int ktot = f16_scale_exp(absmax_read(a.amax_in)) + f16_scale_exp(absmax_read(a.amax_w));
+  int voff[NPS], woff[NWS];
+#pragma unroll
+  for (int j = 0; j < NPS; ++j) {
+    const int e = 64 * (wave + NW * j) + lane;
+    const int q = e / PS, pos = e - q * PS, t = q >> 1, hh = q & 1;     // plane q = term * 2 + half
+    const int rr = pos / PC, c = pos - rr * PC;
+    const int img = NI > 1 ? rr / (IH + 2) : 0, r = NI > 1 ? rr - img * (IH + 2) : rr;
+    const int yy = y0 + r - 1, xx = x0 + c - 1;
+    const bool inb = e < PV && yy >= 0 && yy < H && xx >= 0 && xx < W && b + img < a.B;
+    voff[j] = inb ? ((((b + img) * G + hh) * 2 + t) * HW + (int)p16_pos((unsigned)(yy * W + xx))) * 16 : (int)0x7FFFF000;
+  }
+#pragma unroll
+  for (int j = 0; j < NWS; ++j) { const int r = wave + NW * j; woff[j] = r < WROWS ? (r * a.cout_pad + o0 + lane) * 16 : (int)0x7FFFF000; }
+#define GR_P16_DMA(ch_)                                                                                   \
+  {                                                                                                       \
+    const int psoff_ = (ch_) * HW * 64;                                                                   \
+    _Pragma("unroll") for (int j = 0; j < NPS; ++j) {                                                     \
+      const int i_ = wave + NW * j;                                                                       \
+      if (i_ < NPI) lds_dma16(rin, lds + 64 * i_, voff[j], psoff_);                                       \
+    }                                                                                                     \
+    const int wsoff_ = (ch_) * WROWS * a.cout_pad * 16;                                                   \
+    _Pragma("unroll") for (int j = 0; j < NWS; ++j) {                                                     \
+      const int r_ = wave + NW * j;                                                                       \
+      if (r_ < WROWS) lds_dma16(rwt, lds + PVP + 64 * r_, woff[j], wsoff_);                               \
+    }                                                                                                     \
+  }
+  f32x16 acc[MT][NG];
+  int pix[NG];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;
+    pix[ng] = h * PS + pr * PC + pc;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][ng][r] = 0.f;
+  const uint4* patch = lds; const uint4* wts = lds + PVP;
+  // diagnostic build path (dbg & 32, never in production): wave 0 stamps its phases into a.wt (reused as a debug buffer)
+  unsigned long long* stamps = (dbg & 32) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.wt)) + (size_t)blockIdx.x * 32 : nullptr;
+  int nstamp = 0;
+#define GR_STAMP() if (stamps && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[nstamp++] = t_; }
+  if (stamps && tid == 0) {
+    stamps[nstamp++] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | ((32 - 1) << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((32 - 1) << 11)) << 32);
+    unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[nstamp++] = t_;
+  }
+  GR_STAMP()
+  // The two workgroups of a CU should alternate (one multiplies while the other stages / stores).  A grid that fits the chip
+  // in one round starts them all together, in phase; the workgroups dispatched second (ids >= 256: observed placement, used
+  // for speed only) therefore start half a compute phase late.
+  // (which two workgroups share a CU is the dispatcher's business: the second one to arrive finds its waves in the odd wave
+  // slots of the SIMDs - HW_ID.wave_id - whatever its block index is)
+  if (a.nchunks > 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));     // HW_REG_HW_ID bits [3:0] = wave slot on its SIMD
+    if (hwid & 1) {
+#pragma unroll 1
+      for (int i = 0; i < a.nchunks; ++i) __builtin_amdgcn_s_sleep(8);  // a.nchunks (unused otherwise on this path) = the delay in units of 8 x 64 clocks
+    }
+  }
+  if (!(dbg & 4)) GR_P16_DMA(0)
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();                                                 // vmcnt(0) + barrier: the image holds chunk ch
+    GR_STAMP()
+    if (!(dbg & 8)) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = (tap / 3) * PC + (tap % 3);
+        uint4 av[MT][NTERM], bv[NG][NTERM];
+#pragma unroll
+        for (int s = 0; s < NTERM; ++s) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) av[mt][s] = wts[((s * 9 + tap) * 2 + h) * CT + mt * 32 + l31];
+#pragma unroll
+          for (int ng = 0; ng < NG; ++ng) bv[ng][s] = patch[s * 2 * PS + pix[ng] + toff];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int ng = 0; ng < NG; ++ng) acc[mt][ng] = split_mma<NTERM>(av[mt], bv[ng], acc[mt][ng]);
+      }
+    }
+    __syncthreads();                                                 // every wave is past the image
+    GR_STAMP()
+    if (ch + 1 < nchunks && !(dbg & 4)) GR_P16_DMA(ch + 1)
+  }
+#undef GR_P16_DMA
+  bool pin[NG]; size_t obase[NG];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
+    const int y = y0 + pr, x = x0 + pc;
+    pin[ng] = y < H && x < W && b + img < a.B;
+    obase[ng] = ((size_t)(b + img) * a.Cout * H + y) * W + x;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float bvv = (a.bias && o < a.Cout) ? a.bias[o] : 0.f;
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) acc[mt][ng][r] = ldexpf(acc[mt][ng][r], -ktot) + bvv;
+    }
+  if (a.stat_part && !(dbg & 2)) {
+    // BatchNorm batch statistics of what is about to be stored: per (wave, channel) 128 pixels = four per lane over 32 lanes;
+    // the per-lane sums go through LDS transposed ([wave][quantity][channel][lane], row stride 33), one thread adds a row in
+    // lane order, then the 4 waves are added in fp64 - a fixed order.  The operand image is dead by now.
+    float* red = reinterpret_cast<float*>(smem_raw);             // [4 waves][2][32 channels][33]
+    float* rowsum = red + NW * 2 * 32 * 33;                      // [256]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng) { const float v = pin[ng] ? acc[mt][ng][r] : 0.f; sv += v; qv += v * v; }
+        const int chl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        red[((wave * 2 + 0) * 32 + chl) * 33 + l31] = sv;
+        red[((wave * 2 + 1) * 32 + chl) * 33 + l31] = qv;
+      }
+      __syncthreads();
+      {
+        const float* row = red + tid * 33;                         // row tid = (wave, quantity, channel)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += row[i];
+        rowsum[tid] = t;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int wh = tid >> 5, chl = tid & 31;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += (double)rowsum[(w * 2 + wh) * 32 + chl];
+        const int o = o0 + mt * 32 + chl;
+        if (o < a.Cout) a.stat_part[((size_t)o * a.stat_tiles + tile) * 2 + wh] = t;
+      }
+      __syncthreads();
+    }
+  }
+  // Output stores through an LDS transpose.  The accumulator layout (lane = pixel, register = channel) gives one dword per
+  // lane per store: 256 store instructions per lane and tile, 2.2 TB/s (store-issue-bound: 30 of the kernel's 69 us on R.conv2
+  // at cfg2).  Per 32-channel block each wave writes its 128 pixels x 32 channels to its own LDS region [channel][pixel]
+  // (row stride 132 floats) and reads them back as 4 consecutive pixels of one channel per lane: 16-byte stores, a
+  // wave-instruction covering all 128 pixels (512 contiguous bytes on a 32-wide plane) of two channels - 32 store
+  // instructions per lane and tile.  The operand image is dead by now; the regions are per wave, so no barrier is needed
+  // (a wave's LDS operations execute in order).
+  float omax = 0.f;
+  {
+    constexpr int RS = 132;
+    static_assert(NW * 32 * RS * 4 <= LBUF * 16, "staging fits the operand image");
+    float* stg = reinterpret_cast<float*>(smem_raw) + wave * 32 * RS;
+    // this lane's quad of pixels: k = lane & 31 -> pixels 4k .. 4k+3 of the wave's 128 (consecutive in x)
+    const int kq = lane & 31, hq = lane >> 5;
+    const int pq = (wave * NG + (kq >> 3)) * 32 + 4 * (kq & 7); int prrq, pcq; tile_pixel<TW>(pq, prrq, pcq);
+    const int imgq = NI > 1 ? prrq / IH : 0, prq = NI > 1 ? prrq - imgq * IH : prrq;
+    const int yq = y0 + prq, xq = x0 + pcq;
+    const bool inq = yq < H && xq < W && b + imgq < a.B && !(dbg & 1);
+    float* outq = a.out + ((size_t)(b + imgq) * a.Cout * H + yq) * W + xq;
+    // (training-mode stages store the raw output: the per-element epilogue switch is taken once per workgroup, not 128 times)
+    const bool plain = a.ep.mean == nullptr && a.ep.act == ACT_NONE;
+    const bool want_max = a.amax_out != nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (plain) {
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * RS + ng * 32 + l31] = acc[mt][ng][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int chl = (r & 3) + 8 * (r >> 2) + 4 * h, o = min(o0 + mt * 32 + chl, a.Cout - 1);
+          float v4[NG];
+#pragma unroll
+          for (int ng = 0; ng < NG; ++ng) v4[ng] = a.ep.mean ? __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(acc[mt][ng][r], a.ep.mean[o]), a.ep.invstd[o]), a.ep.gamma[o]), a.ep.beta[o]) : acc[mt][ng][r];
+          conv_act_block<NG>(a.ep, v4);
+#pragma unroll
+          for (int ng = 0; ng < NG; ++ng) stg[chl * RS + ng * 32 + l31] = v4[ng];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int chl = 2 * i + hq, o = o0 + mt * 32 + chl;
+        const float4 v = *reinterpret_cast<const float4*>(stg + chl * RS + 4 * kq);
+        if (inq && o < a.Cout) {
+          *reinterpret_cast<float4*>(outq + (size_t)o * H * W) = v;
+          if (want_max) omax = absmax4(omax, v);
+        }
+      }
+    }
+  }
+  if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GR_STAMP() if (tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[nstamp++] = t_; stamps[31] = nstamp; } }
+#undef GR_STAMP
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
@@ -1743,16 +1993,45 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
 }
 
 // f16x3 convolution on an operand-ready (P16) activation: see conv3x3_p16_wide_kernel
+int g_p16_debug = 0;
+void* g_p16_stamps = nullptr;     // diagnostic: device buffer of 32 x 8 bytes per workgroup (gr_debug_stamps)
+int g_p16_min_tiles = 256;      // fewer tiles than CUs: the 256-pixel-tile kernels fill the chip better (gr_set_tuning("p16_min_tiles"): tests force the path)
 bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("GR_NO_P16"); on = e ? 0 : 1; }
-  if (!on || Cin % 16 != 0 || round_up(Cout, 32) % 64 != 0 || (size_t)B * Cin * H * W * 4 >= 0x7FFFF000ul) return false;
+  if (!on || Cin % 16 != 0 || (H * W) % 256 != 0 || round_up(Cout, 32) % 64 != 0 || (size_t)B * Cin * H * W * 4 >= 0x7FFFF000ul) return false;
   const long otiles = round_up(Cout, 32) / 64;
-  if (H == 16 && W == 16) return (long)((B + 1) / 2) * otiles >= 256;
-  return W >= 32 && W % 32 == 0 && H % 16 == 0 && (long)B * (H / 16) * (W / 32) * otiles >= 256;
+  if (H == 16 && W == 16) return (long)((B + 1) / 2) * otiles >= g_p16_min_tiles;
+  return W >= 32 && W % 32 == 0 && H % 16 == 0 && (long)B * (H / 16) * (W / 32) * otiles >= g_p16_min_tiles;
+}
+int g_p16_stagger = 0;           // start delay (x 512 clocks) of the second-dispatched workgroups: measured useless (tools/stagger_p16.py), kept as a knob
+int g_p16_variant = 1;          // 1: four-wave workgroups, two per CU (conv3x3_p16_quad_kernel); 0: eight-wave persistent (conv3x3_p16_wide_kernel)
+template <int TW, int NI>
+static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {
+  constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
+  constexpr int PVP = (4 * PS + P16_PAD - 1) / P16_PAD * P16_PAD, LBUF = PVP + 36 * CT;
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;
+  a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
+  const size_t lds = 16 * (size_t)LBUF;
+  a.n_tiles = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
+  a.stat_tiles = a.n_tiles / a.n_otiles;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true;
+    if (getenv("GR_DEBUG_OCC")) {
+      int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI>), 256, lds);
+      fprintf(stderr, "conv3x3_p16_quad_kernel<%d, %d>: %zu B LDS per workgroup, occupancy query says %d workgroups per CU\n", TW, NI, lds, nb);
+    }
+  }
+  static const std::string name = "conv3x3_p16_quad_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";   // as rocprofv3 prints it
+  const double px = (double)a.B * a.H * a.W;
+  KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+  hipLaunchKernelGGL((conv3x3_p16_quad_kernel<TW, NI>), dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
+  return a.stat_tiles;
 }
 template <int TW, int NI>
 static int launch_conv_p16_t(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {
+  if (g_p16_variant == 1) return launch_conv_p16_quad<TW, NI>(a, wsplit, xin, s);
   constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
   constexpr int PVP = (4 * PS + P16_PAD - 1) / P16_PAD * P16_PAD, LBUF = PVP + 36 * CT;
   a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;
@@ -1774,8 +2053,8 @@ void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias
                         double* stat_part, int* stat_tiles) {
   ConvArgs a{};
   if (ep) a.ep = *ep;
-  a.in = nullptr; a.wt = nullptr; a.bias = bias; a.out = out;
-  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = 0;
+  a.in = nullptr; a.wt = (g_p16_debug & 32) ? reinterpret_cast<const float*>(g_p16_stamps) : nullptr; a.bias = bias; a.out = out;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = g_p16_debug; a.nchunks = g_p16_stagger;
   a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
   a.stat_part = stat_tiles ? stat_part : nullptr;
   const int nt = (H == 16 && W == 16) ? launch_conv_p16_t<16, 2>(a, wsplit, x_p16, s) : launch_conv_p16_t<32, 1>(a, wsplit, x_p16, s);

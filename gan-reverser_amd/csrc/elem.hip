@@ -28,7 +28,11 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sh) {
 
 __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
   switch (act) {
-    case ACT_ELU: return z <= 0.f ? (expf(z) - 1.f) * 1.f : z;
+    // ELU on the hardware exponential (v_exp_f32 of z * log2 e: 2 instructions instead of expf's ~15; these pipelines are
+    // VALU-bound, not HBM-bound: ~35 instructions per element before).  For z <= 0 the result's absolute error stays below
+    // 3e-7 (measured against expf over [-30, 0]): two orders below the 1e-4 bar, and expf was never bit-identical to the
+    // host libm anyway.
+    case ACT_ELU: return z <= 0.f ? (__expf(z) - 1.f) * 1.f : z;
     case ACT_RELU: return z > 0.f ? z : 0.f;
     case ACT_LEAKYRELU: return z > 0.f ? z : z * slope;
     case ACT_SIGMOID: return 1.f / (1.f + expf(-z));
@@ -104,6 +108,16 @@ __device__ __forceinline__ float4 mask4(const MaskRef& m, unsigned e, unsigned b
   }
   return r;
 }
+__device__ __forceinline__ uint32_t mask_word(const MaskRef& m, unsigned e, unsigned bc) {      // the mask bits of elements e.. (e % 4 == 0), bit 0 first
+  if (m.kind == MASK_ELEM) return m.bits[e >> 5] >> (e & 31);
+  if (m.kind == MASK_SPATIAL) return ((m.bits[bc >> 5] >> (bc & 31)) & 1u) ? 0xFu : 0u;
+  return 0xFu;
+}
+__device__ __forceinline__ float4 mask4_of(const MaskRef& m, uint32_t w) {
+  if (m.kind == MASK_NONE) return make_float4(1.f, 1.f, 1.f, 1.f);
+  if (m.kind == MASK_SCALE) return make_float4(m.scale, m.scale, m.scale, m.scale);
+  return make_float4((w & 1u) ? m.scale : 0.f, (w & 2u) ? m.scale : 0.f, (w & 4u) ? m.scale : 0.f, (w & 8u) ? m.scale : 0.f);
+}
 __device__ __forceinline__ float4 bn_act4(const PostArgs& a, float4 v, float mean, float invstd, float g, float bt) {
   if (a.has_bn) {
     v.x = ((v.x - mean) * invstd) * g + bt; v.y = ((v.y - mean) * invstd) * g + bt;
@@ -161,12 +175,14 @@ __global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
 // fp32 tensor it writes the consumer's image p16[b][g][term][pixel] (16 bytes = the 8 channels' fp16 halves of one term),
 // scaled by the power of two that the consumer's slot - an upper bound of max|out| fixed before this launch - defines: a wave's
 // stores per term are 4 KB contiguous.  Same arithmetic per element as post_forward_vec_kernel.
-bool post_g8_supported(int C, int H, int W, bool pool) {
+bool post_g8_supported(int C, int H, int W, bool pool, bool backward) {
   const int Ho = pool ? H >> 1 : H, Wo = pool ? W >> 1 : W;
-  return C % 8 == 0 && (pool ? (W % 8 == 0 && H % 2 == 0) : (W % 4 == 0)) && (Ho * Wo) % 256 == 0;   // a wave stays inside one (b, g) plane
+  if (C % 8 != 0 || !(pool ? (W % 8 == 0 && H % 2 == 0) : (W % 4 == 0)) || H * W < 64) return false;
+  return backward ? (H * W) % 256 == 0 : (Ho * Wo) % 256 == 0;      // the image is quad-major in runs of 256 pixels; forward: a wave stays inside one (b, g) plane of the OUTPUT
 }
+template <bool POOL>
 __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
-  const unsigned H = a.H, W = a.W, Ho = a.pool ? H >> 1 : H, Wo = a.pool ? W >> 1 : W;
+  const unsigned H = a.H, W = a.W, Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
   const unsigned HW = H * W, HWo = Ho * Wo, q_per_plane = HWo >> 2, wq = Wo >> 2, G = (unsigned)a.C >> 3;
   const unsigned n4 = (unsigned)a.B * G * q_per_plane;
   const float sc = pow2f(f16_scale_exp(absmax_read(a.p16_scale)));
@@ -175,6 +191,23 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
     const unsigned bg = __builtin_amdgcn_readfirstlane(i4 / q_per_plane);      // wave-uniform: (Ho * Wo) % 256 == 0
     const unsigned within = i4 - bg * q_per_plane, b = bg / G, g = bg - b * G;
     float vals[8][4];
+    // phase 1: every load of the eight channels (so that they are in flight together), phase 2: the arithmetic and the stores
+    float4 ld[8][POOL ? 4 : 1]; uint32_t m1w[8][POOL ? 4 : 1], m2w[8];
+    const unsigned yo = POOL ? within / wq : 0, xo = POOL ? (within - yo * wq) * 4 : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned bc = b * (unsigned)a.C + 8 * g + j, eo = bc * HWo + within * 4;
+      if constexpr (POOL) {
+        const unsigned e0 = bc * HW + (2 * yo) * W + 2 * xo, e1 = e0 + W;
+        ld[j][0] = *reinterpret_cast<const float4*>(a.y + e0); ld[j][1] = *reinterpret_cast<const float4*>(a.y + e0 + 4);
+        ld[j][2] = *reinterpret_cast<const float4*>(a.y + e1); ld[j][3] = *reinterpret_cast<const float4*>(a.y + e1 + 4);
+        m1w[j][0] = mask_word(a.m1, e0, bc); m1w[j][1] = mask_word(a.m1, e0 + 4, bc); m1w[j][2] = mask_word(a.m1, e1, bc); m1w[j][3] = mask_word(a.m1, e1 + 4, bc);
+      } else {
+        ld[j][0] = *reinterpret_cast<const float4*>(a.y + eo);
+        m1w[j][0] = mask_word(a.m1, eo, bc);
+      }
+      m2w[j] = mask_word(a.m2, eo, bc);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const unsigned c = 8 * g + j, bc = b * (unsigned)a.C + c;
@@ -182,13 +215,11 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
       if (a.has_bn) { mean = a.mean[c]; invstd = a.invstd[c]; gm = a.gamma[c]; bt = a.beta[c]; }
       const unsigned eo = bc * HWo + within * 4;
       float4 r;
-      if (a.pool) {
-        const unsigned yo = within / wq, xo = (within - yo * wq) * 4;
-        const unsigned e0 = bc * HW + (2 * yo) * W + 2 * xo, e1 = e0 + W;
-        const float4 t0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0), mean, invstd, gm, bt), mask4(a.m1, e0, bc));
-        const float4 t1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0 + 4), mean, invstd, gm, bt), mask4(a.m1, e0 + 4, bc));
-        const float4 b0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1), mean, invstd, gm, bt), mask4(a.m1, e1, bc));
-        const float4 b1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1 + 4), mean, invstd, gm, bt), mask4(a.m1, e1 + 4, bc));
+      if constexpr (POOL) {
+        const float4 t0 = mul4(bn_act4(a, ld[j][0], mean, invstd, gm, bt), mask4_of(a.m1, m1w[j][0]));
+        const float4 t1 = mul4(bn_act4(a, ld[j][1], mean, invstd, gm, bt), mask4_of(a.m1, m1w[j][1]));
+        const float4 b0 = mul4(bn_act4(a, ld[j][2], mean, invstd, gm, bt), mask4_of(a.m1, m1w[j][2]));
+        const float4 b1 = mul4(bn_act4(a, ld[j][3], mean, invstd, gm, bt), mask4_of(a.m1, m1w[j][3]));
         const float top[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         const float bot[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float o[4]; uint32_t idx = 0;
@@ -204,21 +235,50 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
         *reinterpret_cast<uint32_t*>(a.pool_idx + eo) = idx;
         r = make_float4(o[0], o[1], o[2], o[3]);
       } else {
-        r = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + eo), mean, invstd, gm, bt), mask4(a.m1, eo, bc));
+        r = mul4(bn_act4(a, ld[j][0], mean, invstd, gm, bt), mask4_of(a.m1, m1w[j][0]));
       }
-      const float4 res = mul4(r, mask4(a.m2, eo, bc));
+      const float4 res = mul4(r, mask4_of(a.m2, m2w[j]));
       *reinterpret_cast<float4*>(a.out + eo) = res;
       vals[j][0] = res.x; vals[j][1] = res.y; vals[j][2] = res.z; vals[j][3] = res.w;
     }
-    uint4* dst = p16 + (size_t)bg * 2 * HWo + within * 4;
+    uint4* dst = p16 + (size_t)bg * 2 * HWo + ((within >> 6) << 8) + (within & 63);      // quad-major inside runs of 256 pixels (p16_pos)
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
       const float x8[8] = {vals[0][px], vals[1][px], vals[2][px], vals[3][px], vals[4][px], vals[5][px], vals[6][px], vals[7][px]};
       uint4 t0, t1;
       split8_f16(x8, sc, t0, t1);
-      dst[px] = t0; dst[HWo + px] = t1;
+      dst[64 * px] = t0; dst[HWo + 64 * px] = t1;
     }
   }
+}
+
+// fp32 NCHW -> operand-ready image, scaled by the slot's power of two (stand-alone entry points, micro-benchmarks; inside a
+// net the pipeline kernels write the image directly)
+__global__ __launch_bounds__(256) void to_p16_kernel(const float* __restrict__ x, uint4* __restrict__ p16, int B, int C, int HW, const unsigned* __restrict__ slot) {
+  const float sc = pow2f(f16_scale_exp(absmax_read(slot)));
+  const unsigned qpp = (unsigned)HW >> 2, G = (unsigned)C >> 3, n4 = (unsigned)B * G * qpp;
+  for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
+    const unsigned bg = i4 / qpp, within = i4 - bg * qpp;
+    float vals[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)bg * 8 + j) * HW + within * 4);
+      vals[j][0] = v.x; vals[j][1] = v.y; vals[j][2] = v.z; vals[j][3] = v.w;
+    }
+    uint4* dst = p16 + (size_t)bg * 2 * HW + ((within >> 6) << 8) + (within & 63);           // quad-major inside runs of 256 pixels (p16_pos)
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const float x8[8] = {vals[0][px], vals[1][px], vals[2][px], vals[3][px], vals[4][px], vals[5][px], vals[6][px], vals[7][px]};
+      uint4 t0, t1;
+      split8_f16(x8, sc, t0, t1);
+      dst[64 * px] = t0; dst[HW + 64 * px] = t1;
+    }
+  }
+}
+void launch_to_p16(const float* x, void* p16, int B, int C, int HW, const unsigned* slot, hipStream_t s) {
+  long blocks = ((long)B * (C / 8) * (HW / 4) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(to_p16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, reinterpret_cast<uint4*>(p16), B, C, HW, slot);
 }
 
 void launch_post_forward(const PostArgs& a, hipStream_t s) {
@@ -227,7 +287,8 @@ void launch_post_forward(const PostArgs& a, hipStream_t s) {
     long blocks = (n / 32 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     KtScope kt("post_forward_g8_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + 2.0 * (double)n), s);
-    hipLaunchKernelGGL(post_forward_g8_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (a.pool) hipLaunchKernelGGL(post_forward_g8_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(post_forward_g8_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return;
   }
   const bool vec = (a.pool ? (a.W % 8 == 0 && a.H % 2 == 0) : (a.W % 4 == 0)) && (long)a.B * a.C * a.H * a.W < (1l << 32);
@@ -433,6 +494,56 @@ __global__ __launch_bounds__(256) void post_backward_a_kernel(PostBwdArgs a, int
 // gradOutput routed back through mask 2, the pool argmax, mask 1 and the activation.  Pass A sums it, pass B needs it again:
 // with BatchNorm both passes call this (bit-identical results) and dz is never written to memory - one tensor write and one
 // tensor read less than storing it.
+// The same in two phases for kernels that work on several channels per thread: all loads of a channel first (so that the loads
+// of eight channels are in flight together), the arithmetic afterwards.  Same operations in the same order as post_bwd_dz4.
+struct BwdRaw { float4 g, y; uint32_t id2, m2w, m1w, t0; };
+__device__ __forceinline__ BwdRaw post_bwd_load4(const PostBwdArgs& a, unsigned bc, unsigned e, unsigned i, unsigned obase, unsigned wq, unsigned Wo) {
+  const PostArgs& f = a.f;
+  BwdRaw r;
+  if (f.pool) {
+    const unsigned yy = i / wq, xx = (i - yy * wq) * 4, eo = obase + (yy >> 1) * Wo + (xx >> 1);
+    const float2 go = *reinterpret_cast<const float2*>(a.gout + eo);
+    r.g = make_float4(go.x, go.y, 0.f, 0.f);
+    r.id2 = *reinterpret_cast<const uint16_t*>(f.pool_idx + eo);
+    r.m2w = mask_word(f.m2, eo, bc);                  // eo is even: the bits of eo and eo + 1 sit in one word
+    r.t0 = (yy & 1) << 1;
+  } else {
+    r.g = *reinterpret_cast<const float4*>(a.gout + e);
+    r.id2 = 0; r.t0 = 0;
+    r.m2w = mask_word(f.m2, e, bc);
+  }
+  r.m1w = mask_word(f.m1, e, bc);
+  r.y = *reinterpret_cast<const float4*>(f.y + e);
+  return r;
+}
+__device__ __forceinline__ float4 post_bwd_dz_of(const PostBwdArgs& a, const BwdRaw& r, float mean, float invstd, float gm, float bt) {
+  const PostArgs& f = a.f;
+  float4 g;
+  if (f.pool) {
+    const float4 m2 = mask4_of(f.m2, r.m2w);
+    const float m20 = m2.x, m21 = m2.y;
+    g.x = ((r.id2 & 0xff) == r.t0) ? r.g.x * m20 : 0.f;
+    g.y = ((r.id2 & 0xff) == (r.t0 | 1)) ? r.g.x * m20 : 0.f;
+    g.z = ((r.id2 >> 8) == r.t0) ? r.g.y * m21 : 0.f;
+    g.w = ((r.id2 >> 8) == (r.t0 | 1)) ? r.g.y * m21 : 0.f;
+  } else {
+    g = mul4(r.g, mask4_of(f.m2, r.m2w));
+  }
+  g = mul4(g, mask4_of(f.m1, r.m1w));
+  const float4 yv = r.y;
+  float4 z = yv;
+  if (f.has_bn) {
+    z.x = ((yv.x - mean) * invstd) * gm + bt; z.y = ((yv.y - mean) * invstd) * gm + bt;
+    z.z = ((yv.z - mean) * invstd) * gm + bt; z.w = ((yv.w - mean) * invstd) * gm + bt;
+  }
+  float4 dz;
+  dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, f.slope), f.act, f.slope);
+  dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, f.slope), f.act, f.slope);
+  dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, f.slope), f.act, f.slope);
+  dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, f.slope), f.act, f.slope);
+  return dz;
+}
+
 __device__ __forceinline__ float4 post_bwd_dz4(const PostBwdArgs& a, unsigned bc, unsigned e, unsigned i, unsigned obase, unsigned wq, unsigned Wo,
                                                float mean, float invstd, float gm, float bt, float4& yv) {
   const PostArgs& f = a.f;
@@ -559,10 +670,18 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
   const PostArgs& f = a.f;
   const int g = blockIdx.x, sp = blockIdx.y;
   const float bound = __uint_as_float(absmax_read(a.amax_dz)) * __uint_as_float(absmax_read(a.kb));
+  // pass A's partial sums of the 8 channels: fetched by all threads at once (8 x 2 x splits doubles, contiguous), then added
+  // per channel in split order (the order post_bwd_coef uses)
+  __shared__ double sh_part[8 * 2 * STAT_SPLITS];
+  for (int i = threadIdx.x; i < 8 * 2 * STAT_SPLITS; i += 256) {
+    const int jc = i / (2 * STAT_SPLITS), r = i - jc * 2 * STAT_SPLITS;
+    sh_part[i] = r < 2 * splits ? a.partials[(long)(8 * g + jc) * STAT_SPLITS * 2 + r] : 0.0;
+  }
+  __syncthreads();
   if (threadIdx.x < 8) {
     const int c = 8 * g + threadIdx.x;
     double s = 0, q = 0;
-    for (int k = 0; k < splits; ++k) { s += a.partials[((long)c * STAT_SPLITS + k) * 2]; q += a.partials[((long)c * STAT_SPLITS + k) * 2 + 1]; }
+    for (int k = 0; k < splits; ++k) { s += sh_part[threadIdx.x * 2 * STAT_SPLITS + 2 * k]; q += sh_part[threadIdx.x * 2 * STAT_SPLITS + 2 * k + 1]; }
     const double invstd = f.invstd[c];
     par[threadIdx.x][0] = f.mean[c]; par[threadIdx.x][1] = f.invstd[c]; par[threadIdx.x][2] = f.gamma[c]; par[threadIdx.x][3] = f.beta[c];
     par[threadIdx.x][4] = (float)(s / n);
@@ -581,12 +700,18 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
   for (unsigned j = threadIdx.x; j < tot; j += 256) {
     const unsigned bb = j / q4, i = j - bb * q4, b = (unsigned)b0 + bb;
     float vals[8][4];
+    BwdRaw raw[8];
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc) {                     // phase 1: every load of the eight channels
+      const unsigned bc = b * f.C + 8 * g + jc;
+      raw[jc] = post_bwd_load4(a, bc, bc * HW + i * 4, i, bc * HWo, wq, Wo);
+    }
 #pragma unroll
     for (int jc = 0; jc < 8; ++jc) {
-      const unsigned c = 8 * g + jc, bc = b * f.C + c;
+      const unsigned bc = b * f.C + 8 * g + jc;
       const float mean = par[jc][0], invstd = par[jc][1], w = par[jc][2], bt = par[jc][3], gm = par[jc][4], k = par[jc][5];
-      float4 yv;
-      const float4 dz = post_bwd_dz4(a, bc, bc * HW + i * 4, i, bc * HWo, wq, Wo, mean, invstd, w, bt, yv);   // as pass A computed it
+      const float4 yv = raw[jc].y;
+      const float4 dz = post_bwd_dz_of(a, raw[jc], mean, invstd, w, bt);                    // as pass A computed it
       float4 d;
       d.x = ((dz.x - gm) - (yv.x - mean) * k) * invstd * w; d.y = ((dz.y - gm) - (yv.y - mean) * k) * invstd * w;
       d.z = ((dz.z - gm) - (yv.z - mean) * k) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * k) * invstd * w;
@@ -594,13 +719,13 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
       sums[jc] += (double)d.x + (double)d.y + (double)d.z + (double)d.w;
       vals[jc][0] = d.x; vals[jc][1] = d.y; vals[jc][2] = d.z; vals[jc][3] = d.w;
     }
-    uint4* dst = p16 + ((size_t)b * G + g) * 2 * HW + i * 4;
+    uint4* dst = p16 + ((size_t)b * G + g) * 2 * HW + ((i >> 6) << 8) + (i & 63);          // quad-major inside runs of 256 pixels (p16_pos)
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
       const float x8[8] = {vals[0][px], vals[1][px], vals[2][px], vals[3][px], vals[4][px], vals[5][px], vals[6][px], vals[7][px]};
       uint4 t0, t1;
       split8_f16(x8, sc, t0, t1);
-      dst[px] = t0; dst[HW + px] = t1;
+      dst[64 * px] = t0; dst[HW + 64 * px] = t1;
     }
   }
 #pragma unroll

@@ -140,9 +140,19 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
                           // conv_stat_tiles_max tiles); *stat_tiles = tiles written per channel, 0 when the kernel chosen
                           // for this shape does not produce them (then run launch_bn_stats on the output)
                           double* stat_part = nullptr, int* stat_tiles = nullptr);
-// Operand-ready activations ("P16"): p16[b][c / 8][term][pixel] = 16 bytes = the 8 fp16 halves of term `term` (hi, lo) of
+// Operand-ready activations ("P16"): p16[b][c / 8][term][p16_pos(pixel)] = 16 bytes = the 8 fp16 halves of term `term` (hi, lo) of
 // channels 8(c/8) .. +7 at that pixel, scaled by the power of two the tensor's scale slot defines (f16_scale_exp of its
-// bits).  Same bytes as the fp32 tensor.  Written by the pipeline kernels (elem.hip), read by LDS-DMA in conv3x3_p16_wide_kernel.
+// bits).  Same bytes as the fp32 tensor.  Written by the pipeline kernels (elem.hip), read by LDS-DMA in the conv3x3_p16_* kernels.
+// Inside every run of 256 pixels the vectors are stored "quad-major": pixel 4q + k sits at 64k + q.  A producer thread owns 4
+// consecutive pixels (it loads float4s), so its k-th store lands at 64k + lane: every store instruction of a wave writes 1 KB
+// contiguous instead of 16 bytes in each of 64 different 64-byte sectors.  The consumers gather by per-lane address anyway.
+extern int g_p16_min_tiles, g_p16_variant, g_p16_stagger;
+extern void* g_p16_stamps;
+extern int g_p16_debug;       // diagnostic builds only (GR_P16_DEBUG bit mask: 1 no output stores, 2 no statistics, 4 no DMA, 8 no MFMA)
+void launch_to_p16(const float* x, void* p16, int B, int C, int HW, const unsigned* slot, hipStream_t s);   // C % 8 == 0, HW % 4 == 0
+#if defined(__HIPCC__)
+__host__ __device__ __forceinline__ unsigned p16_pos(unsigned p) { return (p & ~255u) | ((p & 3u) << 6) | ((p >> 2) & 63u); }   // H * W % 256 == 0
+#endif
 bool conv_p16_supported(int B, int Cin, int Cout, int H, int W);
 void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                         hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out,
@@ -239,7 +249,7 @@ struct PostBwdArgs {
   // (which then must not be accumulated into) and scales by it.
   void* dy_p16; unsigned* amax_dz; const unsigned* kb;
 };
-bool post_g8_supported(int C, int H, int W, bool pool);
+bool post_g8_supported(int C, int H, int W, bool pool, bool backward = false);
 // Bias gradients are summed from partials_b by one batched launch for several stages (launch_bias_grad_batch) when
 // `defer` is given; otherwise inside the call.
 struct BiasJob { const double* partials; float* gbias; int C, splits; };

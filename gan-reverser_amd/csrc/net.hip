@@ -151,6 +151,16 @@ extern "C" int gr_set_conv_mode(gr_ctx* c, int mode) {
   return GR_OK;
 }
 extern "C" int gr_get_conv_mode(gr_ctx* c) { return c ? c->conv_mode : GR_ERR_INVALID; }
+// diagnostic: give the P16 kernels a device buffer (32 x 8 bytes per workgroup) for in-kernel time stamps ("p16_debug" bit 32)
+extern "C" int gr_debug_stamps(gr_ctx* c, void* dev_buf) { if (!c) return GR_ERR_INVALID; gr::g_p16_stamps = dev_buf; return GR_OK; }
+extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
+  if (!c || !key) return GR_ERR_INVALID;
+  if (!strcmp(key, "p16_min_tiles")) { gr::g_p16_min_tiles = value; return GR_OK; }
+  if (!strcmp(key, "p16_stagger")) { gr::g_p16_stagger = value; return GR_OK; }
+  if (!strcmp(key, "p16_variant")) { gr::g_p16_variant = value; return GR_OK; }
+  if (!strcmp(key, "p16_debug")) { gr::g_p16_debug = value; return GR_OK; }     // diagnostic ablations (outputs are then wrong by design)
+  return fail(c, GR_ERR_INVALID, "gr_set_tuning: unknown key %s", key);
+}
 extern "C" int gr_set_timing(gr_ctx* c, int en) {
   if (!c) return GR_ERR_INVALID;
   c->timing = en == 1;
@@ -910,7 +920,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     pb.amax_dy = (f16 && ((s.kind == ST_CONV && !s.up && !s.fullconv) || use_f16_gemm(n, s))) ? s.amax_dy : nullptr;
     // operand-ready dy for the data-gradient convolution: needs the forward's bound factor of THIS forward (kb_gen)
     const bool dy_p16 = f16 && s.kind == ST_CONV && !s.up && !s.fullconv && s.has_bn && need_gin && n->dy_p16 && s.kb_gen == n->amax_gen &&
-                        post_g8_supported(s.Cout, s.H, s.W, s.pool) && conv_p16_supported(B, s.Cout, s.Cin, s.H, s.W);
+                        post_g8_supported(s.Cout, s.H, s.W, s.pool, true) && conv_p16_supported(B, s.Cout, s.Cin, s.H, s.W);
     pb.dy_p16 = dy_p16 ? n->dy_p16 : nullptr; pb.amax_dz = dy_p16 ? s.amax_dz : nullptr; pb.kb = s.amax_kb;
     launch_post_backward(pb, c->stream, &bias_jobs);       // bias gradients of several stages are summed by one launch
     LAUNCHCHK(c);
@@ -1318,7 +1328,16 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
     HIPCHK(c, hipMalloc(&wup, conv_weight_up2_bytes(cin, cout)));
     launch_conv_weight_up2_split(w, wup, cin, cout, c->stream, c->amax + 2 * AMAX_WORDS, true);
   }
+  void* xp16 = nullptr; double* statp = nullptr;
+  if (which == 4 || which == 5) {   // operand-ready forward (5: with the BatchNorm statistics epilogue): x converted once outside the loop
+    if (c->conv_mode != 2 || !conv_p16_supported(B, cin, cout, h, wd)) return fail(c, GR_ERR_UNSUPPORTED, "p16 bench needs f16x3 mode and a supported shape");
+    HIPCHK(c, hipMalloc(&xp16, sizeof(float) * nin));
+    HIPCHK(c, hipMalloc((void**)&statp, sizeof(double) * 2 * cout * conv_stat_tiles_max(B, h, wd)));
+    launch_to_p16(x, xp16, B, cin, h * wd, c->amax, c->stream);
+    r = conv_split_once(c, w, cin, cout, false, &wsp); if (r) return r;
+  }
   auto run = [&]() {
+    if (which == 4 || which == 5) { int st = 0; launch_conv3x3_p16(xp16, wsp, nullptr, y, B, cin, cout, h, wd, c->stream, nullptr, c->amax, c->amax + 2 * AMAX_WORDS, nullptr, which == 5 ? statp : nullptr, which == 5 ? &st : nullptr); return; }
     if (which == 3) { launch_conv3x3_up2_f16x3(x, wup, nullptr, y, B, cin, cout, h, wd, c->stream, nullptr, c->amax, c->amax + 2 * AMAX_WORDS, nullptr); return; }
     if (amax_each && c->conv_mode == 2) { if (which != 1) launch_absmax(x, (long)nin, c->amax, c->stream); if (which != 0) launch_absmax(y, (long)nout, c->amax + AMAX_WORDS, c->stream); }
     if (split && which == 0) launch_conv3x3_split(x, wsp, nullptr, y, B, cin, cout, h, wd, false, c->stream, nullptr, nterm, c->amax, c->amax + 2 * AMAX_WORDS);
@@ -1336,7 +1355,7 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
   *avg_ms = ms / iters;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(wt); (void)hipFree(gw); (void)hipFree(wsp); (void)hipFree(wup);
+  (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(wt); (void)hipFree(gw); (void)hipFree(wsp); (void)hipFree(wup); (void)hipFree(xp16); (void)hipFree(statp);
   LAUNCHCHK(c);
   return GR_OK;
 }

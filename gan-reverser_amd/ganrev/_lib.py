@@ -100,6 +100,8 @@ _SIGS = {
     "gr_train_r_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(Hyper), C.c_int, C.POINTER(C.c_double)]),
     "gr_set_conv_mode": (C.c_int, [_P, C.c_int]),
     "gr_get_conv_mode": (C.c_int, [_P]),
+    "gr_set_tuning": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "gr_debug_stamps": (C.c_int, [_P, _P]),
     "gr_set_timing": (C.c_int, [_P, C.c_int]),
     "gr_last_step_times": (C.c_int, [_P, _P]),
     "gr_event_record": (C.c_int, [_P, C.c_int]),
@@ -295,6 +297,9 @@ class Context:
         2 / "f16x3": fp32-accurate 2-term fp16 split of power-of-two-scaled operands on the f16 MFMA (3 products)."""
         mode = {"f32": 0, "bf16x6": 1, "f16x3": 2}.get(mode, mode)
         self.check(self.lib.gr_set_conv_mode(self.h, int(mode)), "gr_set_conv_mode")
+
+    def set_tuning(self, key, value):
+        self.check(self.lib.gr_set_tuning(self.h, key.encode(), int(value)), "gr_set_tuning")
 
     def conv_mode(self):
         return ("f32", "bf16x6", "f16x3")[self.lib.gr_get_conv_mode(self.h)]

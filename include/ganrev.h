@@ -144,6 +144,10 @@ int gr_train_r_step(gr_net* gnet, gr_net* rnet, const float* noise_dev, int batc
  * 0 = exact fp32 on v_mfma_f32_32x32x2_f32.  Also settable with the environment variable GR_CONV_MODE=f32|bf16x6|f16x3 before gr_init. */
 int gr_set_conv_mode(gr_ctx* ctx, int mode);
 int gr_get_conv_mode(gr_ctx* ctx);
+/* kernel-selection thresholds (process-wide).  "p16_min_tiles" (default 256): smallest tile count at which a convolution takes the
+ * operand-ready (P16) kernel; tests set 1 to exercise that path on small shapes. */
+int gr_set_tuning(gr_ctx* ctx, const char* key, int value);
+int gr_debug_stamps(gr_ctx* ctx, void* dev_buf);   /* diagnostic builds: device buffer for in-kernel time stamps (tools/stamps_p16.py) */
 int gr_set_timing(gr_ctx* ctx, int mode /*0 off, 1 per-phase events in gr_train_r_step, 2 per-kernel events*/);
 /* mode 2: JSON array of {kernel, phase, launches, total_ms, flops, bytes} (algorithmic flops/bytes) accumulated since it was
  * enabled; phase = the part of gr_train_r_step that launched it ("G forward", "R forward", "loss", "R backward", "adam") or "" */

@@ -36,3 +36,17 @@ def conv_mode(request):
     c.set_conv_mode(request.param)
     yield request.param
     c.set_conv_mode(prev)
+
+
+@pytest.fixture(params=["f16x3", "f16x3-p16"])
+def f16_path(request):
+    """f16x3 arithmetic with the default kernel selection, and with the operand-ready (P16: LDS-DMA convolution kernels fed by the
+    8-channel-group pipeline kernels) path forced onto shapes with fewer tiles than the chip has CUs."""
+    import ganrev._lib as L
+    c = L.default_context()
+    prev = c.conv_mode()
+    c.set_conv_mode("f16x3")
+    c.set_tuning("p16_min_tiles", 1 if request.param.endswith("p16") else 256)
+    yield request.param
+    c.set_tuning("p16_min_tiles", 256)
+    c.set_conv_mode(prev)

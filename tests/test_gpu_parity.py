@@ -214,6 +214,64 @@ def test_R_batch_sizes_with_uneven_channel_slices(oracle, conv_mode, dims, nd, B
     assert_grads_close(R, grads, onet.grads, 1e-4, 1e-3)
 
 
+@pytest.mark.parametrize("dims,nd,B", [((1, 32, 32), 8, 8), ((1, 32, 32), 8, 5), ((3, 64, 64), 16, 3)])
+def test_R_operand_ready_path_vs_oracle(oracle, f16_path, dims, nd, B):
+    """f16x3 with the operand-ready (P16) pipeline forced onto small shapes (conftest.f16_path): the pipeline kernels of a
+    stage write the next convolution's input - and pass B of the backward the data-gradient convolution's input - as
+    [8-channel group][term][pixel] fp16 hi/lo vectors scaled by an A-PRIORI bound of the tensor's maximum (BatchNorm
+    statistics + max|y|; K * max|dz|), and conv3x3_p16_wide_kernel stages them by LDS-DMA.  32x32 planes (one image = two
+    tiles), 16x16 planes (two stacked images per tile; odd batch: a half-empty tile), 64x64 (two column tiles).  Same bars as
+    every other R case; the default-selection run of the same shapes is the control."""
+    from ganrev import models, synth
+    from helpers import adopt_device_argmax, assert_grads_close
+    R = models.create_R(dims, nd)
+    synth.init_params(R, 3)
+    flat, grads = R.getParameters()
+    onet = oracle.from_model(R, dims)
+    R.training(); onet.set_training(True)
+    x = synth.uniform((B,) + dims, 5, 0, 1)
+    inject_noise(R, onet, B, 7)
+    ref = onet.forward(x)
+    out = R.forward(x)
+    assert_close(out, ref, TOL, "R forward (training)")
+    adopt_device_argmax(R, onet, B, 8)
+    ref = onet.forward(x)
+    assert_close(out, ref, TOL, "R forward vs the argmax-forced oracle")
+    gy = synth.normal(ref.shape, 9) * np.float32(0.1)
+    grads[...] = 0; onet.zero_grads()
+    gin = R.backward(x, gy)
+    ref_gin = onet.backward(x, gy)
+    assert_close(gin, ref_gin, TOL * max(1.0, float(np.abs(ref_gin).max())), "R gradInput")
+    assert_grads_close(R, grads, onet.grads, 1e-4, 1e-3)
+
+
+def test_operand_ready_kernels_are_selected(ctx):
+    """At the benchmark geometry (cfg2: batch 256) the f16x3 training step must take the operand-ready kernels: R's five
+    512-pixel-tile forward convolutions and four of its data-gradient convolutions run as conv3x3_p16_quad_kernel, fed by
+    post_forward_g8_kernel / post_backward_b_g8_kernel; the kernel table of a step says so."""
+    import ganrev._lib as L
+    from ganrev import models, synth
+    from ganrev.parallel import DeviceTrainer
+    prev = ctx.conv_mode(); ctx.set_conv_mode("f16x3")
+    try:
+        dims, nd, B = (1, 32, 32), 32, 256
+        G = models.create_G(dims, nd); synth.init_params(G, 1)
+        R = models.create_R(dims, nd); synth.init_params(R, 2)
+        G.evaluate(); G.forward(synth.normal((2, nd), 1))
+        R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
+        tr = DeviceTrainer(ctx, G._net, R._net, L.Hyper(), B)
+        tr.new_noise(1); tr.step()
+        ctx.set_timing(2)
+        tr.new_noise(2); tr.step()
+        kt = ctx.kernel_times(); ctx.set_timing(0)
+        count = lambda prefix: sum(k["launches"] for k in kt if k["kernel"].startswith(prefix))
+        assert count("conv3x3_p16_") == 9, sorted((k["kernel"], k["launches"]) for k in kt if k["kernel"].startswith("conv3x3"))
+        assert count("post_forward_g8_kernel") == 5 and count("post_backward_b_g8_kernel") == 4
+        assert count("conv3x3_split_wide_kernel") == 0
+    finally:
+        ctx.set_conv_mode(prev)
+
+
 @pytest.mark.parametrize("B,nin,nmid,nout", [(130, 1030, 1100, 37), (257, 2052, 640, 129), (128, 1024, 1024, 128)])
 def test_large_linear_ragged_shapes_vs_oracle(oracle, conv_mode, B, nin, nmid, nout):
     """nn.Linear layers big enough for the f16x3 GEMM (>= 2^20 weights) at sizes that are not multiples of anything: partial
