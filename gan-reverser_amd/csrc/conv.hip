@@ -1995,7 +1995,7 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
 // f16x3 convolution on an operand-ready (P16) activation: see conv3x3_p16_wide_kernel
 int g_p16_debug = 0;
 void* g_p16_stamps = nullptr;     // diagnostic: device buffer of 32 x 8 bytes per workgroup (gr_debug_stamps)
-int g_p16_min_tiles = 256;      // fewer tiles than CUs: the 256-pixel-tile kernels fill the chip better (gr_set_tuning("p16_min_tiles"): tests force the path)
+int g_p16_min_tiles = 128;      // below half a workgroup per CU the 256-pixel-tile kernels fill the chip better (gr_set_tuning("p16_min_tiles"): tests force the path)
 bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("GR_NO_P16"); on = e ? 0 : 1; }
@@ -2857,6 +2857,122 @@ __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, floa
   gw[((size_t)o * Cin + ci) * 9 + tap] += s;
 }
 
+// ---------------------------------------------------------------- weight gradient on operand-ready (P16) x and dy
+// gw[o][ci][ky][kx] += sum over (b, y, x) of dy[b, o, y, x] * x[b, ci, y + ky - 1, x + kx - 1]  as nine GEMMs with
+// M = o, N = ci, K = pixels, three f16 MFMA products per 16-pixel step (dy0 x0, dy0 x1, dy1 x0).  Both operands sit in HBM as
+// [pixel][8 channels] fp16 vectors (P16) whose K index - the pixel - is the ROW of the LDS image, so the MFMA fragments (8
+// consecutive k of one channel per lane) come out of LDS by the transposing read ds_read_b64_tr_b16 (4 pixels x 16 channels
+// per 16 lanes), and a tap is nothing but a row offset into the zero-padded x patch: no shifted copies, no v_alignbit, no
+// conversion - the image of 64 pixels (dy: 16 KB) and its padded x patch (35 KB) arrive by LDS-DMA.  Workgroup = 4 waves =
+// 64 o x 64 ci (wave: 32 x 32, nine accumulators), single LDS image, two workgroups per CU; K is split over workgroups
+// (contiguous runs of 64-pixel chunks), partial sums go to the slab the existing reduction adds up.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16(const uint4* vec, int byte_off) {     // vec: a 16-byte LDS vector; byte_off: 0 or 8
+#if defined(__HIP_DEVICE_COMPILE__)
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(reinterpret_cast<const unsigned char*>(vec) + byte_off));
+  return __builtin_bit_cast(uint2, v);
+#else
+  (void)vec; (void)byte_off; return make_uint2(0, 0);
+#endif
+}
+struct WgradP16Args {
+  const uint4* x; const uint4* dy; float* slab;
+  int B, Cin, Cout, H, W, n_ob, n_cb, nsplit, cinp, coutp, units;     // units = B * H * W / 64 chunks of 64 pixels
+  const unsigned *amax_x, *amax_dy;
+};
+template <int W_>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args a) {
+  constexpr int R = 64 / W_ > 0 ? 64 / W_ : 1;                 // image rows per 64-pixel chunk (W_ = 16, 32 or 64)
+  constexpr int PR = R + 2, PC = W_ + 2, PS = PR * PC;          // x patch positions
+  constexpr int XV = 16 * PS, XVP = (XV + 63) / 64 * 64, DV = 16 * 64;      // vectors: 8 groups x 2 terms x positions
+  constexpr int NXI = XVP / 64, NXS = (NXI + 3) / 4, NDS = 4;   // DMA instructions per wave: x patch, dy (16 planes / 4 waves)
+  static_assert(W_ == 16 || W_ == 32 || W_ == 64, "plane widths of this path");
+  static_assert(2 * (XVP + DV) * 16 <= 160 * 1024, "two workgroups per CU");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* xs = reinterpret_cast<uint4*>(smem_raw);               // [ci group 8][term 2][PS]
+  uint4* ds = xs + XVP;                                         // [o group 8][term 2][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wo = wave >> 1, wc = wave & 1;                      // this wave's 32-o and 32-ci halves of the 64 x 64 block
+  int bid = blockIdx.x;
+  const int cb = bid % a.n_cb; bid /= a.n_cb;
+  const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
+  const int H = a.H, HW = H * W_, Gin = a.Cin >> 3, Gout = a.Cout >> 3;
+  const int cpi = HW / 64;                                      // chunks per image
+  const int u0 = (int)((long)split * a.units / a.nsplit), u1 = (int)((long)(split + 1) * a.units / a.nsplit);
+  const size_t xbytes = (size_t)a.B * Gin * 2 * HW * 16, dbytes = (size_t)a.B * Gout * 2 * HW * 16;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.x), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.dy), 0, (int)(dbytes < 0x7FFFF000ul ? dbytes : 0x7FFFF000ul), 0x00020000);
+  const int ktot = f16_scale_exp(absmax_read(a.amax_x)) + f16_scale_exp(absmax_read(a.amax_dy));
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // transposing-read addresses: 16-lane group G = lane >> 4 covers channels 16 (G & 1) .. +15 and pixels 8 (G >> 1) .. +3
+  // (+4 for the second read); lane 4q + p of the group points at pixel row q, channels 4p .. 4p+3 of that 16-channel block
+  const int li = lane & 15, q = li >> 2, pp = li & 3, G = lane >> 4;
+  const int chg = 2 * (G & 1) + (pp >> 1), boff = 8 * (pp & 1);  // 8-channel group within the wave's 32 channels, byte offset in the vector
+  const int pxl = 8 * (G >> 1) + q;                              // pixel within a 16-pixel step (first read; second: + 4)
+  // per-lane vector addresses of step 0 (the lane's pixel row pxl of the step, its 8-channel group); a step adds a uniform offset
+  const uint4* abase = ds + (wo * 4 + chg) * 2 * 64 + pxl;
+  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PS + pxl;
+  for (int u = u0; u < u1; ++u) {
+    const int b = u / cpi, cidx = u - b * cpi, p0 = cidx * 64, y0 = p0 / W_;      // the chunk's 64 pixels: rows y0 .. y0 + R - 1 (W_ = 64: one row)
+    __syncthreads();                                             // every wave is past the previous chunk's image
+    // x patch: flat vector index e = 64 i + lane over [group][term][position]
+#pragma unroll
+    for (int j = 0; j < NXS; ++j) {
+      const int i = wave + 4 * j, e = 64 * i + lane;
+      const int pl = e / PS, pos = e - pl * PS, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC;
+      const int yy = y0 + rr - 1, xx = c - 1;
+      const bool inb = e < XV && yy >= 0 && yy < H && xx >= 0 && xx < W_;
+      const int voff = inb ? (((b * Gin + cb * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(yy * W_ + xx))) * 16 : (int)0x7FFFF000;
+      if (i < NXI) lds_dma16(rx, xs + 64 * i, voff, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NDS; ++j) {
+      const int pl = wave + 4 * j, g = pl >> 1, t = pl & 1;      // plane = (o group, term): 64 pixels = one instruction
+      const int voff = (((b * Gout + ob * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(p0 + lane))) * 16;
+      lds_dma16(rd, ds + 64 * pl, voff, 0);
+    }
+    __syncthreads();                                             // vmcnt(0) + barrier: the image has landed
+#pragma unroll 1
+    for (int ks = 0; ks < 4; ++ks) {
+      const int srow = (16 * ks) / W_, scol = 16 * ks - srow * W_;     // the step's 16 pixels: row srow of the chunk, columns scol .. scol + 15
+      // A = dy: [o][k]; two transposing reads (4 pixels each) per term
+      uint4 av[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint4* base = abase + t * 64 + 16 * ks;
+        const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+        av[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+      const uint4* bstep = bbase + srow * PC + scol;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        uint4 bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          // (the second read is 4 pixels further along x: same row - 16-pixel steps never straddle a row, W_ % 16 == 0)
+          const uint4* base = bstep + t * PS + ky * PC + kx;
+          const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+          bv[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        acc[tap] = split_mma<2>(av, bv, acc[tap]);
+      }
+    }
+  }
+  float* slp = a.slab + (size_t)split * 9 * a.coutp * a.cinp;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob * 64 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, ci = cb * 64 + wc * 32 + l31;
+      slp[((size_t)tap * a.coutp + o) * a.cinp + ci] = ldexpf(acc[tap][r], -ktot);
+    }
+}
+
 static bool wgrad_use_vec(int W) { return W >= 16 && W % 4 == 0; }
 static bool wgrad_use_small(int Cin, int W) { return Cin <= 3 && W >= 16 && W % 4 == 0; }
 static bool wgrad_use_bf16x6(int mode, int Cin, int W) { return mode >= 1 && Cin > 3 && W >= 16 && W % 8 == 0; }   // either split flavour
@@ -2899,6 +3015,49 @@ static void launch_wgrad_split(const WgradArgs& a, int TW, int rps, int wv, int 
     if (wv == 1) hipLaunchKernelGGL((conv3x3_wgrad_split_kernel<32, 1, NTERM>), dim3(grid_), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_split_kernel<32, 2, NTERM>), dim3(grid_), dim3(256), 0, s, a);
   }
+}
+
+bool conv_wgrad_p16_supported(int B, int Cin, int Cout, int H, int W) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("GR_NO_P16_WGRAD"); on = e ? 0 : 1; }
+  return on && Cin % 64 == 0 && Cout % 64 == 0 && (W == 16 || W == 32 || W == 64) && (H * W) % 256 == 0 &&
+         (size_t)B * (Cin > Cout ? Cin : Cout) * H * W * 4 < 0x7FFFF000ul;
+}
+static int wgrad_p16_splits(int B, int Cin, int Cout, int H, int W) {
+  const int blocks = (Cin / 64) * (Cout / 64);
+  int want = 512 / blocks; if (want < 1) want = 1;            // two workgroups per CU
+  const long units = (long)B * H * W / 64;
+  if (want > units) want = (int)units;
+  return want;
+}
+size_t conv_wgrad_p16_workspace_bytes(int B, int Cin, int Cout, int H, int W) {
+  return sizeof(float) * (size_t)wgrad_p16_splits(B, Cin, Cout, H, W) * 9 * Cin * Cout;
+}
+template <int W_>
+static void launch_wgrad_p16_t(const WgradP16Args& a, int grid, size_t lds, hipStream_t s) {
+  static bool st = false;
+  if (!st) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_p16_kernel<W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); st = true; }
+  hipLaunchKernelGGL(conv3x3_wgrad_p16_kernel<W_>, dim3(grid), dim3(256), lds, s, a);
+}
+void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, void* workspace, int B, int Cin, int Cout, int H, int W,
+                              hipStream_t s, const unsigned* amax_x, const unsigned* amax_dy) {
+  WgradP16Args a{};
+  a.x = reinterpret_cast<const uint4*>(x_p16); a.dy = reinterpret_cast<const uint4*>(dy_p16); a.slab = reinterpret_cast<float*>(workspace);
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.n_ob = Cout / 64; a.n_cb = Cin / 64; a.cinp = Cin; a.coutp = Cout;
+  a.nsplit = wgrad_p16_splits(B, Cin, Cout, H, W); a.units = (int)((long)B * H * W / 64);
+  a.amax_x = amax_x; a.amax_dy = amax_dy;
+  const int grid = a.nsplit * a.n_ob * a.n_cb;
+  const double px = (double)B * H * W;
+  {
+    const int R = 64 / W > 0 ? 64 / W : 1, PS = (R + 2) * (W + 2);
+    const size_t lds = 16 * (size_t)((16 * PS + 63) / 64 * 64 + 1024);
+    const std::string nm = "conv3x3_wgrad_p16_kernel<" + std::to_string(W) + ">";
+    KtScope kt(nm.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
+    if (W == 16) launch_wgrad_p16_t<16>(a, grid, lds, s); else if (W == 32) launch_wgrad_p16_t<32>(a, grid, lds, s); else launch_wgrad_p16_t<64>(a, grid, lds, s);
+  }
+  const long n_ = (long)9 * Cout * a.cinp;
+  KtScope kt("conv3x3_wgrad_reduce8_kernel", (double)n_ * a.nsplit, 4.0 * n_ * (a.nsplit + 2.0), s);
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce8_kernel, dim3((unsigned)((n_ + 31) / 32)), dim3(256), 0, s, a.slab, gw, Cin, Cout, a.cinp, a.coutp, a.nsplit);
 }
 
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
         r = mul4(bn_act4(a, ld[j][0], mean, invstd, gm, bt), mask4_of(a.m1, m1w[j][0]));
       }
       const float4 res = mul4(r, mask4_of(a.m2, m2w[j]));
-      *reinterpret_cast<float4*>(a.out + eo) = res;
+      if (a.out) *reinterpret_cast<float4*>(a.out + eo) = res;          // (null: every consumer takes the operand-ready image)
       vals[j][0] = res.x; vals[j][1] = res.y; vals[j][2] = res.z; vals[j][3] = res.w;
     }
     uint4* dst = p16 + (size_t)bg * 2 * HWo + ((within >> 6) << 8) + (within & 63);      // quad-major inside runs of 256 pixels (p16_pos)
@@ -286,7 +286,7 @@ void launch_post_forward(const PostArgs& a, hipStream_t s) {
   if (a.p16) {      // caller checked post_g8_supported
     long blocks = (n / 32 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    KtScope kt("post_forward_g8_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + 2.0 * (double)n), s);
+    KtScope kt("post_forward_g8_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + (a.out ? 2.0 : 1.0) * (double)n), s);
     if (a.pool) hipLaunchKernelGGL(post_forward_g8_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(post_forward_g8_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return;
@@ -700,24 +700,28 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
   for (unsigned j = threadIdx.x; j < tot; j += 256) {
     const unsigned bb = j / q4, i = j - bb * q4, b = (unsigned)b0 + bb;
     float vals[8][4];
-    BwdRaw raw[8];
 #pragma unroll
-    for (int jc = 0; jc < 8; ++jc) {                     // phase 1: every load of the eight channels
-      const unsigned bc = b * f.C + 8 * g + jc;
-      raw[jc] = post_bwd_load4(a, bc, bc * HW + i * 4, i, bc * HWo, wq, Wo);
-    }
+    for (int half = 0; half < 2; ++half) {               // four channels at a time: their loads in flight together (12 registers each)
+      BwdRaw raw[4];
 #pragma unroll
-    for (int jc = 0; jc < 8; ++jc) {
-      const unsigned bc = b * f.C + 8 * g + jc;
-      const float mean = par[jc][0], invstd = par[jc][1], w = par[jc][2], bt = par[jc][3], gm = par[jc][4], k = par[jc][5];
-      const float4 yv = raw[jc].y;
-      const float4 dz = post_bwd_dz_of(a, raw[jc], mean, invstd, w, bt);                    // as pass A computed it
-      float4 d;
-      d.x = ((dz.x - gm) - (yv.x - mean) * k) * invstd * w; d.y = ((dz.y - gm) - (yv.y - mean) * k) * invstd * w;
-      d.z = ((dz.z - gm) - (yv.z - mean) * k) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * k) * invstd * w;
-      reinterpret_cast<float4*>(a.dy + (size_t)bc * HW)[i] = d;
-      sums[jc] += (double)d.x + (double)d.y + (double)d.z + (double)d.w;
-      vals[jc][0] = d.x; vals[jc][1] = d.y; vals[jc][2] = d.z; vals[jc][3] = d.w;
+      for (int jj = 0; jj < 4; ++jj) {
+        const unsigned bc = b * f.C + 8 * g + 4 * half + jj;
+        raw[jj] = post_bwd_load4(a, bc, bc * HW + i * 4, i, bc * HWo, wq, Wo);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int jc = 4 * half + jj;
+        const unsigned bc = b * f.C + 8 * g + jc;
+        const float mean = par[jc][0], invstd = par[jc][1], w = par[jc][2], bt = par[jc][3], gm = par[jc][4], k = par[jc][5];
+        const float4 yv = raw[jj].y;
+        const float4 dz = post_bwd_dz_of(a, raw[jj], mean, invstd, w, bt);                    // as pass A computed it
+        float4 d;
+        d.x = ((dz.x - gm) - (yv.x - mean) * k) * invstd * w; d.y = ((dz.y - gm) - (yv.y - mean) * k) * invstd * w;
+        d.z = ((dz.z - gm) - (yv.z - mean) * k) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * k) * invstd * w;
+        if (a.dy) reinterpret_cast<float4*>(a.dy + (size_t)bc * HW)[i] = d;      // (null: both gradient kernels take the operand-ready image)
+        sums[jc] += (double)d.x + (double)d.y + (double)d.z + (double)d.w;
+        vals[jc][0] = d.x; vals[jc][1] = d.y; vals[jc][2] = d.z; vals[jc][3] = d.w;
+      }
     }
     uint4* dst = p16 + ((size_t)b * G + g) * 2 * HW + ((i >> 6) << 8) + (i & 63);          // quad-major inside runs of 256 pixels (p16_pos)
 #pragma unroll
@@ -816,7 +820,7 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
     return;
   }
   if (vec && a.dy_p16) {      // caller checked post_g8_supported
-    KtScope kt("post_backward_b_g8_kernel", 0.0, 4.0 * (3.0 * pre + post), s);                       // reads g and y, writes dy twice (fp32 + operand-ready)
+    KtScope kt("post_backward_b_g8_kernel", 0.0, 4.0 * ((a.dy ? 3.0 : 2.0) * pre + post), s);        // reads g and y, writes dy operand-ready (and as fp32 when a consumer needs that)
     hipLaunchKernelGGL(post_backward_b_g8_kernel, dim3(f.C / 8, splits), dim3(256), 0, s, a, splits, (double)n);
   } else if (vec) {
     KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);                      // reads g and y, writes dy

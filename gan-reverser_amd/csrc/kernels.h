@@ -190,6 +190,11 @@ size_t conv_wgrad_workspace_bytes(int B, int Cin, int Cout, int H, int W, int mo
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,
                           int B, int Cin, int Cout, int H, int W, hipStream_t s, int mode = 0,
                           const unsigned* amax_x = nullptr, const unsigned* amax_dy = nullptr);
+// weight gradient with BOTH operands operand-ready (P16): x = the stage's input image, dy = pass B's image
+bool conv_wgrad_p16_supported(int B, int Cin, int Cout, int H, int W);
+size_t conv_wgrad_p16_workspace_bytes(int B, int Cin, int Cout, int H, int W);
+void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, void* workspace, int B, int Cin, int Cout, int H, int W,
+                              hipStream_t s, const unsigned* amax_x, const unsigned* amax_dy);
 inline bool conv_wgrad_is_split(int mode, int Cin, int W) { return mode >= 1 && Cin > 3 && W >= 16 && W % 8 == 0; }
 
 // ---------------------------------------------------------------- GEMM (Linear) on fp32 MFMA

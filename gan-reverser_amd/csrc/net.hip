@@ -253,6 +253,7 @@ struct Stage {
   bool eval_ready = false;                  // mean / invstd hold the evaluate()-mode values of the current running statistics
   const float* x_in = nullptr;              // input of the last forward
   bool fused_epilogue = false;              // last forward wrote `out` straight from the conv epilogue (y not materialised)
+  bool out_skipped = false;                 // last forward left `out` operand-ready only (the next stage's x_p16): no fp32 copy exists
 };
 
 struct gr_net {
@@ -701,7 +702,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     Stage* nx = (f16 && si + 1 < nst && (use_bf16x6(n, n->st[si + 1]) || use_f16_gemm(n, n->st[si + 1]))) ? &n->st[si + 1] : nullptr;
     unsigned* amax_next = nx ? nx->amax_x : nullptr;
     s.x_in = x;
-    s.fused_epilogue = false;
+    s.fused_epilogue = false; s.out_skipped = false;
     if (s.kind == ST_CONV) {
       // evaluate() mode: BatchNorm is a per-channel affine map of running statistics, so BN + activation ride in the conv
       // epilogue and the raw conv output is never written (G on this path).  Needs: no pool, no active dropout noise.
@@ -809,6 +810,13 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     }
     pa.amax_out = p16_out ? nullptr : amax_next;      // operand-ready: the slot already holds the bound and must not move
     pa.p16 = p16_out ? nx->x_p16 : nullptr; pa.p16_scale = p16_out ? nx->amax_x : nullptr;
+    // The fp32 copy of the stage output has one more reader than the next convolution's forward: that convolution's weight
+    // gradient.  When it will take the operand-ready image too (every condition is fixed by the shapes and this forward), the
+    // fp32 tensor is not written at all: the pipeline kernel writes 4 bytes per element, as it did before it wrote two formats.
+    static const bool lean_on = !getenv("GR_P16_KEEP_FP32");
+    s.out_skipped = lean_on && p16_out && nx->has_bn && n->dy_p16 && post_g8_supported(nx->Cout, nx->H, nx->W, nx->pool, true) &&
+                    conv_wgrad_p16_supported(B, nx->Cin, nx->Cout, nx->H, nx->W) && nx->stat_part;
+    if (s.out_skipped) pa.out = nullptr;
     launch_post_forward(pa, c->stream);
     if (p16_out) nx->x_p16_gen = n->amax_gen;
     if (nx) nx->amax_x_fwd = n->amax_gen;
@@ -846,7 +854,10 @@ extern "C" int gr_net_layer_output(gr_net* n, int layer, float* host, int64_t cn
   for (auto& s : n->st) {
     const float* p = nullptr; int64_t e = 0;
     if (layer == s.main_layer && !s.fused_epilogue) { p = s.y; e = (int64_t)n->lastB * vol3(s.Cout, s.H, s.W); }
-    else if (layer == s.last && s.has_post) { p = s.out; e = (int64_t)n->lastB * vol3(s.outC, s.outH, s.outW); }
+    else if (layer == s.last && s.has_post) {
+      if (s.out_skipped) return fail(c, GR_ERR_UNSUPPORTED, "layer %d: the last forward left this output operand-ready (fp16 hi/lo image of the next convolution) only", layer);
+      p = s.out; e = (int64_t)n->lastB * vol3(s.outC, s.outH, s.outW);
+    }
     if (p) {
       if (cnt != e) return fail(c, GR_ERR_INVALID, "layer %d output has %lld elements", layer, (long long)e);
       HIPCHK(c, hipMemcpyAsync(host, p, sizeof(float) * (size_t)e, hipMemcpyDeviceToHost, c->stream));
@@ -919,9 +930,18 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     pb.gbias = s.kind == ST_ELEM ? nullptr : n->grads + s.b_off;
     pb.amax_dy = (f16 && ((s.kind == ST_CONV && !s.up && !s.fullconv) || use_f16_gemm(n, s))) ? s.amax_dy : nullptr;
     // operand-ready dy for the data-gradient convolution: needs the forward's bound factor of THIS forward (kb_gen)
-    const bool dy_p16 = f16 && s.kind == ST_CONV && !s.up && !s.fullconv && s.has_bn && need_gin && n->dy_p16 && s.kb_gen == n->amax_gen &&
-                        post_g8_supported(s.Cout, s.H, s.W, s.pool, true) && conv_p16_supported(B, s.Cout, s.Cin, s.H, s.W);
+    const bool dy_ok = f16 && s.kind == ST_CONV && !s.up && !s.fullconv && s.has_bn && n->dy_p16 && s.kb_gen == n->amax_gen &&
+                       post_g8_supported(s.Cout, s.H, s.W, s.pool, true);
+    const bool dgrad_p16 = dy_ok && need_gin && conv_p16_supported(B, s.Cout, s.Cin, s.H, s.W);
+    // weight gradient with both operands operand-ready: this stage's input image (written by the previous stage's forward
+    // pipeline kernel in THIS forward) and pass B's dy image
+    const bool wgrad_p16 = dy_ok && s.x_p16 && s.x_p16_gen == n->amax_gen && conv_wgrad_p16_supported(B, s.Cin, s.Cout, s.H, s.W);
+    const bool dy_p16 = dgrad_p16 || wgrad_p16;
     pb.dy_p16 = dy_p16 ? n->dy_p16 : nullptr; pb.amax_dz = dy_p16 ? s.amax_dz : nullptr; pb.kb = s.amax_kb;
+    if (s.kind == ST_CONV && si > 0 && n->st[si - 1].out_skipped && !wgrad_p16)
+      return fail(c, GR_ERR_STATE, "stage %d: the forward left this stage's input operand-ready only (f16x3); backward in another arithmetic mode needs a new forward", si);
+    static const bool lean_on = !getenv("GR_P16_KEEP_FP32");
+    if (lean_on && wgrad_p16 && (dgrad_p16 || !need_gin)) pb.dy = nullptr;      // no fp32 reader of dy is left
     launch_post_backward(pb, c->stream, &bias_jobs);       // bias gradients of several stages are summed by one launch
     LAUNCHCHK(c);
     if (s.kind == ST_CONV) {
@@ -933,10 +953,14 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
         // x's maximum is current when this stage's forward ran on the f16x3 kernel; otherwise (few-channel input, mode switched) take it now
         if (conv_wgrad_is_split(2, s.Cin, s.W) && s.amax_x_fwd != n->amax_gen) launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream);
       }
+      if (wgrad_p16) {
+        r = ensure_ws(c, conv_wgrad_p16_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W)); if (r) return r;
+        launch_conv3x3_wgrad_p16(s.x_p16, n->dy_p16, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, s.amax_x, s.amax_dy);
+      } else
       launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode, s.amax_x, s.amax_dy);
       if (need_gin) {
         // backward-data = the same convolution on the transposed + flipped weights (Cout -> Cin)
-        if (dy_p16) launch_conv3x3_p16(n->dy_p16, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, c->stream, nullptr, s.amax_dy, s.amax_w, nullptr, nullptr, nullptr);
+        if (dgrad_p16) launch_conv3x3_p16(n->dy_p16, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, c->stream, nullptr, s.amax_dy, s.amax_w, nullptr, nullptr, nullptr);
         else if (c->conv_mode >= 1) launch_conv3x3_split(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
         else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
       }
