@@ -143,15 +143,15 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
 // Operand-ready activations ("P16"): p16[b][c / 8][term][p16_pos(pixel)] = 16 bytes = the 8 fp16 halves of term `term` (hi, lo) of
 // channels 8(c/8) .. +7 at that pixel, scaled by the power of two the tensor's scale slot defines (f16_scale_exp of its
 // bits).  Same bytes as the fp32 tensor.  Written by the pipeline kernels (elem.hip), read by LDS-DMA in the conv3x3_p16_* kernels.
-// Inside every run of 256 pixels the vectors are stored "quad-major": pixel 4q + k sits at 64k + q.  A producer thread owns 4
-// consecutive pixels (it loads float4s), so its k-th store lands at 64k + lane: every store instruction of a wave writes 1 KB
-// contiguous instead of 16 bytes in each of 64 different 64-byte sectors.  The consumers gather by per-lane address anyway.
+// Pixels are linear inside a plane: the pipeline kernels assemble the vectors through an LDS transpose (elem.hip, t8_emit), so
+// consecutive lanes hold consecutive pixels and a wave's store is 1 KB contiguous.  (A "quad-major" order - pixel 4q + k at
+// 64k + q, for producers whose threads own 4 pixels x 8 channels - was measured first: those threads were too heavy.)
 extern int g_p16_min_tiles, g_p16_variant, g_p16_stagger;
 extern void* g_p16_stamps;
 extern int g_p16_debug;       // diagnostic builds only (GR_P16_DEBUG bit mask: 1 no output stores, 2 no statistics, 4 no DMA, 8 no MFMA)
 void launch_to_p16(const float* x, void* p16, int B, int C, int HW, const unsigned* slot, hipStream_t s);   // C % 8 == 0, HW % 4 == 0
 #if defined(__HIPCC__)
-__host__ __device__ __forceinline__ unsigned p16_pos(unsigned p) { return (p & ~255u) | ((p & 3u) << 6) | ((p >> 2) & 63u); }   // H * W % 256 == 0
+__host__ __device__ __forceinline__ unsigned p16_pos(unsigned p) { return p; }   // position of pixel p inside a (group, term) plane: linear
 #endif
 bool conv_p16_supported(int B, int Cin, int Cout, int H, int W);
 void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
@@ -232,6 +232,7 @@ struct PostArgs {
 };
 void launch_post_forward(const PostArgs& a, hipStream_t s);
 
+constexpr int PB_SPLITS = 256;   // row length of partials_b: pass B of the operand-ready pipeline slices the batch finer than pass A (blocks of 8 channels)
 constexpr int STAT_SPLITS = 64;  // partial sums per channel (16 -> 64: 4 -> 16 waves per SIMD in flight on the 64-channel layers; pass A 1.41 -> 1.12 ms at cfg3)
 // per-channel (sum, sumsq) partials in double -> mean / invstd (+ running stats update when run_mean != null)
 void launch_bn_stats(const float* y, int B, int C, int HW, double* partials /*[C][STAT_SPLITS][2]*/,
@@ -247,7 +248,7 @@ struct PostBwdArgs {
   float* ggamma; float* gbeta;   // += (BN)
   float* gbias;            // += sum dy per channel (conv / linear bias), nullable
   unsigned* amax_dy;       // nullable: max|dy| is folded into this slot (f16x3 scale of the weight / data gradients)
-  double* partials_b;      // [C][STAT_SPLITS] pass B's per-channel sums of dy (bias gradient); separate from `partials`,
+  double* partials_b;      // [C][PB_SPLITS] pass B's per-channel sums of dy (bias gradient); separate from `partials`,
                            // which every pass-B workgroup of the channel still reads (BN coefficients are derived in pass B)
   // operand-ready copy of dy for the data-gradient convolution: dy_p16 != null selects the 8-channel-group pass B.  amax_dz
   // receives max|dz| from pass A; kb holds the forward's factor K (BnBounds); pass B writes the bound K * max|dz| into amax_dy
@@ -257,7 +258,7 @@ struct PostBwdArgs {
 bool post_g8_supported(int C, int H, int W, bool pool, bool backward = false);
 // Bias gradients are summed from partials_b by one batched launch for several stages (launch_bias_grad_batch) when
 // `defer` is given; otherwise inside the call.
-struct BiasJob { const double* partials; float* gbias; int C, splits; };
+struct BiasJob { const double* partials; float* gbias; int C, splits; };     // partials: rows of PB_SPLITS
 struct BiasJobs { BiasJob job[16]; int n; };
 void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer = nullptr);
 void launch_bias_grad_batch(BiasJobs& jobs, hipStream_t s);    // runs and empties the list

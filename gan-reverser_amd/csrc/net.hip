@@ -110,6 +110,7 @@ extern "C" int gr_init(int device, gr_ctx** out) {
     delete c; return GR_ERR_HIP;
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
+  { const char* d = getenv("GR_P16_DEBUG"); if (d) gr::g_p16_debug = atoi(d); }      // diagnostic ablations (tools/ablate_p16.py)
   { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "f32") || !strcmp(m, "0")) ? 0 : ((!strcmp(m, "bf16x6") || !strcmp(m, "1")) ? 1 : 2); }
   (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
@@ -406,7 +407,7 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
     }
     if (hipMalloc((void**)&s.mean, sizeof(float) * C) || hipMalloc((void**)&s.invstd, sizeof(float) * C) ||
         hipMalloc((void**)&s.coef, sizeof(float) * 2 * C) || hipMalloc((void**)&s.partials, sizeof(double) * 2 * STAT_SPLITS * C) ||
-        hipMalloc((void**)&s.partials_b, sizeof(double) * STAT_SPLITS * C)) {
+        hipMalloc((void**)&s.partials_b, sizeof(double) * PB_SPLITS * C)) {
       gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed");
     }
     if (s.kind == ST_CONV) {
