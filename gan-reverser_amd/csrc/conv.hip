@@ -1009,6 +1009,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_wide_kernel(ConvArgs a, 
 // Two LDS images; the DMA of the next chunk IN THE STREAM (tiles are walked persistently, so that is the next tile's first
 // chunk at a tile's end) is issued at the top of a chunk and waited for (vmcnt(0) + barrier) at its bottom.
 constexpr int P16_PAD = 64;          // LDS regions are multiples of one wave-instruction's 64 vectors
+// Barrier that PUBLISHES LDS-DMA data: every wave first waits for its own DMA (s_waitcnt vmcnt(0), written out: hipcc's own
+// wait in front of __syncthreads() came out as vmcnt(8) in conv3x3_p16_quad_kernel - a wave could pass the barrier with DMA
+// still in flight and another wave read the stale image: rare, run-to-run different results), then the workgroup barrier.
+__device__ __forceinline__ void dma_publish_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes land at lds_dst + 16 * lane, lane l fetching rsrc[voff_l + soff]
 // (out-of-range lanes write zeros - verified on gfx950 by tools/probe/dma_probe.hip).  The builtin only exists in the device
 // pass; hipcc drops the kernel's host stub if the host pass meets it, hence the guard.
@@ -1115,7 +1122,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
   weight_offsets(g);
   int cc = 0;                                                        // chunks consumed so far: image cc & 1 holds the current one
   GR_P16_DMA(0, 0, voff)
-  __syncthreads();                                                   // (vmcnt(0) for the DMA just issued, then the barrier)
+  dma_publish_barrier();
   for (;;) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1149,7 +1156,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
       GR_BF_OPS(pc_, wc_, 8, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
       GR_BF_MMA(avA, bvA)
       }
-      __syncthreads();                                               // vmcnt(0): the DMA issued above has landed; every wave is past image cc & 1
+      dma_publish_barrier();                                         // the DMA issued above has landed; every wave is past image cc & 1
     }
     const int y0 = g.y0, x0 = g.x0, o0 = g.o0, b = g.b;
     bool pin[NG]; size_t obase[NG];
@@ -1337,7 +1344,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_quad_kernel(ConvArgs a, co
   }
   if (!(dbg & 4)) GR_P16_DMA(0)
   for (int ch = 0; ch < nchunks; ++ch) {
-    __syncthreads();                                                 // vmcnt(0) + barrier: the image holds chunk ch
+    dma_publish_barrier();                                           // the image holds chunk ch
     GR_STAMP()
     if (!(dbg & 8)) {
 #pragma unroll
@@ -2935,7 +2942,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
       const int voff = (((b * Gout + ob * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(p0 + lane))) * 16;
       lds_dma16(rd, ds + 64 * pl, voff, 0);
     }
-    __syncthreads();                                             // vmcnt(0) + barrier: the image has landed
+    dma_publish_barrier();                                       // the image has landed
 #pragma unroll 1
     for (int ks = 0; ks < 4; ++ks) {
       const int srow = (16 * ks) / W_, scol = 16 * ks - srow * W_;     // the step's 16 pixels: row srow of the chunk, columns scol .. scol + 15

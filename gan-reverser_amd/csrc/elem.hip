@@ -1074,6 +1074,33 @@ void launch_l2_distance_rows(const float* a, const float* b, long n, long d, dou
   hipLaunchKernelGGL(l2_distance_rows_kernel, dim3((unsigned)n), dim3(256), 0, s, a, b, d, out);
 }
 
+// nn.SpatialUpSamplingNearest(2) (models.lua:121,127) as stand-alone passes: only the BACKWARD of the fused up-sampling +
+// convolution stage materialises the up-sampled input (weight gradient) and folds the data gradient back (sum of each 2x2
+// block) - G's forward never does (conv3x3_up2_f16x3_kernel), and G is forward-only on the train_r path.
+__global__ __launch_bounds__(256) void upsample2_kernel(const float* __restrict__ x, float* __restrict__ up, long n_out, int Ho, int Wo) {
+  const int Ws = Wo >> 1, Hs = Ho >> 1;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_out; i += (long)gridDim.x * blockDim.x) {
+    const long bc = i / ((long)Ho * Wo); const int p = (int)(i - bc * Ho * Wo), yy = p / Wo, xx = p - yy * Wo;
+    up[i] = x[bc * Hs * Ws + (long)(yy >> 1) * Ws + (xx >> 1)];
+  }
+}
+__global__ __launch_bounds__(256) void downsum2_kernel(const float* __restrict__ gup, float* __restrict__ gin, long n_in, int Hs, int Ws) {
+  const int Wo = Ws * 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_in; i += (long)gridDim.x * blockDim.x) {
+    const long bc = i / ((long)Hs * Ws); const int p = (int)(i - bc * Hs * Ws), y = p / Ws, xx = p - y * Ws;
+    const float* g = gup + bc * 4 * Hs * Ws + (long)(2 * y) * Wo + 2 * xx;
+    gin[i] = ((g[0] + g[1]) + g[Wo]) + g[Wo + 1];       // THNN SpatialUpSamplingNearest.updateGradInput adds the four in scan order
+  }
+}
+void launch_upsample2(const float* x, float* up, int B, int C, int Ho, int Wo, hipStream_t s) {
+  const long n = (long)B * C * Ho * Wo; long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, up, n, Ho, Wo);
+}
+void launch_downsum2(const float* gup, float* gin, int B, int C, int Hs, int Ws, hipStream_t s) {
+  const long n = (long)B * C * Hs * Ws; long blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(downsum2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gup, gin, n, Hs, Ws);
+}
+
 __global__ void scale_copy_kernel(const float* src, float* dst, long n, float scale) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
 }

@@ -279,6 +279,8 @@ void launch_fill_normal(float* dst, long n, uint64_t seed, hipStream_t s);
 void launch_fill_uniform(float* dst, long n, float lo, float hi, uint64_t seed, hipStream_t s);
 void launch_l2_distance_rows(const float* a, const float* b, long n, long d, double* out, hipStream_t s);
 void launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s);
+void launch_upsample2(const float* x, float* up, int B, int C, int Ho, int Wo, hipStream_t s);       // nearest x2, [B,C,Ho/2,Wo/2] -> [B,C,Ho,Wo]
+void launch_downsum2(const float* gup, float* gin, int B, int C, int Hs, int Ws, hipStream_t s);   // its backward: sum of each 2x2 block
 
 // ---------------------------------------------------------------- cosine top-k search
 size_t cosine_topk_workspace_bytes(long N, int d, int Q, int k);

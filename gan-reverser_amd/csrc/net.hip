@@ -273,6 +273,7 @@ struct gr_net {
   int capB = 0, lastB = 0;
   float *in_buf = nullptr, *gout_buf = nullptr, *dy_buf = nullptr, *g_buf[2] = {nullptr, nullptr};
   void* dy_p16 = nullptr;            // operand-ready copy of dy_buf for the data-gradient convolution
+  float* up_tmp[2] = {nullptr, nullptr}; size_t up_cap = 0;    // backward of a fused up-sampling stage: up-sampled input / data gradient at the up-sampled size
   size_t max_y = 0, max_in = 0;      // per-sample element counts
   uint8_t* mask_stage = nullptr; size_t mask_stage_cap = 0;
   PrepJob* jobs_dev[3] = {nullptr, nullptr, nullptr}; int njobs[3] = {0, 0, 0};   // [0] fp32 k-major images, [1] bf16x6, [2] f16x3 split images
@@ -300,7 +301,7 @@ extern "C" int gr_net_destroy(gr_net* n) {
   for (auto& m : n->masks) (void)hipFree(m.bits);
   (void)hipFree(n->params); (void)hipFree(n->grads); (void)hipFree(n->adam_m); (void)hipFree(n->adam_v);
   (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
-  (void)hipFree(n->dy_p16); (void)hipFree(n->mask_stage); (void)hipFree(n->jobs_dev[0]); (void)hipFree(n->jobs_dev[1]); (void)hipFree(n->jobs_dev[2]); (void)hipFree(n->amax);
+  (void)hipFree(n->dy_p16); (void)hipFree(n->up_tmp[0]); (void)hipFree(n->up_tmp[1]); (void)hipFree(n->mask_stage); (void)hipFree(n->jobs_dev[0]); (void)hipFree(n->jobs_dev[1]); (void)hipFree(n->jobs_dev[2]); (void)hipFree(n->amax);
   delete n;
   return GR_OK;
 }
@@ -416,6 +417,9 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
       const ConvWeightLayout lb = conv_weight_layout(s.Cout, s.Cin);
       if (hipMalloc((void**)&s.wt_fwd, sizeof(float) * lf.elems()) || hipMalloc((void**)&s.wt_bwd, sizeof(float) * lb.elems())) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
       if (!s.fullconv && (hipMalloc(&s.ws_fwd, conv_weight_split_bytes(s.Cin, s.Cout, false)) || hipMalloc(&s.ws_bwd, conv_weight_split_bytes(s.Cin, s.Cout, true)))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
+      // SpatialFullConvolution(Cin -> Cout), weight [Cin][Cout][3][3] = the native weight of a convolution Cout -> Cin: its forward is
+      // that convolution's backward-data, its backward-data that convolution's forward
+      if (s.fullconv && (hipMalloc(&s.ws_fwd, conv_weight_split_bytes(s.Cout, s.Cin, true)) || hipMalloc(&s.ws_bwd, conv_weight_split_bytes(s.Cout, s.Cin, false)))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
       if (!s.fullconv && s.up && conv_up2_supported(s.Cin, s.Cout, s.H, s.W) && hipMalloc(&s.ws_up, conv_weight_up2_bytes(s.Cin, s.Cout))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
     }
     const size_t ye = (size_t)vol3(s.Cout, s.H, s.W), ie = (size_t)vol3(s.inC, s.inH, s.inW);
@@ -444,6 +448,10 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
         // SpatialFullConvolution weight is [Cin][Cout][3][3]: its forward is the backward-data of a (Cout -> Cin) conv
         jf.push_back(make_prep_job(s.w_off, s.wt_fwd, s.Cout, s.Cin, true, 0));
         jf.push_back(make_prep_job(s.w_off, s.wt_bwd, s.Cout, s.Cin, false, 0));
+        js.push_back(make_prep_job(s.w_off, s.ws_fwd, s.Cout, s.Cin, true, 1));
+        js.push_back(make_prep_job(s.w_off, s.ws_bwd, s.Cout, s.Cin, false, 1));
+        jh.push_back(make_prep_job(s.w_off, s.ws_fwd, s.Cout, s.Cin, true, 2, s.amax_w));
+        jh.push_back(make_prep_job(s.w_off, s.ws_bwd, s.Cout, s.Cin, false, 2, s.amax_w));
       }
     }
     for (auto& s : n->st)          // nn.Linear weights: only their maximum (f16x3 GEMM scales)
@@ -561,7 +569,7 @@ static int ensure_batch(gr_net* n, int B) {
   for (auto& s : n->st) {
     if (s.kind != ST_ELEM) { (void)hipFree(s.y); s.y = nullptr; HIPCHK(c, hipMalloc((void**)&s.y, sizeof(float) * (size_t)B * vol3(s.Cout, s.H, s.W))); }
     if (s.has_post) { (void)hipFree(s.out); s.out = nullptr; HIPCHK(c, hipMalloc((void**)&s.out, sizeof(float) * (size_t)B * vol3(s.outC, s.outH, s.outW))); }
-    if (s.kind == ST_CONV && s.has_bn && !s.fullconv && !s.up) {
+    if (s.kind == ST_CONV && s.has_bn && !s.up) {
       (void)hipFree(s.stat_part); s.stat_part = nullptr;
       HIPCHK(c, hipMalloc((void**)&s.stat_part, sizeof(double) * 2 * (size_t)s.Cout * conv_stat_tiles_max(B, s.H, s.W)));
     }
@@ -592,7 +600,7 @@ static bool use_f16_gemm(gr_net* n, const Stage& s) {
   static const bool on = !getenv("GR_NO_F16_GEMM");
   return on && n->ctx->conv_mode == 2 && s.kind == ST_LINEAR && (int64_t)s.Cin * s.Cout >= (1 << 20);
 }
-static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode >= 1 && s.kind == ST_CONV && !s.fullconv && !fewout_applies(s); }   // either split flavour
+static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode >= 1 && s.kind == ST_CONV && !fewout_applies(s); }   // either split flavour
 // Re-lay every convolution's weights (one launch) when the parameters changed since the last time.  bf16x6 mode needs the
 // split images; the fp32 k-major images are still needed there by SpatialFullConvolution stages (no split kernel).
 static int prep_weights(gr_net* n) {
@@ -710,7 +718,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
       ConvEpilogue ep; const ConvEpilogue* epp = nullptr; float* dst = s.y;
       bool nb1 = false, nb2 = false;
       const MaskRef r1 = mask_ref(n, s.m1, nb1), r2 = mask_ref(n, s.m2, nb2);
-      if (!n->training && s.has_post && !s.pool && !s.fullconv && r1.kind == MASK_NONE && r2.kind == MASK_NONE) {
+      if (!n->training && s.has_post && !s.pool && r1.kind == MASK_NONE && r2.kind == MASK_NONE) {
         if (s.has_bn) {
           if (!s.eval_ready) { launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream); s.eval_ready = true; }
           ep.mean = s.mean; ep.invstd = s.invstd; ep.gamma = n->params + s.g_off; ep.beta = n->params + s.be_off;
@@ -929,7 +937,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     pb.partials = s.partials; pb.partials_b = s.partials_b; pb.coef = s.coef;
     pb.ggamma = s.has_bn ? n->grads + s.g_off : nullptr; pb.gbeta = s.has_bn ? n->grads + s.be_off : nullptr;
     pb.gbias = s.kind == ST_ELEM ? nullptr : n->grads + s.b_off;
-    pb.amax_dy = (f16 && ((s.kind == ST_CONV && !s.up && !s.fullconv) || use_f16_gemm(n, s))) ? s.amax_dy : nullptr;
+    pb.amax_dy = (f16 && (s.kind == ST_CONV || use_f16_gemm(n, s))) ? s.amax_dy : nullptr;
     // operand-ready dy for the data-gradient convolution: needs the forward's bound factor of THIS forward (kb_gen)
     const bool dy_ok = f16 && s.kind == ST_CONV && !s.up && !s.fullconv && s.has_bn && n->dy_p16 && s.kb_gen == n->amax_gen &&
                        post_g8_supported(s.Cout, s.H, s.W, s.pool, true);
@@ -946,8 +954,38 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     launch_post_backward(pb, c->stream, &bias_jobs);       // bias gradients of several stages are summed by one launch
     LAUNCHCHK(c);
     if (s.kind == ST_CONV) {
-      if (s.up) return fail(c, GR_ERR_UNSUPPORTED, "backward through the fused UpSamplingNearest is not implemented (G is forward-only on this path)");
-      if (s.fullconv) return fail(c, GR_ERR_UNSUPPORTED, "SpatialFullConvolution backward is not implemented");
+      if (s.up) {
+        // SpatialUpSamplingNearest(2) + SpatialConvolution backward (adversarial.lua:37-205 trains G through it): the weight
+        // gradient needs the up-sampled input, the data gradient is folded back by summing each 2x2 block
+        const size_t need = (size_t)B * vol3(s.Cin, s.H, s.W);
+        if (need > n->up_cap) {
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          (void)hipFree(n->up_tmp[0]); (void)hipFree(n->up_tmp[1]); n->up_tmp[0] = n->up_tmp[1] = nullptr; n->up_cap = 0;
+          HIPCHK(c, hipMalloc((void**)&n->up_tmp[0], sizeof(float) * need)); HIPCHK(c, hipMalloc((void**)&n->up_tmp[1], sizeof(float) * need));
+          n->up_cap = need;
+        }
+        launch_upsample2(x, n->up_tmp[0], B, s.Cin, s.H, s.W, c->stream);
+        int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W, c->conv_mode)); if (r) return r;
+        if (c->conv_mode == 2 && conv_wgrad_is_split(2, s.Cin, s.W) && s.amax_x_fwd != n->amax_gen) launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream);
+        launch_conv3x3_wgrad(n->up_tmp[0], n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode, s.amax_x, s.amax_dy);
+        if (need_gin) {
+          if (c->conv_mode >= 1 && s.Cin > 4) launch_conv3x3_split(n->dy_buf, s.ws_bwd, nullptr, n->up_tmp[1], B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
+          else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, n->up_tmp[1], B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+          launch_downsum2(n->up_tmp[1], gin, B, s.Cin, s.H / 2, s.W / 2, c->stream);
+        }
+        LAUNCHCHK(c);
+      } else if (s.fullconv) {
+        // nn.SpatialFullConvolution:accGradParameters: gradWeight[i][o] += x[i] (x) gradOutput[o] = the weight gradient of the convolution
+        // Cout -> Cin with the roles of input and gradOutput swapped; gradInput = that convolution's forward of gradOutput
+        int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cout, s.Cin, s.H, s.W, c->conv_mode)); if (r) return r;
+        if (c->conv_mode == 2 && conv_wgrad_is_split(2, s.Cout, s.W) && s.amax_x_fwd != n->amax_gen) launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream);
+        launch_conv3x3_wgrad(n->dy_buf, x, n->grads + s.w_off, c->ws, B, s.Cout, s.Cin, s.H, s.W, c->stream, c->conv_mode, s.amax_dy, s.amax_x);
+        if (need_gin) {
+          if (c->conv_mode >= 1 && s.Cin > 4) launch_conv3x3_split(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
+          else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+        }
+        LAUNCHCHK(c);
+      } else {
       int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W, c->conv_mode)); if (r) return r;
       if (c->conv_mode == 2) {
         // max|dy| was folded into s.amax_dy by the pipeline-backward kernel that wrote dy_buf
@@ -966,6 +1004,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
         else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
       }
       LAUNCHCHK(c);
+      }
     } else if (s.kind == ST_LINEAR) {
       size_t wsb = gemm_workspace_bytes(s.Cout, s.Cin, B);
       const size_t wsb2 = gemm_workspace_bytes(B, s.Cin, s.Cout);

@@ -89,6 +89,7 @@ int go_net_backward(go_net*, const float* in, const float* gout, int B, float* g
  * given one (NULL: compute it again).  Parity-test hooks: see oracle_net.c. */
 int64_t go_net_get_pool_index(const go_net*, int layer_index, uint8_t* out /*nullable: returns the count*/, int64_t cap);
 int go_net_force_pool_index(go_net*, int layer_index, const uint8_t* idx /*nullable*/, int64_t n);
+int go_net_force_act_side(go_net* n, int li, const uint8_t* side, int64_t cnt);   /* ReLU / LeakyReLU: side of the kink to USE in backward (test hook) */
 /* intermediate module outputs, for layer-by-layer debugging of the HIP path */
 const float* go_net_layer_output(const go_net*, int layer_index, int64_t* n);
 

@@ -64,6 +64,7 @@ def lib():
         L.go_net_get_pool_index.restype = C.c_int64
         L.go_net_get_pool_index.argtypes = [_P, C.c_int, _P, C.c_int64]
         L.go_net_force_pool_index.argtypes = [_P, C.c_int, _P, C.c_int64]
+        L.go_net_force_act_side.argtypes = [_P, C.c_int, _P, C.c_int64]
         L.go_mse.restype = C.c_double
         L.go_mse.argtypes = [_P, _P, C.c_int64, _P]
         L.go_mse_scaled.restype = C.c_double
@@ -185,6 +186,15 @@ class Net:
         else:
             idx = np.ascontiguousarray(idx, dtype=np.uint8)
             rc = self.L.go_net_force_pool_index(self.h, layer, _p(idx), idx.size)
+        assert rc == 0, rc
+
+    def force_act_side(self, layer, side):
+        """ReLU / LeakyReLU `layer`: side[k] != 0 = treat input k as positive in the following backwards (None: its own sign)"""
+        if side is None:
+            rc = self.L.go_net_force_act_side(self.h, layer, None, 0)
+        else:
+            side = np.ascontiguousarray(side, dtype=np.uint8)
+            rc = self.L.go_net_force_act_side(self.h, layer, _p(side), side.size)
         assert rc == 0, rc
 
     def layer_output(self, layer):

@@ -245,6 +245,17 @@ int go_net_force_pool_index(go_net* n, int li, const uint8_t* idx, int64_t cnt) 
   return 0;
 }
 
+/* The same for the kink of nn.ReLU / nn.LeakyReLU: an input within rounding noise of zero may fall on either side in two
+ * correct fp32 implementations, and the derivative jumps there (by gout * (1 - slope)).  side[k] = 1: treat input k as
+ * positive in the backward pass; NULL: back to the input's own sign. */
+int go_net_force_act_side(go_net* n, int li, const uint8_t* side, int64_t cnt) {
+  if (li < 0 || li >= n->n || (n->L[li].d.kind != GO_RELU && n->L[li].d.kind != GO_LEAKYRELU)) return -1;
+  olayer* l = &n->L[li];
+  free(l->forced_idx); l->forced_idx = NULL; l->forced_n = 0;
+  if (side) { l->forced_idx = (uint8_t*)malloc(cnt); memcpy(l->forced_idx, side, cnt); l->forced_n = cnt; }
+  return 0;
+}
+
 static float* ensure(float** p, int64_t* cap, int64_t n) {
   if (*cap < n) { free(*p); *p = (float*)malloc(sizeof(float) * n); *cap = n; }
   return *p;
@@ -388,9 +399,11 @@ int go_net_backward(go_net* net, const float* in, const float* gout, int B, floa
         for (int64_t k = 0; k < nin; ++k) gi[k] = yout[k] <= 0 ? g[k] * (yout[k] + 1.f) : g[k];
         break;
       case GO_RELU:
+        if (l->forced_idx && l->forced_n == nin) { for (int64_t k = 0; k < nin; ++k) gi[k] = l->forced_idx[k] ? g[k] : 0.f; break; }
         for (int64_t k = 0; k < nin; ++k) gi[k] = yout[k] > 0 ? g[k] : 0.f;
         break;
       case GO_LEAKYRELU:
+        if (l->forced_idx && l->forced_n == nin) { for (int64_t k = 0; k < nin; ++k) gi[k] = l->forced_idx[k] ? g[k] : g[k] * l->d.p; break; }
         for (int64_t k = 0; k < nin; ++k) gi[k] = x[k] > 0 ? g[k] : g[k] * l->d.p;
         break;
       case GO_SIGMOID:

@@ -106,6 +106,39 @@ def adopt_device_argmax(model, onet, B, max_flips):
     return flips
 
 
+def adopt_device_kinks(model, onet, B, max_flips):
+    """The same for the kink of nn.ReLU / nn.LeakyReLU: an input within rounding noise of zero can land on either side, and the
+    derivative jumps there by gout * (1 - slope) - one such element moves a BatchNorm bias gradient by more than the bar.
+    The device never materialises the activation's input, but the sign of the stage output it does keep (after the Dropout
+    that may follow; a dropped element passes no gradient on either side) tells the side it took.  Requires the elements
+    where that differs from the oracle's own side to be few and within NEAR_TIE of zero in the oracle's forward, then forces
+    the device's side onto the oracle's backward (go_net_force_act_side).  Returns the number of such elements per layer;
+    activations whose stage output the device does not keep as fp32 (a max-pool follows, lean f16x3 stages) stay unforced."""
+    import ganrev._lib as L
+    leaves = model.leaves()
+    flips = []
+    for i, m in enumerate(leaves):
+        if m.typename not in ("nn.ReLU", "nn.LeakyReLU"):
+            continue
+        li = onet.layer_index[id(m)]
+        z = onet.layer_output(li - 1)
+        own = z > 0
+        lj = li + 1 if i + 1 < len(leaves) and leaves[i + 1].typename in ("nn.Dropout", "nn.SpatialDropout") else li
+        try:
+            dev = model._net.layer_output(lj, (z.size,))
+        except L.GanrevError:
+            continue
+        side = np.where(dev != 0, dev > 0, own if m.typename == "nn.LeakyReLU" or lj != li else False)
+        diff = np.nonzero(side != own)[0]
+        if diff.size:
+            assert np.abs(z[diff]).max() < NEAR_TIE, (f"activation layer {li}: {diff.size} inputs on the other side of zero, "
+                                                      f"largest |input| {np.abs(z[diff]).max():.3e}: not rounding-level")
+        assert diff.size <= max_flips, f"activation layer {li}: {diff.size} of {z.size} inputs on the other side of zero (allowed {max_flips})"
+        onet.force_act_side(li, side)
+        flips.append(int(diff.size))
+    return flips
+
+
 def release_argmax(model, onet):
     for m, li, _ in pool_layers(model, onet):
         onet.force_pool_index(li, None)

@@ -245,9 +245,67 @@ def test_R_operand_ready_path_vs_oracle(oracle, f16_path, dims, nd, B):
     assert_grads_close(R, grads, onet.grads, 1e-4, 1e-3)
 
 
+@pytest.mark.parametrize("B,Cin,Cmid,Cout,H,W", [(6, 16, 24, 20, 12, 12), (4, 64, 64, 32, 32, 32), (3, 8, 40, 3, 16, 16)])
+def test_fullconv_bn_leakyrelu_dropout_stage_vs_oracle(oracle, conv_mode, B, Cin, Cmid, Cout, H, W):
+    """BASELINE.json north_star names nn.SpatialFullConvolution and a SpatialBatchNormalization + LeakyReLU + Dropout epilogue
+    (the live reference has neither: models.lua:121-122 up-samples with UpSamplingNearest + SpatialConvolution, LeakyReLU(0.333)
+    only appears in the never-called models.lua:8-55).  Two such stages back to back - FullConv(3,3,1,1,1,1) -> SBN ->
+    LeakyReLU(0.333) -> Dropout - in training mode (forward, gradInput, every gradient tensor: the weight [nIn][nOut][3][3],
+    bias, BN) and in evaluate() mode (BN + LeakyReLU ride in the convolution's epilogue), all three arithmetics."""
+    from ganrev import nn, synth
+    from helpers import adopt_device_kinks, assert_grads_close
+    net = nn.Sequential()
+    net.add(nn.SpatialFullConvolution(Cin, Cmid, 3, 3, 1, 1, 1, 1)); net.add(nn.SpatialBatchNormalization(Cmid)); net.add(nn.LeakyReLU(0.333)); net.add(nn.Dropout(0.5))
+    net.add(nn.SpatialFullConvolution(Cmid, Cout, 3, 3, 1, 1, 1, 1)); net.add(nn.SpatialBatchNormalization(Cout)); net.add(nn.LeakyReLU(0.333)); net.add(nn.Dropout(0.5))
+    synth.init_params(net, 23)
+    flat, grads = net.getParameters()
+    onet = oracle.from_model(net, (Cin, H, W))
+    x = synth.normal((B, Cin, H, W), 31)
+    net.training(); onet.set_training(True)
+    inject_noise(net, onet, B, 5)
+    ref = onet.forward(x)
+    out = net.forward(x)
+    assert_close(out, ref, TOL * max(1.0, float(np.abs(ref).max())), "forward (training)")
+    adopt_device_kinks(net, onet, B, 8)      # a LeakyReLU input within rounding of zero: use the side the device took
+    gy = synth.normal(ref.shape, 9) * np.float32(0.1)
+    grads[...] = 0; onet.zero_grads()
+    gin = net.backward(x, gy)
+    ref_gin = onet.backward(x, gy)
+    assert_close(gin, ref_gin, TOL * max(1.0, float(np.abs(ref_gin).max())), "gradInput")
+    assert_grads_close(net, grads, onet.grads, 1e-4, 1e-3)
+    net.evaluate(); onet.set_training(False)
+    ref_e = onet.forward(x)
+    assert_close(net.forward(x), ref_e, TOL * max(1.0, float(np.abs(ref_e).max())), "forward (evaluate)")
+
+
+@pytest.mark.parametrize("dims,nd,B", [((1, 16, 16), 8, 6), ((3, 32, 32), 16, 4)])
+def test_G_training_forward_backward_vs_oracle(oracle, conv_mode, dims, nd, B):
+    """First slice of the GAN step (adversarial.lua:37-205 trains G through D): MODEL_G:forward / :backward in TRAINING mode -
+    batch-statistics BatchNorm, and the backward of the fused SpatialUpSamplingNearest(2) + SpatialConvolution stages
+    (models.lua:121-122,127-128): weight gradient against the up-sampled input, data gradient folded back over 2x2 blocks.
+    Images, gradInput (w.r.t. the noise) and every gradient tensor of G against the oracle, three arithmetics."""
+    from ganrev import models, synth
+    from helpers import adopt_device_kinks, assert_grads_close
+    G = models.create_G(dims, nd); synth.init_params(G, 2)
+    flat, grads = G.getParameters()
+    onet = oracle.from_model(G, (nd, 1, 1))
+    z = synth.normal((B, nd), 8)
+    G.training(); onet.set_training(True)
+    ref = onet.forward(z)
+    img = G.forward(z)
+    assert_close(img, ref, TOL, "G images (training mode)")
+    adopt_device_kinks(G, onet, B, 8)        # a ReLU input within rounding of zero: use the side the device took
+    gy = synth.normal(ref.shape, 9) * np.float32(0.1)
+    grads[...] = 0; onet.zero_grads()
+    gin = G.backward(z, gy)
+    ref_gin = onet.backward(z, gy)
+    assert_close(gin, ref_gin, TOL * max(1.0, float(np.abs(ref_gin).max())), "gradInput (noise)")
+    assert_grads_close(G, grads, onet.grads, 1e-4, 1e-3)
+
+
 def test_operand_ready_kernels_are_selected(ctx):
     """At the benchmark geometry (cfg2: batch 256) the f16x3 training step must take the operand-ready kernels: R's five
-    512-pixel-tile forward convolutions and four of its data-gradient convolutions run as conv3x3_p16_quad_kernel, fed by
+    512-pixel-tile forward convolutions and at least four of its data-gradient convolutions run as conv3x3_p16_*_kernel, fed by
     post_forward_g8_kernel / post_backward_b_g8_kernel; the kernel table of a step says so."""
     import ganrev._lib as L
     from ganrev import models, synth
@@ -265,7 +323,7 @@ def test_operand_ready_kernels_are_selected(ctx):
         tr.new_noise(2); tr.step()
         kt = ctx.kernel_times(); ctx.set_timing(0)
         count = lambda prefix: sum(k["launches"] for k in kt if k["kernel"].startswith(prefix))
-        assert count("conv3x3_p16_") == 9, sorted((k["kernel"], k["launches"]) for k in kt if k["kernel"].startswith("conv3x3"))
+        assert count("conv3x3_p16_") >= 9, sorted((k["kernel"], k["launches"]) for k in kt if k["kernel"].startswith("conv3x3"))
         assert count("post_forward_g8_kernel") == 5 and count("post_backward_b_g8_kernel") == 5
         assert count("conv3x3_wgrad_p16_kernel") == 5, "R.conv2 .. conv6: weight gradients from the operand-ready x and dy images"
         assert count("conv3x3_split_wide_kernel") == 0

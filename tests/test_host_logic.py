@@ -232,3 +232,27 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+def test_oracle_act_side_hook_moves_exactly_the_forced_elements():
+    """go_net_force_act_side: forcing the side the oracle would take anyway changes nothing; flipping one LeakyReLU input's side
+    changes gradInput of the activation by gout * (1 - slope) at that element only (seen through a 1x1 identity-free net:
+    LeakyReLU alone)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "gan-reverser_amd"))
+    from ganrev import nn, synth
+    from oracle import oracle
+    net = nn.Sequential(); net.add(nn.LeakyReLU(0.333))
+    onet = oracle.from_model(net, (3, 4, 4))
+    x = synth.normal((2, 3, 4, 4), 1); g = synth.normal((2, 3, 4, 4), 2)
+    onet.forward(x); base = onet.backward(x, g).copy()
+    own = (x.reshape(-1) > 0)
+    onet.force_act_side(0, own)
+    onet.forward(x); assert np.array_equal(onet.backward(x, g), base)
+    flipped = own.copy(); flipped[5] = not flipped[5]
+    onet.force_act_side(0, flipped)
+    onet.forward(x); got = onet.backward(x, g).reshape(-1)
+    d = got - base.reshape(-1)
+    assert np.count_nonzero(d) == 1 and abs(abs(d[5]) - abs(g.reshape(-1)[5]) * (1 - 0.333)) < 1e-6
+    onet.force_act_side(0, None)
+    onet.forward(x); assert np.array_equal(onet.backward(x, g), base)
