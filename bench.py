@@ -199,7 +199,7 @@ def kernel_report(kt, nprof, dims, nd, B, traffic=None):
         targs = [t.strip() for t in kname[kname.index("<") + 1:kname.rindex(">")].split(",")]
         nterm = int(targs[2]) if ("split_wide" in kname or kname.startswith("conv3x3_split_kernel")) else int(targs[-1])
         passes = {3: BF16X6_PASSES, 2: F16X3_PASSES}[nterm]
-    elif "f16x3" in kname:
+    elif "f16x3" in kname or "_p16_" in kname:        # operand-ready kernels (conv3x3_p16_*, conv3x3_wgrad_p16_*): fp16 hi/lo, 3 products
         passes = F16X3_PASSES
     split = passes > 0
     # split modes: the kernel issues `passes` 16-bit MFMA products per algorithmic multiply-add; its ceiling for ALGORITHMIC

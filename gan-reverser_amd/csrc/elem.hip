@@ -891,6 +891,68 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
   }
 }
 
+// ------------------------------------------------------------------ f16x3 range guard (kernels.h)
+__global__ __launch_bounds__(256) void channel_absmax_kernel(const float* __restrict__ t, int B, long HW, long sB, long sC, unsigned* __restrict__ chmax) {
+  const int c = blockIdx.x;
+  const long n = (long)B * HW;
+  float m = 0.f;
+  for (long j = (long)blockIdx.y * 256 + threadIdx.x; j < n; j += (long)gridDim.y * 256) {
+    const long b = j / HW, i = j - b * HW;
+    m = fmaxf(m, fabsf(t[b * sB + (long)c * sC + i]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(chmax + c, __float_as_uint(m));
+}
+// one block: fold every thread's (max, smallest non-zero) pair, then thread 0 enters the spread (in bits: exponent of the
+// maximum minus exponent of the smallest non-zero channel maximum, + 1 for the mantissas) into the two largest seen so far -
+// *top2 = first | second << 16.  Kernels of one stream run one after the other, so the read-modify-write needs no atomics.
+__device__ __forceinline__ void spread_enter(float mx, float mn, unsigned* top2) {
+  __shared__ float tmx[256], tmn[256];
+  tmx[threadIdx.x] = mx; tmn[threadIdx.x] = mn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 256; ++i) { mx = fmaxf(mx, tmx[i]); mn = fminf(mn, tmn[i]); }
+    if (mx > 0.f && mn < mx) {
+      const unsigned bits = (unsigned)min(ilogbf(mx) - ilogbf(mn) + 1, 0xffff);
+      const unsigned w = *top2;
+      unsigned a = w & 0xffffu, b = w >> 16;
+      if (bits > a) { b = a; a = bits; } else if (bits > b) b = bits;
+      *top2 = a | b << 16;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void spread_verdict_kernel(unsigned* chmax, int C, unsigned* top2) {
+  float mx = 0.f, mn = INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float v = __uint_as_float(chmax[c]); chmax[c] = 0u;
+    mx = fmaxf(mx, v); if (v > 0.f) mn = fminf(mn, v);
+  }
+  spread_enter(mx, mn, top2);
+}
+__global__ __launch_bounds__(256) void pair_spread_kernel(const float* __restrict__ a, const float* __restrict__ b, int C, unsigned* top2) {
+  float mx = 0.f, mn = INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float v = fmaxf(fabsf(a[c]), b ? fabsf(b[c]) : 0.f);
+    mx = fmaxf(mx, v); if (v > 0.f) mn = fminf(mn, v);
+  }
+  spread_enter(mx, mn, top2);
+}
+void launch_channel_absmax(const float* t, int B, int C, long HW, long sB, long sC, unsigned* chmax, hipStream_t s) {
+  const long n = (long)B * HW;
+  int splits = (int)((n + 4095) / 4096);
+  if (splits < 1) splits = 1;
+  if ((long)splits * C > 8192) splits = (int)(8192 / C > 0 ? 8192 / C : 1);
+  KtScope kt("range_guard_scan", 0.0, 4.0 * (double)n * C, s);
+  hipLaunchKernelGGL(channel_absmax_kernel, dim3(C, splits), dim3(256), 0, s, t, B, HW, sB, sC, chmax);
+}
+void launch_spread_verdict(unsigned* chmax, int C, unsigned* top2, hipStream_t s) {
+  hipLaunchKernelGGL(spread_verdict_kernel, dim3(1), dim3(256), 0, s, chmax, C, top2);
+}
+void launch_pair_spread(const float* a, const float* b, int C, unsigned* top2, hipStream_t s) {
+  hipLaunchKernelGGL(pair_spread_kernel, dim3(1), dim3(256), 0, s, a, b, C, top2);
+}
+
 // ------------------------------------------------------------------ nn.MSECriterion
 __global__ __launch_bounds__(1024) void mse_kernel(const float* __restrict__ x, const float* __restrict__ t, long n, double inv_n,
                                                    float norm, double* loss, float* grad) {
@@ -909,25 +971,42 @@ void launch_mse(const float* x, const float* t, long n, long n_global, double* l
 }
 
 // ------------------------------------------------------------------ penalty + clamp + Adam, one pass over (theta, g, m, v)
+__device__ __forceinline__ void adam_one(float& th, float& gv, float& mv, float& vv, const AdamConsts& c) {
+  if (c.use_penalty) {
+    const float sg = th > 0.f ? 1.f : (th < 0.f ? -1.f : 0.f);
+    const float pen = sg * c.l1 + th * c.l2;
+    gv = gv + pen;
+  }
+  if (c.use_clamp) gv = gv < -c.clamp ? -c.clamp : (gv > c.clamp ? c.clamp : gv);
+  mv = mv * c.b1 + c.c1 * gv;
+  vv = vv * c.b2 + (c.c2 * gv) * gv;
+  const float denom = sqrtf(vv) + c.eps;
+  th = th + (c.step * mv) / denom;
+}
+// four entries per thread as one 16-byte access per array (the flat vectors are hipMalloc'ed: 256-byte aligned); the last
+// n % 4 entries go through the scalar path of the thread that would own the next vector
 __global__ __launch_bounds__(256) void penalty_clamp_adam_kernel(float* __restrict__ theta, float* __restrict__ g, float* __restrict__ m,
                                                                  float* __restrict__ v, long n, AdamConsts c) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float th = theta[i], gv = g[i], mv = m[i], vv = v[i];
-    if (c.use_penalty) {
-      const float sg = th > 0.f ? 1.f : (th < 0.f ? -1.f : 0.f);
-      const float pen = sg * c.l1 + th * c.l2;
-      gv = gv + pen;
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i <= n4; i += (long)gridDim.x * blockDim.x) {
+    if (i < n4) {
+      float4 th = reinterpret_cast<float4*>(theta)[i], gv = reinterpret_cast<float4*>(g)[i];
+      float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+      adam_one(th.x, gv.x, mv.x, vv.x, c); adam_one(th.y, gv.y, mv.y, vv.y, c);
+      adam_one(th.z, gv.z, mv.z, vv.z, c); adam_one(th.w, gv.w, mv.w, vv.w, c);
+      reinterpret_cast<float4*>(theta)[i] = th; reinterpret_cast<float4*>(g)[i] = gv;
+      reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+    } else {
+      for (long j = n4 << 2; j < n; ++j) {
+        float th = theta[j], gv = g[j], mv = m[j], vv = v[j];
+        adam_one(th, gv, mv, vv, c);
+        theta[j] = th; g[j] = gv; m[j] = mv; v[j] = vv;
+      }
     }
-    if (c.use_clamp) gv = gv < -c.clamp ? -c.clamp : (gv > c.clamp ? c.clamp : gv);
-    mv = mv * c.b1 + c.c1 * gv;
-    vv = vv * c.b2 + (c.c2 * gv) * gv;
-    const float denom = sqrtf(vv) + c.eps;
-    th = th + (c.step * mv) / denom;
-    theta[i] = th; g[i] = gv; m[i] = mv; v[i] = vv;
   }
 }
 void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long n, const AdamConsts& c, hipStream_t s) {
-  long blocks = (n + 255) / 256;
+  long blocks = ((n >> 2) + 1 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   KtScope kt("penalty_clamp_adam_kernel", 0.0, 32.0 * (double)n, s);   // read theta,g,m,v + write theta,g,m,v

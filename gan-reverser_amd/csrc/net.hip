@@ -36,6 +36,15 @@ struct gr_ctx {
   hipEvent_t ev[7] = {};
   std::vector<hipEvent_t> marks;  // gr_event_record slots (bench: per-step times on THIS stream)
   float times[6] = {0, 0, 0, 0, 0, 0};
+  // f16x3 range guard (kernels.h "range guard"): the alarm word lives behind the loss scalar (d_loss + 16 bytes,
+  // mirrored at h_loss + 16), chmax is the per-channel scratch of the scans
+  int range_guard = 1;                 // 1: on (gr_set_tuning "range_guard")
+  unsigned* guard_chmax = nullptr; size_t guard_chmax_cap = 0;
+  long guard_scans = 0, guard_fallbacks = 0;
+  long search_reruns = 0;              // searches whose sample-bound filter overflowed and ran again unfiltered
+  void* pin = nullptr; size_t pin_bytes = 0;   // pinned staging for small results (search)
+  hipEvent_t ev_guard = nullptr; bool guard_pending = false;   // device-resident trainer: sampled scans, verdict read one call later
+  bool guard_tripped = false;          // ... which found a hostile range: the context stays on bf16x6
 };
 
 // ---- per-kernel event timer (gr_set_timing(ctx, 2)) -------------------------------------------------------------
@@ -110,6 +119,10 @@ extern "C" int gr_init(int device, gr_ctx** out) {
     delete c; return GR_ERR_HIP;
   }
   for (auto& e : c->ev) (void)hipEventCreate(&e);
+  (void)hipEventCreateWithFlags(&c->ev_guard, hipEventDisableTiming);
+  (void)hipMemsetAsync(c->d_loss, 0, 64, c->stream);
+  memset(c->h_loss, 0, 64);
+  { const char* d = getenv("GR_RANGE_GUARD"); if (d) c->range_guard = atoi(d); }
   { const char* d = getenv("GR_P16_DEBUG"); if (d) gr::g_p16_debug = atoi(d); }      // diagnostic ablations (tools/ablate_p16.py)
   { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "f32") || !strcmp(m, "0")) ? 0 : ((!strcmp(m, "bf16x6") || !strcmp(m, "1")) ? 1 : 2); }
   (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
@@ -125,6 +138,9 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
   if (c->ws) (void)hipFree(c->ws);
+  if (c->guard_chmax) (void)hipFree(c->guard_chmax);
+  if (c->pin) (void)hipHostFree(c->pin);
+  if (c->ev_guard) (void)hipEventDestroy(c->ev_guard);
   (void)hipFree(c->d_loss); (void)hipFree(c->amax); (void)hipHostFree(c->h_loss);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : c->marks) if (e) (void)hipEventDestroy(e);
@@ -160,8 +176,16 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!strcmp(key, "p16_stagger")) { gr::g_p16_stagger = value; return GR_OK; }
   if (!strcmp(key, "p16_variant")) { gr::g_p16_variant = value; return GR_OK; }
   if (!strcmp(key, "p16_debug")) { gr::g_p16_debug = value; return GR_OK; }     // diagnostic ablations (outputs are then wrong by design)
+  if (!strcmp(key, "range_guard")) { c->range_guard = value; if (!value) c->guard_tripped = false; return GR_OK; }   // f16x3 range guard on / off (off also clears a tripped trainer guard)
   return fail(c, GR_ERR_INVALID, "gr_set_tuning: unknown key %s", key);
 }
+extern "C" int gr_range_guard_stats(gr_ctx* c, int64_t* scans, int64_t* fallbacks) {
+  if (!c) return GR_ERR_INVALID;
+  if (scans) *scans = c->guard_scans;
+  if (fallbacks) *fallbacks = c->guard_fallbacks;
+  return GR_OK;
+}
+extern "C" int gr_search_stats(gr_ctx* c, int64_t* reruns) { if (!c) return GR_ERR_INVALID; if (reruns) *reruns = c->search_reruns; return GR_OK; }
 extern "C" int gr_set_timing(gr_ctx* c, int en) {
   if (!c) return GR_ERR_INVALID;
   c->timing = en == 1;
@@ -186,6 +210,12 @@ extern "C" int gr_kernel_times(gr_ctx* c, char* buf, int buflen) {
     static const char* phase_names[] = {"", "G forward", "R forward", "loss", "R backward", "adam"};
     snprintf(line, sizeof line, "%s{\"kernel\": \"%s\", \"phase\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
              i ? ", " : "", kv.first.first.c_str(), phase_names[kv.first.second], kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes);
+    out += line;
+  }
+  if (c->guard_fallbacks > 0) {      // passes the f16x3 range guard sent to bf16x6 since gr_init (not a kernel: a count)
+    char line[256];
+    snprintf(line, sizeof line, "%s{\"kernel\": \"range_guard_fallback\", \"phase\": \"\", \"launches\": %ld, \"total_ms\": 0.0, \"flops\": 0.0, \"bytes\": 0.0}",
+             g_evtimer->agg.empty() ? "" : ", ", c->guard_fallbacks);
     out += line;
   }
   out += "]";
@@ -280,6 +310,9 @@ struct gr_net {
   uint64_t prepped_version[3] = {0, 0, 0};
   unsigned* amax = nullptr;          // f16x3 scale tracking, groups of [nst] slots: x | y | kb | dy | dz | w  (AMAX_GROUPS)
   bool dy_slots_zeroed = false, w_slots_zeroed = false;   // set by forward_impl's single fill, consumed by backward / weight prep
+  bool keep_fp32 = false;            // range-guarded host calls: no lean (operand-ready only) tensors, so a backward can still fall back to bf16x6
+  bool last_fwd_fell_back = false;   // the last guarded forward ran on bf16x6: its backward does too
+  unsigned guard_top2 = 0;           // the two largest spreads (bits) the last guarded forward measured
 };
 
 enum { AG_X = 0, AG_Y = 1, AG_KB = 2, AG_DY = 3, AG_DZ = 4, AG_W = 5, AMAX_GROUPS = 6 };
@@ -661,6 +694,91 @@ static PostArgs post_args(gr_net* n, Stage& s, int B) {
   return a;
 }
 
+// ------------------------------------------------------------------ f16x3 range guard
+// f16x3 scales each tensor by ONE power of two: an entry 2^k below the tensor's maximum keeps about 40 - k bits (fp16's exponent
+// range ends 2^-40 below the scaled maximum), and the relative error of an output channel grows with the product of the
+// per-channel spreads of the two tensors a kernel multiplies (x and the weights' output-channel view in the forward, dy and
+// their input-channel view in the data gradient, x and dy in the weight gradient).  bf16x6 has fp32's exponent range and no
+// such limit.  The guard measures, before a pass computes anything, the per-channel spread (log2 of largest / smallest
+// non-zero channel maximum) of what enters it: the net input (forward) or gradOutput (backward), every weight tensor an
+// f16x3 kernel will read (per input channel and per output channel), and the BatchNorm (gamma, beta) pairs that set the
+// channel ranges of every tensor behind a BatchNorm.  When the two largest spreads add up to more than GUARD_BUDGET_BITS the
+// whole pass runs on bf16x6 (counted: gr_kernel_times "range_guard_fallback", gr_range_guard_stats).  Budget: 40 bits of
+// range - 20 bits of spread leaves 20 bits per entry of the smallest channel, ~1e-6 of that channel's maximum.
+enum { GUARD_BUDGET_BITS = 20 };
+static bool guard_over_budget(unsigned top2) { return (top2 & 0xffffu) + (top2 >> 16) > (unsigned)GUARD_BUDGET_BITS; }
+static unsigned guard_merge(unsigned t, unsigned u) {        // the two largest of both words' entries
+  unsigned v[4] = {t & 0xffffu, t >> 16, u & 0xffffu, u >> 16};
+  for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) if (v[j] > v[i]) { unsigned x = v[i]; v[i] = v[j]; v[j] = x; }
+  return v[0] | v[1] << 16;
+}
+static unsigned* guard_alarm_dev(gr_ctx* c) { return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->d_loss) + 16); }
+static volatile unsigned* guard_alarm_host(gr_ctx* c) { return reinterpret_cast<volatile unsigned*>(reinterpret_cast<char*>(c->h_loss) + 16); }
+static bool f16_consumer(gr_net* n, const Stage& s) { return use_bf16x6(n, s) || use_f16_gemm(n, s); }     // (context in f16x3 mode)
+static int guard_scan(gr_ctx* c, const float* t, int B, int C, long HW, long sB, long sC) {
+  if (C < 2) return GR_OK;
+  if ((size_t)C > c->guard_chmax_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->guard_chmax) (void)hipFree(c->guard_chmax);
+    c->guard_chmax = nullptr; c->guard_chmax_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->guard_chmax, sizeof(unsigned) * (size_t)C));
+    HIPCHK(c, hipMemsetAsync(c->guard_chmax, 0, sizeof(unsigned) * (size_t)C, c->stream));
+    c->guard_chmax_cap = (size_t)C;
+  }
+  launch_channel_absmax(t, B, C, HW, sB, sC, c->guard_chmax, c->stream);
+  launch_spread_verdict(c->guard_chmax, C, guard_alarm_dev(c), c->stream);
+  c->guard_scans++;
+  LAUNCHCHK(c);
+  return GR_OK;
+}
+// weights and BatchNorm scales of every stage an f16x3 kernel serves
+static int guard_scan_params(gr_net* n) {
+  gr_ctx* c = n->ctx;
+  for (auto& s : n->st) {
+    if (!f16_consumer(n, s)) continue;
+    const float* w = n->params + s.w_off;
+    int r = 0;
+    if (s.kind == ST_LINEAR) {             // W[out][in]
+      r = guard_scan(c, w, s.Cout, s.Cin, 1, s.Cin, 1); if (r) return r;
+      r = guard_scan(c, w, 1, s.Cout, s.Cin, 0, s.Cin); if (r) return r;
+    } else if (s.fullconv) {               // W[in][out][3][3]
+      r = guard_scan(c, w, 1, s.Cin, (long)s.Cout * 9, 0, (long)s.Cout * 9); if (r) return r;
+      r = guard_scan(c, w, s.Cin, s.Cout, 9, (long)s.Cout * 9, 9); if (r) return r;
+    } else {                               // W[out][in][3][3]
+      r = guard_scan(c, w, s.Cout, s.Cin, 9, (long)s.Cin * 9, 9); if (r) return r;
+      r = guard_scan(c, w, 1, s.Cout, (long)s.Cin * 9, 0, (long)s.Cin * 9); if (r) return r;
+    }
+  }
+  for (size_t si = 0; si < n->st.size(); ++si) {
+    Stage& s = n->st[si];
+    const bool feeds = si + 1 < n->st.size() && f16_consumer(n, n->st[si + 1]);
+    if (!s.has_bn || !(feeds || f16_consumer(n, s))) continue;
+    launch_pair_spread(n->params + s.g_off, n->params + s.be_off, s.Cout, guard_alarm_dev(c), c->stream);
+    c->guard_scans++;
+  }
+  LAUNCHCHK(c);
+  return GR_OK;
+}
+// read the spread word (one stream synchronisation) and clear it
+static int guard_verdict(gr_ctx* c, unsigned* alarm) {
+  HIPCHK(c, hipMemcpyAsync((void*)guard_alarm_host(c), guard_alarm_dev(c), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemsetAsync(guard_alarm_dev(c), 0, sizeof(unsigned), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *alarm = *guard_alarm_host(c);
+  return GR_OK;
+}
+static bool guard_applies(gr_net* n) {
+  gr_ctx* c = n->ctx;
+  if (c->conv_mode != 2 || !c->range_guard) return false;
+  for (auto& s : n->st) if (f16_consumer(n, s)) return true;
+  return false;
+}
+// view of a per-sample [C][H][W] tensor as channels: a flat feature vector (H = W = 1 behind a Linear) has C "channels" of one element
+static int guard_scan_activation(gr_ctx* c, const float* t, int B, int C, int H, int W) {
+  const long hw = (long)H * W;
+  return guard_scan(c, t, B, C, hw, (long)C * hw, hw);
+}
+
 static int forward_impl(gr_net* n, const float* in_dev, int B) {
   gr_ctx* c = n->ctx;
   HIPCHK(c, hipSetDevice(c->device));
@@ -823,7 +941,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     // gradient.  When it will take the operand-ready image too (every condition is fixed by the shapes and this forward), the
     // fp32 tensor is not written at all: the pipeline kernel writes 4 bytes per element, as it did before it wrote two formats.
     static const bool lean_on = !getenv("GR_P16_KEEP_FP32");
-    s.out_skipped = lean_on && p16_out && nx->has_bn && n->dy_p16 && post_g8_supported(nx->Cout, nx->H, nx->W, nx->pool, true) &&
+    s.out_skipped = lean_on && !n->keep_fp32 && p16_out && nx->has_bn && n->dy_p16 && post_g8_supported(nx->Cout, nx->H, nx->W, nx->pool, true) &&
                     conv_wgrad_p16_supported(B, nx->Cin, nx->Cout, nx->H, nx->W) && nx->stat_part;
     if (s.out_skipped) pa.out = nullptr;
     launch_post_forward(pa, c->stream);
@@ -840,6 +958,7 @@ extern "C" float* gr_net_output_dev(gr_net* n) { return (n && !n->st.empty()) ? 
 
 extern "C" int gr_net_forward_dev(gr_net* n, const float* in_dev, int B, float* out_dev) {
   if (!n || !in_dev || B <= 0) return GR_ERR_INVALID;
+  n->keep_fp32 = false; n->last_fwd_fell_back = false;      // device-resident callers: no stream synchronisation, so no range guard here (gr_train_r_step samples one)
   int r = forward_impl(n, in_dev, B); if (r) return r;
   if (out_dev) HIPCHK(n->ctx, hipMemcpyAsync(out_dev, n->st.back().out, sizeof(float) * (size_t)B * vol3(n->outC, n->outH, n->outW), hipMemcpyDeviceToDevice, n->ctx->stream));
   return GR_OK;
@@ -851,7 +970,24 @@ extern "C" int gr_net_forward_host(gr_net* n, const float* in_host, int B, float
   HIPCHK(c, hipSetDevice(c->device));
   int r = ensure_batch(n, B); if (r) return r;
   HIPCHK(c, hipMemcpyAsync(n->in_buf, in_host, sizeof(float) * (size_t)B * vol3(n->inC, n->inH, n->inW), hipMemcpyHostToDevice, c->stream));
-  r = forward_impl(n, n->in_buf, B); if (r) return r;
+  n->last_fwd_fell_back = false;
+  n->keep_fp32 = guard_applies(n);
+  if (n->keep_fp32) {
+    // the first stage's view of the input: a Linear reads it as a flat feature vector
+    const Stage& s0 = n->st.front();
+    if (s0.kind == ST_LINEAR) r = guard_scan_activation(c, n->in_buf, B, s0.Cin, 1, 1);
+    else r = guard_scan_activation(c, n->in_buf, B, n->inC, n->inH, n->inW);
+    if (r) return r;
+    r = guard_scan_params(n); if (r) return r;
+    unsigned top2 = 0;
+    r = guard_verdict(c, &top2); if (r) return r;
+    n->guard_top2 = top2;
+    n->last_fwd_fell_back = guard_over_budget(top2);
+  }
+  if (n->last_fwd_fell_back) { c->guard_fallbacks++; c->conv_mode = 1; }
+  r = forward_impl(n, n->in_buf, B);
+  if (n->last_fwd_fell_back) c->conv_mode = 2;
+  if (r) return r;
   if (out_host) HIPCHK(c, hipMemcpyAsync(out_host, n->st.back().out, sizeof(float) * (size_t)B * vol3(n->outC, n->outH, n->outW), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GR_OK;
@@ -950,7 +1086,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     if (s.kind == ST_CONV && si > 0 && n->st[si - 1].out_skipped && !wgrad_p16)
       return fail(c, GR_ERR_STATE, "stage %d: the forward left this stage's input operand-ready only (f16x3); backward in another arithmetic mode needs a new forward", si);
     static const bool lean_on = !getenv("GR_P16_KEEP_FP32");
-    if (lean_on && wgrad_p16 && (dgrad_p16 || !need_gin)) pb.dy = nullptr;      // no fp32 reader of dy is left
+    if (lean_on && !n->keep_fp32 && wgrad_p16 && (dgrad_p16 || !need_gin)) pb.dy = nullptr;      // no fp32 reader of dy is left
     launch_post_backward(pb, c->stream, &bias_jobs);       // bias gradients of several stages are summed by one launch
     LAUNCHCHK(c);
     if (s.kind == ST_CONV) {
@@ -1058,7 +1194,23 @@ extern "C" int gr_net_backward_host(gr_net* n, const float* in_host, const float
   HIPCHK(c, hipMemcpyAsync(n->gout_buf, gout_host, sizeof(float) * (size_t)B * vol3(n->outC, n->outH, n->outW), hipMemcpyHostToDevice, c->stream));
   float* gin_dev = nullptr;
   if (gin_host) gin_dev = n->g_buf[0];   // stage 0 writes g_buf[0] anyway
-  int r = backward_impl(n, n->in_buf, n->gout_buf, B, gin_dev); if (r) return r;
+  bool fall_back = false;
+  if (guard_applies(n) && n->keep_fp32) {
+    fall_back = n->last_fwd_fell_back;       // hostile input / parameters: they enter the gradients too
+    if (!fall_back) {
+      const Stage& sl = n->st.back();
+      int r = sl.kind == ST_LINEAR ? guard_scan_activation(c, n->gout_buf, B, sl.Cout, 1, 1)
+                                   : guard_scan_activation(c, n->gout_buf, B, n->outC, n->outH, n->outW);
+      if (r) return r;
+      unsigned top2 = 0;
+      r = guard_verdict(c, &top2); if (r) return r;
+      fall_back = guard_over_budget(guard_merge(top2, n->guard_top2));      // gradOutput's spread joins the forward's
+    }
+  }
+  if (fall_back) { c->guard_fallbacks++; c->conv_mode = 1; }
+  int r = backward_impl(n, n->in_buf, n->gout_buf, B, gin_dev);
+  if (fall_back) c->conv_mode = 2;
+  if (r) return r;
   if (gin_host) HIPCHK(c, hipMemcpyAsync(gin_host, gin_dev, sizeof(float) * (size_t)B * vol3(n->inC, n->inH, n->inW), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GR_OK;
@@ -1161,6 +1313,24 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   if (vol3(g->outC, g->outH, g->outW) != vol3(rn->inC, rn->inH, rn->inW)) return fail(c, GR_ERR_INVALID, "image dim mismatch between G and R");
   const bool tm = c->timing;
   int r;
+  // Range guard of the device-resident loop: no synchronisation is allowed here, so the parameter scans (weights, BatchNorm
+  // scales of G and R) run every GUARD_PERIOD-th step and their verdict is read, without waiting, by a later call.  Once a
+  // hostile spread shows, the context stays on bf16x6 (gr_set_tuning "range_guard" 0 clears it).  Latency: under 2 periods.
+  enum { GUARD_PERIOD = 64 };
+  g->keep_fp32 = rn->keep_fp32 = false; g->last_fwd_fell_back = rn->last_fwd_fell_back = false;
+  if (c->guard_pending && hipEventQuery(c->ev_guard) == hipSuccess) {
+    c->guard_pending = false;
+    if (guard_over_budget(*guard_alarm_host(c)) && !c->guard_tripped) { c->guard_tripped = true; c->guard_fallbacks++; }
+  }
+  if (c->guard_tripped && c->conv_mode == 2) c->conv_mode = 1;
+  if (c->conv_mode == 2 && c->range_guard && !c->guard_pending && t % GUARD_PERIOD == 1) {
+    r = guard_scan_params(g); if (r) return r;
+    r = guard_scan_params(rn); if (r) return r;
+    HIPCHK(c, hipMemcpyAsync((void*)guard_alarm_host(c), guard_alarm_dev(c), sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(guard_alarm_dev(c), 0, sizeof(unsigned), c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_guard, c->stream));
+    c->guard_pending = true;
+  }
   if (tm) (void)hipEventRecord(c->ev[0], c->stream);
   g->training = false;                                         // train_r.lua:70  MODEL_G:evaluate()
   g_kphase = 1;
@@ -1208,17 +1378,36 @@ extern "C" int gr_cosine_topk_dev(gr_ctx* c, const float* emb, int64_t N, int d,
   for (int q = 0; q < Q; ++q) if (qrows[q] < 0 || qrows[q] >= N) return fail(c, GR_ERR_INVALID, "query row %lld out of range", (long long)qrows[q]);
   if (k > 1024) return fail(c, GR_ERR_UNSUPPORTED, "k > 1024");
   HIPCHK(c, hipSetDevice(c->device));
-  const size_t tail = sizeof(long) * (size_t)Q * (k + 1) + sizeof(float) * (size_t)Q * k + 256;
+  const size_t tail = sizeof(long) * (size_t)Q * (k + 1) + sizeof(float) * (size_t)Q * k + 512;
   const size_t wsb = cosine_topk_workspace_bytes(N, d, Q, k);
   int r = ensure_ws(c, wsb + tail); if (r) return r;
   char* base = (char*)c->ws + ((wsb + 255) & ~(size_t)255);
-  long* d_q = (long*)base; long* d_idx = d_q + Q; float* d_sc = (float*)(d_idx + (size_t)Q * k);
+  // results [idx | scores | status] are contiguous on the device: ONE copy into pinned memory and one wait per search (three
+  // copies into pageable memory cost about 30 us of the 0.25 ms a cfg5 search takes)
+  long* d_q = (long*)base; long* d_idx = d_q + Q; float* d_sc = (float*)(d_idx + (size_t)Q * k); unsigned* d_status = (unsigned*)(d_sc + (size_t)Q * k);
+  const size_t res_bytes = sizeof(long) * (size_t)Q * k + sizeof(float) * (size_t)Q * k + sizeof(unsigned);
+  if (res_bytes > c->pin_bytes) {
+    if (c->pin) (void)hipHostFree(c->pin);
+    c->pin = nullptr; c->pin_bytes = 0;
+    HIPCHK(c, hipHostMalloc(&c->pin, res_bytes * 2));
+    c->pin_bytes = res_bytes * 2;
+  }
   HIPCHK(c, hipMemcpyAsync(d_q, qrows, sizeof(long) * Q, hipMemcpyHostToDevice, c->stream));
-  if (launch_cosine_topk(emb, N, d, d_q, Q, k, d_idx, d_sc, accf, c->ws, c->stream)) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
-  LAUNCHCHK(c);
-  HIPCHK(c, hipMemcpyAsync(idx_out, d_idx, sizeof(long) * (size_t)Q * k, hipMemcpyDeviceToHost, c->stream));
-  if (score_out) HIPCHK(c, hipMemcpyAsync(score_out, d_sc, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  static const bool filter_on = !getenv("GR_SEARCH_UNFILTERED");
+  for (int unfiltered = filter_on ? 0 : 1; unfiltered < 2; ++unfiltered) {
+    if (launch_cosine_topk(emb, N, d, d_q, Q, k, d_idx, d_sc, accf, c->ws, c->stream, d_status, unfiltered)) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
+    LAUNCHCHK(c);
+    HIPCHK(c, hipMemcpyAsync(c->pin, d_idx, res_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const char* h = (const char*)c->pin;
+    unsigned status; memcpy(&status, h + res_bytes - sizeof(unsigned), sizeof status);
+    if (status == 0 || unfiltered) {
+      memcpy(idx_out, h, sizeof(long) * (size_t)Q * k);
+      if (score_out) memcpy(score_out, h + sizeof(long) * (size_t)Q * k, sizeof(float) * (size_t)Q * k);
+      break;
+    }
+    c->search_reruns++;       // 1: the sample-bound filter overflowed (adversarial row order): rerun on every key
+  }
   return GR_OK;
 }
 extern "C" int gr_cosine_topk_host(gr_ctx* c, const float* emb, int64_t N, int d, const int64_t* qrows, int Q, int k,

@@ -7,6 +7,12 @@
 //   3. topk_pass:     per 2048-key chunk a bitonic sort in LDS keeps the k largest keys; repeated until one chunk is
 //                     left.  Largest key first == (score desc, index asc): the tie order the oracle defines
 //                     (the reference's table.sort is unstable, apply_r.lua:275).
+// Large tables (N >= FILTER_MIN_ROWS) never write the N x Q keys: a strided SAMPLE of SAMPLE_ROWS rows is scored and
+// sorted first; its k-th largest key is a lower bound of the true k-th largest key (the sample is a subset), so the one
+// pass over emb keeps only keys >= that bound - about N * k / SAMPLE_ROWS of them per needle, each workgroup writing into
+// its own SLOT entries - and one selection kernel (radix-select of the k-th score, then a sort of the few keys at or above it) finishes.
+// Same scores, same keys, same result, bit for bit; a list that overflows (adversarial order) raises a status word and the
+// caller reruns the unfiltered path.
 #include "kernels.h"
 #include <type_traits>
 
@@ -14,14 +20,19 @@ namespace gr {
 
 constexpr int QG = 8;        // needles scored per pass of cos_keys (register accumulators)
 constexpr int ROWS = 256;    // rows per workgroup
-constexpr int DC = 32;       // columns staged per step
 constexpr int CHUNK = 2048;  // keys per top-k workgroup
+constexpr long FILTER_MIN_ROWS = 1 << 17;   // below this the unfiltered path is a handful of microseconds anyway
+constexpr int SAMPLE_ROWS = 16384;          // rows scored ahead for the filter bound
+constexpr int SLOT = 32;                    // candidate keys a workgroup (ROWS rows) may keep per needle: expected ROWS * k / SAMPLE_ROWS = 0.8
 
 template <bool ACCF>
 __global__ void needle_prep_kernel(const float* __restrict__ emb, int d, const long* __restrict__ rows, int Q,
-                                   float* __restrict__ needles, float* __restrict__ w22) {
+                                   float* __restrict__ needles, float* __restrict__ w22, unsigned* __restrict__ counts,
+                                   unsigned* __restrict__ status) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q == 0 && status) *status = 0u;
   if (q >= Q) return;
+  if (counts) counts[q] = 0u;
   const float* a = emb + rows[q] * (long)d;
   typename std::conditional<ACCF, float, double>::type s = 0;
   for (int i = 0; i < d; ++i) { const float v = a[i]; needles[(long)q * d + i] = v; s += v * v; }
@@ -40,67 +51,211 @@ __device__ __forceinline__ float unorderable(uint32_t u) {
   return __uint_as_float(b);
 }
 
-template <bool ACCF>
+// MODE 0: keys[q][j] for every row j.  MODE 1 (sample): block rows are i = 0 .. N - 1 of the strided sample, row j = i * stride;
+// keys[q][i] carry the true index j.  MODE 2 (filter): keys >= bound[q] go to the workgroup's own entries keys[q][workgroup][SLOT]
+// (counts[q][workgroup] = how many wanted in; the selection kernel checks it against SLOT).  NQ needles per pass, compile-time: their values for the
+// staged columns sit in LDS next to the row tile and are read as broadcast float4s (a scalar load per needle and column
+// inside the loop serialised on the scalar cache: 259 us at cfg5 against 5x less now).  Columns past d are staged as zeros on
+// both sides: they add exact zeros to the sums, so every chunk runs the full unrolled DC columns.
+// DC columns per chunk (32, or 20 when that divides d and 32 does not - d = 100 of cfg5: five full chunks instead of three and
+// one of 4 real columns); tile row stride TS = DC + 4 or + 8 floats: rows stay 16-byte aligned and TS / 4 is odd, so the float4
+// reads of 16 lanes hit 64 distinct banks
+template <bool ACCF, int MODE, int NQ, int DC>
 __global__ __launch_bounds__(ROWS) void cos_keys_kernel(const float* __restrict__ emb, long N, int d,
                                                          const float* __restrict__ needles, const float* __restrict__ w22,
-                                                         int q0, int Q, unsigned long long* __restrict__ keys) {
+                                                         int q0, unsigned long long* __restrict__ keys, long stride,
+                                                         const unsigned long long* __restrict__ bound, unsigned* __restrict__ counts, int dbg) {
   typedef typename std::conditional<ACCF, float, double>::type acc_t;
-  __shared__ __attribute__((aligned(16))) float tile[ROWS * (DC + 1)];
+  constexpr int TS = ((DC / 4) & 1) ? DC + 8 : DC + 4;
+  __shared__ __attribute__((aligned(16))) float tile[ROWS * TS];
+  __shared__ __attribute__((aligned(16))) float ndt[QG * DC];
+  __shared__ unsigned lds_cnt[QG];
   const int tid = threadIdx.x;
+  if (MODE == 2 && tid < QG) lds_cnt[tid] = 0u;          // (published by the first barrier of the column loop)
   const long r0 = (long)blockIdx.x * ROWS;
-  const int nq = min(QG, Q - q0);
   const bool vec = (d & 3) == 0;                 // rows are 16-byte aligned: stage with float4 loads
-  acc_t s1[QG], s3 = 0;
+  acc_t s1[NQ], s3 = 0;
 #pragma unroll
-  for (int q = 0; q < QG; ++q) s1[q] = 0;
+  for (int q = 0; q < NQ; ++q) s1[q] = 0;
+  // 8 lanes cover one 128-byte row segment.  All DC / 4 loads of a thread are issued back to back (out-of-range slots read a
+  // valid address and are zeroed afterwards: a branch around each load made the compiler wait for every load before issuing
+  // the next), and the NEXT chunk's loads are issued before the arithmetic on the current one, so HBM latency hides behind it.
+  float4 v[DC / 4]; float nreg = 0.f;
+  auto fetch = [&](int c0) {
+    const int dc = min(DC, d - c0);
+#pragma unroll
+    for (int i = 0; i < DC / 4; ++i) {
+      const int e = tid + i * ROWS, r = e / (DC / 4), c = (e - r * (DC / 4)) * 4;
+      const bool ok = r0 + r < N && c < dc && !(dbg & 1);
+      const long row = ok ? (MODE == 1 ? (r0 + r) * stride : r0 + r) : 0;
+      v[i] = *reinterpret_cast<const float4*>(emb + row * (long)d + (ok ? c0 + c : 0));
+      if (!ok) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < NQ * DC) { const int q = tid / DC, c = tid - q * DC; nreg = c < dc ? needles[(long)(q0 + q) * d + c0 + c] : 0.f; }
+  };
+  if (vec) fetch(0);
   for (int c0 = 0; c0 < d; c0 += DC) {
     const int dc = min(DC, d - c0);
     if (vec) {
-      // 8 lanes cover one 128-byte row segment
-      for (int e = tid; e < ROWS * (DC / 4); e += ROWS) {
-        const int r = e / (DC / 4), c = (e - r * (DC / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + r < N && c < dc) v = *reinterpret_cast<const float4*>(emb + (r0 + r) * (long)d + c0 + c);
-        float* t = tile + r * (DC + 1) + c;
-        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+#pragma unroll
+      for (int i = 0; i < DC / 4; ++i) {
+        const int e = tid + i * ROWS, r = e / (DC / 4), c = (e - r * (DC / 4)) * 4;
+        *reinterpret_cast<float4*>(tile + r * TS + c) = v[i];
       }
+      if (tid < NQ * DC) ndt[tid] = nreg;
     } else {
       for (int e = tid; e < ROWS * DC; e += ROWS) {
         const int r = e / DC, c = e - r * DC;
-        float v = 0.f;
-        if (r0 + r < N && c < dc) v = emb[(r0 + r) * (long)d + c0 + c];
-        tile[r * (DC + 1) + c] = v;
+        float x = 0.f;
+        if (r0 + r < N && c < dc) x = emb[(MODE == 1 ? (r0 + r) * stride : r0 + r) * (long)d + c0 + c];
+        tile[r * TS + c] = x;
       }
+      if (tid < NQ * DC) { const int q = tid / DC, c = tid - q * DC; ndt[tid] = c < dc ? needles[(long)(q0 + q) * d + c0 + c] : 0.f; }
     }
     __syncthreads();
-    const float* row = tile + tid * (DC + 1);
-    const float* nd = needles + (long)q0 * d + c0;      // wave-uniform addresses: the needle values travel in SGPRs
-    for (int c = 0; c < dc; ++c) {
-      const float b = row[c];
-      s3 += (acc_t)(b * b);
+    if (vec && c0 + DC < d) fetch(c0 + DC);
+    const float4* row4 = reinterpret_cast<const float4*>(tile + tid * TS);
+    const float4* nd4 = reinterpret_cast<const float4*>(ndt);
+    if (!(dbg & 2))
 #pragma unroll
-      for (int q = 0; q < QG; ++q)
-        if (q < nq) s1[q] += (acc_t)(nd[(long)q * d + c] * b);
+    for (int c4 = 0; c4 < DC / 4; ++c4) {
+      const float4 bv = row4[c4];
+      const float b[4] = {bv.x, bv.y, bv.z, bv.w};
+      float nv[NQ][4];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) { const float4 t = nd4[q * (DC / 4) + c4]; nv[q][0] = t.x; nv[q][1] = t.y; nv[q][2] = t.z; nv[q][3] = t.w; }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {            // column order inside the chunk = the reference's summation order
+        s3 += (acc_t)(b[jj] * b[jj]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) s1[q] += (acc_t)(nv[q][jj] * b[jj]);
+      }
     }
     __syncthreads();
   }
   const long j = r0 + tid;
-  if (j < N) {
+  if (j < N && !(dbg & 4)) {
     float w32 = (float)s3;
     w32 = w32 + 1e-12f;
     w32 = 1.f / w32;
 #pragma unroll
-    for (int q = 0; q < QG; ++q)
-      if (q < nq) {
-        float w = w22[q0 + q] * w32;
-        w = sqrtf(w);
-        const float sc = (float)s1[q] * w;
-        keys[(long)(q0 + q) * N + j] = ((unsigned long long)orderable(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)j);
-      }
+    for (int q = 0; q < NQ; ++q) {
+      float w = w22[q0 + q] * w32;
+      w = sqrtf(w);
+      const float sc = (float)s1[q] * w;
+      const long row = MODE == 1 ? j * stride : j;
+      const unsigned long long key = ((unsigned long long)orderable(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)row);
+      if (MODE == 2) {
+        // candidates go to this workgroup's own SLOT entries of needle q (position from an LDS counter): a global counter per
+        // needle serialised 15 000 returning atomics on five addresses - 330 of the kernel's 460 us at cfg5
+        if (key >= bound[q0 + q]) {
+          const unsigned pos = atomicAdd(&lds_cnt[q], 1u);
+          if (pos < (unsigned)SLOT) keys[((long)(q0 + q) * gridDim.x + blockIdx.x) * SLOT + pos] = key;
+        }
+      } else keys[(long)(q0 + q) * N + j] = key;
+    }
+  }
+  if (MODE == 2) {
+    __syncthreads();
+    if (tid < NQ) counts[(long)(q0 + tid) * gridDim.x + blockIdx.x] = (dbg & 4) ? 0u : lds_cnt[tid];     // every workgroup writes its count: no fill needed
   }
 }
 
-// keys_in: [Q][n_in] ; keys_out: [Q][nchunks*k]
+// One workgroup (1024 threads) per needle, over either the dense sample keys[q][n] (BOUND_ONLY) or the filter's per-workgroup
+// entries keys[q][n][SLOT] with counts[q][n].  Every thread takes the LARGEST of the keys it walks; the k-th largest of those
+// 1024 maxima is a lower bound of the k-th largest key overall - the k maxima above it are k distinct keys.  BOUND_ONLY: (that key's score << 32) is the filter
+// bound.  Otherwise the keys at or above that maximum - k of them plus the few the bound lets through - are gathered, sorted in
+// LDS and the first k decoded into (index, score).  A workgroup that wanted more than SLOT entries, or more than CHUNK gathered
+// keys, raises *status: the caller reruns the unfiltered path.
+template <bool BOUND_ONLY, typename F>
+__device__ __forceinline__ void for_each_key(const unsigned long long* __restrict__ src, long n, const unsigned* __restrict__ cnt, F f) {
+  if (BOUND_ONLY) {
+    for (long i0 = threadIdx.x; i0 < n; i0 += 8 * 1024) {       // 8 independent loads in flight per thread
+      unsigned long long kk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) kk[u] = i0 + u * 1024 < n ? src[i0 + u * 1024] : 0ull;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (i0 + u * 1024 < n) f(kk[u]);
+    }
+  } else {
+    for (long g0 = threadIdx.x; g0 < n; g0 += 4 * 1024) {       // n workgroups' entries; counts of 4 workgroups first, then their keys
+      unsigned c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = g0 + u * 1024 < n ? min(cnt[g0 + u * 1024], (unsigned)SLOT) : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        for (unsigned e = 0; e < c[u]; ++e) f(src[(g0 + u * 1024) * SLOT + e]);
+    }
+  }
+}
+template <bool BOUND_ONLY>
+__global__ __launch_bounds__(1024) void topk_select_kernel(const unsigned long long* __restrict__ keys, long n,
+                                                           const unsigned* __restrict__ counts, int k,
+                                                           unsigned long long* __restrict__ bound_out,
+                                                           long* __restrict__ idx, float* __restrict__ score, unsigned* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) unsigned long long list[CHUNK];       // first the 1024 thread maxima, then the gathered keys
+  __shared__ unsigned long long sh_bound;
+  __shared__ unsigned list_n, over;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const unsigned long long* src = keys + (long)q * n * (BOUND_ONLY ? 1 : SLOT);
+  const unsigned* cnt = BOUND_ONLY ? nullptr : counts + (long)q * n;
+  if (tid == 0) { sh_bound = 0ull; list_n = 0u; over = 0u; }
+  __syncthreads();
+  unsigned long long mine = 0ull;
+  if (!BOUND_ONLY) {
+    unsigned o = 0u;
+    for (long g = tid; g < n; g += 1024) o |= cnt[g] > (unsigned)SLOT ? 1u : 0u;
+    if (o) over = 1u;
+  }
+  for_each_key<BOUND_ONLY>(src, n, cnt, [&](unsigned long long key) { mine = key > mine ? key : mine; });
+  list[tid] = mine;
+  __syncthreads();
+  if (!BOUND_ONLY && over) { if (tid == 0 && status) *status = 1u; return; }
+  // k-th largest of the 1024 maxima: bitonic sort in LDS, descending (ranking each maximum against the other 1023 costs 8 MB
+  // of LDS reads per needle - 30 us on one CU; the sort moves 0.9 MB).  Empty threads hold 0: with fewer than k non-empty
+  // threads entry k - 1 is 0 and everything passes.
+  for (int size = 2; size <= 1024; size <<= 1)
+    for (int st = size >> 1; st > 0; st >>= 1) {
+      if (tid < 512) {
+        const int lo = ((tid / st) * st * 2) + (tid % st), hi = lo + st;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = list[lo], b = list[hi];
+        if ((a < b) == desc) { list[lo] = b; list[hi] = a; }
+      }
+      __syncthreads();
+    }
+  if (tid == 0) sh_bound = list[k - 1];
+  __syncthreads();
+  const unsigned long long bnd = sh_bound;
+  if (BOUND_ONLY) { if (tid == 0) bound_out[q] = bnd & 0xFFFFFFFF00000000ull; return; }
+  __syncthreads();                                  // every thread has read the maxima: the list is reused for the gathered keys
+  for_each_key<BOUND_ONLY>(src, n, cnt, [&](unsigned long long key) {
+    if (key >= bnd) { const unsigned pos = atomicAdd(&list_n, 1u); if (pos < (unsigned)CHUNK) list[pos] = key; }
+  });
+  __syncthreads();
+  const unsigned m = list_n;
+  if (m > (unsigned)CHUNK) { if (tid == 0 && status) *status = 1u; return; }
+  int P = 64; while (P < (int)m) P <<= 1;
+  for (int i = tid; i < P; i += 1024) if (i >= (int)m) list[i] = 0ull;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int st = size >> 1; st > 0; st >>= 1) {
+      if (tid < P / 2) {
+        const int lo = ((tid / st) * st * 2) + (tid % st), hi = lo + st;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = list[lo], b = list[hi];
+        if ((a < b) == desc) { list[lo] = b; list[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int r = tid; r < k; r += 1024) {
+    const unsigned long long key = list[r];
+    idx[(long)q * k + r] = (long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+    if (score) score[(long)q * k + r] = unorderable((uint32_t)(key >> 32));
+  }
+}
+
+// unfiltered path.  keys_in: [Q][n_in] ; keys_out: [Q][nchunks*k]
 __global__ __launch_bounds__(1024) void topk_pass_kernel(const unsigned long long* __restrict__ kin, long n_in, int k,
                                                          unsigned long long* __restrict__ kout, long n_out) {
   __shared__ unsigned long long sk[CHUNK];
@@ -135,28 +290,79 @@ static long chunks_of(long n) { return (n + CHUNK - 1) / CHUNK; }
 
 size_t cosine_topk_workspace_bytes(long N, int d, int Q, int k) {
   const long n1 = chunks_of(N) * k, n2 = chunks_of(n1) * k;
-  return sizeof(float) * ((size_t)Q * d + Q + 8) + 512 + sizeof(unsigned long long) * (size_t)Q * (N + n1 + n2);
+  return sizeof(float) * ((size_t)Q * d + Q + 8) + sizeof(unsigned) * (size_t)(Q + 8) + 1024 + sizeof(unsigned long long) * (size_t)Q * (N + n1 + n2);
 }
 
+int g_search_debug = 0;      // diagnostic ablations (GR_SEARCH_DEBUG: 1 no global loads, 2 no arithmetic, 4 no epilogue; results are then wrong by design)
+template <bool ACCF, int MODE>
+static void launch_keys_nq(int nq, unsigned nb, hipStream_t s, const float* emb, long N, int d, const float* needles, const float* w22, int q0,
+                           unsigned long long* keys, long stride, const unsigned long long* bound, unsigned* counts) {
+  const bool dc20 = d % 20 == 0 && d % 32 != 0;
+#define GR_KEYS(NQ_) do { if (dc20) hipLaunchKernelGGL((cos_keys_kernel<ACCF, MODE, NQ_, 20>), dim3(nb), dim3(ROWS), 0, s, emb, N, d, needles, w22, q0, keys, stride, bound, counts, g_search_debug); \
+                          else hipLaunchKernelGGL((cos_keys_kernel<ACCF, MODE, NQ_, 32>), dim3(nb), dim3(ROWS), 0, s, emb, N, d, needles, w22, q0, keys, stride, bound, counts, g_search_debug); } while (0)
+  switch (nq) {
+    case 1: GR_KEYS(1); break; case 2: GR_KEYS(2); break; case 3: GR_KEYS(3); break; case 4: GR_KEYS(4); break;
+    case 5: GR_KEYS(5); break; case 6: GR_KEYS(6); break; case 7: GR_KEYS(7); break; default: GR_KEYS(8); break;
+  }
+#undef GR_KEYS
+}
+static void launch_keys(bool accf, int mode, int nq, unsigned nb, hipStream_t s, const float* emb, long N, int d, const float* needles, const float* w22,
+                        int q0, unsigned long long* keys, long stride, const unsigned long long* bound, unsigned* counts) {
+  if (accf) {
+    if (mode == 0) launch_keys_nq<true, 0>(nq, nb, s, emb, N, d, needles, w22, q0, keys, stride, bound, counts);
+    else if (mode == 1) launch_keys_nq<true, 1>(nq, nb, s, emb, N, d, needles, w22, q0, keys, stride, bound, counts);
+    else launch_keys_nq<true, 2>(nq, nb, s, emb, N, d, needles, w22, q0, keys, stride, bound, counts);
+  } else {
+    if (mode == 0) launch_keys_nq<false, 0>(nq, nb, s, emb, N, d, needles, w22, q0, keys, stride, bound, counts);
+    else if (mode == 1) launch_keys_nq<false, 1>(nq, nb, s, emb, N, d, needles, w22, q0, keys, stride, bound, counts);
+    else launch_keys_nq<false, 2>(nq, nb, s, emb, N, d, needles, w22, q0, keys, stride, bound, counts);
+  }
+}
+
+// status_dev (nullable): receives 0, or 1 when the filtered path dropped candidates (rerun with unfiltered = 1)
 int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_dev, int Q, int k,
-                       long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s) {
+                       long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s, unsigned* status_dev, int unfiltered) {
   if (k > 1024 || k < 1 || k > N || N >= 0xFFFFFFFFl || d < 1 || d > 4096 * 4) return -1;
-  // workspace carve: needles [Q][d] | w22 [Q] | keys A | keys B | keys C
+  { static const char* e = getenv("GR_SEARCH_DEBUG"); if (e) g_search_debug = atoi(e); }
+  // workspace carve: needles [Q][d] | w22 [Q] | counts [Q] | keys A | keys B | keys C
   char* w = reinterpret_cast<char*>(workspace);
   float* needles = reinterpret_cast<float*>(w); w += sizeof(float) * (size_t)Q * d;
   float* w22 = reinterpret_cast<float*>(w); w += sizeof(float) * (size_t)((Q + 3) / 4 * 4);
+  unsigned* counts = reinterpret_cast<unsigned*>(w); w += sizeof(unsigned) * (size_t)((Q + 3) / 4 * 4);
   w = reinterpret_cast<char*>(((uintptr_t)w + 255) & ~(uintptr_t)255);
   unsigned long long* keysA = reinterpret_cast<unsigned long long*>(w);
   const long n1 = chunks_of(N) * k;
   unsigned long long* keysB = keysA + (size_t)Q * N;
   unsigned long long* keysC = keysB + (size_t)Q * n1;
-  if (accf) hipLaunchKernelGGL(needle_prep_kernel<true>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22);
-  else hipLaunchKernelGGL(needle_prep_kernel<false>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22);
+  const bool filter = !unfiltered && status_dev && N >= FILTER_MIN_ROWS && k * 8 <= SAMPLE_ROWS && k <= CHUNK / 2;      // (entries + sample + bounds + counts fit the N keys of region A: SLOT * 8 / ROWS + ... < 8 bytes per row)
+  if (accf) hipLaunchKernelGGL(needle_prep_kernel<true>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
+  else hipLaunchKernelGGL(needle_prep_kernel<false>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
+  if (filter) {
+    // keys A = candidate entries [Q][nb][SLOT] | sample keys [Q][SAMPLE_ROWS] | bounds [Q] | counts [Q][nb]
+    const unsigned nbs = (unsigned)((SAMPLE_ROWS + ROWS - 1) / ROWS), nb = (unsigned)((N + ROWS - 1) / ROWS);
+    unsigned long long* cand = keysA; unsigned long long* samp = keysA + (size_t)Q * nb * SLOT; unsigned long long* bnd = samp + (size_t)Q * SAMPLE_ROWS;
+    unsigned* wg_counts = reinterpret_cast<unsigned*>(bnd + ((Q + 3) / 4 * 4));
+    const long stride = N / SAMPLE_ROWS;
+    for (int q0 = 0; q0 < Q; q0 += QG) {
+      KtScope kt("cos_keys_kernel (sample)", 0.0, 4.0 * SAMPLE_ROWS * d, s);
+      launch_keys(accf != 0, 1, min(QG, Q - q0), nbs, s, emb, SAMPLE_ROWS, d, needles, w22, q0, samp, stride, nullptr, nullptr);
+    }
+    {
+      KtScope kt("topk_select_kernel (bound)", 0.0, 8.0 * Q * SAMPLE_ROWS, s);
+      hipLaunchKernelGGL(topk_select_kernel<true>, dim3(Q), dim3(1024), 0, s, samp, (long)SAMPLE_ROWS, nullptr, k, bnd, nullptr, nullptr, nullptr);
+    }
+    for (int q0 = 0; q0 < Q; q0 += QG) {
+      KtScope kt("cos_keys_kernel", 2.0 * N * d * (Q - q0 < QG ? Q - q0 : QG), 4.0 * N * d, s);
+      launch_keys(accf != 0, 2, min(QG, Q - q0), nb, s, emb, N, d, needles, w22, q0, cand, 1, bnd, wg_counts);
+    }
+    KtScope kt("topk_select_kernel", 0.0, 8.0 * Q * 4096, s);
+    hipLaunchKernelGGL(topk_select_kernel<false>, dim3(Q), dim3(1024), 0, s, cand, (long)nb, wg_counts, k, nullptr, idx_out, score_out, status_dev);
+    return 0;
+  }
   const unsigned nb = (unsigned)((N + ROWS - 1) / ROWS);
   for (int q0 = 0; q0 < Q; q0 += QG) {
     KtScope kt("cos_keys_kernel", 2.0 * N * d * (Q - q0 < QG ? Q - q0 : QG), 4.0 * N * d + 8.0 * N * (Q - q0 < QG ? Q - q0 : QG), s);
-    if (accf) hipLaunchKernelGGL(cos_keys_kernel<true>, dim3(nb), dim3(ROWS), 0, s, emb, N, d, needles, w22, q0, Q, keysA);
-    else hipLaunchKernelGGL(cos_keys_kernel<false>, dim3(nb), dim3(ROWS), 0, s, emb, N, d, needles, w22, q0, Q, keysA);
+    launch_keys(accf != 0, 0, min(QG, Q - q0), nb, s, emb, N, d, needles, w22, q0, keysA, 1, nullptr, nullptr);
   }
   const unsigned long long* cur = keysA; long n_cur = N;
   unsigned long long* bufs[2] = {keysB, keysC};

@@ -101,6 +101,8 @@ _SIGS = {
     "gr_set_conv_mode": (C.c_int, [_P, C.c_int]),
     "gr_get_conv_mode": (C.c_int, [_P]),
     "gr_set_tuning": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "gr_range_guard_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gr_search_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "gr_debug_stamps": (C.c_int, [_P, _P]),
     "gr_set_timing": (C.c_int, [_P, C.c_int]),
     "gr_last_step_times": (C.c_int, [_P, _P]),
@@ -300,6 +302,18 @@ class Context:
 
     def set_tuning(self, key, value):
         self.check(self.lib.gr_set_tuning(self.h, key.encode(), int(value)), "gr_set_tuning")
+
+    def search_reruns(self):
+        """searches whose sample-bound filter overflowed and ran again on every key, since gr_init"""
+        a = C.c_int64(0)
+        self.check(self.lib.gr_search_stats(self.h, C.byref(a)), "gr_search_stats")
+        return a.value
+
+    def range_guard_stats(self):
+        """(scan launches, passes sent to bf16x6) of the f16x3 range guard since gr_init"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.check(self.lib.gr_range_guard_stats(self.h, C.byref(a), C.byref(b)), "gr_range_guard_stats")
+        return a.value, b.value
 
     def conv_mode(self):
         return ("f32", "bf16x6", "f16x3")[self.lib.gr_get_conv_mode(self.h)]

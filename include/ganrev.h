@@ -147,6 +147,16 @@ int gr_get_conv_mode(gr_ctx* ctx);
 /* kernel-selection thresholds (process-wide).  "p16_min_tiles" (default 256): smallest tile count at which a convolution takes the
  * operand-ready (P16) kernel; tests set 1 to exercise that path on small shapes. */
 int gr_set_tuning(gr_ctx* ctx, const char* key, int value);
+/* f16x3 range guard ("range_guard" 1/0 in gr_set_tuning, default on; GR_RANGE_GUARD=0 before gr_init turns it off).  f16x3 scales a
+ * tensor by one power of two: an entry 2^k below the tensor maximum keeps about 40 - k bits, and an output channel's relative
+ * error grows with the product of the per-channel spreads of the two tensors multiplied.  The host-memory calls
+ * (gr_net_forward_host / gr_net_backward_host) measure, before computing, the per-channel spread (log2 largest / smallest
+ * non-zero channel maximum) of the input / gradOutput, of every weight tensor an f16x3 kernel reads (per input and per output
+ * channel) and of the BatchNorm (gamma, beta) pairs, and run the pass on bf16x6 (fp32 exponent range) when the two largest
+ * spreads add up to more than 20 bits.  gr_train_r_step scans the parameters every 64th step without synchronising and
+ * switches the context to bf16x6 when a scan trips.  Counters: scan launches and passes sent to bf16x6 since gr_init (the
+ * latter also in gr_kernel_times as "range_guard_fallback"). */
+int gr_range_guard_stats(gr_ctx* ctx, int64_t* scans, int64_t* fallbacks);
 int gr_debug_stamps(gr_ctx* ctx, void* dev_buf);   /* diagnostic builds: device buffer for in-kernel time stamps (tools/stamps_p16.py) */
 int gr_set_timing(gr_ctx* ctx, int mode /*0 off, 1 per-phase events in gr_train_r_step, 2 per-kernel events*/);
 /* mode 2: JSON array of {kernel, phase, launches, total_ms, flops, bytes} (algorithmic flops/bytes) accumulated since it was
@@ -167,6 +177,10 @@ int gr_cosine_topk_host(gr_ctx* ctx, const float* emb_host, int64_t n, int d, co
 int gr_cosine_topk_dev(gr_ctx* ctx, const float* emb_dev, int64_t n, int d, const int64_t* query_rows_host, int q, int k,
                        int64_t* idx_out_host, float* score_out_host, int accumulate_in_float);
 int gr_cosine_similarity_host(gr_ctx* ctx, const float* a_host, const float* b_host, int d, float* out);
+/* Tables of 2^17 rows or more are searched through a bound taken from a strided 16384-row sample (only keys at or above the
+ * sample's k-th largest key are kept: same result, bit for bit, without writing n x q keys); when a table's order defeats the
+ * sample (a candidate list overflows) the search runs again on every key.  reruns = how often that happened since gr_init. */
+int gr_search_stats(gr_ctx* ctx, int64_t* reruns);
 
 /* ---- apply_r.lua:355-372 (detectAnomalies): out[i] = torch.dist(a[i], b[i]) = sqrt(sum_j (a_ij - b_ij)^2), rows of length d ---- */
 int gr_l2_distance_rows_host(gr_ctx* ctx, const float* a_host, const float* b_host, int64_t n, int64_t d, double* out_host);

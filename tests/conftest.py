@@ -46,7 +46,7 @@ def f16_path(request):
     c = L.default_context()
     prev = c.conv_mode()
     c.set_conv_mode("f16x3")
-    c.set_tuning("p16_min_tiles", 1 if request.param.endswith("p16") else 256)
+    c.set_tuning("p16_min_tiles", 1 if request.param.endswith("p16") else 128)
     yield request.param
-    c.set_tuning("p16_min_tiles", 256)
+    c.set_tuning("p16_min_tiles", 128)     # the library default (conv.hip g_p16_min_tiles)
     c.set_conv_mode(prev)

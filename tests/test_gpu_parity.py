@@ -303,6 +303,106 @@ def test_G_training_forward_backward_vs_oracle(oracle, conv_mode, dims, nd, B):
     assert_grads_close(G, grads, onet.grads, 1e-4, 1e-3)
 
 
+@pytest.mark.parametrize("kind", ["conv", "fullconv", "linear"])
+@pytest.mark.parametrize("e", [4, 20])
+def test_f16x3_hostile_channel_ranges(ctx, oracle, kind, e):
+    """f16x3 scales a tensor by one power of two, so hostile per-channel ranges are where it could lose digits: x[:, c] *= s_c,
+    W[o][c] *= t_o / s_c, bias_o *= t_o, gradOutput[:, o] /= t_o with s, t spanning 2^-e .. 2^e - every channel still
+    contributes equally to every output, so a channel that lost its digits shows.  Forward, gradInput and the weight
+    gradient are held to 1e-4 of the largest reference entry OF THEIR OWN CHANNEL (weight gradient: of the natural size of
+    their own (out, in) pair).  e = 4: the two largest spreads add up to 16 bits, inside the range guard's 20-bit budget - the f16x3
+    kernels run and must meet the bar.  e = 20 (channels spanning 2^-20 .. 2^20): the guard must send both passes to
+    bf16x6 (gr_range_guard_stats counts them) and the same bar holds."""
+    from ganrev import nn, synth
+    prev = ctx.conv_mode(); ctx.set_conv_mode("f16x3")
+    try:
+        if kind == "linear":
+            Cin, Cout, B, shape = 1024, 1024, 64, (1024,)
+            net = nn.Sequential(); lay = nn.Linear(Cin, Cout); net.add(lay)
+        else:
+            Cin, Cout, B, shape = 64, 64, 4, (64, 16, 16)
+            net = nn.Sequential()
+            lay = (nn.SpatialFullConvolution if kind == "fullconv" else nn.SpatialConvolution)(Cin, Cout, 3, 3, 1, 1, 1, 1); net.add(lay)
+        synth.init_params(net, 3)
+        rng = np.random.default_rng(11)
+        s_c = np.exp2(rng.permutation(np.linspace(-e, e, Cin))).astype(np.float32)
+        t_o = np.exp2(rng.permutation(np.linspace(-e, e, Cout))).astype(np.float32)
+        flat, grads = net.getParameters()
+        w = lay.weight
+        if kind == "linear": w *= t_o[:, None] / s_c[None, :]
+        elif kind == "fullconv": w *= (t_o[None, :] / s_c[:, None])[:, :, None, None]
+        else: w *= (t_o[:, None] / s_c[None, :])[:, :, None, None]
+        lay.bias *= t_o
+        bshape = (1, -1) + (1,) * (len(shape) - 1)
+        x = synth.normal((B,) + shape, 5) * s_c.reshape(bshape)
+        onet = oracle.from_model(net, shape if len(shape) == 3 else (shape[0], 1, 1))
+        net.training(); onet.set_training(True)
+        scans0, falls0 = ctx.range_guard_stats()
+        ref = onet.forward(x)
+        out = net.forward(x)
+        gy = (synth.normal(ref.shape, 9) / t_o.reshape(bshape)).astype(np.float32)
+        grads[...] = 0; onet.zero_grads()
+        gin = net.backward(x, gy)
+        ref_gin = onet.backward(x, gy)
+        scans1, falls1 = ctx.range_guard_stats()
+        assert scans1 > scans0, "the range guard did not look at this pass"
+        assert falls1 - falls0 == (2 if e == 20 else 0), f"range guard sent {falls1 - falls0} passes to bf16x6"
+
+        def per_channel(a, r, axis_keep, what):
+            a = np.asarray(a, np.float64); r = np.asarray(r, np.float64)
+            red = tuple(i for i in range(r.ndim) if i not in axis_keep)
+            scale = np.abs(r).max(axis=red, keepdims=True)
+            err = np.abs(a - r) / np.maximum(scale, 1e-300)
+            assert err.max() <= TOL, f"{kind} e={e} {what}: {err.max():.3e} of the channel's largest entry"
+        per_channel(out, ref.reshape(out.shape), (1,), "output, per output channel")
+        per_channel(gin, ref_gin.reshape(gin.shape), (1,), "gradInput, per input channel")
+        nW = w.size
+        gw_dev, gw_ref = grads[:nW].reshape(w.shape), onet.grads[:nW].reshape(w.shape)
+        # an entry of the weight gradient is a sum of N = B * H * W products gradOutput_o * x_c of random sign: its own value can
+        # cancel to anything, its natural size is rms(gradOutput_o) * rms(x_c) * sqrt(N) - the bar is 1e-4 of THAT, per (o, c)
+        red = tuple(i for i in range(x.ndim) if i != 1)
+        g_rms = np.sqrt((gy.astype(np.float64) ** 2).mean(axis=red)); x_rms = np.sqrt((x.astype(np.float64) ** 2).mean(axis=red))
+        nat = np.outer(x_rms, g_rms) if kind == "fullconv" else np.outer(g_rms, x_rms)
+        nat = nat * np.sqrt(x.size / Cin)
+        err = np.abs(gw_dev.astype(np.float64) - gw_ref) / nat.reshape(nat.shape + (1,) * (gw_ref.ndim - 2))
+        assert err.max() <= TOL, f"{kind} e={e} weight gradient: {err.max():.3e} of the (out, in) pair's natural size"
+    finally:
+        ctx.set_conv_mode(prev)
+
+
+def test_range_guard_trips_in_the_device_resident_loop(ctx):
+    """gr_train_r_step cannot synchronise, so it samples: parameter scans on the step's own stream every 64th step, verdict read
+    by a later call.  A BatchNorm whose gammas span 2^-12 .. 2^12 (24 bits of spread > the 20-bit budget) must move the
+    context to bf16x6 within a few steps and be counted once; a well-conditioned R must not trip it."""
+    import ganrev._lib as L
+    from ganrev import models, synth
+    from ganrev.parallel import DeviceTrainer
+    prev = ctx.conv_mode(); ctx.set_conv_mode("f16x3")
+    try:
+        dims, nd, B = (1, 16, 16), 8, 8
+        for hostile in (False, True):
+            G = models.create_G(dims, nd); synth.init_params(G, 1)
+            R = models.create_R(dims, nd); synth.init_params(R, 2)
+            if hostile:
+                bn = [m for m in R.leaves() if m.typename == "nn.SpatialBatchNormalization"][1]
+                bn.weight[...] = np.exp2(np.linspace(-12, 12, bn.weight.size)).astype(np.float32)
+            G.evaluate(); G.forward(synth.normal((2, nd), 1))
+            R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
+            ctx.set_conv_mode("f16x3")
+            _, falls0 = ctx.range_guard_stats()
+            tr = DeviceTrainer(ctx, G._net, R._net, L.Hyper(), B)
+            for i in range(4):
+                tr.new_noise(i + 1); tr.step(); ctx.synchronize()
+            _, falls1 = ctx.range_guard_stats()
+            if hostile:
+                assert ctx.conv_mode() == "bf16x6" and falls1 - falls0 == 1, (ctx.conv_mode(), falls1 - falls0)
+            else:
+                assert ctx.conv_mode() == "f16x3" and falls1 == falls0
+    finally:
+        ctx.set_tuning("range_guard", 0); ctx.set_tuning("range_guard", 1)     # clears the tripped state
+        ctx.set_conv_mode(prev)
+
+
 def test_operand_ready_kernels_are_selected(ctx):
     """At the benchmark geometry (cfg2: batch 256) the f16x3 training step must take the operand-ready kernels: R's five
     512-pixel-tile forward convolutions and at least four of its data-gradient convolutions run as conv3x3_p16_*_kernel, fed by
@@ -683,6 +783,30 @@ def test_full_size_cfg5_search_bit_exact(ctx, oracle):
     assert np.all(idx[:, :-1][tie] < idx[:, 1:][tie]), "ties are ordered by ascending index"
     assert set(idx[0, :2]) == {100, 123456} and idx[0, 0] == 100
     assert 999_999 in idx[2, :2]
+
+
+def test_search_filter_bound_and_its_overflow_rerun(ctx, oracle):
+    """Tables of >= 2^17 rows are searched through a bound from a strided 16384-row sample (search.hip).  (1) random order: the
+    filtered result equals the oracle's bit for bit and no rerun happens; (2) a table built against the sample - every
+    sampled row (multiples of n / 16384) random, every other row within 1e-3 of a needle - overflows the candidate lists:
+    the library must notice, run again on every key, and still return the oracle's answer."""
+    from ganrev import synth
+    N, d, k = 150_000, 16, 50
+    stride = N // 16384
+    q = np.array([7, 77_777], dtype=np.int64)
+    emb = synth.normal((N, d), 99)
+    r0 = ctx.search_reruns()
+    idx, sc = ctx.cosine_topk(emb, q, k)
+    ridx, rsc = oracle.cosine_topk(emb, q, k)
+    assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
+    assert ctx.search_reruns() == r0, "random order must not overflow the candidate lists"
+    hostile = emb[7][None, :] + np.float32(1e-3) * synth.normal((N, d), 5)
+    hostile[::stride] = emb[::stride]
+    hostile[7] = emb[7]; hostile[77_777] = emb[77_777]
+    idx, sc = ctx.cosine_topk(hostile, q, k)
+    ridx, rsc = oracle.cosine_topk(hostile, q, k)
+    assert ctx.search_reruns() == r0 + 1, "the overflow must be detected and the search rerun unfiltered"
+    assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
 
 
 def test_rccl_single_rank_allreduce(ctx):
