@@ -28,6 +28,13 @@ struct gr_ctx {
   hipStream_t comm_stream = nullptr;          // gradient buckets are reduced here, behind the rest of backward
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   void* ws = nullptr; size_t ws_bytes = 0;
+  // weight gradients run beside the rest of backward (backward_impl): their own stream, workspace and events
+  hipStream_t side_stream = nullptr; void* ws2 = nullptr; size_t ws2_bytes = 0;
+  hipEvent_t ev_dy_ready = nullptr, ev_wgrad_done[2] = {nullptr, nullptr};
+  int side_wgrad = 0;                  // gr_set_tuning "side_wgrad" / GR_SIDE_WGRAD=1.  Off by default: measured +1.1 % at cfg2 (2.331 -> 2.304 ms) - the
+                                       // MFMA kernels take the whole register file of a CU (2 waves x 256 VGPRs per SIMD), so the pipeline kernels of the main
+                                       // stream cannot become resident beside a weight gradient and only kernel tails overlap - not worth per-kernel
+                                       // timings that no longer add up to the step
   double* d_loss = nullptr;     // device scalar
   double* h_loss = nullptr;     // pinned host scalar
   bool timing = false;
@@ -100,8 +107,17 @@ static int ensure_ws(gr_ctx* c, size_t bytes) {
   c->ws_bytes = bytes;
   return GR_OK;
 }
+// workspace of the side stream (weight gradients running beside the rest of backward)
+static int ensure_ws2(gr_ctx* c, size_t bytes) {
+  if (bytes <= c->ws2_bytes) return GR_OK;
+  if (c->ws2) { HIPCHK(c, hipStreamSynchronize(c->side_stream)); HIPCHK(c, hipFree(c->ws2)); c->ws2 = nullptr; c->ws2_bytes = 0; }
+  bytes = (bytes + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+  HIPCHK(c, hipMalloc(&c->ws2, bytes));
+  c->ws2_bytes = bytes;
+  return GR_OK;
+}
 
-extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.1 (round 1)"; }
+extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.2 (round 2)"; }
 
 extern "C" int gr_init(int device, gr_ctx** out) {
   if (!out) return GR_ERR_INVALID;
@@ -126,6 +142,10 @@ extern "C" int gr_init(int device, gr_ctx** out) {
   { const char* d = getenv("GR_P16_DEBUG"); if (d) gr::g_p16_debug = atoi(d); }      // diagnostic ablations (tools/ablate_p16.py)
   { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "f32") || !strcmp(m, "0")) ? 0 : ((!strcmp(m, "bf16x6") || !strcmp(m, "1")) ? 1 : 2); }
   (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+  (void)hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&c->ev_dy_ready, hipEventDisableTiming);
+  for (auto& e : c->ev_wgrad_done) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  { const char* e = getenv("GR_SIDE_WGRAD"); if (e) c->side_wgrad = atoi(e); }
   (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
   *out = c;
@@ -138,6 +158,10 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
   if (c->ws) (void)hipFree(c->ws);
+  if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+  if (c->ws2) (void)hipFree(c->ws2);
+  if (c->ev_dy_ready) (void)hipEventDestroy(c->ev_dy_ready);
+  for (auto& e : c->ev_wgrad_done) if (e) (void)hipEventDestroy(e);
   if (c->guard_chmax) (void)hipFree(c->guard_chmax);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->ev_guard) (void)hipEventDestroy(c->ev_guard);
@@ -176,6 +200,7 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!strcmp(key, "p16_stagger")) { gr::g_p16_stagger = value; return GR_OK; }
   if (!strcmp(key, "p16_variant")) { gr::g_p16_variant = value; return GR_OK; }
   if (!strcmp(key, "p16_debug")) { gr::g_p16_debug = value; return GR_OK; }     // diagnostic ablations (outputs are then wrong by design)
+  if (!strcmp(key, "side_wgrad")) { c->side_wgrad = value; return GR_OK; }          // weight gradients on the side stream (1) or in line (0, default)
   if (!strcmp(key, "range_guard")) { c->range_guard = value; if (!value) c->guard_tripped = false; return GR_OK; }   // f16x3 range guard on / off (off also clears a tripped trainer guard)
   return fail(c, GR_ERR_INVALID, "gr_set_tuning: unknown key %s", key);
 }
@@ -303,6 +328,8 @@ struct gr_net {
   int capB = 0, lastB = 0;
   float *in_buf = nullptr, *gout_buf = nullptr, *dy_buf = nullptr, *g_buf[2] = {nullptr, nullptr};
   void* dy_p16 = nullptr;            // operand-ready copy of dy_buf for the data-gradient convolution
+  float* dy_buf_b = nullptr; void* dy_p16_b = nullptr;   // second pair: stages alternate, so stage s - 1 can write its dy while stage s's weight gradient (side stream) still reads
+  bool wg_pending[2] = {false, false};                   // a side-stream weight gradient may still be reading dy pair k
   float* up_tmp[2] = {nullptr, nullptr}; size_t up_cap = 0;    // backward of a fused up-sampling stage: up-sampled input / data gradient at the up-sampled size
   size_t max_y = 0, max_in = 0;      // per-sample element counts
   uint8_t* mask_stage = nullptr; size_t mask_stage_cap = 0;
@@ -334,7 +361,7 @@ extern "C" int gr_net_destroy(gr_net* n) {
   for (auto& m : n->masks) (void)hipFree(m.bits);
   (void)hipFree(n->params); (void)hipFree(n->grads); (void)hipFree(n->adam_m); (void)hipFree(n->adam_v);
   (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
-  (void)hipFree(n->dy_p16); (void)hipFree(n->up_tmp[0]); (void)hipFree(n->up_tmp[1]); (void)hipFree(n->mask_stage); (void)hipFree(n->jobs_dev[0]); (void)hipFree(n->jobs_dev[1]); (void)hipFree(n->jobs_dev[2]); (void)hipFree(n->amax);
+  (void)hipFree(n->dy_p16); (void)hipFree(n->dy_p16_b); (void)hipFree(n->dy_buf_b); (void)hipFree(n->up_tmp[0]); (void)hipFree(n->up_tmp[1]); (void)hipFree(n->mask_stage); (void)hipFree(n->jobs_dev[0]); (void)hipFree(n->jobs_dev[1]); (void)hipFree(n->jobs_dev[2]); (void)hipFree(n->amax);
   delete n;
   return GR_OK;
 }
@@ -612,8 +639,10 @@ static int ensure_batch(gr_net* n, int B) {
       HIPCHK(c, hipMalloc(&s.x_p16, sizeof(float) * (size_t)B * vol3(s.inC, s.inH, s.inW)));
     }
   }
-  (void)hipFree(n->dy_p16); n->dy_p16 = nullptr;
+  (void)hipFree(n->dy_p16); n->dy_p16 = nullptr; (void)hipFree(n->dy_p16_b); n->dy_p16_b = nullptr; (void)hipFree(n->dy_buf_b); n->dy_buf_b = nullptr;
   HIPCHK(c, hipMalloc(&n->dy_p16, sizeof(float) * (size_t)B * n->max_y));
+  HIPCHK(c, hipMalloc(&n->dy_p16_b, sizeof(float) * (size_t)B * n->max_y));
+  HIPCHK(c, hipMalloc((void**)&n->dy_buf_b, sizeof(float) * (size_t)B * n->max_y));
   (void)hipFree(n->in_buf); (void)hipFree(n->gout_buf); (void)hipFree(n->dy_buf); (void)hipFree(n->g_buf[0]); (void)hipFree(n->g_buf[1]);
   n->in_buf = n->gout_buf = n->dy_buf = n->g_buf[0] = n->g_buf[1] = nullptr;
   HIPCHK(c, hipMalloc((void**)&n->in_buf, sizeof(float) * (size_t)B * vol3(n->inC, n->inH, n->inW)));
@@ -1065,11 +1094,15 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     const bool need_gin = si > 0 || gin_dev != nullptr;
     float* gin = (si == 0 && gin_dev) ? gin_dev : n->g_buf[si & 1];
     // pipeline backward: g (wrt stage output) -> dy (wrt raw main-op output / ELEM input)
+    // dy pair of this stage; the side-stream weight gradient that last read it (two stages ago) must be done before it is rewritten
+    const int dk = si & 1;
+    float* const dyb = dk ? n->dy_buf_b : n->dy_buf; void* const dyp = dk ? n->dy_p16_b : n->dy_p16;
+    if (n->wg_pending[dk]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wgrad_done[dk], 0)); n->wg_pending[dk] = false; }
     PostBwdArgs pb{};
     pb.f = post_args(n, s, B);
     if (!s.has_post) { pb.f.out = nullptr; }
     pb.gout = g;
-    pb.dy = s.kind == ST_ELEM ? gin : n->dy_buf;
+    pb.dy = s.kind == ST_ELEM ? gin : dyb;
     pb.partials = s.partials; pb.partials_b = s.partials_b; pb.coef = s.coef;
     pb.ggamma = s.has_bn ? n->grads + s.g_off : nullptr; pb.gbeta = s.has_bn ? n->grads + s.be_off : nullptr;
     pb.gbias = s.kind == ST_ELEM ? nullptr : n->grads + s.b_off;
@@ -1082,7 +1115,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     // pipeline kernel in THIS forward) and pass B's dy image
     const bool wgrad_p16 = dy_ok && s.x_p16 && s.x_p16_gen == n->amax_gen && conv_wgrad_p16_supported(B, s.Cin, s.Cout, s.H, s.W);
     const bool dy_p16 = dgrad_p16 || wgrad_p16;
-    pb.dy_p16 = dy_p16 ? n->dy_p16 : nullptr; pb.amax_dz = dy_p16 ? s.amax_dz : nullptr; pb.kb = s.amax_kb;
+    pb.dy_p16 = dy_p16 ? dyp : nullptr; pb.amax_dz = dy_p16 ? s.amax_dz : nullptr; pb.kb = s.amax_kb;
     if (s.kind == ST_CONV && si > 0 && n->st[si - 1].out_skipped && !wgrad_p16)
       return fail(c, GR_ERR_STATE, "stage %d: the forward left this stage's input operand-ready only (f16x3); backward in another arithmetic mode needs a new forward", si);
     static const bool lean_on = !getenv("GR_P16_KEEP_FP32");
@@ -1103,10 +1136,10 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
         launch_upsample2(x, n->up_tmp[0], B, s.Cin, s.H, s.W, c->stream);
         int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W, c->conv_mode)); if (r) return r;
         if (c->conv_mode == 2 && conv_wgrad_is_split(2, s.Cin, s.W) && s.amax_x_fwd != n->amax_gen) launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream);
-        launch_conv3x3_wgrad(n->up_tmp[0], n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode, s.amax_x, s.amax_dy);
+        launch_conv3x3_wgrad(n->up_tmp[0], dyb, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode, s.amax_x, s.amax_dy);
         if (need_gin) {
-          if (c->conv_mode >= 1 && s.Cin > 4) launch_conv3x3_split(n->dy_buf, s.ws_bwd, nullptr, n->up_tmp[1], B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
-          else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, n->up_tmp[1], B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+          if (c->conv_mode >= 1 && s.Cin > 4) launch_conv3x3_split(dyb, s.ws_bwd, nullptr, n->up_tmp[1], B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
+          else launch_conv3x3(dyb, s.wt_bwd, nullptr, n->up_tmp[1], B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
           launch_downsum2(n->up_tmp[1], gin, B, s.Cin, s.H / 2, s.W / 2, c->stream);
         }
         LAUNCHCHK(c);
@@ -1115,10 +1148,10 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
         // Cout -> Cin with the roles of input and gradOutput swapped; gradInput = that convolution's forward of gradOutput
         int r = ensure_ws(c, conv_wgrad_workspace_bytes(B, s.Cout, s.Cin, s.H, s.W, c->conv_mode)); if (r) return r;
         if (c->conv_mode == 2 && conv_wgrad_is_split(2, s.Cout, s.W) && s.amax_x_fwd != n->amax_gen) launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream);
-        launch_conv3x3_wgrad(n->dy_buf, x, n->grads + s.w_off, c->ws, B, s.Cout, s.Cin, s.H, s.W, c->stream, c->conv_mode, s.amax_dy, s.amax_x);
+        launch_conv3x3_wgrad(dyb, x, n->grads + s.w_off, c->ws, B, s.Cout, s.Cin, s.H, s.W, c->stream, c->conv_mode, s.amax_dy, s.amax_x);
         if (need_gin) {
-          if (c->conv_mode >= 1 && s.Cin > 4) launch_conv3x3_split(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
-          else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+          if (c->conv_mode >= 1 && s.Cin > 4) launch_conv3x3_split(dyb, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
+          else launch_conv3x3(dyb, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
         }
         LAUNCHCHK(c);
       } else {
@@ -1128,16 +1161,29 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
         // x's maximum is current when this stage's forward ran on the f16x3 kernel; otherwise (few-channel input, mode switched) take it now
         if (conv_wgrad_is_split(2, s.Cin, s.W) && s.amax_x_fwd != n->amax_gen) launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream);
       }
+      // The weight gradient has no consumer before Adam / the gradient all-reduce: it runs on the side stream, beside this
+      // stage's data gradient and the memory-bound pipeline kernels of the stages after it (they leave the matrix pipe idle).
+      // Its own workspace; the dy pair it reads is not rewritten before ev_wgrad_done[dk] (waited for two stages on).
+      const bool side = c->side_wgrad && c->side_stream != nullptr;
+      hipStream_t ws_ = side ? c->side_stream : c->stream;
+      void* wsp_ = c->ws;
+      if (side) {
+        r = ensure_ws2(c, wgrad_p16 ? conv_wgrad_p16_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W) : conv_wgrad_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W, c->conv_mode)); if (r) return r;
+        wsp_ = c->ws2;
+        HIPCHK(c, hipEventRecord(c->ev_dy_ready, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_dy_ready, 0));
+      }
       if (wgrad_p16) {
-        r = ensure_ws(c, conv_wgrad_p16_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W)); if (r) return r;
-        launch_conv3x3_wgrad_p16(s.x_p16, n->dy_p16, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, s.amax_x, s.amax_dy);
+        if (!side) { r = ensure_ws(c, conv_wgrad_p16_workspace_bytes(B, s.Cin, s.Cout, s.H, s.W)); if (r) return r; wsp_ = c->ws; }
+        launch_conv3x3_wgrad_p16(s.x_p16, dyp, n->grads + s.w_off, wsp_, B, s.Cin, s.Cout, s.H, s.W, ws_, s.amax_x, s.amax_dy);
       } else
-      launch_conv3x3_wgrad(x, n->dy_buf, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, c->stream, c->conv_mode, s.amax_x, s.amax_dy);
+      launch_conv3x3_wgrad(x, dyb, n->grads + s.w_off, wsp_, B, s.Cin, s.Cout, s.H, s.W, ws_, c->conv_mode, s.amax_x, s.amax_dy);
+      if (side) { HIPCHK(c, hipEventRecord(c->ev_wgrad_done[dk], c->side_stream)); n->wg_pending[dk] = true; }
       if (need_gin) {
         // backward-data = the same convolution on the transposed + flipped weights (Cout -> Cin)
-        if (dgrad_p16) launch_conv3x3_p16(n->dy_p16, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, c->stream, nullptr, s.amax_dy, s.amax_w, nullptr, nullptr, nullptr);
-        else if (c->conv_mode >= 1) launch_conv3x3_split(n->dy_buf, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
-        else launch_conv3x3(n->dy_buf, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
+        if (dgrad_p16) launch_conv3x3_p16(dyp, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, c->stream, nullptr, s.amax_dy, s.amax_w, nullptr, nullptr, nullptr);
+        else if (c->conv_mode >= 1) launch_conv3x3_split(dyb, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream, nullptr, c->conv_mode == 2 ? 2 : 3, s.amax_dy, s.amax_w);
+        else launch_conv3x3(dyb, s.wt_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, false, c->stream);
       }
       LAUNCHCHK(c);
       }
@@ -1149,10 +1195,10 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       const bool f16g = use_f16_gemm(n, s);
       if (f16g && s.amax_x_fwd != n->amax_gen) launch_absmax(x, (long)B * s.Cin, s.amax_x, c->stream);   // (mode switched since the forward)
       // gW[o][i] += sum_b dy[b][o] x[b][i]
-      launch_gemm(n->dy_buf, 1, s.Cout, x, 1, s.Cin, n->grads + s.w_off, s.Cin, nullptr, true, s.Cout, s.Cin, B, c->ws, c->stream,
+      launch_gemm(dyb, 1, s.Cout, x, 1, s.Cin, n->grads + s.w_off, s.Cin, nullptr, true, s.Cout, s.Cin, B, c->ws, c->stream,
                   nullptr, nullptr, f16g ? s.amax_dy : nullptr, f16g ? s.amax_x : nullptr);
       // gx[b][i] = sum_o dy[b][o] W[o][i]
-      if (need_gin) launch_gemm(n->dy_buf, s.Cout, 1, n->params + s.w_off, 1, s.Cin, gin, s.Cin, nullptr, false, B, s.Cin, s.Cout, c->ws, c->stream,
+      if (need_gin) launch_gemm(dyb, s.Cout, 1, n->params + s.w_off, 1, s.Cin, gin, s.Cin, nullptr, false, B, s.Cin, s.Cout, c->ws, c->stream,
                                 nullptr, nullptr, f16g ? s.amax_dy : nullptr, f16g ? s.amax_w : nullptr);
       LAUNCHCHK(c);
     }
@@ -1162,12 +1208,14 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       int64_t lo = -1;
       if (s.w_off >= 0) lo = s.w_off; else if (s.g_off >= 0) lo = s.g_off;
       if (lo >= 0 && (bucket_hi - lo >= BUCKET_MIN_ELEMS || si == 0)) {
+        for (int k2 = 0; k2 < 2; ++k2) if (n->wg_pending[k2]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wgrad_done[k2], 0)); n->wg_pending[k2] = false; }   // ... and final weight gradients
         launch_bias_grad_batch(bias_jobs, c->stream);             // the bucket must hold final bias gradients
         int r = reduce_bucket(n, lo, bucket_hi); if (r) return r;
         bucket_hi = lo;
       }
     }
   }
+  for (int k2 = 0; k2 < 2; ++k2) if (n->wg_pending[k2]) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wgrad_done[k2], 0)); n->wg_pending[k2] = false; }   // join the side stream
   launch_bias_grad_batch(bias_jobs, c->stream);
   LAUNCHCHK(c);
   if (reduce) {
