@@ -403,6 +403,36 @@ def test_range_guard_trips_in_the_device_resident_loop(ctx):
         ctx.set_conv_mode(prev)
 
 
+def test_side_stream_weight_gradients_change_nothing(ctx):
+    """gr_set_tuning "side_wgrad" 1 runs R's convolution weight gradients on a second stream beside the rest of backward (dy
+    double-buffered, events both ways).  Same kernels, same operands, same order inside each kernel: three training steps
+    from the same state must leave bit-identical parameters and gradients with the knob on and off (cfg2 geometry, f16x3)."""
+    import ganrev._lib as L
+    from ganrev import models, synth
+    from ganrev.parallel import DeviceTrainer
+    prev = ctx.conv_mode(); ctx.set_conv_mode("f16x3")
+    try:
+        dims, nd, B = (1, 32, 32), 32, 64
+        G = models.create_G(dims, nd); synth.init_params(G, 1)
+        R = models.create_R(dims, nd); synth.init_params(R, 2)
+        G.evaluate(); G.forward(synth.normal((2, nd), 1))
+        R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
+        theta0 = R._net.get_params()
+        res = []
+        for side in (0, 1):
+            ctx.set_tuning("side_wgrad", side)
+            R._net.set_params(theta0); R._net.adam_reset(); R._net.set_seed(7)
+            tr = DeviceTrainer(ctx, G._net, R._net, L.Hyper(), B)
+            for i in range(3):
+                tr.new_noise(i + 1); tr.step()
+            ctx.synchronize()
+            res.append((R._net.get_params(), R._net.get_grads()))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    finally:
+        ctx.set_tuning("side_wgrad", 0)
+        ctx.set_conv_mode(prev)
+
+
 def test_operand_ready_kernels_are_selected(ctx):
     """At the benchmark geometry (cfg2: batch 256) the f16x3 training step must take the operand-ready kernels: R's five
     512-pixel-tile forward convolutions and at least four of its data-gradient convolutions run as conv3x3_p16_*_kernel, fed by
