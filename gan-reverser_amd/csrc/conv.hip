@@ -1252,15 +1252,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
 // out of phase by themselves, so while one waits for its DMA or stores its tile the other one has the matrix pipe.  An operand
 // vector feeds more MFMAs than before (12 reads per 24 MFMAs per tap); staging and compute of ONE workgroup are serial
 // (DMA -> barrier -> 216 MFMAs per wave -> barrier).
-template <int TW, int NI>
+// NG = 32-pixel groups per wave: 4 (512-pixel tiles) or 2 (256-pixel tiles = ONE 16x16 image: a batch-256 layer on 16x16 planes
+// has only 128 two-image tiles per 64 output channels - one workgroup or none per CU, so nothing hides a workgroup's DMA
+// waits and epilogue; single-image tiles double the grid).
+template <int TW, int NI, int NG = 4>
 __global__ __launch_bounds__(256, 2) void conv3x3_p16_quad_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
   constexpr int MT = 2, NTERM = 2, NW = 4;
-  constexpr int NG = 4, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
+  constexpr int PT = 128 * NG, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int PV = NTERM * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;
   constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT;
   constexpr int LBUF = PVP + WV;
   constexpr int NPI = PVP / 64, NPS = (NPI + NW - 1) / NW, NWS = (WROWS + NW - 1) / NW;
-  static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2), "tile_pixel assumes these tilings");
+  static_assert((TW == 32 && NI == 1 && NG == 4) || (TW == 16 && NI == 2 && NG == 4) || (TW == 16 && NI == 1 && NG == 2) || (TW == 32 && NI == 1 && NG == 2), "tile_pixel assumes these tilings");
   static_assert(2 * LBUF * 16 <= 160 * 1024, "two workgroups per CU");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint4* lds = reinterpret_cast<uint4*>(smem_raw);
@@ -1433,11 +1436,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_quad_kernel(ConvArgs a, co
   // (a wave's LDS operations execute in order).
   float omax = 0.f;
   {
-    constexpr int RS = 132;
+    constexpr int RS = 32 * NG + 4, NQ = 8 * NG, CPI = 64 / NQ;      // row stride, pixel quads per wave, channels per store instruction
     static_assert(NW * 32 * RS * 4 <= LBUF * 16, "staging fits the operand image");
     float* stg = reinterpret_cast<float*>(smem_raw) + wave * 32 * RS;
-    // this lane's quad of pixels: k = lane & 31 -> pixels 4k .. 4k+3 of the wave's 128 (consecutive in x)
-    const int kq = lane & 31, hq = lane >> 5;
+    // this lane's quad of pixels: k = lane % NQ -> pixels 4k .. 4k+3 of the wave's 32 * NG (consecutive in x)
+    const int kq = lane % NQ, hq = lane / NQ;
     const int pq = (wave * NG + (kq >> 3)) * 32 + 4 * (kq & 7); int prrq, pcq; tile_pixel<TW>(pq, prrq, pcq);
     const int imgq = NI > 1 ? prrq / IH : 0, prq = NI > 1 ? prrq - imgq * IH : prrq;
     const int yq = y0 + prq, xq = x0 + pcq;
@@ -1466,8 +1469,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_quad_kernel(ConvArgs a, co
         }
       }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int chl = 2 * i + hq, o = o0 + mt * 32 + chl;
+      for (int i = 0; i < 32 / CPI; ++i) {
+        const int chl = CPI * i + hq, o = o0 + mt * 32 + chl;
         const float4 v = *reinterpret_cast<const float4*>(stg + chl * RS + 4 * kq);
         if (inq && o < a.Cout) {
           *reinterpret_cast<float4*>(outq + (size_t)o * H * W) = v;
@@ -2013,9 +2016,9 @@ bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {
 }
 int g_p16_stagger = 0;           // start delay (x 512 clocks) of the second-dispatched workgroups: measured useless (tools/stagger_p16.py), kept as a knob
 int g_p16_variant = 1;          // 1: four-wave workgroups, two per CU (conv3x3_p16_quad_kernel); 0: eight-wave persistent (conv3x3_p16_wide_kernel)
-template <int TW, int NI>
+template <int TW, int NI, int NG = 4>
 static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {
-  constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
+  constexpr int PT = 128 * NG, TR = PT / TW, IH = PT / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
   constexpr int PVP = (4 * PS + P16_PAD - 1) / P16_PAD * P16_PAD, LBUF = PVP + 36 * CT;
   a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
@@ -2024,16 +2027,16 @@ static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin,
   a.stat_tiles = a.n_tiles / a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true;
     if (getenv("GR_DEBUG_OCC")) {
-      int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI>), 256, lds);
-      fprintf(stderr, "conv3x3_p16_quad_kernel<%d, %d>: %zu B LDS per workgroup, occupancy query says %d workgroups per CU\n", TW, NI, lds, nb);
+      int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI, NG>), 256, lds);
+      fprintf(stderr, "conv3x3_p16_quad_kernel<%d, %d> (NG %d): %zu B LDS per workgroup, occupancy query says %d workgroups per CU\n", TW, NI, NG, lds, nb);
     }
   }
-  static const std::string name = "conv3x3_p16_quad_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";   // as rocprofv3 prints it
+  static const std::string name = "conv3x3_p16_quad_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + (NG == 4 ? ">" : ", " + std::to_string(NG) + ">");   // as rocprofv3 prints it
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_p16_quad_kernel<TW, NI>), dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
+  hipLaunchKernelGGL((conv3x3_p16_quad_kernel<TW, NI, NG>), dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
   return a.stat_tiles;
 }
 template <int TW, int NI>
@@ -2064,7 +2067,16 @@ void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = g_p16_debug; a.nchunks = g_p16_stagger;
   a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
   a.stat_part = stat_tiles ? stat_part : nullptr;
-  const int nt = (H == 16 && W == 16) ? launch_conv_p16_t<16, 2>(a, wsplit, x_p16, s) : launch_conv_p16_t<32, 1>(a, wsplit, x_p16, s);
+  // 16x16 planes: two-image tiles when they still give two workgroups per CU, single-image tiles otherwise
+  static const int single = getenv("GR_P16_SINGLE") ? atoi(getenv("GR_P16_SINGLE")) : 1;
+  const long two_img_tiles = (long)((B + 1) / 2) * (round_up(Cout, 32) / 64);
+  int nt;
+  if (H == 16 && W == 16) nt = (single && g_p16_variant == 1 && two_img_tiles < 512) ? launch_conv_p16_quad<16, 1, 2>(a, wsplit, x_p16, s) : launch_conv_p16_t<16, 2>(a, wsplit, x_p16, s);
+  else {
+    static const int half32 = getenv("GR_P16_HALF32") ? atoi(getenv("GR_P16_HALF32")) : 0;     // 256-pixel tiles (8 rows x 32) on wider planes
+    const long tiles512 = (long)B * ((H + 15) / 16) * ((W + 31) / 32) * (round_up(Cout, 32) / 64);
+    nt = (half32 && g_p16_variant == 1 && H % 8 == 0 && tiles512 < half32) ? launch_conv_p16_quad<32, 1, 2>(a, wsplit, x_p16, s) : launch_conv_p16_t<32, 1>(a, wsplit, x_p16, s);
+  }
   if (stat_tiles) *stat_tiles = stat_part ? nt : 0;
 }
 
@@ -3032,7 +3044,9 @@ bool conv_wgrad_p16_supported(int B, int Cin, int Cout, int H, int W) {
 }
 static int wgrad_p16_splits(int B, int Cin, int Cout, int H, int W) {
   const int blocks = (Cin / 64) * (Cout / 64);
-  int want = 512 / blocks; if (want < 1) want = 1;            // two workgroups per CU
+  static int wgs = -1;
+  if (wgs < 0) { const char* e = getenv("GR_WGRAD_P16_WGS"); wgs = e ? atoi(e) : 512; }
+  int want = wgs / blocks; if (want < 1) want = 1;            // two workgroups per CU
   const long units = (long)B * H * W / 64;
   if (want > units) want = (int)units;
   return want;

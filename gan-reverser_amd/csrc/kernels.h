@@ -157,7 +157,7 @@ bool conv_p16_supported(int B, int Cin, int Cout, int H, int W);
 void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                         hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out,
                         double* stat_part, int* stat_tiles);
-inline size_t conv_stat_tiles_max(int B, int H, int W) { return (size_t)B * ((H + 15) / 16) * ((W + 31) / 32) + 1; }
+inline size_t conv_stat_tiles_max(int B, int H, int W) { return (size_t)B * ((H + 7) / 8) * ((W + 31) / 32) + 1; }     // smallest tile: 8 rows x 32 (or one 16x16 image)
 // mean / invstd (+ running statistics) from the per-tile (sum, sum of squares) the conv epilogue wrote
 // bounds (nullable): from max|y| (slot amax_y) and the fresh statistics, an upper bound of max|pipeline output| is folded into
 // bound_out (the consuming convolution's scale slot) and the factor K with max|dy| <= K * max|dz| of the stage's backward
