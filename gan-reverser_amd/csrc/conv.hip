@@ -2033,7 +2033,7 @@ static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin,
       fprintf(stderr, "conv3x3_p16_quad_kernel<%d, %d> (NG %d): %zu B LDS per workgroup, occupancy query says %d workgroups per CU\n", TW, NI, NG, lds, nb);
     }
   }
-  static const std::string name = "conv3x3_p16_quad_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + (NG == 4 ? ">" : ", " + std::to_string(NG) + ">");   // as rocprofv3 prints it
+  static const std::string name = "conv3x3_p16_quad_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ", " + std::to_string(NG) + ">";   // as rocprofv3 prints it (default template arguments included)
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_p16_quad_kernel<TW, NI, NG>), dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));

@@ -815,6 +815,23 @@ def test_full_size_cfg5_search_bit_exact(ctx, oracle):
     assert 999_999 in idx[2, :2]
 
 
+def test_search_1024_needles_bit_exact(ctx, oracle):
+    """Q = 1024 needles in one call (128 passes of 8 needles over the table, the needle groups ragged at the end of the list:
+    1021 is prime): indices and scores bit-exact against the oracle, on a table small enough for the unfiltered path and
+    on one large enough for the sample-bound filter."""
+    import os
+    from ganrev import synth
+    oracle.set_threads(max(1, min(32, os.cpu_count() or 1)))
+    for N, d, Q, k in ((20_000, 32, 1024, 50), (140_000, 32, 1021, 50)):
+        emb = synth.normal((N, d), 77 + d)
+        q = (np.arange(Q, dtype=np.int64) * 19 + 3) % N
+        idx, sc = ctx.cosine_topk(emb, q, k)
+        ridx, rsc = oracle.cosine_topk(emb, q, k)
+        assert np.array_equal(idx, ridx), (N, Q)
+        assert np.array_equal(sc, rsc), (N, Q)
+        assert np.array_equal(idx[:, 0], q), "every needle is its own best match"
+
+
 def test_search_filter_bound_and_its_overflow_rerun(ctx, oracle):
     """Tables of >= 2^17 rows are searched through a bound from a strided 16384-row sample (search.hip).  (1) random order: the
     filtered result equals the oracle's bit for bit and no rerun happens; (2) a table built against the sample - every

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "gan-reverser_amd"))
 import ganrev._lib as L
 ctx = L.default_context()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-which_names = {0: "fwd", 1: "dgrad", 2: "wgrad", 3: "up2fwd"}
+which_names = {0: "fwd", 1: "dgrad", 2: "wgrad", 3: "up2fwd", 4: "p16fwd", 5: "p16fwd+stats"}
 shapes = [("R.conv2/3", 64, 64, 32, 32), ("R.conv4", 64, 128, 16, 16), ("R.conv5/6", 128, 128, 16, 16),
           ("G.convA", 512, 256, 16, 16), ("G.convB", 256, 128, 32, 32), ("R.conv1", 1, 64, 32, 32), ("G.convC", 128, 1, 32, 32),
           ("G2.convA", 128, 256, 16, 16), ("G2.convB", 256, 128, 32, 32)]      # G2: G at cfg2 (gray 32x32)
@@ -14,8 +14,10 @@ sel = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 for name, cin, cout, h, w in shapes:
     if sel and not any(s in name for s in sel):
         continue
-    for which in (0, 1, 2, 3):
-        if name.startswith("G.") and which not in (0, 3):
+    for which in (0, 1, 2, 3, 4, 5):
+        if name.startswith("G") and which not in (0, 3):
+            continue
+        if which in (4, 5) and (ctx.conv_mode() != "f16x3" or cin % 16 or cout % 64):
             continue
         if which == 3 and (not name.split(".")[1].startswith("conv") or name.endswith("convC") or ctx.conv_mode() != "f16x3"):
             continue
