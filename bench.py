@@ -168,12 +168,26 @@ def search_cfg5(ctx):
         idx, sc = ctx.cosine_topk(None, needles, k, emb_dev=dev, n=N, d=d)
     ctx.event_record(60001)
     ms = ctx.event_elapsed_ms(60000, 60001) / reps
+    # many needles at once (the batched path: bf16 MFMA candidates + exact re-score): 1024 needles, the five above among them
+    many = np.concatenate([needles, (np.arange(1019, dtype=np.int64) * 977 + 13) % N])
+    ctx.cosine_topk(None, many, k, emb_dev=dev, n=N, d=d)
+    r0 = ctx.search_reruns()
+    ctx.event_record(60002)
+    for _ in range(3):
+        midx, msc = ctx.cosine_topk(None, many, k, emb_dev=dev, n=N, d=d)
+    ctx.event_record(60003)
+    ms_many = ctx.event_elapsed_ms(60002, 60003) / 3
+    batched = dict(needles=int(many.size), ms=round(ms_many, 4), mfma_tflops=round(2.0 * N * d * many.size / ms_many / 1e9, 1),
+                   us_per_needle=round(ms_many * 1e3 / many.size, 3), reruns_unbatched=int(ctx.search_reruns() - r0),
+                   first5_equal_single_path=bool(np.array_equal(midx[:5], idx) and np.array_equal(msc[:5], sc)),
+                   note="approximate cosines on v_mfma_f32_32x32x16_bf16 pick candidates, the exact TH-order re-score decides: bit-identical results")
     emb = ctx.download(dev, (N, d)); ctx.free(dev)
     oracle.set_threads(min(32, os.cpu_count() or 1))
     t0 = time.perf_counter(); ridx, rsc = oracle.cosine_topk(emb, needles, k); t_cpu = time.perf_counter() - t0
     return dict(n=N, d=d, k=k, needles=int(needles.size), ms=round(ms, 4), hbm_gbs=round(N * d * 4 / ms / 1e6, 1),
                 hbm_frac=round(N * d * 4 / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
                 exact_match=bool(np.array_equal(idx, ridx) and np.array_equal(sc, rsc)), cpu_ms=round(t_cpu * 1e3, 1),
+                batched_1024=batched,
                 note="ms includes the D2H copy of the 5 x 50 results and one host sync per search (gr_cosine_topk_dev)")
 
 

@@ -286,6 +286,297 @@ __global__ void topk_decode_kernel(const unsigned long long* __restrict__ keys, 
   if (score) score[i] = unorderable((uint32_t)(key >> 32));
 }
 
+// ------------------------------------------------------------------ many needles at once: candidates from one MFMA GEMM, exact re-score
+// For Q >= BATCH_MIN_Q needles the exact pass above is compute-bound (N * d * Q fp32 products with fp64 sums on the VALU: 16 ms
+// for 1024 needles over 10^6 x 100).  The batched path (north_star: "one MFMA GEMM + top-k") keeps the RESULT exact and uses the
+// matrix pipe only to decide which rows can matter:
+//   1. approximate cosines  emb x needles^T  on v_mfma_f32_32x32x16_bf16 (both operands rounded to bf16 while staged, row norms
+//      from the bf16 values): |approximate - exact| <= BERR = 2^-7 for every pair (2^-8 |a||b| from the two roundings by
+//      Cauchy-Schwarz, 2^-9 from the norm, fp32 accumulation far below);
+//   2. a strided sample of SAMPLE_ROWS rows first: tau_q = (k-th largest approximate sample score) - 2 BERR is a lower bound
+//      of every approximate score whose exact score can reach the true k-th largest one;
+//   3. the pass over the table keeps (row, approximate score) pairs >= tau_q, each workgroup in its own BSLOT entries per needle;
+//   4. per needle: the k-th largest approximate candidate score minus 2 BERR cuts the ~3000 candidates down to ~k + a few,
+//      those are re-scored EXACTLY (the op order of cos_keys_kernel: fp32 products, sequential fp64 sums, same w22 / w32
+//      arithmetic), turned into the same 64-bit keys, sorted, decoded.
+// Every row whose exact score is among the k best passes both cuts, so indices and scores are bit-identical to the unbatched
+// search; an overflowing entry list raises the status word and the caller reruns the unbatched path.
+constexpr int BATCH_MIN_Q = 32;
+constexpr int BQ_MAX = 2048;          // needles per call of the batched path (LDS counters)
+constexpr int BSLOT = 16;             // (row, score) entries per workgroup (256 rows) and needle: expected 1.2 at cfg5, P(> 16) ~ 1e-14
+constexpr int BD_MAX = 128;           // widest row the batched kernel stages whole
+#define GR_BERR 0.0078125f
+typedef short bf16x8s __attribute__((ext_vector_type(8)));
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ unsigned short to_bf16(float x) { const __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ float from_bf16(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+
+// needles as the MFMA kernel stages them: bf16 rows [Qpad64][KS] (zero columns past d, zero rows past Q), sqrt(w22), tau = +inf past Q
+__global__ void needles_bf16_kernel(const float* __restrict__ needles, const float* __restrict__ w22, int Q, int Qpad, int d, int KS,
+                                    unsigned short* __restrict__ nb16, float* __restrict__ sw22s, float* __restrict__ tau) {
+  const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (e < (long)Qpad * KS) {
+    const int q = (int)(e / KS), c = (int)(e - (long)q * KS);
+    nb16[e] = to_bf16((q < Q && c < d) ? needles[(long)q * d + c] : 0.f);
+  }
+  if (e < Qpad) { sw22s[e] = e < Q ? sqrtf(w22[e]) : 0.f; if (e >= Q) tau[e] = INFINITY; }
+}
+
+// MODE 0: rows are i * stride (the sample), scores out[q][i].  MODE 1: every row, candidates >= tau[q].
+// Workgroup = 256 rows (4 waves x 64) against ALL needles, 64 at a time.  The row tile goes through LDS once (fp32 -> bf16, the
+// MFMA B-operand layout, row norms) and then lives in registers (2 row blocks x NK k-steps of 16-byte vectors per lane); the LDS
+// it used holds the needle tiles from then on, double-buffered: the next tile's vectors are requested before the current tile's
+// MFMAs (its bf16 image is prepared once by needles_bf16_kernel, so staging is plain 16-byte copies).
+template <int MODE, int NK>
+__global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restrict__ emb, long N, int d, long stride,
+                                                          const unsigned short* __restrict__ nb16, const float* __restrict__ sw22s, int Q,
+                                                          const float* __restrict__ tau, float* __restrict__ out,
+                                                          unsigned* __restrict__ cand_idx, float* __restrict__ cand_sc, unsigned* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int KP = NK * 16, KS = KP + 8;                      // bf16 elements per staged row; KS / 8 is odd: conflict-free 16-byte reads
+  constexpr int TV = 64 * KS / 8, NTV = (TV + 255) / 256;         // 16-byte vectors of one needle tile, per thread
+  unsigned short* rowsB = reinterpret_cast<unsigned short*>(smem);              // [256][KS], later two needle tiles [2][64][KS]
+  float* sw32s = reinterpret_cast<float*>(rowsB + 256 * KS);                     // [256] sqrt(1 / (|row|^2 + 1e-12))
+  float* sw22t = sw32s + 256;                                                    // [2][64]
+  float* taut = sw22t + 128;                                                     // [2][64]
+  unsigned* lds_cnt = reinterpret_cast<unsigned*>(taut + 128);                   // [Q] (MODE 1)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const long r0 = (long)blockIdx.x * 256;
+  if (MODE == 1) for (int q = tid; q < Q; q += 256) lds_cnt[q] = 0u;
+  // stage the row tile as bf16 (zero columns past d, zero rows past N): float4 loads when the rows are 16-byte aligned
+  if ((d & 3) == 0) {
+    constexpr int C4 = KP / 4, TOT = 256 * C4, PER = (TOT + 255) / 256, HALF = (PER + 1) / 2;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      float4 v[HALF];
+#pragma unroll
+      for (int u = 0; u < HALF; ++u) {
+        const int e = tid + 256 * (part * HALF + u), r = e / C4, c = (e - r * C4) * 4;
+        const bool ok = e < TOT && c < d && r0 + r < N;
+        const long row = ok ? (MODE == 0 ? (r0 + r) * stride : r0 + r) : 0;
+        v[u] = *reinterpret_cast<const float4*>(emb + row * (long)d + (ok ? c : 0));
+        if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < HALF; ++u) {
+        const int e = tid + 256 * (part * HALF + u), r = e / C4, c = (e - r * C4) * 4;
+        if (e < TOT) {
+          uint2 pk;
+          pk.x = to_bf16(v[u].x) | (unsigned)to_bf16(v[u].y) << 16; pk.y = to_bf16(v[u].z) | (unsigned)to_bf16(v[u].w) << 16;
+          *reinterpret_cast<uint2*>(rowsB + r * KS + c) = pk;
+        }
+      }
+    }
+  } else {
+    for (int e0 = tid; e0 < 256 * KP; e0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u, r = e / KP, c = e - r * KP;
+        const bool ok = e < 256 * KP && c < d && r0 + r < N;
+        const long row = ok ? (MODE == 0 ? (r0 + r) * stride : r0 + r) : 0;
+        v[u] = emb[row * (long)d + (ok ? c : 0)];
+        if (!ok) v[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + 256 * u, r = e / KP, c = e - r * KP;
+        if (e < 256 * KP) rowsB[r * KS + c] = to_bf16(v[u]);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    float nrm = 0.f;
+    const uint4* rv = reinterpret_cast<const uint4*>(rowsB + tid * KS);
+#pragma unroll
+    for (int c8 = 0; c8 < KP / 8; ++c8) {
+      const uint4 t = rv[c8];
+      const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float a = from_bf16((unsigned short)(w[j] & 0xffffu)), b = from_bf16((unsigned short)(w[j] >> 16)); nrm += a * a; nrm += b * b; }
+    }
+    sw32s[tid] = sqrtf(1.f / (nrm + 1e-12f));
+  }
+  uint4 bop[2][NK];                                             // this lane's B operands: rows 64 wave + 32 rb + l31, k octet h of every k-step
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) bop[rb][kk] = *reinterpret_cast<const uint4*>(rowsB + (64 * wave + 32 * rb + l31) * KS + kk * 16 + 8 * h);
+  __syncthreads();                                              // rows are in registers: the tile region now holds needle tiles
+  float s32[2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) s32[rb] = sw32s[64 * wave + 32 * rb + l31];
+  uint4* ndA = reinterpret_cast<uint4*>(rowsB);                 // [2][TV]
+  const uint4* nsrc = reinterpret_cast<const uint4*>(nb16);
+  const int ntiles = (Q + 63) / 64;
+  uint4 pre[NTV]; float pre_w = 0.f, pre_t = 0.f;
+  auto fetch = [&](int nt) {
+#pragma unroll
+    for (int u = 0; u < NTV; ++u) { const int e = tid + 256 * u; pre[u] = e < TV ? nsrc[(long)nt * TV + e] : make_uint4(0, 0, 0, 0); }
+    if (tid < 64) { pre_w = sw22s[nt * 64 + tid]; if (MODE == 1) pre_t = tau[nt * 64 + tid]; }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NTV; ++u) { const int e = tid + 256 * u; if (e < TV) ndA[buf * TV + e] = pre[u]; }
+    if (tid < 64) { sw22t[buf * 64 + tid] = pre_w; if (MODE == 1) taut[buf * 64 + tid] = pre_t; }
+  };
+  fetch(0); commit(0);
+  for (int nt = 0; nt < ntiles; ++nt) {
+    const int q0 = nt * 64, cur = nt & 1;
+    __syncthreads();                                            // tile nt is published; tile nt - 1's buffer is free
+    if (nt + 1 < ntiles) fetch(nt + 1);
+    const unsigned short* at = reinterpret_cast<const unsigned short*>(ndA + cur * TV);
+    f32x16s acc[2][2];                                          // [needle block][row block]
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][rb][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      uint4 a[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) a[nb] = *reinterpret_cast<const uint4*>(at + (32 * nb + l31) * KS + kk * 16 + 8 * h);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+          acc[nb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, a[nb]), __builtin_bit_cast(bf16x8s, bop[rb][kk]), acc[nb][rb], 0, 0, 0);
+    }
+    // this lane's 32 needles of the tile are 8 runs of 4 (accumulator register r <-> needle 32 nb + 8 (r >> 2) + 4 h + (r & 3)):
+    // their thresholds (MODE 1: tau / sqrt(w22), so that one multiply per value decides) or scales (MODE 0) come in as 8
+    // float4s up front - one LDS read and wait per value made the epilogue 20x longer than the tile's MFMAs
+    float4 pv[2][4];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) pv[nb][rq] = *reinterpret_cast<const float4*>((MODE == 1 ? taut : sw22t) + cur * 64 + 32 * nb + 8 * rq + 4 * h);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const long i = r0 + 64 * wave + 32 * rb + l31;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h, q = q0 + ql;
+          const float4 p4 = pv[nb][r >> 2];
+          const float pq = (r & 3) == 0 ? p4.x : ((r & 3) == 1 ? p4.y : ((r & 3) == 2 ? p4.z : p4.w));
+          const float v = acc[nb][rb][r] * s32[rb];
+          if (MODE == 0) { if (q < Q && i < N) out[(long)q * N + i] = v * pq; }
+          else if (v >= pq && i < N) {                          // (the threshold is +inf past Q)
+            const unsigned pos = atomicAdd(&lds_cnt[q], 1u);
+            if (pos < (unsigned)BSLOT) { const long at2 = ((long)q * gridDim.x + blockIdx.x) * BSLOT + pos; cand_idx[at2] = (unsigned)i; cand_sc[at2] = v * sw22t[cur * 64 + ql]; }
+          }
+        }
+    }
+    if (nt + 1 < ntiles) commit(cur ^ 1);
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    for (int q = tid; q < Q; q += 256) counts[(long)q * gridDim.x + blockIdx.x] = lds_cnt[q];
+  }
+}
+
+// k-th largest of up to 1024 per-thread maxima (orderable 32-bit scores), as in topk_select_kernel: sorted descending in LDS
+__device__ __forceinline__ unsigned kth_of_maxima(unsigned mine, unsigned* list, int k) {
+  list[threadIdx.x] = mine;
+  __syncthreads();
+  for (int size = 2; size <= 1024; size <<= 1)
+    for (int st = size >> 1; st > 0; st >>= 1) {
+      if (threadIdx.x < 512) {
+        const int lo = ((threadIdx.x / st) * st * 2) + (threadIdx.x % st), hi = lo + st;
+        const bool desc = ((lo & size) == 0);
+        const unsigned a = list[lo], b = list[hi];
+        if ((a < b) == desc) { list[lo] = b; list[hi] = a; }
+      }
+      __syncthreads();
+    }
+  const unsigned r = list[k - 1];
+  __syncthreads();
+  return r;
+}
+// tau[q] from the approximate sample scores [Q][S]
+__global__ __launch_bounds__(1024) void batched_tau_kernel(const float* __restrict__ samp, long S, int k, const float* __restrict__ sw22s, float* __restrict__ tau) {
+  __shared__ unsigned list[1024];
+  const int q = blockIdx.x;
+  unsigned mine = 0u;
+  for (long i = threadIdx.x; i < S; i += 1024) { const unsigned o = orderable(samp[(long)q * S + i]); mine = o > mine ? o : mine; }
+  const unsigned kth = kth_of_maxima(mine, list, k);
+  // stored divided by sqrt(w22): cos_mfma_kernel compares (dot * sqrt(w32)) with it; the rounding of the division is far inside the 2 BERR slack
+  if (threadIdx.x == 0) tau[q] = kth ? (unorderable(kth) - 2.f * GR_BERR) / sw22s[q] : -INFINITY;
+}
+// per needle: second cut on the approximate scores, exact re-score of what is left, sort, decode
+template <bool ACCF>
+__global__ __launch_bounds__(1024) void batched_select_kernel(const float* __restrict__ emb, int d, const float* __restrict__ needles,
+                                                              const float* __restrict__ w22, const unsigned* __restrict__ cand_idx,
+                                                              const float* __restrict__ cand_sc, const unsigned* __restrict__ counts, long nwg, int k,
+                                                              long* __restrict__ idx, float* __restrict__ score, unsigned* __restrict__ status) {
+  typedef typename std::conditional<ACCF, float, double>::type acc_t;
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[CHUNK];
+  __shared__ unsigned rows[CHUNK];
+  __shared__ unsigned list_n, over;
+  unsigned* list = reinterpret_cast<unsigned*>(keys);            // the 1024 maxima live in the key array before it is needed
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const unsigned* cnt = counts + (long)q * nwg;
+  const unsigned* ci = cand_idx + (long)q * nwg * BSLOT;
+  const float* cs = cand_sc + (long)q * nwg * BSLOT;
+  if (tid == 0) { list_n = 0u; over = 0u; }
+  __syncthreads();
+  unsigned mine = 0u, o = 0u;
+  for (long g = tid; g < nwg; g += 1024) {
+    const unsigned c = cnt[g];
+    if (c > (unsigned)BSLOT) o = 1u;
+    for (unsigned e = 0; e < min(c, (unsigned)BSLOT); ++e) { const unsigned v = orderable(cs[g * BSLOT + e]); mine = v > mine ? v : mine; }
+  }
+  if (o) over = 1u;
+  const unsigned kth = kth_of_maxima(mine, list, k);
+  if (over) { if (tid == 0 && status) *status = 1u; return; }
+  const float tau2 = kth ? unorderable(kth) - 2.f * GR_BERR : -INFINITY;
+  for (long g = tid; g < nwg; g += 1024) {
+    const unsigned c = min(cnt[g], (unsigned)BSLOT);
+    for (unsigned e = 0; e < c; ++e)
+      if (cs[g * BSLOT + e] >= tau2) { const unsigned pos = atomicAdd(&list_n, 1u); if (pos < (unsigned)CHUNK) rows[pos] = ci[g * BSLOT + e]; }
+  }
+  __syncthreads();
+  const unsigned m = list_n;
+  if (m > (unsigned)CHUNK) { if (tid == 0 && status) *status = 1u; return; }
+  // exact scores, cos_keys_kernel's arithmetic: fp32 products, sequential sums over the columns, the same w22 / w32 steps
+  const float* nd = needles + (long)q * d;
+  for (unsigned i = tid; i < m; i += 1024) {
+    const long row = rows[i];
+    const float* b = emb + row * (long)d;
+    acc_t s1 = 0, s3 = 0;
+    for (int c = 0; c < d; ++c) { const float bv = b[c]; s3 += (acc_t)(bv * bv); s1 += (acc_t)(nd[c] * bv); }
+    float w32 = (float)s3;
+    w32 = w32 + 1e-12f;
+    w32 = 1.f / w32;
+    float w = w22[q] * w32;
+    w = sqrtf(w);
+    const float sc = (float)s1 * w;
+    keys[i] = ((unsigned long long)orderable(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)row);
+  }
+  int P = 64; while (P < (int)m) P <<= 1;
+  for (int i = tid; i < P; i += 1024) if (i >= (int)m) keys[i] = 0ull;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1)
+    for (int st = size >> 1; st > 0; st >>= 1) {
+      if (tid < P / 2) {
+        const int lo = ((tid / st) * st * 2) + (tid % st), hi = lo + st;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int r = tid; r < k; r += 1024) {
+    const unsigned long long key = keys[r];
+    idx[(long)q * k + r] = (long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+    if (score) score[(long)q * k + r] = unorderable((uint32_t)(key >> 32));
+  }
+}
+
 static long chunks_of(long n) { return (n + CHUNK - 1) / CHUNK; }
 
 size_t cosine_topk_workspace_bytes(long N, int d, int Q, int k) {
@@ -337,6 +628,44 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
   const bool filter = !unfiltered && status_dev && N >= FILTER_MIN_ROWS && k * 8 <= SAMPLE_ROWS && k <= CHUNK / 2;      // (entries + sample + bounds + counts fit the N keys of region A: SLOT * 8 / ROWS + ... < 8 bytes per row)
   if (accf) hipLaunchKernelGGL(needle_prep_kernel<true>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
   else hipLaunchKernelGGL(needle_prep_kernel<false>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
+  static const bool batched_on = !getenv("GR_SEARCH_NO_BATCHED");
+  if (filter && batched_on && Q >= BATCH_MIN_Q && Q <= BQ_MAX && d <= BD_MAX) {
+    // keys A = sample scores [Q][S] | tau [Qpad] | sqrt(w22) [Qpad] | bf16 needles [Qpad][KS] | candidate rows [Q][nwg][BSLOT] | scores | counts [Q][nwg]
+    const long S = SAMPLE_ROWS, nwg = (N + 255) / 256, stride = N / S;
+    const int NK = d <= 32 ? 2 : (d <= 64 ? 4 : (d <= 112 ? 7 : 8)), KS = NK * 16 + 8, Qpad = (Q + 63) / 64 * 64;
+    float* samp = reinterpret_cast<float*>(keysA); float* tau = samp + (size_t)Q * S; float* sw22s = tau + Qpad;
+    unsigned short* nb16 = reinterpret_cast<unsigned short*>(sw22s + Qpad);
+    unsigned* cidx = reinterpret_cast<unsigned*>(nb16 + (size_t)Qpad * KS); float* csc = reinterpret_cast<float*>(cidx + (size_t)Q * nwg * BSLOT);
+    unsigned* wcnt = reinterpret_cast<unsigned*>(csc + (size_t)Q * nwg * BSLOT);
+    const size_t lds = (size_t)256 * KS * 2 + sizeof(float) * (256 + 128 + 128) + sizeof(unsigned) * (size_t)Q;
+    hipLaunchKernelGGL(needles_bf16_kernel, dim3((unsigned)(((long)Qpad * KS + 255) / 256)), dim3(256), 0, s, needles, w22, Q, Qpad, d, KS, nb16, sw22s, tau);
+#define GR_MFMA(MODE_, grid_, N_, stride_, tau_, out_, ci_, cs_, wc_)                                                                  \
+    do {                                                                                                                              \
+      switch (NK) {                                                                                                                   \
+        case 2: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 2>), dim3(grid_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_); break; \
+        case 4: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 4>), dim3(grid_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_); break; \
+        case 7: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 7>), dim3(grid_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_); break; \
+        default: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 8>), dim3(grid_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_); break; \
+      }                                                                                                                               \
+    } while (0)
+    {
+      KtScope kt("cos_mfma_kernel (sample)", 2.0 * S * d * Q, 4.0 * S * d, s);
+      GR_MFMA(0, (unsigned)((S + 255) / 256), S, stride, (const float*)nullptr, samp, (unsigned*)nullptr, (float*)nullptr, (unsigned*)nullptr);
+    }
+    {
+      KtScope kt("batched_tau_kernel", 0.0, 4.0 * S * Q, s);
+      hipLaunchKernelGGL(batched_tau_kernel, dim3(Q), dim3(1024), 0, s, samp, S, k, sw22s, tau);
+    }
+    {
+      KtScope kt("cos_mfma_kernel", 2.0 * N * d * Q, 4.0 * N * d, s);
+      GR_MFMA(1, (unsigned)nwg, N, 1L, (const float*)tau, (float*)nullptr, cidx, csc, wcnt);
+    }
+#undef GR_MFMA
+    KtScope kt("batched_select_kernel", 0.0, 0.0, s);
+    if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev);
+    else hipLaunchKernelGGL(batched_select_kernel<false>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev);
+    return 0;
+  }
   if (filter) {
     // keys A = candidate entries [Q][nb][SLOT] | sample keys [Q][SAMPLE_ROWS] | bounds [Q] | counts [Q][nb]
     const unsigned nbs = (unsigned)((SAMPLE_ROWS + ROWS - 1) / ROWS), nb = (unsigned)((N + ROWS - 1) / ROWS);

@@ -178,8 +178,11 @@ int gr_cosine_topk_dev(gr_ctx* ctx, const float* emb_dev, int64_t n, int d, cons
                        int64_t* idx_out_host, float* score_out_host, int accumulate_in_float);
 int gr_cosine_similarity_host(gr_ctx* ctx, const float* a_host, const float* b_host, int d, float* out);
 /* Tables of 2^17 rows or more are searched through a bound taken from a strided 16384-row sample (only keys at or above the
- * sample's k-th largest key are kept: same result, bit for bit, without writing n x q keys); when a table's order defeats the
- * sample (a candidate list overflows) the search runs again on every key.  reruns = how often that happened since gr_init. */
+ * sample's k-th largest key are kept: same result, bit for bit, without writing n x q keys).  With 32 or more needles (d <= 128)
+ * the candidates come from ONE bf16 MFMA GEMM of the table against all needles (approximate cosines, error bound 2^-7, two
+ * cuts with a 2^-6 margin) and only they are scored in the exact op order: the result is still bit-identical.  When a table's
+ * order defeats the sample (a candidate list overflows) the search runs again on every key.  reruns = how often that
+ * happened since gr_init. */
 int gr_search_stats(gr_ctx* ctx, int64_t* reruns);
 
 /* ---- apply_r.lua:355-372 (detectAnomalies): out[i] = torch.dist(a[i], b[i]) = sqrt(sum_j (a_ij - b_ij)^2), rows of length d ---- */

@@ -832,6 +832,41 @@ def test_search_1024_needles_bit_exact(ctx, oracle):
         assert np.array_equal(idx[:, 0], q), "every needle is its own best match"
 
 
+def test_search_batched_mfma_path_bit_exact_and_its_rerun(ctx, oracle):
+    """Q >= 32 needles on a table of >= 2^17 rows take the batched path: approximate cosines on the bf16 MFMA select candidates
+    (two cuts with a 2^-6 safety margin around a 2^-7 error bound), the exact op order re-scores them.  (1) 1M x 100, 48
+    needles incl. a duplicated row and a parallel vector: indices and scores bit-exact vs the oracle, no rerun; (2) d = 30 (not
+    a multiple of 4: scalar staging, k padding); (3) a table built against the sample overflows the per-workgroup entries:
+    rerun on the unbatched path, still exact."""
+    import os
+    from ganrev import synth
+    oracle.set_threads(max(1, min(32, os.cpu_count() or 1)))
+    r0 = ctx.search_reruns()
+    N, d, k = 1_000_000, 100, 50
+    emb = synth.normal((N, d), 4242)
+    emb[123456] = emb[100]; emb[999_999] = emb[300] * np.float32(2)
+    q = np.concatenate([np.array([100, 200, 300, 999_900], dtype=np.int64), (np.arange(44, dtype=np.int64) * 20011 + 7) % N])
+    idx, sc = ctx.cosine_topk(emb, q, k)
+    ridx, rsc = oracle.cosine_topk(emb, q, k)
+    assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc), "batched search differs from the oracle at 1M x 100"
+    del emb
+    N, d = 150_000, 30
+    emb = synth.normal((N, d), 31)
+    q = (np.arange(40, dtype=np.int64) * 3001 + 5) % N
+    idx, sc = ctx.cosine_topk(emb, q, k)
+    ridx, rsc = oracle.cosine_topk(emb, q, k)
+    assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc), "batched search differs from the oracle at d = 30"
+    assert ctx.search_reruns() == r0, "well-spread tables must not overflow the candidate entries"
+    stride = N // 16384
+    hostile = emb[q[0]][None, :] + np.float32(1e-3) * synth.normal((N, d), 5)
+    hostile[::stride] = emb[::stride]
+    hostile[q] = emb[q]
+    idx, sc = ctx.cosine_topk(hostile, q, k)
+    ridx, rsc = oracle.cosine_topk(hostile, q, k)
+    assert ctx.search_reruns() == r0 + 1, "the overflow must be detected and the search rerun unbatched"
+    assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
+
+
 def test_search_filter_bound_and_its_overflow_rerun(ctx, oracle):
     """Tables of >= 2^17 rows are searched through a bound from a strided 16384-row sample (search.hip).  (1) random order: the
     filtered result equals the oracle's bit for bit and no rerun happens; (2) a table built against the sample - every
