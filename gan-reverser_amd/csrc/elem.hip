@@ -213,21 +213,25 @@ __device__ __forceinline__ void t8_pack(float4 v, float sc, uint2& hi, uint2& lo
   lo = make_uint2(b[0] | (unsigned)b[1] << 16, b[2] | (unsigned)b[3] << 16);
 }
 // phase 2: the tile's npx pixels x 2 terms, one vector per lane and step; dst = the image's term-0 plane at the tile's first pixel
+template <int RSB>
 __device__ __forceinline__ void t8_emit(const unsigned char* img, int npx, uint4* dst, size_t term_stride) {
   const int lane16 = threadIdx.x & 15, q = lane16 >> 2, pq = lane16 & 3;
   for (int v = threadIdx.x; v < 2 * npx; v += 256) {
     const int t = v / npx, px = v - t * npx, c0 = px & ~15;              // the 16-lane group's block of pixels c0 .. c0 + 15 (t is wave-uniform)
-    const unsigned char* row = img + (size_t)(t * 8 + q) * T8_RSB + (c0 + 4 * pq) * 2;
-    const uint2 lo4 = t8_tr(row), hi4 = t8_tr(row + 4 * T8_RSB);         // channels 0-3 and 4-7 of pixel px
+    const unsigned char* row = img + (size_t)(t * 8 + q) * RSB + (c0 + 4 * pq) * 2;
+    const uint2 lo4 = t8_tr(row), hi4 = t8_tr(row + 4 * RSB);         // channels 0-3 and 4-7 of pixel px
     dst[(size_t)t * term_stride + px] = make_uint4(lo4.x, lo4.y, hi4.x, hi4.y);
   }
 }
-template <bool POOL>
+// PXT = pixels per tile: 1024, or 256 for planes of 256 output pixels (a 34 KB image for 1024 pixels limits a CU to four
+// workgroups; 16x16 planes need 9 KB and fit eight)
+template <bool POOL, int PXT>
 __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char img[16 * T8_RSB];
+  constexpr int RSB = PXT * 2 + 64;                          // bytes per (term, channel) row: 64 (mod 256)
+  __shared__ __attribute__((aligned(16))) unsigned char img[16 * RSB];
   const unsigned H = a.H, W = a.W, Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
   const unsigned HW = H * W, HWo = Ho * Wo, wq = Wo >> 2, G = (unsigned)a.C >> 3;
-  const unsigned npx = HWo < (unsigned)T8_PXT ? HWo : (unsigned)T8_PXT, tiles = HWo / npx, qpt = npx >> 2;   // quads per tile
+  const unsigned npx = HWo < (unsigned)PXT ? HWo : (unsigned)PXT, tiles = HWo / npx, qpt = npx >> 2;   // quads per tile
   const unsigned units = (unsigned)a.B * G * tiles;
   const float sc = pow2f(f16_scale_exp(absmax_read(a.p16_scale)));
   uint4* p16 = reinterpret_cast<uint4*>(a.p16);
@@ -269,11 +273,11 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
       uint2 hi, lo;
       t8_pack(res, sc, hi, lo);
       const unsigned qi = task - j * qpt;
-      *reinterpret_cast<uint2*>(img + (size_t)j * T8_RSB + qi * 8) = hi;
-      *reinterpret_cast<uint2*>(img + (size_t)(8 + j) * T8_RSB + qi * 8) = lo;
+      *reinterpret_cast<uint2*>(img + (size_t)j * RSB + qi * 8) = hi;
+      *reinterpret_cast<uint2*>(img + (size_t)(8 + j) * RSB + qi * 8) = lo;
     }
     __syncthreads();
-    t8_emit(img, (int)npx, p16 + (size_t)bg * 2 * HWo + (size_t)tile * npx, HWo);
+    t8_emit<RSB>(img, (int)npx, p16 + (size_t)bg * 2 * HWo + (size_t)tile * npx, HWo);
     __syncthreads();
   }
 }
@@ -312,10 +316,16 @@ void launch_post_forward(const PostArgs& a, hipStream_t s) {
   if (a.p16) {      // caller checked post_g8_supported
     const long hwo = a.pool ? (long)(a.H >> 1) * (a.W >> 1) : (long)a.H * a.W;
     long blocks = (long)a.B * (a.C / 8) * (hwo > T8_PXT ? hwo / T8_PXT : 1);      // one (image, 8-channel group, pixel tile) per block step
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 4096 && hwo > 256) blocks = 4096;
     KtScope kt("post_forward_g8_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + (a.out ? 2.0 : 1.0) * (double)n), s);
-    if (a.pool) hipLaunchKernelGGL(post_forward_g8_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(post_forward_g8_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (hwo <= 256) {
+      if (blocks > 8192) blocks = 8192;
+      if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((post_forward_g8_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    } else {
+      if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 1024>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((post_forward_g8_kernel<false, 1024>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
     return;
   }
   const bool vec = (a.pool ? (a.W % 8 == 0 && a.H % 2 == 0) : (a.W % 4 == 0)) && (long)a.B * a.C * a.H * a.W < (1l << 32);
@@ -692,8 +702,10 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
 // the LDS transpose of the forward kernel (t8_pack / t8_emit).  Writes dy as the data- / weight-gradient convolutions' image
 // dy_p16[b][g][term][pixel], scaled by the power of two of the bound K * max|dz| (K from the forward's statistics, max|dz| from
 // pass A) that it also leaves in amax_dy, and as fp32 only when a consumer still needs that (a.dy != null).
+template <int PXT>
 __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, int splits, int slices, double n, int dbg) {
-  __shared__ __attribute__((aligned(16))) unsigned char img[16 * T8_RSB];
+  constexpr int RSB = PXT * 2 + 64;
+  __shared__ __attribute__((aligned(16))) unsigned char img[16 * RSB];
   __shared__ double sh_part[16];
   __shared__ float par[8][6];          // mean, invstd, gamma, beta, gm, k
   __shared__ double chsum[8];          // per-channel sums of dy
@@ -728,7 +740,7 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
   const float sc = pow2f(f16_scale_exp(__float_as_uint(bound)));
   const unsigned H = f.H, W = f.W, Wo = f.pool ? W >> 1 : W, HW = H * W, HWo = f.pool ? (H >> 1) * Wo : HW, wq = W >> 2;
   const unsigned G = (unsigned)f.C >> 3;
-  const unsigned npx = HW < (unsigned)T8_PXT ? HW : (unsigned)T8_PXT, tiles = HW / npx, qpt = npx >> 2;
+  const unsigned npx = HW < (unsigned)PXT ? HW : (unsigned)PXT, tiles = HW / npx, qpt = npx >> 2;
   const int per = (f.B + slices - 1) / slices, b0 = sp * per, b1 = min(f.B, b0 + per);      // blockIdx.y = one of `slices` batch slices (finer than pass A's splits)
   uint4* p16 = reinterpret_cast<uint4*>(a.dy_p16);
   const unsigned jc = threadIdx.x >> 5, q0 = threadIdx.x & 31;      // this thread's channel of the group and its first quad
@@ -763,13 +775,13 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
             csum += (double)d.x + (double)d.y + (double)d.z + (double)d.w;
             uint2 hi, lo;
             t8_pack(d, sc, hi, lo);
-            *reinterpret_cast<uint2*>(img + (size_t)jc * T8_RSB + qi * 8) = hi;
-            *reinterpret_cast<uint2*>(img + (size_t)(8 + jc) * T8_RSB + qi * 8) = lo;
+            *reinterpret_cast<uint2*>(img + (size_t)jc * RSB + qi * 8) = hi;
+            *reinterpret_cast<uint2*>(img + (size_t)(8 + jc) * RSB + qi * 8) = lo;
           }
         }
       }
       __syncthreads();
-      if (!(dbg & 64)) t8_emit(img, (int)npx, p16 + ((size_t)b * G + g) * 2 * HW + (size_t)tile * npx, HW);
+      if (!(dbg & 64)) t8_emit<RSB>(img, (int)npx, p16 + ((size_t)b * G + g) * 2 * HW + (size_t)tile * npx, HW);
       __syncthreads();
     }
   // bias gradient: per-channel sums of dy = the 32 threads of a channel (one half-wave), added in a fixed shuffle tree
@@ -866,7 +878,8 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
     // 35 for the per-channel kernel): the batch is sliced down to single images instead, up to PB_SPLITS slices
     int slices = f.B < PB_SPLITS ? f.B : PB_SPLITS;
     { const int per = (f.B + slices - 1) / slices; slices = (f.B + per - 1) / per; }
-    hipLaunchKernelGGL(post_backward_b_g8_kernel, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
+    if (f.H * f.W <= 256) hipLaunchKernelGGL(post_backward_b_g8_kernel<256>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
+    else hipLaunchKernelGGL(post_backward_b_g8_kernel<1024>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
     if (a.gbias) {
       BiasJobs one{}; one.n = 0;
       BiasJobs* q = defer ? defer : &one;
