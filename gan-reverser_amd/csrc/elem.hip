@@ -305,6 +305,10 @@ __global__ __launch_bounds__(256) void to_p16_kernel(const float* __restrict__ x
     }
   }
 }
+// LDS tile of the 8-channel-group pipeline kernels: 2 = 256 pixels (9 KB per workgroup, eight workgroups per CU; default), 1 = 512,
+// 0 = 1024 (34 KB, four per CU).  Measured per step, pass B / forward: cfg2 0.228 / 0.148 -> 0.207 / 0.135 -> 0.199 / 0.139 ms,
+// cfg3 1.74 / 1.09 -> 1.23 / 0.80 -> 1.21 / 0.81 ms.
+static int g8_half_tiles() { static int v = -1; if (v < 0) { const char* e = getenv("GR_G8_HALF_TILES"); v = e ? atoi(e) : 2; } return v; }
 void launch_to_p16(const float* x, void* p16, int B, int C, int HW, const unsigned* slot, hipStream_t s) {
   long blocks = ((long)B * (C / 8) * (HW / 4) + 255) / 256;
   if (blocks > 16384) blocks = 16384;
@@ -322,6 +326,14 @@ void launch_post_forward(const PostArgs& a, hipStream_t s) {
       if (blocks > 8192) blocks = 8192;
       if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((post_forward_g8_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    } else if (g8_half_tiles() == 2) {
+      blocks *= 4; if (blocks > 8192) blocks = 8192;
+      if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((post_forward_g8_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    } else if (g8_half_tiles() && hwo % 512 == 0) {
+      blocks *= 2; if (blocks > 8192) blocks = 8192;
+      if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 512>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((post_forward_g8_kernel<false, 512>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     } else {
       if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 1024>), dim3((unsigned)blocks), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((post_forward_g8_kernel<false, 1024>), dim3((unsigned)blocks), dim3(256), 0, s, a);
@@ -879,6 +891,8 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
     int slices = f.B < PB_SPLITS ? f.B : PB_SPLITS;
     { const int per = (f.B + slices - 1) / slices; slices = (f.B + per - 1) / per; }
     if (f.H * f.W <= 256) hipLaunchKernelGGL(post_backward_b_g8_kernel<256>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
+    else if (g8_half_tiles() == 2) hipLaunchKernelGGL(post_backward_b_g8_kernel<256>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
+    else if (g8_half_tiles() && (f.H * f.W) % 512 == 0) hipLaunchKernelGGL(post_backward_b_g8_kernel<512>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
     else hipLaunchKernelGGL(post_backward_b_g8_kernel<1024>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
     if (a.gbias) {
       BiasJobs one{}; one.n = 0;
