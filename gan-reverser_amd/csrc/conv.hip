@@ -1255,16 +1255,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
 // NG = 32-pixel groups per wave: 4 (512-pixel tiles) or 2 (256-pixel tiles = ONE 16x16 image: a batch-256 layer on 16x16 planes
 // has only 128 two-image tiles per 64 output channels - one workgroup or none per CU, so nothing hides a workgroup's DMA
 // waits and epilogue; single-image tiles double the grid).
-template <int TW, int NI, int NG = 4>
-__global__ __launch_bounds__(256, 2) void conv3x3_p16_quad_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
-  constexpr int MT = 2, NTERM = 2, NW = 4;
+// MT = 32-channel output blocks per workgroup: 2, or 1 (with NG = 2: 256 pixels x 32 channels, a 40 KB image and ~110 registers -
+// four workgroups per CU where the batch-256 16x16 layers would otherwise run two).
+template <int TW, int NI, int NG = 4, int MT = 2>
+__global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
+  constexpr int NTERM = 2, NW = 4;
   constexpr int PT = 128 * NG, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int PV = NTERM * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;
   constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT;
   constexpr int LBUF = PVP + WV;
-  constexpr int NPI = PVP / 64, NPS = (NPI + NW - 1) / NW, NWS = (WROWS + NW - 1) / NW;
+  constexpr int NPI = PVP / 64, NPS = (NPI + NW - 1) / NW, NWI = WV / 64, NWS = (NWI + NW - 1) / NW;   // DMA instructions: 64 vectors each
   static_assert((TW == 32 && NI == 1 && NG == 4) || (TW == 16 && NI == 2 && NG == 4) || (TW == 16 && NI == 1 && NG == 2) || (TW == 32 && NI == 1 && NG == 2), "tile_pixel assumes these tilings");
-  static_assert(2 * LBUF * 16 <= 160 * 1024, "two workgroups per CU");
+  static_assert(MT == 2 || NG == 2, "32-channel tiles only with 256-pixel tiles");
+  static_assert((MT == 1 ? 4 : 2) * LBUF * 16 <= 160 * 1024, "two (MT = 2) or four (MT = 1) workgroups per CU");
+  static_assert(WV % 64 == 0, "whole DMA instructions of weights");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint4* lds = reinterpret_cast<uint4*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -1295,7 +1299,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_quad_kernel(ConvArgs a, co
     voff[j] = inb ? ((((b + img) * G + hh) * 2 + t) * HW + (int)p16_pos((unsigned)(yy * W + xx))) * 16 : (int)0x7FFFF000;
   }
 #pragma unroll
-  for (int j = 0; j < NWS; ++j) { const int r = wave + NW * j; woff[j] = r < WROWS ? (r * a.cout_pad + o0 + lane) * 16 : (int)0x7FFFF000; }
+  for (int j = 0; j < NWS; ++j) {          // weight vector f = 64 * instruction + lane of the [WROWS][CT] image (lane-linear in LDS)
+    const int f = 64 * (wave + NW * j) + lane, r = f / CT, col = f - r * CT;
+    woff[j] = f < WV ? (r * a.cout_pad + o0 + col) * 16 : (int)0x7FFFF000;
+  }
 #define GR_P16_DMA(ch_)                                                                                   \
   {                                                                                                       \
     const int psoff_ = (ch_) * HW * 64;                                                                   \
@@ -1306,7 +1313,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_quad_kernel(ConvArgs a, co
     const int wsoff_ = (ch_) * WROWS * a.cout_pad * 16;                                                   \
     _Pragma("unroll") for (int j = 0; j < NWS; ++j) {                                                     \
       const int r_ = wave + NW * j;                                                                       \
-      if (r_ < WROWS) lds_dma16(rwt, lds + PVP + 64 * r_, woff[j], wsoff_);                               \
+      if (r_ < NWI) lds_dma16(rwt, lds + PVP + 64 * r_, woff[j], wsoff_);                                 \
     }                                                                                                     \
   }
   f32x16 acc[MT][NG];
@@ -2016,9 +2023,9 @@ bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {
 }
 int g_p16_stagger = 0;           // start delay (x 512 clocks) of the second-dispatched workgroups: measured useless (tools/stagger_p16.py), kept as a knob
 int g_p16_variant = 1;          // 1: four-wave workgroups, two per CU (conv3x3_p16_quad_kernel); 0: eight-wave persistent (conv3x3_p16_wide_kernel)
-template <int TW, int NI, int NG = 4>
+template <int TW, int NI, int NG = 4, int MT = 2>
 static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {
-  constexpr int PT = 128 * NG, TR = PT / TW, IH = PT / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
+  constexpr int PT = 128 * NG, TR = PT / TW, IH = PT / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 32 * MT;
   constexpr int PVP = (4 * PS + P16_PAD - 1) / P16_PAD * P16_PAD, LBUF = PVP + 36 * CT;
   a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
@@ -2027,16 +2034,16 @@ static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin,
   a.stat_tiles = a.n_tiles / a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI, NG, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true;
     if (getenv("GR_DEBUG_OCC")) {
-      int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI, NG>), 256, lds);
+      int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI, NG, MT>), 256, lds);
       fprintf(stderr, "conv3x3_p16_quad_kernel<%d, %d> (NG %d): %zu B LDS per workgroup, occupancy query says %d workgroups per CU\n", TW, NI, NG, lds, nb);
     }
   }
-  static const std::string name = "conv3x3_p16_quad_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ", " + std::to_string(NG) + ">";   // as rocprofv3 prints it (default template arguments included)
+  static const std::string name = "conv3x3_p16_quad_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ", " + std::to_string(NG) + ", " + std::to_string(MT) + ">";   // as rocprofv3 prints it (default template arguments included)
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_p16_quad_kernel<TW, NI, NG>), dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
+  hipLaunchKernelGGL((conv3x3_p16_quad_kernel<TW, NI, NG, MT>), dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
   return a.stat_tiles;
 }
 template <int TW, int NI>
@@ -2071,7 +2078,9 @@ void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias
   static const int single = getenv("GR_P16_SINGLE") ? atoi(getenv("GR_P16_SINGLE")) : 1;
   const long two_img_tiles = (long)((B + 1) / 2) * (round_up(Cout, 32) / 64);
   int nt;
-  if (H == 16 && W == 16) nt = (single && g_p16_variant == 1 && two_img_tiles < 512) ? launch_conv_p16_quad<16, 1, 2>(a, wsplit, x_p16, s) : launch_conv_p16_t<16, 2>(a, wsplit, x_p16, s);
+  static const int narrow = getenv("GR_P16_NARROW") ? atoi(getenv("GR_P16_NARROW")) : 1;     // 32-channel output tiles on single-image tiles: four workgroups per CU (six launches 0.303 -> 0.294 ms at cfg2: small, the L2 -> LDS traffic doubles)
+  if (H == 16 && W == 16) nt = (single && g_p16_variant == 1 && two_img_tiles < 512) ? (narrow ? launch_conv_p16_quad<16, 1, 2, 1>(a, wsplit, x_p16, s) : launch_conv_p16_quad<16, 1, 2>(a, wsplit, x_p16, s))
+                                                                                  : launch_conv_p16_t<16, 2>(a, wsplit, x_p16, s);
   else {
     static const int half32 = getenv("GR_P16_HALF32") ? atoi(getenv("GR_P16_HALF32")) : 0;     // 256-pixel tiles (8 rows x 32) on wider planes
     const long tiles512 = (long)B * ((H + 15) / 16) * ((W + 31) / 32) * (round_up(Cout, 32) / 64);
