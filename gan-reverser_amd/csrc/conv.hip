@@ -3029,6 +3029,151 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
     }
 }
 
+// The same with the two workgroups of a CU fused into ONE of eight waves whose halves PING-PONG: while half A multiplies its
+// chunk, half B requests its next chunk by DMA and waits for it; a workgroup barrier swaps the roles.  Four-wave workgroups
+// left this to chance (both resident workgroups often loaded, or multiplied, at the same time); here a multiplying half always
+// has the matrix pipe to itself and a loading half always has a full multiply phase to hide its DMA behind.  Each half
+// accumulates its own part of the workgroup's pixel range; at the end half B's accumulators go through LDS into half A's, so
+// the kernel leaves HALF as many slabs (one per CU instead of two): half the slab write and half the reduction.
+template <int W_>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Args a) {
+  constexpr int R = 64 / W_ > 0 ? 64 / W_ : 1;                 // image rows per 64-pixel chunk (W_ = 16, 32 or 64)
+  constexpr int PR = R + 2, PC = W_ + 2, PS = PR * PC;          // x patch positions
+  constexpr int XV = 16 * PS, XVP = (XV + 63) / 64 * 64, DV = 16 * 64, IMG = XVP + DV;      // vectors: 8 groups x 2 terms x positions
+  constexpr int NXI = XVP / 64, NXS = (NXI + 3) / 4, NDS = 4;   // DMA instructions per wave: x patch, dy (16 planes / 4 waves)
+  static_assert(W_ == 16 || W_ == 32 || W_ == 64, "plane widths of this path");
+  static_assert(2 * IMG * 16 <= 160 * 1024, "two operand images");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  uint4* xs = reinterpret_cast<uint4*>(smem_raw) + half * IMG;  // this half's image: [ci group 8][term 2][PS]
+  uint4* ds = xs + XVP;                                         // [o group 8][term 2][64]
+  const int wo = wave >> 1, wc = wave & 1;                      // this wave's 32-o and 32-ci halves of the 64 x 64 block
+  int bid = blockIdx.x;
+  const int cb = bid % a.n_cb; bid /= a.n_cb;
+  const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
+  const int H = a.H, HW = H * W_, Gin = a.Cin >> 3, Gout = a.Cout >> 3;
+  const int cpi = HW / 64;                                      // chunks per image
+  const int w0 = (int)((long)split * a.units / a.nsplit), w1 = (int)((long)(split + 1) * a.units / a.nsplit), wm = w0 + (w1 - w0 + 1) / 2;
+  const int u0 = half ? wm : w0, u1 = half ? w1 : wm;          // half A: the first (not smaller) part of the workgroup's chunks
+  const int nA = wm - w0, nmine = u1 - u0;
+  const size_t xbytes = (size_t)a.B * Gin * 2 * HW * 16, dbytes = (size_t)a.B * Gout * 2 * HW * 16;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.x), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.dy), 0, (int)(dbytes < 0x7FFFF000ul ? dbytes : 0x7FFFF000ul), 0x00020000);
+  const int ktot = f16_scale_exp(absmax_read(a.amax_x)) + f16_scale_exp(absmax_read(a.amax_dy));
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // transposing-read addresses: 16-lane group G = lane >> 4 covers channels 16 (G & 1) .. +15 and pixels 8 (G >> 1) .. +3
+  // (+4 for the second read); lane 4q + p of the group points at pixel row q, channels 4p .. 4p+3 of that 16-channel block
+  const int li = lane & 15, q = li >> 2, pp = li & 3, G = lane >> 4;
+  const int chg = 2 * (G & 1) + (pp >> 1), boff = 8 * (pp & 1);  // 8-channel group within the wave's 32 channels, byte offset in the vector
+  const int pxl = 8 * (G >> 1) + q;                              // pixel within a 16-pixel step (first read; second: + 4)
+  // per-lane vector addresses of step 0 (the lane's pixel row pxl of the step, its 8-channel group); a step adds a uniform offset
+  const uint4* abase = ds + (wo * 4 + chg) * 2 * 64 + pxl;
+  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PS + pxl;
+  auto load = [&](int u) {                                       // DMA of chunk u into this half's image, complete on return
+    const int b = u / cpi, cidx = u - b * cpi, p0 = cidx * 64, y0 = p0 / W_;      // the chunk's 64 pixels: rows y0 .. y0 + R - 1 (W_ = 64: one row)
+    // x patch: flat vector index e = 64 i + lane over [group][term][position]
+#pragma unroll
+    for (int j = 0; j < NXS; ++j) {
+      const int i = wave + 4 * j, e = 64 * i + lane;
+      const int pl = e / PS, pos = e - pl * PS, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC;
+      const int yy = y0 + rr - 1, xx = c - 1;
+      const bool inb = e < XV && yy >= 0 && yy < H && xx >= 0 && xx < W_;
+      const int voff = inb ? (((b * Gin + cb * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(yy * W_ + xx))) * 16 : (int)0x7FFFF000;
+      if (i < NXI) lds_dma16(rx, xs + 64 * i, voff, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NDS; ++j) {
+      const int pl = wave + 4 * j, g = pl >> 1, t = pl & 1;      // plane = (o group, term): 64 pixels = one instruction
+      const int voff = (((b * Gout + ob * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(p0 + lane))) * 16;
+      lds_dma16(rd, ds + 64 * pl, voff, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto multiply = [&]() {
+#pragma unroll 1
+    for (int ks = 0; ks < 4; ++ks) {
+      const int srow = (16 * ks) / W_, scol = 16 * ks - srow * W_;     // the step's 16 pixels: row srow of the chunk, columns scol .. scol + 15
+      // A = dy: [o][k]; two transposing reads (4 pixels each) per term
+      uint4 av[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const uint4* base = abase + t * 64 + 16 * ks;
+        const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+        av[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+      const uint4* bstep = bbase + srow * PC + scol;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        uint4 bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          // (the second read is 4 pixels further along x: same row - 16-pixel steps never straddle a row, W_ % 16 == 0)
+          const uint4* base = bstep + t * PS + ky * PC + kx;
+          const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+          bv[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+        acc[tap] = split_mma<2>(av, bv, acc[tap]);
+      }
+    }
+  };
+  // step st: half A multiplies its chunk st while half B loads its chunk st; then half B multiplies while half A loads chunk
+  // st + 1 (nA >= nB: the loop runs over half A's chunks; a half past its range idles through the barriers)
+  if (half == 0 && nmine > 0) load(u0);
+  __syncthreads();
+  for (int st = 0; st < nA; ++st) {
+    if (half == 0) multiply(); else if (st < nmine) load(u0 + st);
+    __syncthreads();
+    if (half == 1) { if (st < nmine) multiply(); } else if (st + 1 < nmine) load(u0 + st + 1);
+    __syncthreads();
+  }
+  // half B's accumulators into half A's, through LDS (both images are dead): 9 taps x 1024 floats per wave = 147 KB per half,
+  // handed over in three rounds of three taps
+  float* red = reinterpret_cast<float*>(smem_raw);               // [3 taps][4 waves][16 r][64 lanes]
+  static_assert(3 * 4 * 16 * 64 * 4 <= 2 * IMG * 16, "three taps of partial sums fit the two images");
+#pragma unroll
+  for (int t0 = 0; t0 < 9; t0 += 3) {
+    if (half == 1) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t0 + t][r];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t0 + t][r] += red[((t * 4 + wave) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (half == 1) return;
+  float* slp = a.slab + (size_t)split * 9 * a.coutp * a.cinp;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = ob * 64 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, ci = cb * 64 + wc * 32 + l31;
+      slp[((size_t)tap * a.coutp + o) * a.cinp + ci] = ldexpf(acc[tap][r], -ktot);
+    }
+}
+// GR_WGRAD_PP: 1 (default) = the ping-pong kernel on 16-wide planes only, 2 = everywhere, 0 = never.  Measured at cfg2 per launch:
+// 16-wide 52 -> 50 us, and the slab reduction 16.5 -> 10.8 us; 32-wide 70 -> 98 us (its 34 KB x patch per 64 pixels makes the
+// load phase longer than the multiply phase, and strict alternation then idles the matrix pipe more than chance did).
+static int wgrad_pp_mode() { static int v = -1; if (v < 0) { const char* e = getenv("GR_WGRAD_PP"); v = e ? atoi(e) : 1; } return v; }
+static bool wgrad_pp(int W) { const int m = wgrad_pp_mode(); return m == 2 || (m == 1 && W == 16); }
+template <int W_>
+static void launch_wgrad_p16_pp_t(const WgradP16Args& a, int grid, size_t lds, hipStream_t s) {
+  static bool st = false;
+  if (!st) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_p16_pp_kernel<W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); st = true; }
+  hipLaunchKernelGGL(conv3x3_wgrad_p16_pp_kernel<W_>, dim3(grid), dim3(512), lds, s, a);
+}
+
 static bool wgrad_use_vec(int W) { return W >= 16 && W % 4 == 0; }
 static bool wgrad_use_small(int Cin, int W) { return Cin <= 3 && W >= 16 && W % 4 == 0; }
 static bool wgrad_use_bf16x6(int mode, int Cin, int W) { return mode >= 1 && Cin > 3 && W >= 16 && W % 8 == 0; }   // either split flavour
@@ -3081,9 +3226,10 @@ bool conv_wgrad_p16_supported(int B, int Cin, int Cout, int H, int W) {
 }
 static int wgrad_p16_splits(int B, int Cin, int Cout, int H, int W) {
   const int blocks = (Cin / 64) * (Cout / 64);
-  static int wgs = -1;
-  if (wgs < 0) { const char* e = getenv("GR_WGRAD_P16_WGS"); wgs = e ? atoi(e) : 512; }
-  int want = wgs / blocks; if (want < 1) want = 1;            // two workgroups per CU
+  static int wgs_env = -1;
+  if (wgs_env < 0) { const char* e = getenv("GR_WGRAD_P16_WGS"); wgs_env = e ? atoi(e) : 0; }
+  const int wgs = wgs_env ? wgs_env : (wgrad_pp(W) ? 256 : 512);      // ping-pong: ONE eight-wave workgroup per CU; else two four-wave ones
+  int want = wgs / blocks; if (want < 1) want = 1;
   const long units = (long)B * H * W / 64;
   if (want > units) want = (int)units;
   return want;
@@ -3110,7 +3256,11 @@ void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, 
     const int R = 64 / W > 0 ? 64 / W : 1, PS = (R + 2) * (W + 2);
     const size_t lds = 16 * (size_t)((16 * PS + 63) / 64 * 64 + 1024);
     const std::string nm = "conv3x3_wgrad_p16_kernel<" + std::to_string(W) + ">";
-    KtScope kt(nm.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
+    const std::string nm2 = "conv3x3_wgrad_p16_pp_kernel<" + std::to_string(W) + ">";
+    KtScope kt(wgrad_pp(W) ? nm2.c_str() : nm.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
+    if (wgrad_pp(W)) {
+      if (W == 16) launch_wgrad_p16_pp_t<16>(a, grid, 2 * lds, s); else if (W == 32) launch_wgrad_p16_pp_t<32>(a, grid, 2 * lds, s); else launch_wgrad_p16_pp_t<64>(a, grid, 2 * lds, s);
+    } else
     if (W == 16) launch_wgrad_p16_t<16>(a, grid, lds, s); else if (W == 32) launch_wgrad_p16_t<32>(a, grid, lds, s); else launch_wgrad_p16_t<64>(a, grid, lds, s);
   }
   const long n_ = (long)9 * Cout * a.cinp;
