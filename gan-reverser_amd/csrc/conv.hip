@@ -2940,7 +2940,10 @@ template <int W_>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args a) {
   constexpr int R = 64 / W_ > 0 ? 64 / W_ : 1;                 // image rows per 64-pixel chunk (W_ = 16, 32 or 64)
   constexpr int PR = R + 2, PC = W_ + 2, PS = PR * PC;          // x patch positions
-  constexpr int XV = 16 * PS, XVP = (XV + 63) / 64 * 64, DV = 16 * 64;      // vectors: 8 groups x 2 terms x positions
+  // plane strides (vectors) padded to 2 (mod 8): the four 8-channel groups a transposing read touches then start 64 bytes apart
+  // in the 256-byte bank row (unpadded: 32-wide planes put all four on the same banks, and the dy planes of every width)
+  constexpr int PSP = PS + (10 - PS % 8) % 8, DSP = 66;
+  constexpr int XV = 16 * PSP, XVP = (XV + 63) / 64 * 64, DV = (16 * DSP + 63) / 64 * 64;      // vectors: 8 groups x 2 terms x positions
   constexpr int NXI = XVP / 64, NXS = (NXI + 3) / 4, NDS = 4;   // DMA instructions per wave: x patch, dy (16 planes / 4 waves)
   static_assert(W_ == 16 || W_ == 32 || W_ == 64, "plane widths of this path");
   static_assert(2 * (XVP + DV) * 16 <= 160 * 1024, "two workgroups per CU");
@@ -2970,8 +2973,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
   const int chg = 2 * (G & 1) + (pp >> 1), boff = 8 * (pp & 1);  // 8-channel group within the wave's 32 channels, byte offset in the vector
   const int pxl = 8 * (G >> 1) + q;                              // pixel within a 16-pixel step (first read; second: + 4)
   // per-lane vector addresses of step 0 (the lane's pixel row pxl of the step, its 8-channel group); a step adds a uniform offset
-  const uint4* abase = ds + (wo * 4 + chg) * 2 * 64 + pxl;
-  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PS + pxl;
+  const uint4* abase = ds + (wo * 4 + chg) * 2 * DSP + pxl;
+  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + pxl;
   for (int u = u0; u < u1; ++u) {
     const int b = u / cpi, cidx = u - b * cpi, p0 = cidx * 64, y0 = p0 / W_;      // the chunk's 64 pixels: rows y0 .. y0 + R - 1 (W_ = 64: one row)
     __syncthreads();                                             // every wave is past the previous chunk's image
@@ -2979,9 +2982,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
 #pragma unroll
     for (int j = 0; j < NXS; ++j) {
       const int i = wave + 4 * j, e = 64 * i + lane;
-      const int pl = e / PS, pos = e - pl * PS, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC;
+      const int pl = e / PSP, pos = e - pl * PSP, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC;
       const int yy = y0 + rr - 1, xx = c - 1;
-      const bool inb = e < XV && yy >= 0 && yy < H && xx >= 0 && xx < W_;
+      const bool inb = e < XV && pos < PS && yy >= 0 && yy < H && xx >= 0 && xx < W_;
       const int voff = inb ? (((b * Gin + cb * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(yy * W_ + xx))) * 16 : (int)0x7FFFF000;
       if (i < NXI) lds_dma16(rx, xs + 64 * i, voff, 0);
     }
@@ -2989,7 +2992,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
     for (int j = 0; j < NDS; ++j) {
       const int pl = wave + 4 * j, g = pl >> 1, t = pl & 1;      // plane = (o group, term): 64 pixels = one instruction
       const int voff = (((b * Gout + ob * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(p0 + lane))) * 16;
-      lds_dma16(rd, ds + 64 * pl, voff, 0);
+      lds_dma16(rd, ds + DSP * pl, voff, 0);
     }
     dma_publish_barrier();                                       // the image has landed
 #pragma unroll 1
@@ -2999,7 +3002,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
       uint4 av[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const uint4* base = abase + t * 64 + 16 * ks;
+        const uint4* base = abase + t * DSP + 16 * ks;
         const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
         av[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
@@ -3011,7 +3014,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           // (the second read is 4 pixels further along x: same row - 16-pixel steps never straddle a row, W_ % 16 == 0)
-          const uint4* base = bstep + t * PS + ky * PC + kx;
+          const uint4* base = bstep + t * PSP + ky * PC + kx;
           const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
           bv[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
@@ -3039,7 +3042,10 @@ template <int W_>
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Args a) {
   constexpr int R = 64 / W_ > 0 ? 64 / W_ : 1;                 // image rows per 64-pixel chunk (W_ = 16, 32 or 64)
   constexpr int PR = R + 2, PC = W_ + 2, PS = PR * PC;          // x patch positions
-  constexpr int XV = 16 * PS, XVP = (XV + 63) / 64 * 64, DV = 16 * 64, IMG = XVP + DV;      // vectors: 8 groups x 2 terms x positions
+  // plane strides (vectors) padded to 2 (mod 8): the four 8-channel groups a transposing read touches then start 64 bytes apart
+  // in the 256-byte bank row (unpadded: 32-wide planes put all four on the same banks, and the dy planes of every width)
+  constexpr int PSP = PS + (10 - PS % 8) % 8, DSP = 66;
+  constexpr int XV = 16 * PSP, XVP = (XV + 63) / 64 * 64, DV = (16 * DSP + 63) / 64 * 64, IMG = XVP + DV;      // vectors: 8 groups x 2 terms x positions
   constexpr int NXI = XVP / 64, NXS = (NXI + 3) / 4, NDS = 4;   // DMA instructions per wave: x patch, dy (16 planes / 4 waves)
   static_assert(W_ == 16 || W_ == 32 || W_ == 64, "plane widths of this path");
   static_assert(2 * IMG * 16 <= 160 * 1024, "two operand images");
@@ -3071,17 +3077,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   const int chg = 2 * (G & 1) + (pp >> 1), boff = 8 * (pp & 1);  // 8-channel group within the wave's 32 channels, byte offset in the vector
   const int pxl = 8 * (G >> 1) + q;                              // pixel within a 16-pixel step (first read; second: + 4)
   // per-lane vector addresses of step 0 (the lane's pixel row pxl of the step, its 8-channel group); a step adds a uniform offset
-  const uint4* abase = ds + (wo * 4 + chg) * 2 * 64 + pxl;
-  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PS + pxl;
+  const uint4* abase = ds + (wo * 4 + chg) * 2 * DSP + pxl;
+  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + pxl;
   auto load = [&](int u) {                                       // DMA of chunk u into this half's image, complete on return
     const int b = u / cpi, cidx = u - b * cpi, p0 = cidx * 64, y0 = p0 / W_;      // the chunk's 64 pixels: rows y0 .. y0 + R - 1 (W_ = 64: one row)
     // x patch: flat vector index e = 64 i + lane over [group][term][position]
 #pragma unroll
     for (int j = 0; j < NXS; ++j) {
       const int i = wave + 4 * j, e = 64 * i + lane;
-      const int pl = e / PS, pos = e - pl * PS, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC;
+      const int pl = e / PSP, pos = e - pl * PSP, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC;
       const int yy = y0 + rr - 1, xx = c - 1;
-      const bool inb = e < XV && yy >= 0 && yy < H && xx >= 0 && xx < W_;
+      const bool inb = e < XV && pos < PS && yy >= 0 && yy < H && xx >= 0 && xx < W_;
       const int voff = inb ? (((b * Gin + cb * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(yy * W_ + xx))) * 16 : (int)0x7FFFF000;
       if (i < NXI) lds_dma16(rx, xs + 64 * i, voff, 0);
     }
@@ -3089,7 +3095,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
     for (int j = 0; j < NDS; ++j) {
       const int pl = wave + 4 * j, g = pl >> 1, t = pl & 1;      // plane = (o group, term): 64 pixels = one instruction
       const int voff = (((b * Gout + ob * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(p0 + lane))) * 16;
-      lds_dma16(rd, ds + 64 * pl, voff, 0);
+      lds_dma16(rd, ds + DSP * pl, voff, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
@@ -3101,7 +3107,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
       uint4 av[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const uint4* base = abase + t * 64 + 16 * ks;
+        const uint4* base = abase + t * DSP + 16 * ks;
         const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
         av[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
@@ -3113,7 +3119,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           // (the second read is 4 pixels further along x: same row - 16-pixel steps never straddle a row, W_ % 16 == 0)
-          const uint4* base = bstep + t * PS + ky * PC + kx;
+          const uint4* base = bstep + t * PSP + ky * PC + kx;
           const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
           bv[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
@@ -3253,8 +3259,8 @@ void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, 
   const int grid = a.nsplit * a.n_ob * a.n_cb;
   const double px = (double)B * H * W;
   {
-    const int R = 64 / W > 0 ? 64 / W : 1, PS = (R + 2) * (W + 2);
-    const size_t lds = 16 * (size_t)((16 * PS + 63) / 64 * 64 + 1024);
+    const int R = 64 / W > 0 ? 64 / W : 1, PS = (R + 2) * (W + 2), PSP = PS + (10 - PS % 8) % 8;
+    const size_t lds = 16 * (size_t)((16 * PSP + 63) / 64 * 64 + (16 * 66 + 63) / 64 * 64);
     const std::string nm = "conv3x3_wgrad_p16_kernel<" + std::to_string(W) + ">";
     const std::string nm2 = "conv3x3_wgrad_p16_pp_kernel<" + std::to_string(W) + ">";
     KtScope kt(wgrad_pp(W) ? nm2.c_str() : nm.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
