@@ -997,6 +997,26 @@ void launch_mse(const float* x, const float* t, long n, long n_global, double* l
   hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, x, t, n, 1.0 / (double)n_global, (float)(2.0 / (double)n_global), loss_dev, grad);
 }
 
+// ------------------------------------------------------------------ nn.BCECriterion (sizeAverage; adversarial.lua's CRITERION)
+// THNN BCECriterion.c with EPS = 1e-12: every term in double (the C source mixes float tensors with double literals), the sum in
+// double; gradInput = -1/n (t - x) / ((1 - x + EPS)(x + EPS)) evaluated in double and rounded once - the same IEEE operations as
+// the oracle, so the gradient is bit-identical; the loss differs by the device's log() (last bits).
+__global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ x, const float* __restrict__ t, long n, double* loss, float* grad) {
+  __shared__ double sh[16];
+  const double EPS = 1e-12, norm = 1.0 / (double)n;
+  double s = 0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const double xv = (double)x[i], tv = (double)t[i];
+    s -= log(xv + EPS) * tv + log(1. - xv + EPS) * (1. - tv);
+    if (grad) grad[i] = (float)(-norm * (tv - xv) / ((1. - xv + EPS) * (xv + EPS)));
+  }
+  s = block_reduce_sum(s, sh);
+  if (threadIdx.x == 0 && loss) *loss = s * norm;
+}
+void launch_bce(const float* x, const float* t, long n, double* loss_dev, float* grad, hipStream_t s) {
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, s, x, t, n, loss_dev, grad);
+}
+
 // ------------------------------------------------------------------ penalty + clamp + Adam, one pass over (theta, g, m, v)
 __device__ __forceinline__ void adam_one(float& th, float& gv, float& mv, float& vv, const AdamConsts& c) {
   if (c.use_penalty) {

@@ -265,6 +265,7 @@ void launch_bias_grad_batch(BiasJobs& jobs, hipStream_t s);    // runs and empti
 
 // ---------------------------------------------------------------- criterion / optimiser / misc
 void launch_mse(const float* x, const float* t, long n, long n_global, double* loss_dev, float* grad, hipStream_t s);
+void launch_bce(const float* x, const float* t, long n, double* loss_dev, float* grad, hipStream_t s);      // nn.BCECriterion (sizeAverage)
 struct AdamConsts { float b1, b2, c1, c2, eps, step, l1, l2, clamp; int use_penalty, use_clamp; };
 void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long n, const AdamConsts& c, hipStream_t s);
 void launch_gen_mask(uint32_t* words, long n_elems, float p_drop, uint64_t seed, uint64_t counter, uint32_t layer, hipStream_t s);

@@ -1284,6 +1284,26 @@ extern "C" int gr_mse_host(gr_ctx* c, const float* x, const float* t, int64_t n,
   if (loss) *loss = *c->h_loss;
   return GR_OK;
 }
+// nn.BCECriterion (sizeAverage): adversarial.lua's CRITERION (the GAN step's loss; first pieces of SURVEY.md 8f rank 4)
+extern "C" int gr_bce_dev(gr_ctx* c, const float* x, const float* t, int64_t n, double* loss_dev, float* grad) {
+  if (!c || !x || !t || n <= 0) return GR_ERR_INVALID;
+  launch_bce(x, t, n, loss_dev, grad, c->stream); LAUNCHCHK(c);
+  return GR_OK;
+}
+extern "C" int gr_bce_host(gr_ctx* c, const float* x, const float* t, int64_t n, double* loss, float* grad) {
+  if (!c || !x || !t || n <= 0) return GR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = ensure_ws(c, sizeof(float) * 3 * (size_t)n); if (r) return r;
+  float* dx = (float*)c->ws; float* dt = dx + n; float* dg = dt + n;
+  HIPCHK(c, hipMemcpyAsync(dx, x, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dt, t, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  launch_bce(dx, dt, n, c->d_loss, grad ? dg : nullptr, c->stream); LAUNCHCHK(c);
+  if (grad) HIPCHK(c, hipMemcpyAsync(grad, dg, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (loss) *loss = *c->h_loss;
+  return GR_OK;
+}
 
 // ------------------------------------------------------------------ optimiser
 static AdamConsts adam_consts(const gr_hyper* h, int t) {

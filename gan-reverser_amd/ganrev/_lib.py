@@ -86,6 +86,8 @@ _SIGS = {
     "gr_net_get_pool_index": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
     "gr_mse_host": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_double), _P]),
     "gr_mse_dev": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, _P, _P]),
+    "gr_bce_host": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), _P]),
+    "gr_bce_dev": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P]),
     "gr_adam_step": (C.c_int, [_P, C.POINTER(Hyper), C.c_int]),
     "gr_adam_reset": (C.c_int, [_P]),
     "gr_adam_get_state": (C.c_int, [_P, _P, _P]),
@@ -226,6 +228,14 @@ class Context:
         loss = C.c_double()
         g = np.empty_like(x) if want_grad else None
         self.check(self.lib.gr_mse_host(self.h, _ptr(x), _ptr(t), x.size, int(n_global or x.size), C.byref(loss), _ptr(g)), "gr_mse_host")
+        return loss.value, g
+
+    def bce(self, x, t, want_grad=True):
+        """nn.BCECriterion (sizeAverage): (loss, gradInput)"""
+        x, t = f32(x), f32(t)
+        loss = C.c_double()
+        g = np.empty_like(x) if want_grad else None
+        self.check(self.lib.gr_bce_host(self.h, _ptr(x), _ptr(t), x.size, C.byref(loss), _ptr(g)), "gr_bce_host")
         return loss.value, g
 
     def cosine_topk(self, emb, query_rows, k, accumulate_in_float=False, emb_dev=None, n=None, d=None):

@@ -559,6 +559,25 @@ class MSECriterion:
         return self.gradInput
 
 
+class BCECriterion:
+    """nn.BCECriterion (sizeAverage): adversarial.lua's CRITERION."""
+
+    def __init__(self, sizeAverage=True):
+        if not sizeAverage:
+            raise L.GanrevError("only sizeAverage=true is implemented")
+        self.output = 0.0
+        self.gradInput = None
+
+    def forward(self, input, target):
+        self.output, _ = L.default_context().bce(input, target, want_grad=False)
+        return self.output
+
+    def backward(self, input, target):
+        _, g = L.default_context().bce(input, target)
+        self.gradInput = g.reshape(np.shape(input))
+        return self.gradInput
+
+
 class CosineDistance:
     """nn.CosineDistance on a pair of vectors (apply_r.lua:396-400)."""
 

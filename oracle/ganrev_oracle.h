@@ -96,6 +96,7 @@ const float* go_net_layer_output(const go_net*, int layer_index, int64_t* n);
 /* nn.MSECriterion (train_r.lua:119,147,150): returns loss; grad nullable */
 double go_mse(const float* x, const float* t, int64_t n, float* grad);
 double go_mse_scaled(const float* x, const float* t, int64_t n, int64_t n_global, float* grad);
+double go_bce(const float* x, const float* t, int64_t n, float* grad /*nullable*/);   /* nn.BCECriterion (sizeAverage) */
 
 typedef struct {
   double lr, beta1, beta2, eps;  /* Lua numbers; optim.adam defaults 1e-3, .9, .999, 1e-8 (train_r.lua:125,170) */

@@ -69,6 +69,8 @@ def lib():
         L.go_mse.argtypes = [_P, _P, C.c_int64, _P]
         L.go_mse_scaled.restype = C.c_double
         L.go_mse_scaled.argtypes = [_P, _P, C.c_int64, C.c_int64, _P]
+        L.go_bce.restype = C.c_double
+        L.go_bce.argtypes = [_P, _P, C.c_int64, _P]
         L.go_penalty_clamp_adam.argtypes = [_P, _P, _P, _P, C.c_int64, C.POINTER(GoHyper), C.c_int, C.POINTER(C.c_double)]
         L.go_train_r_step.argtypes = [_P, _P, _P, C.c_int, C.POINTER(GoHyper), _P, _P, C.c_int, C.POINTER(C.c_double), _P]
         L.go_cosine_similarity.restype = C.c_float
@@ -212,6 +214,14 @@ def mse(x, t, n_global=None):
     x, t = f32(x), f32(t)
     g = np.empty_like(x)
     loss = lib().go_mse_scaled(_p(x), _p(t), x.size, int(n_global or x.size), _p(g))
+    return loss, g
+
+
+def bce(x, t):
+    """nn.BCECriterion (sizeAverage): (loss, gradInput)"""
+    x, t = f32(x), f32(t)
+    g = np.empty_like(x)
+    loss = lib().go_bce(_p(x), _p(t), x.size, _p(g))
     return loss, g
 
 

@@ -465,6 +465,19 @@ double go_mse_scaled(const float* x, const float* t, int64_t n, int64_t n_global
 }
 double go_mse(const float* x, const float* t, int64_t n, float* grad) { return go_mse_scaled(x, t, n, n, grad); }
 
+/* nn.BCECriterion, sizeAverage (adversarial.lua: CRITERION = nn.BCECriterion(); THNN BCECriterion.c, EPS 1e-12):
+ *   output    = -1/n sum( log(x + EPS) * t + log(1 - x + EPS) * (1 - t) )
+ *   gradInput = -1/n * (t - x) / ((1 - x + EPS) * (x + EPS))
+ * The C expressions mix float tensors with double literals, so each term is evaluated in double; the sum is kept in double here
+ * (THNN's accumulator type changed between revisions; same choice as go_mse). */
+double go_bce(const float* x, const float* t, int64_t n, float* grad) {
+  const double EPS = 1e-12, norm = 1.0 / (double)n;
+  double s = 0;
+  for (int64_t k = 0; k < n; ++k) s -= log((double)x[k] + EPS) * (double)t[k] + log(1. - (double)x[k] + EPS) * (1. - (double)t[k]);
+  if (grad) for (int64_t k = 0; k < n; ++k) grad[k] = (float)(-norm * ((double)t[k] - (double)x[k]) / ((1. - (double)x[k] + EPS) * ((double)x[k] + EPS)));
+  return s * norm;
+}
+
 /* ------------------------------------------------------------------ fevalR penalty+clamp, optim.adam
  * train_r.lua:153-165:  g += sign(theta)*L1 + theta*L2 ; g = clamp(g, -c, c)      (fp32 tensor ops)
  * optim/adam.lua (2016): m = m*b1 + (1-b1)*g ; v = v*b2 + (1-b2)*g*g ; denom = sqrt(v)+eps ;

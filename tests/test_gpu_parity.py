@@ -815,6 +815,20 @@ def test_full_size_cfg5_search_bit_exact(ctx, oracle):
     assert 999_999 in idx[2, :2]
 
 
+def test_bce_criterion_vs_oracle(ctx, oracle):
+    """nn.BCECriterion (adversarial.lua's CRITERION): loss to 1e-12 relative (the device's log), gradInput bit-exact (IEEE +, -, x, /
+    in double on both sides), through the criterion class the reference scripts use."""
+    from ganrev import nn, synth
+    for n, seed in ((1, 1), (37, 2), (4096, 3)):
+        x = synth.uniform((n,), seed, 0.001, 0.999); t = (synth.uniform((n,), seed + 9, 0, 1) < 0.5).astype(np.float32)
+        if n > 2: x[:2] = (0.0, 1.0); t[:2] = (0.0, 1.0)
+        crit = nn.BCECriterion()
+        loss = crit.forward(x, t); g = crit.backward(x, t)
+        rl, rg = oracle.bce(x, t)
+        assert abs(loss - rl) <= 1e-12 * max(1.0, abs(rl)), (n, loss, rl)
+        assert np.array_equal(g, rg), f"BCE gradient must be bit-exact (n = {n})"
+
+
 def test_search_1024_needles_bit_exact(ctx, oracle):
     """Q = 1024 needles in one call (128 passes of 8 needles over the table, the needle groups ragged at the end of the list:
     1021 is prime): indices and scores bit-exact against the oracle, on a table small enough for the unfiltered path and

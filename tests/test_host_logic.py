@@ -256,3 +256,17 @@ def test_oracle_act_side_hook_moves_exactly_the_forced_elements():
     assert np.count_nonzero(d) == 1 and abs(abs(d[5]) - abs(g.reshape(-1)[5]) * (1 - 0.333)) < 1e-6
     onet.force_act_side(0, None)
     onet.forward(x); assert np.array_equal(onet.backward(x, g), base)
+
+
+def test_oracle_bce_matches_float64_formula():
+    """go_bce against the THNN formula in numpy float64 (EPS = 1e-12, sizeAverage), incl. predictions at exactly 0 and 1."""
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    x = rng.random(1000).astype(np.float32); t = (rng.random(1000) < 0.5).astype(np.float32)
+    x[:2] = (0.0, 1.0); t[:2] = (0.0, 1.0)
+    loss, g = oracle.bce(x, t)
+    xd, td = x.astype(np.float64), t.astype(np.float64)
+    ref = -np.mean(np.log(xd + 1e-12) * td + np.log(1 - xd + 1e-12) * (1 - td))
+    gref = (-(td - xd) / ((1 - xd + 1e-12) * (xd + 1e-12)) / x.size).astype(np.float32)
+    assert abs(loss - ref) <= 1e-12 * max(1.0, abs(ref))
+    assert np.array_equal(g, gref)
