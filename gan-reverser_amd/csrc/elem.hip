@@ -997,7 +997,7 @@ void launch_mse(const float* x, const float* t, long n, long n_global, double* l
   hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, x, t, n, 1.0 / (double)n_global, (float)(2.0 / (double)n_global), loss_dev, grad);
 }
 
-// ------------------------------------------------------------------ nn.BCECriterion (sizeAverage; adversarial.lua's CRITERION)
+// ------------------------------------------------------------------ nn.BCECriterion (sizeAverage; train.lua:173's CRITERION, used by adversarial.lua)
 // THNN BCECriterion.c with EPS = 1e-12: every term in double (the C source mixes float tensors with double literals), the sum in
 // double; gradInput = -1/n (t - x) / ((1 - x + EPS)(x + EPS)) evaluated in double and rounded once - the same IEEE operations as
 // the oracle, so the gradient is bit-identical; the loss differs by the device's log() (last bits).

@@ -1284,7 +1284,7 @@ extern "C" int gr_mse_host(gr_ctx* c, const float* x, const float* t, int64_t n,
   if (loss) *loss = *c->h_loss;
   return GR_OK;
 }
-// nn.BCECriterion (sizeAverage): adversarial.lua's CRITERION (the GAN step's loss; first pieces of SURVEY.md 8f rank 4)
+// nn.BCECriterion (sizeAverage): train.lua:173's CRITERION, used by adversarial.lua (the GAN step's loss; first pieces of SURVEY.md 8f rank 4)
 extern "C" int gr_bce_dev(gr_ctx* c, const float* x, const float* t, int64_t n, double* loss_dev, float* grad) {
   if (!c || !x || !t || n <= 0) return GR_ERR_INVALID;
   launch_bce(x, t, n, loss_dev, grad, c->stream); LAUNCHCHK(c);

@@ -560,7 +560,7 @@ class MSECriterion:
 
 
 class BCECriterion:
-    """nn.BCECriterion (sizeAverage): adversarial.lua's CRITERION."""
+    """nn.BCECriterion (sizeAverage): train.lua:173's CRITERION, used by adversarial.lua."""
 
     def __init__(self, sizeAverage=True):
         if not sizeAverage:

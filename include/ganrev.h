@@ -109,7 +109,7 @@ int gr_net_layer_output(gr_net* net, int layer_index, float* host, int64_t n);
  * (= n on one GPU; = global batch * nd under data parallelism so a SUM all-reduce reproduces the reference). ---- */
 int gr_mse_host(gr_ctx* ctx, const float* x_host, const float* t_host, int64_t n, int64_t n_global, double* loss_out, float* grad_host /*nullable*/);
 int gr_mse_dev(gr_ctx* ctx, const float* x_dev, const float* t_dev, int64_t n, int64_t n_global, double* loss_dev /*1 double*/, float* grad_dev /*nullable*/);
-/* nn.BCECriterion, sizeAverage = true (adversarial.lua: CRITERION = nn.BCECriterion(); THNN BCECriterion.c, EPS = 1e-12):
+/* nn.BCECriterion, sizeAverage = true (train.lua:173: CRITERION = nn.BCECriterion(), used by adversarial.lua; THNN BCECriterion.c, EPS = 1e-12):
  * loss = -1/n sum(log(x + EPS) t + log(1 - x + EPS) (1 - t)), gradInput = -1/n (t - x) / ((1 - x + EPS)(x + EPS)); terms in double. */
 int gr_bce_host(gr_ctx* ctx, const float* x_host, const float* t_host, int64_t n, double* loss_out, float* grad_host /*nullable*/);
 int gr_bce_dev(gr_ctx* ctx, const float* x_dev, const float* t_dev, int64_t n, double* loss_dev /*1 double*/, float* grad_dev /*nullable*/);

@@ -465,7 +465,7 @@ double go_mse_scaled(const float* x, const float* t, int64_t n, int64_t n_global
 }
 double go_mse(const float* x, const float* t, int64_t n, float* grad) { return go_mse_scaled(x, t, n, n, grad); }
 
-/* nn.BCECriterion, sizeAverage (adversarial.lua: CRITERION = nn.BCECriterion(); THNN BCECriterion.c, EPS 1e-12):
+/* nn.BCECriterion, sizeAverage (train.lua:173: CRITERION = nn.BCECriterion(), used by adversarial.lua; THNN BCECriterion.c, EPS 1e-12):
  *   output    = -1/n sum( log(x + EPS) * t + log(1 - x + EPS) * (1 - t) )
  *   gradInput = -1/n * (t - x) / ((1 - x + EPS) * (x + EPS))
  * The C expressions mix float tensors with double literals, so each term is evaluated in double; the sum is kept in double here

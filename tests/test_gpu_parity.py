@@ -816,7 +816,7 @@ def test_full_size_cfg5_search_bit_exact(ctx, oracle):
 
 
 def test_bce_criterion_vs_oracle(ctx, oracle):
-    """nn.BCECriterion (adversarial.lua's CRITERION): loss to 1e-12 relative (the device's log), gradInput bit-exact (IEEE +, -, x, /
+    """nn.BCECriterion (train.lua:173's CRITERION, used by adversarial.lua): loss to 1e-12 relative (the device's log), gradInput bit-exact (IEEE +, -, x, /
     in double on both sides), through the criterion class the reference scripts use."""
     from ganrev import nn, synth
     for n, seed in ((1, 1), (37, 2), (4096, 3)):
