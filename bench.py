@@ -139,6 +139,7 @@ def cpu_baseline(dims, nd, ctx=None):
                sample=f"{nb} steps of the same step at batch {B} = BASELINE configs[0] ({dtb:.1f} s); oracle = C restatement of the Torch7 nn CPU "
                       "path (direct-loop convolutions, OpenMP), not Torch7 itself",
                reference_default_threads=dict(value=round(B * n8 / dt8, 2), cores=t8, sample=f"{n8} steps ({dt8:.1f} s), --threads 8 = train_r.lua:21"))
+    out["torch_cpu"] = torch_cpu_column(dims, nd, B)
     if ctx is not None:
         # second half of BASELINE.json's metric - "cosine top-50 exact-match vs ref" - at the size north_star names (10k x 32-d
         # embeddings, apply_r.lua:266-282): the HIP search against the oracle's, index lists compared element by element
@@ -150,6 +151,61 @@ def cpu_baseline(dims, nd, ctx=None):
         out["search_top50"] = dict(n=N, d=d, k=k, needles=len(needles), exact_match=bool(np.array_equal(idx, ridx) and np.array_equal(sc, rsc)),
                                    gpu_ms_incl_h2d=round(t_gpu * 1e3, 3), cpu_ms=round(t_cpu * 1e3, 3))
     return out
+
+
+def torch_cpu_column(dims, nd, B):
+    """A second CPU column for orientation: the same G forward + R forward / backward + Adam step written
+    with stock PyTorch CPU modules (oneDNN / im2col + sgemm convolutions - the structure Torch7's nn CPU path has, which the
+    oracle's direct loops do not), timed at 8 threads and at the box's best of (16, 32).  Timing only: its numerics are not
+    compared with anything, and it is not the oracle."""
+    try:
+        import torch
+        import torch.nn as tnn
+    except Exception as e:  # noqa: BLE001
+        return dict(error=f"torch not importable: {e}")
+    c, h, w = dims
+    sh, sw = h // 4, w // 4
+    G = tnn.Sequential(tnn.Linear(nd, 512 * sh * sw), tnn.BatchNorm1d(512 * sh * sw), tnn.ReLU(), tnn.Unflatten(1, (512, sh, sw)),
+                       tnn.Upsample(scale_factor=2), tnn.Conv2d(512, 256, 3, padding=1), tnn.BatchNorm2d(256), tnn.ReLU(),
+                       tnn.Upsample(scale_factor=2), tnn.Conv2d(256, 128, 3, padding=1), tnn.BatchNorm2d(128), tnn.ReLU(),
+                       tnn.Conv2d(128, c, 3, padding=1), tnn.Sigmoid()).eval()
+    layers = []
+    for i, (ci, co) in enumerate([(c, 64), (64, 64), (64, 64), (64, 128), (128, 128), (128, 128)]):
+        layers += [tnn.Conv2d(ci, co, 3, padding=1), tnn.BatchNorm2d(co), tnn.ELU()]
+        if i == 2: layers += [tnn.MaxPool2d(2), tnn.Dropout()]
+        elif i == 5: layers += [tnn.Dropout2d(0.25), tnn.MaxPool2d(2)]
+        else: layers += [tnn.Dropout()]
+    R = tnn.Sequential(*layers, tnn.Flatten(), tnn.Linear(128 * sh * sw, 512), tnn.BatchNorm1d(512), tnn.ELU(), tnn.Dropout(0.5), tnn.Linear(512, nd)).train()
+    opt = torch.optim.Adam(R.parameters(), lr=1e-3)
+    crit = tnn.MSELoss()
+    res = {}
+    prev = torch.get_num_threads()
+    try:
+        for threads in (8, 16, 32):
+            if threads > (os.cpu_count() or 1):
+                continue
+            torch.set_num_threads(threads)
+
+            def one():
+                noise = torch.randn(B, nd)
+                with torch.no_grad():
+                    img = G(noise)
+                opt.zero_grad()
+                loss = crit(R(img), noise)
+                loss.backward()
+                for p_ in R.parameters():
+                    p_.grad.add_(p_.detach(), alpha=1e-4).clamp_(-5, 5)      # train_r.lua:153-165 (L2 + clamp), cost only
+                opt.step()
+            one(); one()
+            t0 = time.perf_counter(); n = 0
+            while time.perf_counter() - t0 < 3.0 and n < 200:
+                one(); n += 1
+            res[str(threads)] = round(B * n / (time.perf_counter() - t0), 1)
+    finally:
+        torch.set_num_threads(prev)
+    best = max(res, key=lambda k: res[k]) if res else None
+    return dict(images_per_sec_by_threads=res, best_threads=int(best) if best else None, batch=B,
+                note="stock PyTorch CPU modules (oneDNN convolutions), same layer lists and step; timing only, numerics unchecked")
 
 
 def search_cfg5(ctx):
