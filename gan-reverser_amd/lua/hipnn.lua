@@ -34,6 +34,7 @@ int gr_net_set_training(gr_net*, int);   int gr_net_set_seed(gr_net*, uint64_t);
 int gr_net_forward_host(gr_net*, const float* in_host, int batch, float* out_host);
 int gr_net_backward_host(gr_net*, const float* in_host, const float* gout_host, int batch, float* gin_host);
 int gr_mse_host(gr_ctx*, const float*, const float*, int64_t n, int64_t n_global, double* loss, float* grad);
+int gr_bce_host(gr_ctx*, const float*, const float*, int64_t n, double* loss, float* grad);     /* nn.BCECriterion (train.lua:173) */
 int gr_adam_step(gr_net*, const gr_hyper*, int t);
 int gr_cosine_topk_host(gr_ctx*, const float* emb, int64_t n, int d, const int64_t* rows, int q, int k,
                         int64_t* idx, float* score, int accumulate_in_float);
@@ -42,6 +43,9 @@ int gr_l2_distance_rows_host(gr_ctx*, const float* a, const float* b, int64_t n,
 int gr_kmeans_host(gr_ctx*, const float* x, int64_t n, int d, int k, int niter, float* centroids_inout, float* total_counts, int32_t* labels);
 int gr_cosine_assign_host(gr_ctx*, const float* x, int64_t n, int d, const float* centroids, int k, int take_min, int32_t* labels, float* sims);
 int gr_set_conv_mode(gr_ctx*, int mode);   /* 0 exact fp32 MFMA, 1 bf16x6, 2 f16x3 (default) */
+int gr_set_tuning(gr_ctx*, const char* key, int value);                    /* "range_guard" 0|1 ... (include/ganrev.h) */
+int gr_range_guard_stats(gr_ctx*, int64_t* scans, int64_t* fallbacks);     /* f16x3 passes the range guard sent to bf16x6 */
+int gr_search_stats(gr_ctx*, int64_t* reruns);
 /* fast mode: everything resident on the GPU (INTEGRATION.md section 2) */
 int gr_malloc(gr_ctx*, int64_t bytes, void** out_dev);  int gr_free(gr_ctx*, void* dev);
 int gr_memcpy_h2d(gr_ctx*, void* dst_dev, const void* src_host, int64_t bytes);
@@ -217,6 +221,15 @@ function hipnn.trainer(G, R, batchSize, pen, noiseMethod)
 end
 
 -- apply_r.lua:396-400 replacement
+-- nn.BCECriterion (train.lua:173) over FloatTensors: returns loss, gradInput
+function hipnn.bce(input, target)
+  local x, t = input:contiguous(), target:contiguous()
+  local g = torch.FloatTensor():resizeAs(x)
+  local loss = ffi.new('double[1]')
+  check(C.gr_bce_host(ctx, x:data(), t:data(), x:nElement(), loss, g:data()), 'gr_bce_host')
+  return loss[0], g
+end
+
 function hipnn.cosineSimilarity(v1, v2)
    local out = ffi.new('float[1]')
    check(C.gr_cosine_similarity_host(context(), v1:contiguous():data(), v2:contiguous():data(), v1:nElement(), out), 'cosine')
