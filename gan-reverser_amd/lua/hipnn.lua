@@ -226,7 +226,7 @@ function hipnn.bce(input, target)
   local x, t = input:contiguous(), target:contiguous()
   local g = torch.FloatTensor():resizeAs(x)
   local loss = ffi.new('double[1]')
-  check(C.gr_bce_host(ctx, x:data(), t:data(), x:nElement(), loss, g:data()), 'gr_bce_host')
+  check(C.gr_bce_host(context(), x:data(), t:data(), x:nElement(), loss, g:data()), 'gr_bce_host')
   return loss[0], g
 end
 
