@@ -2975,25 +2975,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
   // per-lane vector addresses of step 0 (the lane's pixel row pxl of the step, its 8-channel group); a step adds a uniform offset
   const uint4* abase = ds + (wo * 4 + chg) * 2 * DSP + pxl;
   const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + pxl;
+  // DMA addresses: the flat index -> (plane, row, column) decomposition of a patch vector does not depend on the chunk, only the
+  // image (scalar offset of the instruction) and the chunk's first row do.  Per lane and instruction: static byte offset with the
+  // patch row in its low 4 bits (15 = never valid).  (Recomputing it per chunk cost ~30 VALU instructions per DMA instruction:
+  // 7 VALU per MFMA on the counters.)
+  int xst[NXS], dst_[NDS];
+#pragma unroll
+  for (int j = 0; j < NXS; ++j) {
+    const int i = wave + 4 * j, e = 64 * i + lane;
+    const int pl = e / PSP, pos = e - pl * PSP, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC, xx = c - 1;
+    const bool valid = i < NXI && e < XV && pos < PS && xx >= 0 && xx < W_;
+    xst[j] = valid ? (((((cb * 8 + g) * 2 + t) * HW + (rr - 1) * W_ + xx) * 16 + W_ * 16) | rr) : 15;      // (+ one row: rr - 1 may be -1; taken off again below)
+  }
+#pragma unroll
+  for (int j = 0; j < NDS; ++j) {
+    const int pl = wave + 4 * j, g = pl >> 1, t = pl & 1;
+    dst_[j] = (((ob * 8 + g) * 2 + t) * HW + lane) * 16;
+  }
   for (int u = u0; u < u1; ++u) {
     const int b = u / cpi, cidx = u - b * cpi, p0 = cidx * 64, y0 = p0 / W_;      // the chunk's 64 pixels: rows y0 .. y0 + R - 1 (W_ = 64: one row)
     __syncthreads();                                             // every wave is past the previous chunk's image
     // x patch: flat vector index e = 64 i + lane over [group][term][position]
+    const int xsoff = b * Gin * 2 * HW * 16, dsoff = b * Gout * 2 * HW * 16;      // the image: scalar offsets (uniform)
+    const int yrow = (y0 - 1) * W_ * 16, p0b = p0 * 16;
 #pragma unroll
     for (int j = 0; j < NXS; ++j) {
-      const int i = wave + 4 * j, e = 64 * i + lane;
-      const int pl = e / PSP, pos = e - pl * PSP, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC;
-      const int yy = y0 + rr - 1, xx = c - 1;
-      const bool inb = e < XV && pos < PS && yy >= 0 && yy < H && xx >= 0 && xx < W_;
-      const int voff = inb ? (((b * Gin + cb * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(yy * W_ + xx))) * 16 : (int)0x7FFFF000;
-      if (i < NXI) lds_dma16(rx, xs + 64 * i, voff, 0);
+      const int i = wave + 4 * j, rr = xst[j] & 15;
+      const bool inb = rr != 15 && (unsigned)(y0 + rr - 1) < (unsigned)H;
+      const int voff = inb ? (xst[j] & ~15) + yrow : (int)0x7FFFF000;
+      if (i < NXI) lds_dma16(rx, xs + 64 * i, voff, xsoff);
     }
 #pragma unroll
-    for (int j = 0; j < NDS; ++j) {
-      const int pl = wave + 4 * j, g = pl >> 1, t = pl & 1;      // plane = (o group, term): 64 pixels = one instruction
-      const int voff = (((b * Gout + ob * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(p0 + lane))) * 16;
-      lds_dma16(rd, ds + DSP * pl, voff, 0);
-    }
+    for (int j = 0; j < NDS; ++j) lds_dma16(rd, ds + DSP * (wave + 4 * j), dst_[j] + p0b, dsoff);      // plane = (o group, term): 64 pixels = one instruction
     dma_publish_barrier();                                       // the image has landed
 #pragma unroll 1
     for (int ks = 0; ks < 4; ++ks) {
@@ -3079,24 +3092,37 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   // per-lane vector addresses of step 0 (the lane's pixel row pxl of the step, its 8-channel group); a step adds a uniform offset
   const uint4* abase = ds + (wo * 4 + chg) * 2 * DSP + pxl;
   const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + pxl;
+  // DMA addresses: the flat index -> (plane, row, column) decomposition of a patch vector does not depend on the chunk, only the
+  // image (scalar offset of the instruction) and the chunk's first row do.  Per lane and instruction: static byte offset with the
+  // patch row in its low 4 bits (15 = never valid).  (Recomputing it per chunk cost ~30 VALU instructions per DMA instruction:
+  // 7 VALU per MFMA on the counters.)
+  int xst[NXS], dst_[NDS];
+#pragma unroll
+  for (int j = 0; j < NXS; ++j) {
+    const int i = wave + 4 * j, e = 64 * i + lane;
+    const int pl = e / PSP, pos = e - pl * PSP, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC, xx = c - 1;
+    const bool valid = i < NXI && e < XV && pos < PS && xx >= 0 && xx < W_;
+    xst[j] = valid ? (((((cb * 8 + g) * 2 + t) * HW + (rr - 1) * W_ + xx) * 16 + W_ * 16) | rr) : 15;      // (+ one row: rr - 1 may be -1; taken off again below)
+  }
+#pragma unroll
+  for (int j = 0; j < NDS; ++j) {
+    const int pl = wave + 4 * j, g = pl >> 1, t = pl & 1;
+    dst_[j] = (((ob * 8 + g) * 2 + t) * HW + lane) * 16;
+  }
   auto load = [&](int u) {                                       // DMA of chunk u into this half's image, complete on return
     const int b = u / cpi, cidx = u - b * cpi, p0 = cidx * 64, y0 = p0 / W_;      // the chunk's 64 pixels: rows y0 .. y0 + R - 1 (W_ = 64: one row)
     // x patch: flat vector index e = 64 i + lane over [group][term][position]
+    const int xsoff = b * Gin * 2 * HW * 16, dsoff = b * Gout * 2 * HW * 16;      // the image: scalar offsets (uniform)
+    const int yrow = (y0 - 1) * W_ * 16, p0b = p0 * 16;
 #pragma unroll
     for (int j = 0; j < NXS; ++j) {
-      const int i = wave + 4 * j, e = 64 * i + lane;
-      const int pl = e / PSP, pos = e - pl * PSP, g = pl >> 1, t = pl & 1, rr = pos / PC, c = pos - rr * PC;
-      const int yy = y0 + rr - 1, xx = c - 1;
-      const bool inb = e < XV && pos < PS && yy >= 0 && yy < H && xx >= 0 && xx < W_;
-      const int voff = inb ? (((b * Gin + cb * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(yy * W_ + xx))) * 16 : (int)0x7FFFF000;
-      if (i < NXI) lds_dma16(rx, xs + 64 * i, voff, 0);
+      const int i = wave + 4 * j, rr = xst[j] & 15;
+      const bool inb = rr != 15 && (unsigned)(y0 + rr - 1) < (unsigned)H;
+      const int voff = inb ? (xst[j] & ~15) + yrow : (int)0x7FFFF000;
+      if (i < NXI) lds_dma16(rx, xs + 64 * i, voff, xsoff);
     }
 #pragma unroll
-    for (int j = 0; j < NDS; ++j) {
-      const int pl = wave + 4 * j, g = pl >> 1, t = pl & 1;      // plane = (o group, term): 64 pixels = one instruction
-      const int voff = (((b * Gout + ob * 8 + g) * 2 + t) * HW + (int)p16_pos((unsigned)(p0 + lane))) * 16;
-      lds_dma16(rd, ds + DSP * pl, voff, 0);
-    }
+    for (int j = 0; j < NDS; ++j) lds_dma16(rd, ds + DSP * (wave + 4 * j), dst_[j] + p0b, dsoff);      // plane = (o group, term): 64 pixels = one instruction
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto multiply = [&]() {
