@@ -308,7 +308,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
         for (int ky = 0; ky < 3; ++ky) {
           const float* pr = patch + cil * PS + (row + ky) * PCS + 4 * strip;
           const float4 m = *reinterpret_cast<const float4*>(pr + 4);
-          const float v[6] = {pr[3], m.x, m.y, m.z, m.w, pr[8]};
+          // the pixels left and right of this thread's four come from the neighbouring lanes' vectors (DPP row shifts: the 8
+          // strips of a patch row are 8 consecutive lanes of a 16-lane DPP row); only the two edge strips read the halo columns
+          // from LDS, in one instruction.  (Both neighbours as single-dword LDS reads: 64 lanes on 16 banks, 59 % of this kernel's
+          // LDS cycles were bank conflicts on the counters.)
+          float lf = dpp_take<0x111, 0xF>(m.w), rt = dpp_take<0x101, 0xF>(m.x);      // row_shr:1 / row_shl:1
+          if (strip == 0 || strip == 7) { const float hv = pr[strip == 0 ? 3 : 8]; if (strip == 0) lf = hv; else rt = hv; }
+          const float v[6] = {lf, m.x, m.y, m.z, m.w, rt};
 #pragma unroll
           for (int o = 0; o < CO; ++o) {
             const float w0 = wr[o * 9 + ky * 3], w1 = wr[o * 9 + ky * 3 + 1], w2 = wr[o * 9 + ky * 3 + 2];
