@@ -26,6 +26,7 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sh) {
   return r;  // valid on thread 0
 }
 
+__device__ __forceinline__ float post_slope(const PostArgs& a) { return a.act == ACT_PRELU ? *a.slope_dev : a.slope; }
 __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
   switch (act) {
     // ELU on the hardware exponential (v_exp_f32 of z * log2 e: 2 instructions instead of expf's ~15; these pipelines are
@@ -34,7 +35,7 @@ __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
     // host libm anyway.
     case ACT_ELU: return z <= 0.f ? (__expf(z) - 1.f) * 1.f : z;
     case ACT_RELU: return z > 0.f ? z : 0.f;
-    case ACT_LEAKYRELU: return z > 0.f ? z : z * slope;
+    case ACT_LEAKYRELU: case ACT_PRELU: return z > 0.f ? z : z * slope;
     case ACT_SIGMOID: return 1.f / (1.f + expf(-z));
     case ACT_TANH: return tanhf(z);
     default: return z;
@@ -44,7 +45,7 @@ __device__ __forceinline__ float act_bwd(float g, float z, float a, int act, flo
   switch (act) {
     case ACT_ELU: return a <= 0.f ? g * (a + 1.f) : g;
     case ACT_RELU: return a > 0.f ? g : 0.f;
-    case ACT_LEAKYRELU: return z > 0.f ? g : g * slope;
+    case ACT_LEAKYRELU: case ACT_PRELU: return z > 0.f ? g : g * slope;
     case ACT_SIGMOID: return g * (1.f - a) * a;
     case ACT_TANH: return g * (1.f - a * a);
     default: return g;
@@ -78,13 +79,13 @@ __global__ __launch_bounds__(256) void post_forward_kernel(PostArgs a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const long e = bc * HW + (long)(2 * yo + (t >> 1)) * W + 2 * xo + (t & 1);
-        const float v = act_fwd(bn_apply(a, a.y[e], c), a.act, a.slope) * mask_mul(a.m1, e, bc);
+        const float v = act_fwd(bn_apply(a, a.y[e], c), a.act, post_slope(a)) * mask_mul(a.m1, e, bc);
         if (v > best) { best = v; bi = t; }
       }
       a.pool_idx[i] = (uint8_t)bi;
       r = best;
     } else {
-      r = act_fwd(bn_apply(a, a.y[i], c), a.act, a.slope) * mask_mul(a.m1, i, bc);
+      r = act_fwd(bn_apply(a, a.y[i], c), a.act, post_slope(a)) * mask_mul(a.m1, i, bc);
     }
     const float res = r * mask_mul(a.m2, i, bc);
     a.out[i] = res;
@@ -123,8 +124,8 @@ __device__ __forceinline__ float4 bn_act4(const PostArgs& a, float4 v, float mea
     v.x = ((v.x - mean) * invstd) * g + bt; v.y = ((v.y - mean) * invstd) * g + bt;
     v.z = ((v.z - mean) * invstd) * g + bt; v.w = ((v.w - mean) * invstd) * g + bt;
   }
-  v.x = act_fwd(v.x, a.act, a.slope); v.y = act_fwd(v.y, a.act, a.slope);
-  v.z = act_fwd(v.z, a.act, a.slope); v.w = act_fwd(v.w, a.act, a.slope);
+  v.x = act_fwd(v.x, a.act, post_slope(a)); v.y = act_fwd(v.y, a.act, post_slope(a));
+  v.z = act_fwd(v.z, a.act, post_slope(a)); v.w = act_fwd(v.w, a.act, post_slope(a));
   return v;
 }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
@@ -526,8 +527,8 @@ __global__ __launch_bounds__(256) void post_backward_a_kernel(PostBwdArgs a, int
     g = g * mask_mul(f.m1, e, bc);
     const float yv = f.y[e];
     const float z = bn_apply(f, yv, c);
-    const float av = act_fwd(z, f.act, f.slope);
-    const float dz = act_bwd(g, z, av, f.act, f.slope);
+    const float av = act_fwd(z, f.act, post_slope(f));
+    const float dz = act_bwd(g, z, av, f.act, post_slope(f));
     a.dy[e] = dz;
     dmax = fmaxf(dmax, fabsf(dz));
     s += (double)dz;
@@ -586,10 +587,10 @@ __device__ __forceinline__ float4 post_bwd_dz_of(const PostBwdArgs& a, const Bwd
     z.z = ((yv.z - mean) * invstd) * gm + bt; z.w = ((yv.w - mean) * invstd) * gm + bt;
   }
   float4 dz;
-  dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, f.slope), f.act, f.slope);
-  dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, f.slope), f.act, f.slope);
-  dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, f.slope), f.act, f.slope);
-  dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, f.slope), f.act, f.slope);
+  dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, post_slope(f)), f.act, post_slope(f));
+  dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, post_slope(f)), f.act, post_slope(f));
+  dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, post_slope(f)), f.act, post_slope(f));
+  dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, post_slope(f)), f.act, post_slope(f));
   return dz;
 }
 
@@ -618,10 +619,10 @@ __device__ __forceinline__ float4 post_bwd_dz4(const PostBwdArgs& a, unsigned bc
     z.z = ((yv.z - mean) * invstd) * gm + bt; z.w = ((yv.w - mean) * invstd) * gm + bt;
   }
   float4 dz;
-  dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, f.slope), f.act, f.slope);
-  dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, f.slope), f.act, f.slope);
-  dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, f.slope), f.act, f.slope);
-  dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, f.slope), f.act, f.slope);
+  dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, post_slope(f)), f.act, post_slope(f));
+  dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, post_slope(f)), f.act, post_slope(f));
+  dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, post_slope(f)), f.act, post_slope(f));
+  dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, post_slope(f)), f.act, post_slope(f));
   return dz;
 }
 

@@ -209,7 +209,8 @@ void launch_gemm(const float* A, long rsA, long ksA, const float* Bm, long rsB, 
                  const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr);
 
 // ---------------------------------------------------------------- per-channel pipelines (BN / act / dropout / pool)
-enum Act { ACT_NONE = 0, ACT_ELU = 3, ACT_RELU = 4, ACT_LEAKYRELU = 5, ACT_SIGMOID = 6, ACT_TANH = 7 };
+enum Act { ACT_NONE = 0, ACT_ELU = 3, ACT_RELU = 4, ACT_LEAKYRELU = 5, ACT_SIGMOID = 6, ACT_TANH = 7,
+           ACT_PRELU = 16 /* nn.PReLU() with one shared slope: LeakyReLU whose slope is read from device memory (PostArgs::slope_dev) */ };
 enum MaskKind { MASK_NONE = 0, MASK_ELEM = 1, MASK_SPATIAL = 2, MASK_SCALE = 3 /* evaluate(): x*(1-p) */ };
 struct MaskRef { int kind; const uint32_t* bits; float scale; };
 
@@ -220,6 +221,7 @@ struct PostArgs {
   int has_bn;
   const float *mean, *invstd, *gamma, *beta;  // per channel
   int act; float slope;
+  const float* slope_dev;  // ACT_PRELU: the learnable slope (one float in the net's flat parameter vector)
   MaskRef m1;              // applied before the pool, indexed at [B,C,H,W] (ELEM) or [B,C] (SPATIAL)
   int pool;                // 2x2 max pool, stride 2
   uint8_t* pool_idx;       // [B,C,Ho,Wo] argmax 0..3
@@ -262,6 +264,15 @@ struct BiasJob { const double* partials; float* gbias; int C, splits; };     // 
 struct BiasJobs { BiasJob job[16]; int n; };
 void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer = nullptr);
 void launch_bias_grad_batch(BiasJobs& jobs, hipStream_t s);    // runs and empties the list
+
+// ---------------------------------------------------------------- K x K convolution (odd K other than 3) and nn.PReLU: convk.hip
+bool convk_supported(int K);
+size_t convk_workspace_bytes(int B, int Cin, int Cout, int K);
+void launch_convk_forward(const float* in, const float* w /*[Cout][Cin][K][K]*/, const float* bias, float* out, void* ws, int B, int Cin, int Cout, int H, int W, int K, hipStream_t s);
+void launch_convk_backward_data(const float* gout, const float* w, float* gin, void* ws, int B, int Cin, int Cout, int H, int W, int K, hipStream_t s);
+void launch_convk_backward_weight(const float* in, const float* gout, float* gw /*+=*/, void* ws, int B, int Cin, int Cout, int H, int W, int K, hipStream_t s);
+size_t prelu_grad_workspace_bytes();
+void launch_prelu_grad(const float* g, const float* z, long n, double* part, float* gslope /*+=*/, hipStream_t s);
 
 // ---------------------------------------------------------------- criterion / optimiser / misc
 void launch_mse(const float* x, const float* t, long n, long n_global, double* loss_dev, float* grad, hipStream_t s);

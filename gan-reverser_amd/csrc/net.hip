@@ -289,6 +289,8 @@ struct Stage {
   int64_t w_off = -1, b_off = -1;
   bool has_bn = false; int64_t g_off = -1, be_off = -1; int bn_idx = -1;
   int act = ACT_NONE; float slope = 0;
+  int ksz = 3;                              // window of the main convolution: 3 (conv.hip kernels) or an odd K convk.hip covers (GR_CONVK)
+  int64_t slope_off = -1;                   // nn.PReLU: offset of its one learnable slope in the flat vectors
   int m1 = -1, m2 = -1; bool pool = false;
   bool has_post = false;
   int outC = 0, outH = 0, outW = 0;
@@ -344,7 +346,7 @@ struct gr_net {
 
 enum { AG_X = 0, AG_Y = 1, AG_KB = 2, AG_DY = 3, AG_DZ = 4, AG_W = 5, AMAX_GROUPS = 6 };
 static int64_t vol3(int c, int h, int w) { return (int64_t)c * h * w; }
-static bool is_act(int k) { return k == GR_ELU || k == GR_RELU || k == GR_LEAKYRELU || k == GR_SIGMOID || k == GR_TANH; }
+static bool is_act(int k) { return k == GR_ELU || k == GR_RELU || k == GR_LEAKYRELU || k == GR_SIGMOID || k == GR_TANH || k == GR_PRELU; }
 
 extern "C" int gr_net_destroy(gr_net* n) {
   if (!n) return GR_ERR_INVALID;
@@ -382,6 +384,11 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
         case GR_CONV3: case GR_FULLCONV3:
           if (d.a != cc) { delete n; return fail(c, GR_ERR_INVALID, "layer %d: conv expects %d input planes, got %d", i, d.a, cc); }
           woff[i] = off; off += (int64_t)d.a * d.b * 9; boff[i] = off; off += d.b; cc = d.b; break;
+        case GR_CONVK:
+          if (d.a != cc) { delete n; return fail(c, GR_ERR_INVALID, "layer %d: conv expects %d input planes, got %d", i, d.a, cc); }
+          if (!convk_supported(d.c)) { delete n; return fail(c, GR_ERR_UNSUPPORTED, "layer %d: no kernel for a %dx%d convolution (3x3: GR_CONV3; 5x5: GR_CONVK)", i, d.c, d.c); }
+          woff[i] = off; off += (int64_t)d.a * d.b * d.c * d.c; boff[i] = off; off += d.b; cc = d.b; break;
+        case GR_PRELU: woff[i] = off; off += 1; break;          // nn.PReLU(): weight = Tensor(1)
         case GR_LINEAR:
           if (d.a != vol3(cc, h, w)) { delete n; return fail(c, GR_ERR_INVALID, "layer %d: linear expects %d inputs, got %lld", i, d.a, (long long)vol3(cc, h, w)); }
           woff[i] = off; off += (int64_t)d.a * d.b; boff[i] = off; off += d.b; cc = d.b; h = 1; w = 1; break;
@@ -414,8 +421,9 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
         s.up = true; h *= 2; w *= 2; ++i;
       }
       const int k = L[i].kind;
-      if (k == GR_CONV3 || k == GR_FULLCONV3) {
-        s.kind = ST_CONV; s.fullconv = k == GR_FULLCONV3; s.main_layer = i; s.Cin = L[i].a; s.Cout = L[i].b; s.H = h; s.W = w;
+      if (k == GR_CONVK && s.up) { gr_net_destroy(n); return fail(c, GR_ERR_UNSUPPORTED, "layer %d: UpSamplingNearest(2) is only fused in front of a 3x3 convolution", i); }
+      if (k == GR_CONV3 || k == GR_FULLCONV3 || k == GR_CONVK) {
+        s.kind = ST_CONV; s.fullconv = k == GR_FULLCONV3; s.ksz = k == GR_CONVK ? L[i].c : 3; s.main_layer = i; s.Cin = L[i].a; s.Cout = L[i].b; s.H = h; s.W = w;
         s.w_off = woff[i]; s.b_off = boff[i]; cc = s.Cout; ++i;
       } else if (k == GR_LINEAR) {
         s.kind = ST_LINEAR; s.main_layer = i; s.Cin = L[i].a; s.Cout = L[i].b; s.H = 1; s.W = 1;
@@ -433,9 +441,12 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
         else if (d.kind == GR_MAXPOOL2) ph = 3;
         else break;
         if (ph <= phase) break;
+        // nn.PReLU's slope gradient needs the activation's own input and gradOutput as tensors: the PReLU closes its stage (what
+        // follows it - dropout, pooling - is the next, element-wise stage), and behind a BatchNorm it opens a stage of its own
+        if (d.kind == GR_PRELU && s.has_bn) break;
         phase = ph; s.has_post = true;
         if (ph == 0) { s.has_bn = true; s.g_off = woff[i]; s.be_off = boff[i]; s.bn_idx = (int)n->bn_stage.size(); n->bn_stage.push_back((int)n->st.size()); }
-        else if (ph == 1) { s.act = d.kind; s.slope = d.p; }
+        else if (ph == 1) { s.act = d.kind; s.slope = d.p; if (d.kind == GR_PRELU) { s.slope_off = woff[i]; ++i; break; } }
         else if (ph == 3) { s.pool = true; h /= 2; w /= 2; }
         else {
           MaskSlot m; m.layer = i; m.kind = d.kind == GR_DROPOUT ? MASK_ELEM : MASK_SPATIAL; m.p = d.p; m.flags = d.flags;
@@ -471,7 +482,7 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
         hipMalloc((void**)&s.partials_b, sizeof(double) * PB_SPLITS * C)) {
       gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed");
     }
-    if (s.kind == ST_CONV) {
+    if (s.kind == ST_CONV && s.ksz == 3) {
       // forward reduces over Cin; backward-data reduces over Cout.  (FullConvolution swaps the two roles.)
       const ConvWeightLayout lf = s.fullconv ? conv_weight_layout(s.Cin, s.Cout) : conv_weight_layout(s.Cin, s.Cout);
       const ConvWeightLayout lb = conv_weight_layout(s.Cout, s.Cin);
@@ -496,7 +507,7 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
       s.amax_x = slot(AG_X); s.amax_y = slot(AG_Y); s.amax_kb = slot(AG_KB); s.amax_dy = slot(AG_DY); s.amax_dz = slot(AG_DZ); s.amax_w = slot(AG_W);
     }
     for (auto& s : n->st) {
-      if (s.kind != ST_CONV) continue;
+      if (s.kind != ST_CONV || s.ksz != 3) continue;
       if (!s.fullconv) {
         jf.push_back(make_prep_job(s.w_off, s.wt_fwd, s.Cin, s.Cout, false, 0));
         jf.push_back(make_prep_job(s.w_off, s.wt_bwd, s.Cin, s.Cout, true, 0));
@@ -634,7 +645,7 @@ static int ensure_batch(gr_net* n, int B) {
       HIPCHK(c, hipMalloc((void**)&s.stat_part, sizeof(double) * 2 * (size_t)s.Cout * conv_stat_tiles_max(B, s.H, s.W)));
     }
     if (s.pool) { (void)hipFree(s.pool_idx); s.pool_idx = nullptr; HIPCHK(c, hipMalloc((void**)&s.pool_idx, (size_t)B * vol3(s.outC, s.outH, s.outW))); }
-    if (s.kind == ST_CONV && !s.up && !s.fullconv && s.Cin % 16 == 0) {       // operand-ready input image (same bytes as the fp32 input)
+    if (s.kind == ST_CONV && s.ksz == 3 && !s.up && !s.fullconv && s.Cin % 16 == 0) {       // operand-ready input image (same bytes as the fp32 input)
       (void)hipFree(s.x_p16); s.x_p16 = nullptr; s.x_p16_gen = 0;
       HIPCHK(c, hipMalloc(&s.x_p16, sizeof(float) * (size_t)B * vol3(s.inC, s.inH, s.inW)));
     }
@@ -656,13 +667,13 @@ static int ensure_batch(gr_net* n, int B) {
 
 // bf16x6 mode: every plain convolution runs on the split kernel except few-output-channel layers the HBM-bound VALU
 // kernel covers (same predicate as launch_conv3x3); only the split images are kept current in that mode.
-static bool fewout_applies(const Stage& s) { return s.Cout <= 4 && !s.up && s.W % 4 == 0 && s.W >= 16; }
+static bool fewout_applies(const Stage& s) { return s.ksz == 3 && s.Cout <= 4 && !s.up && s.W % 4 == 0 && s.W >= 16; }
 // f16x3 GEMM for the large nn.Linear layers (R.fc1: 90-97 % of R's parameters); small ones stay on the fp32 MFMA kernel
 static bool use_f16_gemm(gr_net* n, const Stage& s) {
   static const bool on = !getenv("GR_NO_F16_GEMM");
   return on && n->ctx->conv_mode == 2 && s.kind == ST_LINEAR && (int64_t)s.Cin * s.Cout >= (1 << 20);
 }
-static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode >= 1 && s.kind == ST_CONV && !fewout_applies(s); }   // either split flavour
+static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode >= 1 && s.kind == ST_CONV && s.ksz == 3 && !fewout_applies(s); }   // either split flavour
 // Re-lay every convolution's weights (one launch) when the parameters changed since the last time.  bf16x6 mode needs the
 // split images; the fp32 k-major images are still needed there by SpatialFullConvolution stages (no split kernel).
 static int prep_weights(gr_net* n) {
@@ -715,7 +726,7 @@ static PostArgs post_args(gr_net* n, Stage& s, int B) {
   a.has_bn = s.has_bn ? 1 : 0;
   a.mean = s.mean; a.invstd = s.invstd;
   a.gamma = s.has_bn ? n->params + s.g_off : nullptr; a.beta = s.has_bn ? n->params + s.be_off : nullptr;
-  a.act = s.act; a.slope = s.slope;
+  a.act = s.act; a.slope = s.slope; a.slope_dev = s.act == ACT_PRELU ? n->params + s.slope_off : nullptr;
   bool nb;
   a.m1 = mask_ref(n, s.m1, nb); a.m2 = mask_ref(n, s.m2, nb);
   a.pool = s.pool ? 1 : 0; a.pool_idx = s.pool_idx;
@@ -859,13 +870,18 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
     unsigned* amax_next = nx ? nx->amax_x : nullptr;
     s.x_in = x;
     s.fused_epilogue = false; s.out_skipped = false;
-    if (s.kind == ST_CONV) {
+    if (s.kind == ST_CONV && s.ksz != 3) {
+      // K x K convolution (the D network's 5x5 layer): fp32 direct kernel, raw output always written, statistics by the pipeline
+      r = ensure_ws(c, convk_workspace_bytes(B, s.Cin, s.Cout, s.ksz)); if (r) return r;
+      launch_convk_forward(x, n->params + s.w_off, n->params + s.b_off, s.y, c->ws, B, s.Cin, s.Cout, s.H, s.W, s.ksz, c->stream);
+      s.stat_tiles_last = 0;
+    } else if (s.kind == ST_CONV) {
       // evaluate() mode: BatchNorm is a per-channel affine map of running statistics, so BN + activation ride in the conv
       // epilogue and the raw conv output is never written (G on this path).  Needs: no pool, no active dropout noise.
       ConvEpilogue ep; const ConvEpilogue* epp = nullptr; float* dst = s.y;
       bool nb1 = false, nb2 = false;
       const MaskRef r1 = mask_ref(n, s.m1, nb1), r2 = mask_ref(n, s.m2, nb2);
-      if (!n->training && s.has_post && !s.pool && r1.kind == MASK_NONE && r2.kind == MASK_NONE) {
+      if (!n->training && s.has_post && !s.pool && r1.kind == MASK_NONE && r2.kind == MASK_NONE && s.act != ACT_PRELU) {
         if (s.has_bn) {
           if (!s.eval_ready) { launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream); s.eval_ready = true; }
           ep.mean = s.mean; ep.invstd = s.invstd; ep.gamma = n->params + s.g_off; ep.beta = n->params + s.be_off;
@@ -916,7 +932,7 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
       // the raw Linear output - 268 MB at cfg3 - is never written)
       bool nb1 = false, nb2 = false;
       const MaskRef r1 = mask_ref(n, s.m1, nb1), r2 = mask_ref(n, s.m2, nb2);
-      if (!n->training && s.has_post && !s.pool && r1.kind == MASK_NONE && r2.kind == MASK_NONE && s.H == 1 && s.W == 1 &&
+      if (!n->training && s.has_post && !s.pool && r1.kind == MASK_NONE && r2.kind == MASK_NONE && s.H == 1 && s.W == 1 && s.act != ACT_PRELU &&
           gemm_epilogue_possible(B, s.Cout, s.Cin)) {
         ConvEpilogue ep;
         if (s.has_bn) {
@@ -1108,7 +1124,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     pb.gbias = s.kind == ST_ELEM ? nullptr : n->grads + s.b_off;
     pb.amax_dy = (f16 && (s.kind == ST_CONV || use_f16_gemm(n, s))) ? s.amax_dy : nullptr;
     // operand-ready dy for the data-gradient convolution: needs the forward's bound factor of THIS forward (kb_gen)
-    const bool dy_ok = f16 && s.kind == ST_CONV && !s.up && !s.fullconv && s.has_bn && n->dy_p16 && s.kb_gen == n->amax_gen &&
+    const bool dy_ok = f16 && s.kind == ST_CONV && s.ksz == 3 && !s.up && !s.fullconv && s.has_bn && n->dy_p16 && s.kb_gen == n->amax_gen &&
                        post_g8_supported(s.Cout, s.H, s.W, s.pool, true);
     const bool dgrad_p16 = dy_ok && need_gin && conv_p16_supported(B, s.Cout, s.Cin, s.H, s.W);
     // weight gradient with both operands operand-ready: this stage's input image (written by the previous stage's forward
@@ -1120,9 +1136,20 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       return fail(c, GR_ERR_STATE, "stage %d: the forward left this stage's input operand-ready only (f16x3); backward in another arithmetic mode needs a new forward", si);
     static const bool lean_on = !getenv("GR_P16_KEEP_FP32");
     if (lean_on && !n->keep_fp32 && wgrad_p16 && (dgrad_p16 || !need_gin)) pb.dy = nullptr;      // no fp32 reader of dy is left
+    if (s.act == ACT_PRELU) {
+      // nn.PReLU accGradParameters: the stage ends at the PReLU, so g is its gradOutput and the raw main-op output (the stage
+      // input for an element-wise stage) its input
+      int r = ensure_ws(c, prelu_grad_workspace_bytes()); if (r) return r;
+      launch_prelu_grad(g, s.kind == ST_ELEM ? x : s.y, (long)B * vol3(s.Cout, s.H, s.W), static_cast<double*>(c->ws), n->grads + s.slope_off, c->stream);
+    }
     launch_post_backward(pb, c->stream, &bias_jobs);       // bias gradients of several stages are summed by one launch
     LAUNCHCHK(c);
-    if (s.kind == ST_CONV) {
+    if (s.kind == ST_CONV && s.ksz != 3) {
+      int r = ensure_ws(c, convk_workspace_bytes(B, s.Cin, s.Cout, s.ksz)); if (r) return r;
+      launch_convk_backward_weight(x, dyb, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, s.ksz, c->stream);
+      if (need_gin) launch_convk_backward_data(dyb, n->params + s.w_off, gin, c->ws, B, s.Cin, s.Cout, s.H, s.W, s.ksz, c->stream);
+      LAUNCHCHK(c);
+    } else if (s.kind == ST_CONV) {
       if (s.up) {
         // SpatialUpSamplingNearest(2) + SpatialConvolution backward (adversarial.lua:37-205 trains G through it): the weight
         // gradient needs the up-sampled input, the data gradient is folded back by summing each 2x2 block

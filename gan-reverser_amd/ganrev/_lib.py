@@ -30,6 +30,7 @@ STATUS = {0: "GR_OK", -1: "GR_ERR_INVALID", -2: "GR_ERR_UNSUPPORTED", -3: "GR_ER
 
 # layer kinds (shared numeric values with the oracle's go_layer)
 CONV3, BN, ELU, RELU, LEAKYRELU, SIGMOID, TANH, DROPOUT, SPATIAL_DROPOUT, MAXPOOL2, UPSAMPLE2, VIEW, LINEAR, FULLCONV3 = range(1, 15)
+CONVK, PRELU = 15, 16       # the D network's extra module types (models.lua:272-337)
 DROPOUT_V2, DROPOUT_ALWAYS_ON = 1, 2
 COMM_ID_BYTES = 128
 

@@ -175,21 +175,32 @@ class Module:
     def getParameters(self):
         """Flattens every parameter into one storage; module weight/bias become views into it (train_r.lua:122)."""
         if self._flat is None:
-            if self._net is not None:
-                self.pull_params()
-            flat = self._flat_host()
-            grads = np.zeros_like(flat)
-            off = 0
-            for m in self.leaves():
-                views, gviews = [], []
-                for a in m.param_arrays():
-                    views.append(flat[off:off + a.size].reshape(a.shape))
-                    gviews.append(grads[off:off + a.size].reshape(a.shape))
-                    off += a.size
-                m.set_param_arrays(views)
-                m.set_grad_arrays(gviews)
-            self._flat = (flat, grads)
+            n = self._param_count()
+            self._bind_flat(np.zeros(n, np.float32), np.zeros(n, np.float32))
         return self._flat
+
+    def _param_count(self):
+        return int(sum(a.size for m in self.leaves() for a in m.param_arrays()))
+
+    def _bind_flat(self, flat, grads):
+        """Make `flat` / `grads` (given storage: a container hands each compiled part its slice) this module's flat vectors."""
+        if self._net is not None:
+            self.pull_params()
+        flat[...] = self._flat_host()
+        off = 0
+        for m in self.leaves():
+            views, gviews = [], []
+            for a in m.param_arrays():
+                views.append(flat[off:off + a.size].reshape(a.shape))
+                gviews.append(grads[off:off + a.size].reshape(a.shape))
+                off += a.size
+            m.set_param_arrays(views)
+            m.set_grad_arrays(gviews)
+        self._flat = (flat, grads)
+
+    def _param_chunks(self, lo=0):
+        """[(module compiled into one gr_net, lo, hi)]: the slices of the flat vector each device net owns."""
+        return [(self, lo, lo + self._param_count())]
 
     def set_grad_arrays(self, arrays):
         pass
@@ -287,8 +298,231 @@ class Sequential(Module):
             out.extend(m.leaves())
         return out
 
+    # ---- a Sequential that holds an nn.Concat (models.lua:285-315, the D network) cannot be one gr_net: it runs as a chain
+    # of PARTS - every run of plain modules is compiled into one gr_net (a chunk), a branching container runs its branches.
+    # Host arrays travel between the parts, as Torch7 tensors travel between the modules of the reference's containers.
+    def _is_graph(self):
+        return any(isinstance(m, Concat) or (isinstance(m, Sequential) and m._is_graph()) for m in self.modules)
+
+    def parts(self):
+        if getattr(self, "_parts", None) is None:
+            parts, run = [], None
+            for m in self.modules:
+                if isinstance(m, Concat) or (isinstance(m, Sequential) and m._is_graph()):
+                    if run is not None:
+                        parts.append(run)
+                        run = None
+                    parts.append(m)
+                elif m.leaves():
+                    if run is None:
+                        run = Sequential()
+                    run.add(m)
+            if run is not None:
+                parts.append(run)
+            self._parts = parts
+        return self._parts
+
+    def forward(self, input):
+        if not self._is_graph():
+            return Module.forward(self, input)
+        x = L.f32(input)
+        self._part_inputs = []
+        for p in self.parts():
+            self._part_inputs.append(x)
+            x = p.forward(x)
+        self.output = x
+        return x
+
+    updateOutput = forward
+
+    def backward(self, input, gradOutput, scale=1):
+        if not self._is_graph():
+            return Module.backward(self, input, gradOutput, scale)
+        if getattr(self, "_part_inputs", None) is None:
+            raise L.GanrevError("backward called before forward")
+        g = L.f32(gradOutput)
+        for p, x in zip(reversed(self.parts()), reversed(self._part_inputs)):
+            g = p.backward(x, g, scale)
+        self.gradInput = g
+        return g
+
+    def _bind_flat(self, flat, grads):
+        if not self._is_graph():
+            return Module._bind_flat(self, flat, grads)
+        off = 0
+        for p in self.parts():
+            k = p._param_count()
+            p._bind_flat(flat[off:off + k], grads[off:off + k])
+            off += k
+        self._flat = (flat, grads)
+
+    def _param_chunks(self, lo=0):
+        if not self._is_graph():
+            return Module._param_chunks(self, lo)
+        out = []
+        for p in self.parts():
+            out.extend(p._param_chunks(lo))
+            lo += p._param_count()
+        return out
+
+    def push_params(self):
+        if not self._is_graph():
+            return Module.push_params(self)
+        for p in self.parts():
+            p.push_params()
+
+    def pull_params(self):
+        if not self._is_graph():
+            return Module.pull_params(self)
+        for p in self.parts():
+            p.pull_params()
+
+    def zeroGradParameters(self):
+        if not self._is_graph():
+            return Module.zeroGradParameters(self)
+        if self._flat is not None:
+            self._flat[1][...] = 0
+        for p in self.parts():
+            p.zeroGradParameters()
+
+    def manualSeed(self, seed):
+        if not self._is_graph():
+            return Module.manualSeed(self, seed)
+        for i, (chunk, _, _) in enumerate(self._param_chunks()):
+            chunk.manualSeed(int(seed) * 1009 + i)
+
+    def _owner(self, module):
+        """The compiled chunk a leaf module sits in (dropout-noise injection / read-back of a graph model)."""
+        for p in self.parts():
+            if isinstance(p, Concat) or p._is_graph():
+                o = p._owner(module)
+                if o is not None:
+                    return o
+            elif any(m is module for m in p.leaves()):
+                return p
+        return None
+
+    def setNoise(self, module, keep):
+        if not self._is_graph():
+            return Module.setNoise(self, module, keep)
+        self._owner(module).setNoise(module, keep)
+
+    def getNoise(self, module, batch):
+        if not self._is_graph():
+            return Module.getNoise(self, module, batch)
+        return self._owner(module).getNoise(module, batch)
+
     def __repr__(self):
         lines = ["nn.Sequential {"]
+        lines += [f"  ({i + 1}): {m!r}" for i, m in enumerate(self.modules)]
+        return "\n".join(lines + ["}"])
+
+
+class Concat(Module):
+    """nn.Concat(dimension): every branch gets the same input, the outputs are joined along `dimension` (1-based, the batch
+    is dimension 1): the D network's two convolution towers (models.lua:285-315, `nn.Concat(2)` of two [B x 512] feature
+    vectors).  backward hands each branch its slice of gradOutput and sums the branches' gradInputs."""
+    TYPENAME = "nn.Concat"
+
+    def __init__(self, dimension):
+        super().__init__()
+        self.dimension = int(dimension)
+        self.modules = []
+
+    def add(self, m):
+        if not isinstance(m, Sequential):
+            m = Sequential().add(m)
+        self.modules.append(m)
+        return self
+
+    def get(self, i):
+        return self.modules[i - 1]
+
+    def size(self):
+        return len(self.modules)
+
+    def listModules(self):
+        out = [self]
+        for m in self.modules:
+            out.extend(m.listModules())
+        return out
+
+    def leaves(self):
+        out = []
+        for m in self.modules:
+            out.extend(m.leaves())
+        return out
+
+    def _is_graph(self):
+        return True
+
+    def forward(self, input):
+        x = L.f32(input)
+        outs = [b.forward(x) for b in self.modules]
+        ax = self.dimension - 1
+        if any(o.ndim <= ax or o.shape[:ax] != outs[0].shape[:ax] or o.shape[ax + 1:] != outs[0].shape[ax + 1:] for o in outs):
+            raise L.GanrevError(f"nn.Concat({self.dimension}): branch outputs {[o.shape for o in outs]} do not line up")
+        self._sizes = [o.shape[ax] for o in outs]
+        self.output = np.concatenate(outs, axis=ax)
+        return self.output
+
+    updateOutput = forward
+
+    def backward(self, input, gradOutput, scale=1):
+        if getattr(self, "_sizes", None) is None:
+            raise L.GanrevError("backward called before forward")
+        x, g = L.f32(input), L.f32(gradOutput)
+        ax, lo, gin = self.dimension - 1, 0, None
+        for b, k in zip(self.modules, self._sizes):
+            sl = [slice(None)] * g.ndim
+            sl[ax] = slice(lo, lo + k)
+            gi = b.backward(x, np.ascontiguousarray(g[tuple(sl)]), scale)
+            gin = gi.copy() if gin is None else gin + gi
+            lo += k
+        self.gradInput = gin
+        return gin
+
+    def _bind_flat(self, flat, grads):
+        off = 0
+        for b in self.modules:
+            k = b._param_count()
+            b._bind_flat(flat[off:off + k], grads[off:off + k])
+            off += k
+        self._flat = (flat, grads)
+
+    def _param_chunks(self, lo=0):
+        out = []
+        for b in self.modules:
+            out.extend(b._param_chunks(lo))
+            lo += b._param_count()
+        return out
+
+    def push_params(self):
+        for b in self.modules:
+            b.push_params()
+
+    def pull_params(self):
+        for b in self.modules:
+            b.pull_params()
+
+    def zeroGradParameters(self):
+        if self._flat is not None:
+            self._flat[1][...] = 0
+        for b in self.modules:
+            b.zeroGradParameters()
+
+    def _owner(self, module):
+        for b in self.modules:
+            if b._is_graph():
+                o = b._owner(module)
+                if o is not None:
+                    return o
+            elif any(m is module for m in b.leaves()):
+                return b
+        return None
+
+    def __repr__(self):
+        lines = [f"nn.Concat({self.dimension}) {{"]
         lines += [f"  ({i + 1}): {m!r}" for i, m in enumerate(self.modules)]
         return "\n".join(lines + ["}"])
 
@@ -320,23 +554,24 @@ class _Param(Module):
 
 
 class SpatialConvolution(_Param):
-    """nn.SpatialConvolution(nInputPlane, nOutputPlane, kW, kH, dW, dH, padW, padH) — 3x3 s1 p1 only (the
-    one geometry models.lua uses on this path)."""
+    """nn.SpatialConvolution(nInputPlane, nOutputPlane, kW, kH, dW, dH, padW, padH) — 3x3 s1 p1 (the one geometry
+    models.lua uses on the G/R path) and 5x5 s1 p2 (the D network's createNxN(128, 64, 5, ..), models.lua:275,290)."""
     TYPENAME = "nn.SpatialConvolution"
     KIND = L.CONV3
 
     def __init__(self, nInputPlane, nOutputPlane, kW=3, kH=3, dW=1, dH=1, padW=1, padH=None):
         super().__init__()
         padH = padW if padH is None else padH
-        if (kW, kH, dW, dH, padW, padH) != (3, 3, 1, 1, 1, 1):
-            raise L.GanrevError("only 3x3 stride-1 pad-1 convolutions have a gfx950 kernel (models.lua:409-436)")
+        if (kW, kH, dW, dH, padW, padH) not in ((3, 3, 1, 1, 1, 1), (5, 5, 1, 1, 2, 2)) or (kW != 3 and self.KIND != L.CONV3):
+            raise L.GanrevError("only 3x3 stride-1 pad-1 (models.lua:409-436) and 5x5 stride-1 pad-2 (models.lua:290) "
+                                "convolutions have a gfx950 kernel")
         self.nInputPlane, self.nOutputPlane, self.kW, self.kH = nInputPlane, nOutputPlane, kW, kH
         self.weight = np.zeros(self._wshape(), np.float32)
         self.bias = np.zeros(nOutputPlane, np.float32)
         self.reset()
 
     def _wshape(self):
-        return (self.nOutputPlane, self.nInputPlane, 3, 3)
+        return (self.nOutputPlane, self.nInputPlane, self.kH, self.kW)
 
     def reset(self, stdv=None, rng=None):
         """nn.SpatialConvolution:reset — uniform(-stdv, stdv); a given stdv is scaled by sqrt(3) (upstream)."""
@@ -347,10 +582,13 @@ class SpatialConvolution(_Param):
 
     def desc(self, dims):
         c, h, w = dims
+        if self.kW != 3:
+            return [(L.CONVK, self.nInputPlane, self.nOutputPlane, self.kW, 0.0, 0)], (self.nOutputPlane, h, w)
         return [(self.KIND, self.nInputPlane, self.nOutputPlane, 0, 0.0, 0)], (self.nOutputPlane, h, w)
 
     def __repr__(self):
-        return f"{self.typename}({self.nInputPlane} -> {self.nOutputPlane}, 3x3, 1,1, 1,1)"
+        p = (self.kW - 1) // 2
+        return f"{self.typename}({self.nInputPlane} -> {self.nOutputPlane}, {self.kW}x{self.kH}, 1,1, {p},{p})"
 
 
 class SpatialFullConvolution(SpatialConvolution):
@@ -462,6 +700,33 @@ class LeakyReLU(Module):
 
     def desc(self, dims):
         return [(L.LEAKYRELU, 0, 0, 0, self.negval, 0)], dims
+
+
+class PReLU(Module):
+    """nn.PReLU(nOutputPlane=0): y = x > 0 ? x : w * x with ONE learnable slope w, initial value 0.25 (models.lua:276 and
+    every other activation of the D networks).  The slope is a parameter: it sits in getParameters()' flat vector where
+    the module sits in the network."""
+    TYPENAME = "nn.PReLU"
+
+    def __init__(self, nOutputPlane=0):
+        super().__init__()
+        if nOutputPlane not in (0, None):
+            raise L.GanrevError("nn.PReLU: only the shared slope (nn.PReLU() as models.lua writes it) is implemented")
+        self.nOutputPlane = 0
+        self.weight = np.full(1, 0.25, np.float32)
+        self.gradWeight = None
+
+    def param_arrays(self):
+        return [self.weight]
+
+    def set_param_arrays(self, arrays):
+        (self.weight,) = arrays
+
+    def set_grad_arrays(self, arrays):
+        (self.gradWeight,) = arrays
+
+    def desc(self, dims):
+        return [(L.PRELU, 0, 0, 0, 0.0, 0)], dims
 
 
 class Dropout(Module):

@@ -16,19 +16,25 @@ def adam(opfunc, x, config=None, state=None, model=None):
     config = config if config is not None else {}
     state = state if state is not None else config
     fx, dfdx = opfunc(x)
-    if model is None or model._net is None:
-        raise L.GanrevError("optim.adam needs the model whose getParameters() produced x (model=...)")
-    net = model._net
+    chunks = model._param_chunks() if model is not None else []
+    if not chunks or any(ch._net is None for ch, _, _ in chunks):
+        raise L.GanrevError("optim.adam needs the model whose getParameters() produced x (model=...), after a forward")
     state["t"] = state.get("t", 0) + 1
     if "m" not in state:
         state["m"] = np.zeros_like(x)
         state["v"] = np.zeros_like(x)
     h = L.Hyper(lr=config.get("learningRate", 1e-3), beta1=config.get("beta1", 0.9), beta2=config.get("beta2", 0.999),
                 eps=config.get("epsilon", 1e-8), l1=0.0, l2=0.0, clamp=0.0)   # penalties are fevalR's job here
-    net.set_params(x)
-    net.set_grads(dfdx)
-    net.set_adam_state(state["m"], state["v"])
-    net.adam_step(h, state["t"])
-    x[...] = net.get_params()
-    state["m"], state["v"] = net.adam_state()
+    # the update is element-wise: a model that runs as several gr_nets (one with an nn.Concat, the D network) is stepped
+    # slice by slice, each net on the part of the flat vector it owns
+    for ch, lo, hi in chunks:
+        if hi == lo:
+            continue
+        net = ch._net
+        net.set_params(x[lo:hi])
+        net.set_grads(dfdx[lo:hi])
+        net.set_adam_state(state["m"][lo:hi], state["v"][lo:hi])
+        net.adam_step(h, state["t"])
+        x[lo:hi] = net.get_params()
+        state["m"][lo:hi], state["v"][lo:hi] = net.adam_state()
     return x, [fx]

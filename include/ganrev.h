@@ -47,7 +47,10 @@ enum {
   GR_UPSAMPLE2 = 11,       /* nn.SpatialUpSamplingNearest(2)                                     models.lua:121,127 */
   GR_VIEW = 12,            /* nn.View(a[,b,c])                                                   models.lua:118,446 */
   GR_LINEAR = 13,          /* nn.Linear(a=in, b=out)                                             models.lua:115,447,451 */
-  GR_FULLCONV3 = 14        /* nn.SpatialFullConvolution(a,b,3,3,1,1,1,1) (north_star names it; absent from the reference) */
+  GR_FULLCONV3 = 14,       /* nn.SpatialFullConvolution(a,b,3,3,1,1,1,1) (north_star names it; absent from the reference) */
+  /* the module types the D network adds (models.lua:272-337 create_D2, trained by adversarial.lua:37-205) */
+  GR_CONVK = 15,           /* nn.SpatialConvolution(a, b, c=K, K, 1, 1, (K-1)/2, (K-1)/2), K = 5           models.lua:275,290 */
+  GR_PRELU = 16            /* nn.PReLU(): one learnable slope (nOutputPlane 0) in the flat vector; the host mirror starts it at 0.25  models.lua:276 */
 };
 #define GR_DROPOUT_V2 1         /* nn.Dropout default: train-time scale 1/(1-p), identity in evaluate() */
 #define GR_DROPOUT_ALWAYS_ON 2  /* the fixer's `drop.evaluate = function() end` (models.lua:402-405) */

@@ -39,7 +39,10 @@ enum {
   GO_UPSAMPLE2 = 11,   /* nn.SpatialUpSamplingNearest(2) */
   GO_VIEW = 12,        /* nn.View(a[,b,c]) */
   GO_LINEAR = 13,      /* nn.Linear(a=in, b=out) */
-  GO_FULLCONV3 = 14    /* nn.SpatialFullConvolution(a=Cin, b=Cout, 3,3,1,1,1,1) (north_star extra) */
+  GO_FULLCONV3 = 14,   /* nn.SpatialFullConvolution(a=Cin, b=Cout, 3,3,1,1,1,1) (north_star extra) */
+  /* the D network's extra module types (models.lua:272-337 create_D2) */
+  GO_CONVK = 15,       /* nn.SpatialConvolution(a=Cin, b=Cout, c=K, K, 1, 1, (K-1)/2, (K-1)/2), K odd (models.lua:275) */
+  GO_PRELU = 16        /* nn.PReLU(): ONE learnable slope shared by every element (nOutputPlane = 0), initial value 0.25 (models.lua:276) */
 };
 #define GO_DROPOUT_V2 1
 #define GO_DROPOUT_ALWAYS_ON 2
@@ -54,6 +57,9 @@ void go_conv3_backward_data(const float* gout, const float* w, float* gin,
                             int B, int Cin, int Cout, int H, int W);
 void go_conv3_backward_weight(const float* in, const float* gout, float* gw, float* gb,
                               int B, int Cin, int Cout, int H, int W); /* accumulates (+=) */
+void go_convk_forward(const float* in, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W, int K);
+void go_convk_backward_data(const float* gout, const float* w, float* gin, int B, int Cin, int Cout, int H, int W, int K);
+void go_convk_backward_weight(const float* in, const float* gout, float* gw, float* gb, int B, int Cin, int Cout, int H, int W, int K); /* += */
 void go_linear_forward(const float* in, const float* w, const float* bias, float* out, int B, int I, int O);
 void go_linear_backward_data(const float* gout, const float* w, float* gin, int B, int I, int O);
 void go_linear_backward_weight(const float* in, const float* gout, float* gw, float* gb, int B, int I, int O);
@@ -89,7 +95,7 @@ int go_net_backward(go_net*, const float* in, const float* gout, int B, float* g
  * given one (NULL: compute it again).  Parity-test hooks: see oracle_net.c. */
 int64_t go_net_get_pool_index(const go_net*, int layer_index, uint8_t* out /*nullable: returns the count*/, int64_t cap);
 int go_net_force_pool_index(go_net*, int layer_index, const uint8_t* idx /*nullable*/, int64_t n);
-int go_net_force_act_side(go_net* n, int li, const uint8_t* side, int64_t cnt);   /* ReLU / LeakyReLU: side of the kink to USE in backward (test hook) */
+int go_net_force_act_side(go_net* n, int li, const uint8_t* side, int64_t cnt);   /* ReLU / LeakyReLU / PReLU: side of the kink to USE in backward (test hook) */
 /* intermediate module outputs, for layer-by-layer debugging of the HIP path */
 const float* go_net_layer_output(const go_net*, int layer_index, int64_t* n);
 

@@ -82,6 +82,9 @@ def lib():
         L.go_conv3_forward.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
         L.go_conv3_backward_data.argtypes = [_P, _P, _P] + [C.c_int] * 5
         L.go_conv3_backward_weight.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
+        L.go_convk_forward.argtypes = [_P, _P, _P, _P] + [C.c_int] * 6
+        L.go_convk_backward_data.argtypes = [_P, _P, _P] + [C.c_int] * 6
+        L.go_convk_backward_weight.argtypes = [_P, _P, _P, _P] + [C.c_int] * 6
         L.go_linear_forward.argtypes = [_P, _P, _P, _P] + [C.c_int] * 3
         L.go_linear_backward_data.argtypes = [_P, _P, _P] + [C.c_int] * 3
         L.go_linear_backward_weight.argtypes = [_P, _P, _P, _P] + [C.c_int] * 3
@@ -312,6 +315,35 @@ def conv3_backward_weight(x, gout):
     gw = np.zeros((Cout, Cin, 3, 3), np.float32)
     gb = np.zeros(Cout, np.float32)
     lib().go_conv3_backward_weight(_p(x), _p(gout), _p(gw), _p(gb), B, Cin, Cout, H, W)
+    return gw, gb
+
+
+def convk_forward(x, w, b):
+    """nn.SpatialConvolution(Cin, Cout, K, K, 1, 1, (K-1)/2, (K-1)/2) with the window size taken from w."""
+    x, w = f32(x), f32(w)
+    B, Cin, H, W = x.shape
+    Cout, K = w.shape[0], w.shape[2]
+    out = np.empty((B, Cout, H, W), np.float32)
+    lib().go_convk_forward(_p(x), _p(w), _p(f32(b)) if b is not None else None, _p(out), B, Cin, Cout, H, W, K)
+    return out
+
+
+def convk_backward_data(gout, w):
+    gout, w = f32(gout), f32(w)
+    B, Cout, H, W = gout.shape
+    Cin, K = w.shape[1], w.shape[2]
+    gin = np.empty((B, Cin, H, W), np.float32)
+    lib().go_convk_backward_data(_p(gout), _p(w), _p(gin), B, Cin, Cout, H, W, K)
+    return gin
+
+
+def convk_backward_weight(x, gout, K):
+    x, gout = f32(x), f32(gout)
+    B, Cin, H, W = x.shape
+    Cout = gout.shape[1]
+    gw = np.zeros((Cout, Cin, K, K), np.float32)
+    gb = np.zeros(Cout, np.float32)
+    lib().go_convk_backward_weight(_p(x), _p(gout), _p(gw), _p(gb), B, Cin, Cout, H, W, K)
     return gw, gb
 
 

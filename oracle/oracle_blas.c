@@ -114,6 +114,110 @@ void go_conv3_backward_weight(const float* in, const float* gout, float* gw, flo
   }
 }
 
+/* ---- nn.SpatialConvolution(Cin, Cout, K, K, 1, 1, (K-1)/2, (K-1)/2), K odd: the D network's 5x5 layer (models.lua:275,290 createNxN;
+ * SURVEY.md 8f rank 4).  Same loops as the 3x3 functions above with the window size a parameter; THNN evaluates it as im2col +
+ * sgemm per sample (SpatialConvolutionMM), so parity is tolerance-based here too. ---- */
+void go_convk_forward(const float* in, const float* w, const float* bias, float* out,
+                      int B, int Cin, int Cout, int H, int W, int K) {
+  const long HW = (long)H * W; const int P = (K - 1) / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int o = 0; o < Cout; ++o) {
+      float* op = out + ((long)b * Cout + o) * HW;
+      const float bv = bias ? bias[o] : 0.f;
+      for (long p = 0; p < HW; ++p) op[p] = bv;
+      for (int i = 0; i < Cin; ++i) {
+        const float* ip = in + ((long)b * Cin + i) * HW;
+        const float* wp = w + ((long)o * Cin + i) * K * K;
+        for (int ky = 0; ky < K; ++ky) {
+          const int y0 = P - ky > 0 ? P - ky : 0, y1 = H + P - ky < H ? H + P - ky : H;
+          for (int kx = 0; kx < K; ++kx) {
+            const int x0 = P - kx > 0 ? P - kx : 0, x1 = W + P - kx < W ? W + P - kx : W;
+            const float wv = wp[ky * K + kx];
+            for (int y = y0; y < y1; ++y) {
+              float* orow = op + (long)y * W;
+              const float* irow = ip + (long)(y + ky - P) * W + (kx - P);
+#pragma omp simd
+              for (int x = x0; x < x1; ++x) orow[x] += wv * irow[x];
+            }
+          }
+        }
+      }
+    }
+}
+
+void go_convk_backward_data(const float* gout, const float* w, float* gin,
+                            int B, int Cin, int Cout, int H, int W, int K) {
+  const long HW = (long)H * W; const int P = (K - 1) / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < Cin; ++i) {
+      float* gi = gin + ((long)b * Cin + i) * HW;
+      memset(gi, 0, sizeof(float) * HW);
+      for (int o = 0; o < Cout; ++o) {
+        const float* go = gout + ((long)b * Cout + o) * HW;
+        const float* wp = w + ((long)o * Cin + i) * K * K;
+        for (int ky = 0; ky < K; ++ky) {
+          const int y0 = P - ky > 0 ? P - ky : 0, y1 = H + P - ky < H ? H + P - ky : H;
+          for (int kx = 0; kx < K; ++kx) {
+            const int x0 = P - kx > 0 ? P - kx : 0, x1 = W + P - kx < W ? W + P - kx : W;
+            const float wv = wp[ky * K + kx];
+            for (int y = y0; y < y1; ++y) {
+              const float* grow = go + (long)y * W;
+              float* irow = gi + (long)(y + ky - P) * W + (kx - P);
+#pragma omp simd
+              for (int x = x0; x < x1; ++x) irow[x] += wv * grow[x];
+            }
+          }
+        }
+      }
+    }
+}
+
+void go_convk_backward_weight(const float* in, const float* gout, float* gw, float* gb,
+                              int B, int Cin, int Cout, int H, int W, int K) {
+  const long HW = (long)H * W; const int P = (K - 1) / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int o = 0; o < Cout; ++o)
+    for (int i = 0; i < Cin; ++i) {
+      float* g = gw + ((long)o * Cin + i) * K * K;
+      for (int ky = 0; ky < K; ++ky) {
+        const int y0 = P - ky > 0 ? P - ky : 0, y1 = H + P - ky < H ? H + P - ky : H;
+        for (int kx = 0; kx < K; ++kx) {
+          const int x0 = P - kx > 0 ? P - kx : 0, x1 = W + P - kx < W ? W + P - kx : W;
+          float acc = 0.f;
+          for (int b = 0; b < B; ++b) {
+            const float* go = gout + ((long)b * Cout + o) * HW;
+            const float* ip = in + ((long)b * Cin + i) * HW;
+            float s = 0.f;
+            for (int y = y0; y < y1; ++y) {
+              const float* grow = go + (long)y * W;
+              const float* irow = ip + (long)(y + ky - P) * W + (kx - P);
+#pragma omp simd reduction(+ : s)
+              for (int x = x0; x < x1; ++x) s += grow[x] * irow[x];
+            }
+            acc += s;
+          }
+          g[ky * K + kx] += acc;
+        }
+      }
+    }
+  if (gb) {
+#pragma omp parallel for schedule(static)
+    for (int o = 0; o < Cout; ++o) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const float* go = gout + ((long)b * Cout + o) * HW;
+        float sb = 0.f;
+#pragma omp simd reduction(+ : sb)
+        for (long p = 0; p < HW; ++p) sb += go[p];
+        s += sb;
+      }
+      gb[o] += s;
+    }
+  }
+}
+
 /* y = x W^T + b   with W[out][in]  (nn.Linear:updateOutput) */
 void go_linear_forward(const float* in, const float* w, const float* bias, float* out, int B, int I, int O) {
 #pragma omp parallel for collapse(2) schedule(static)

@@ -150,6 +150,12 @@ go_net* go_net_create(const go_layer* layers, int n_layers, int C, int H, int W)
         if (l->d.a != c) goto fail;
         l->w_off = off; l->w_n = (int64_t)l->d.a * l->d.b * 9; off += l->w_n;
         l->b_off = off; l->b_n = l->d.b; off += l->b_n; c = l->d.b; break;
+      case GO_CONVK:
+        if (l->d.a != c || l->d.c < 1 || l->d.c % 2 == 0) goto fail;
+        l->w_off = off; l->w_n = (int64_t)l->d.a * l->d.b * l->d.c * l->d.c; off += l->w_n;
+        l->b_off = off; l->b_n = l->d.b; off += l->b_n; c = l->d.b; break;
+      case GO_PRELU:          /* nn.PReLU(): weight = Tensor(1) (nOutputPlane 0) */
+        l->w_off = off; l->w_n = 1; off += 1; l->b_off = off; l->b_n = 0; break;
       case GO_LINEAR:
         if (l->d.a != vol(c, h, w)) goto fail;
         l->w_off = off; l->w_n = (int64_t)l->d.a * l->d.b; off += l->w_n;
@@ -249,7 +255,7 @@ int go_net_force_pool_index(go_net* n, int li, const uint8_t* idx, int64_t cnt) 
  * correct fp32 implementations, and the derivative jumps there (by gout * (1 - slope)).  side[k] = 1: treat input k as
  * positive in the backward pass; NULL: back to the input's own sign. */
 int go_net_force_act_side(go_net* n, int li, const uint8_t* side, int64_t cnt) {
-  if (li < 0 || li >= n->n || (n->L[li].d.kind != GO_RELU && n->L[li].d.kind != GO_LEAKYRELU)) return -1;
+  if (li < 0 || li >= n->n || (n->L[li].d.kind != GO_RELU && n->L[li].d.kind != GO_LEAKYRELU && n->L[li].d.kind != GO_PRELU)) return -1;
   olayer* l = &n->L[li];
   free(l->forced_idx); l->forced_idx = NULL; l->forced_n = 0;
   if (side) { l->forced_idx = (uint8_t*)malloc(cnt); memcpy(l->forced_idx, side, cnt); l->forced_n = cnt; }
@@ -308,6 +314,13 @@ int go_net_forward(go_net* net, const float* in, int B, float* out_host) {
       case GO_LEAKYRELU:
         for (int64_t k = 0; k < nin; ++k) y[k] = x[k] > 0 ? x[k] : x[k] * l->d.p;
         break;
+      case GO_CONVK:
+        go_convk_forward(x, net->params + l->w_off, net->params + l->b_off, y, B, l->inC, l->outC, l->inH, l->inW, l->d.c);
+        break;
+      case GO_PRELU: {   /* THNN PReLU.c updateOutput, nOutputPlane == 0: x > 0 ? x : w[0] * x */
+        const float w0 = net->params[l->w_off];
+        for (int64_t k = 0; k < nin; ++k) y[k] = x[k] > 0 ? x[k] : w0 * x[k];
+        break; }
       case GO_SIGMOID:
         for (int64_t k = 0; k < nin; ++k) y[k] = 1.f / (1.f + expf(-x[k]));
         break;
@@ -406,6 +419,24 @@ int go_net_backward(go_net* net, const float* in, const float* gout, int B, floa
         if (l->forced_idx && l->forced_n == nin) { for (int64_t k = 0; k < nin; ++k) gi[k] = l->forced_idx[k] ? g[k] : g[k] * l->d.p; break; }
         for (int64_t k = 0; k < nin; ++k) gi[k] = x[k] > 0 ? g[k] : g[k] * l->d.p;
         break;
+      case GO_CONVK:
+        if (i > 0 || gin_host) go_convk_backward_data(g, net->params + l->w_off, gi, B, l->inC, l->outC, l->inH, l->inW, l->d.c);
+        go_convk_backward_weight(x, g, net->grads + l->w_off, net->grads + l->b_off, B, l->inC, l->outC, l->inH, l->inW, l->d.c);
+        break;
+      case GO_PRELU: {
+        /* THNN PReLU.c, nOutputPlane == 0.  updateGradInput: x > 0 ? gout : w[0] * gout.  accGradParameters: gradWeight[0] +=
+         * scale * sum over the elements with x <= 0 of gout * x (upstream sums in `real`; here in double: the parity bar is a
+         * tolerance either way).  forced side (test hook): which elements count as positive. */
+        const float w0 = net->params[l->w_off];
+        const int forced = l->forced_idx && l->forced_n == nin;
+        double sum = 0;
+        for (int64_t k = 0; k < nin; ++k) {
+          const int pos = forced ? l->forced_idx[k] != 0 : x[k] > 0;
+          gi[k] = pos ? g[k] : w0 * g[k];
+          if (!pos) sum += (double)(g[k] * x[k]);
+        }
+        net->grads[l->w_off] += (float)sum;
+        break; }
       case GO_SIGMOID:
         for (int64_t k = 0; k < nin; ++k) gi[k] = g[k] * (1.f - yout[k]) * yout[k];
         break;

@@ -118,17 +118,20 @@ def adopt_device_kinks(model, onet, B, max_flips):
     leaves = model.leaves()
     flips = []
     for i, m in enumerate(leaves):
-        if m.typename not in ("nn.ReLU", "nn.LeakyReLU"):
+        if m.typename not in ("nn.ReLU", "nn.LeakyReLU", "nn.PReLU"):
             continue
         li = onet.layer_index[id(m)]
         z = onet.layer_output(li - 1)
         own = z > 0
         lj = li + 1 if i + 1 < len(leaves) and leaves[i + 1].typename in ("nn.Dropout", "nn.SpatialDropout") else li
+        if m.typename == "nn.PReLU":        # closes its stage on the device: its own output is kept (slope > 0: same sign as the input)
+            lj = li
+            assert float(m.weight[0]) > 0
         try:
             dev = model._net.layer_output(lj, (z.size,))
         except L.GanrevError:
             continue
-        side = np.where(dev != 0, dev > 0, own if m.typename == "nn.LeakyReLU" or lj != li else False)
+        side = np.where(dev != 0, dev > 0, own if m.typename != "nn.ReLU" or lj != li else False)
         diff = np.nonzero(side != own)[0]
         if diff.size:
             assert np.abs(z[diff]).max() < NEAR_TIE, (f"activation layer {li}: {diff.size} inputs on the other side of zero, "
@@ -174,3 +177,84 @@ def assert_grads_close(model, got, ref, rtol=1e-4, floor=1e-3, what=""):
             continue
         d = maxdiff(g, r)
         assert d <= rtol * gmax, f"{what} {mod.typename}.{nm} [{lo}:{hi}]: max |diff| {d:.3e} vs module max |g| {gmax:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Oracle twin of a model that runs as several compiled parts (an nn.Concat inside: the D network, models.lua:272-337).  The
+# oracle's go_net is a plain nn.Sequential, so the twin is one oracle net per compiled chunk of the ganrev model, chained on the
+# host the way nn.Sequential / nn.Concat chain their children (the same composition rule the host mirror implements).
+class OracleGraph:
+    def __init__(self, oracle, model, in_dims):
+        self.pairs = []          # (ganrev chunk, oracle net) in getParameters() order
+        self.plan, self.out_dims = self._plan(oracle, model, tuple(in_dims))
+        self.cache = {}
+
+    def _plan(self, oracle, node, dims):
+        from ganrev import nn
+        if isinstance(node, nn.Concat):
+            plans, outs = [], []
+            for b in node.modules:
+                pl, od = self._plan(oracle, b, dims)
+                plans.append(pl); outs.append(od)
+            ax = node.dimension - 2
+            od = list(outs[0]); od[ax] = sum(o[ax] for o in outs)
+            return ("concat", node.dimension - 1, plans), tuple(od)
+        if node._is_graph():
+            seq = []
+            for p in node.parts():
+                pl, dims = self._plan(oracle, p, dims)
+                seq.append(pl)
+            return ("seq", seq), dims
+        onet = oracle.from_model(node, dims)
+        self.pairs.append((node, onet))
+        d = dims
+        for m in node.leaves():
+            _, d = m.desc(d)
+        return ("net", onet), d
+
+    def set_training(self, t):
+        for _, o in self.pairs:
+            o.set_training(t)
+
+    def zero_grads(self):
+        for _, o in self.pairs:
+            o.zero_grads()
+
+    @property
+    def grads(self):
+        return np.concatenate([o.grads for _, o in self.pairs])
+
+    def forward(self, x):
+        return self._fwd(self.plan, np.ascontiguousarray(x, np.float32))
+
+    def _fwd(self, plan, x):
+        self.cache[id(plan)] = x
+        if plan[0] == "net":
+            return np.array(plan[1].forward(x), copy=True)
+        if plan[0] == "seq":
+            for p in plan[1]:
+                x = self._fwd(p, x)
+            return x
+        outs = [self._fwd(p, x) for p in plan[2]]
+        self.cache[(id(plan), "sizes")] = [o.shape[plan[1]] for o in outs]
+        return np.concatenate(outs, axis=plan[1])
+
+    def backward(self, x, gout):
+        return self._bwd(self.plan, np.ascontiguousarray(gout, np.float32))
+
+    def _bwd(self, plan, g):
+        x = self.cache[id(plan)]
+        if plan[0] == "net":
+            return np.array(plan[1].backward(x, g), copy=True)
+        if plan[0] == "seq":
+            for p in reversed(plan[1]):
+                g = self._bwd(p, g)
+            return g
+        lo, gin = 0, None
+        for p, k in zip(plan[2], self.cache[(id(plan), "sizes")]):
+            sl = [slice(None)] * g.ndim
+            sl[plan[1]] = slice(lo, lo + k)
+            gi = self._bwd(p, np.ascontiguousarray(g[tuple(sl)]))
+            gin = gi if gin is None else gin + gi
+            lo += k
+        return gin

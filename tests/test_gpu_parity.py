@@ -1230,3 +1230,92 @@ def test_train_r_uniform_noise_targets(ctx):
     # both loops start near E[(tanh(~0) - u)^2] ~ var(U(-1,1)) = 1/3, far below the ~1 a N(0,1) target would give
     assert 0.2 < fast[0] < 0.6 and 0.2 < compat[0] < 0.6, (fast[0], compat[0])
     assert np.mean(fast[-10:]) < 0.9 * np.mean(fast[:5])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the module types the D network adds (models.lua:272-337) and the network itself
+def _d_chain(kind):
+    from ganrev import nn
+    if kind == "small":       # odd channel counts, planes smaller than a tile
+        return (nn.Sequential().add(nn.SpatialConvolution(2, 6, 3, 3, 1, 1, 1, 1)).add(nn.PReLU())
+                .add(nn.SpatialConvolution(6, 4, 5, 5, 1, 1, 2, 2)).add(nn.PReLU()).add(nn.SpatialDropout(0.25)).add(nn.SpatialMaxPooling(2, 2))
+                .add(nn.View(4 * 4 * 4)).add(nn.Linear(64, 5)).add(nn.PReLU()).add(nn.Linear(5, 1)).add(nn.Sigmoid())), (2, 8, 8)
+    if kind == "bn":          # a PReLU behind a BatchNorm opens a stage of its own; 5x5 on a plane wider than one tile
+        return (nn.Sequential().add(nn.SpatialConvolution(3, 16, 5, 5, 1, 1, 2, 2)).add(nn.SpatialBatchNormalization(16)).add(nn.PReLU())
+                .add(nn.Dropout(0.5)).add(nn.SpatialConvolution(16, 8, 3, 3, 1, 1, 1, 1)).add(nn.PReLU()).add(nn.SpatialMaxPooling(2, 2))
+                .add(nn.View(8 * 12 * 10)).add(nn.Linear(8 * 12 * 10, 3))), (3, 24, 20)
+    # the D network's own 5x5 layer (models.lua:290) at 32x32 images: createNxN(128, 64, 5, 0.2) on 16x16 planes
+    return (nn.Sequential().add(nn.SpatialConvolution(16, 128, 3, 3, 1, 1, 1, 1)).add(nn.PReLU())
+            .add(nn.SpatialConvolution(128, 64, 5, 5, 1, 1, 2, 2)).add(nn.PReLU()).add(nn.SpatialDropout(0.25)).add(nn.SpatialMaxPooling(2, 2))
+            .add(nn.View(64 * 8 * 8)).add(nn.Linear(64 * 8 * 8, 32)).add(nn.PReLU()).add(nn.Dropout(0.25)).add(nn.Linear(32, 1)).add(nn.Sigmoid())), (16, 16, 16)
+
+
+@pytest.mark.parametrize("kind,B", [("small", 3), ("bn", 4), ("d2_left", 6)])
+def test_5x5_convolution_and_prelu_vs_oracle(oracle, conv_mode, kind, B):
+    """nn.SpatialConvolution(.., 5, 5, 1, 1, 2, 2) and nn.PReLU() (one learnable slope, a parameter in the flat vector) inside
+    nn.Sequential: forward (training and evaluate), gradInput and every gradient tensor - the 5x5 weights and each PReLU's slope
+    included - against the oracle, three arithmetics for the 3x3 / Linear layers around them."""
+    from ganrev import synth
+    from helpers import adopt_device_argmax, adopt_device_kinks, assert_grads_close
+    net, dims = _d_chain(kind)
+    synth.init_params(net, 41)
+    for k, m in enumerate(m for m in net.leaves() if m.typename == "nn.PReLU"):
+        m.weight[0] = np.float32(0.25 + 0.125 * k)
+    flat, grads = net.getParameters()
+    onet = oracle.from_model(net, dims)
+    x = synth.normal((B,) + dims, 43)
+    net.training(); onet.set_training(True)
+    inject_noise(net, onet, B, 6)
+    ref = onet.forward(x)
+    out = net.forward(x)
+    assert_close(out, ref, TOL * max(1.0, float(np.abs(ref).max())), "forward (training)")
+    adopt_device_argmax(net, onet, B, 8)
+    adopt_device_kinks(net, onet, B, 8)
+    gy = synth.normal(ref.shape, 9) * np.float32(0.5)
+    grads[...] = 0; onet.zero_grads()
+    gin = net.backward(x, gy)
+    ref_gin = onet.backward(x, gy)
+    assert_close(gin, ref_gin, TOL * max(1.0, float(np.abs(ref_gin).max())), "gradInput")
+    assert_grads_close(net, grads, onet.grads, 1e-4, 1e-3)
+    slopes = [(lo, m) for m, nm, lo, hi in __import__("helpers").param_segments(net) if m.typename == "nn.PReLU"]
+    assert slopes and max(abs(float(onet.grads[lo])) for lo, _ in slopes) > 1e-3, "no PReLU slope gradient large enough for the bar to see"
+    __import__("helpers").release_argmax(net, onet)
+    net.evaluate(); onet.set_training(False)
+    ref_e = onet.forward(x)
+    assert_close(net.forward(x), ref_e, TOL * max(1.0, float(np.abs(ref_e).max())), "forward (evaluate)")
+
+
+@pytest.mark.parametrize("dims,B", [((1, 32, 32), 6), ((3, 32, 32), 4)])
+def test_D2_forward_backward_vs_oracle(oracle, conv_mode, dims, B):
+    """MODEL_D = models.create_D2 (models.lua:272-337): nn.Concat(2) of the 5x5 tower and the deeper 3x3 tower, run as four
+    compiled parts chained on the host.  Output, gradInput w.r.t. the images (what adversarial.lua:113-118 hands to G) and the
+    whole flat gradient in getParameters() order against the oracle composed the same way."""
+    from ganrev import models, synth
+    from helpers import OracleGraph, adopt_device_argmax, adopt_device_kinks, assert_grads_close
+    D = models.create_D2(dims, seed=3); synth.init_params(D, 19)
+    flat, grads = D.getParameters()
+    assert [type(p).__name__ for p in D.parts()] == ["Sequential", "Concat", "Sequential"]
+    og = OracleGraph(oracle, D, dims)
+    assert sum(o.params.size for _, o in og.pairs) == flat.size and len(og.pairs) == 4
+    x = synth.uniform((B,) + dims, 5, 0, 1)
+    D.training(); og.set_training(True)
+    for chunk, onet in og.pairs:
+        inject_noise(chunk, onet, B, 11)
+    ref = og.forward(x)
+    out = D.forward(x)
+    assert out.shape == (B, 1) and ref.min() > 0 and ref.max() < 1
+    assert_close(out, ref, TOL, "D(x) (training)")
+    for chunk, onet in og.pairs:
+        adopt_device_argmax(chunk, onet, B, 16)
+        adopt_device_kinks(chunk, onet, B, 16)
+    gy = synth.normal(ref.shape, 9)
+    grads[...] = 0; og.zero_grads()
+    gin = D.backward(x, gy)
+    ref_gin = og.backward(x, gy)
+    assert gin.shape == x.shape
+    assert_close(gin, ref_gin, TOL * max(1.0, float(np.abs(ref_gin).max())), "gradInput w.r.t. the images")
+    assert_grads_close(D, grads, og.grads, 1e-4, 1e-3)
+    for chunk, onet in og.pairs:
+        __import__("helpers").release_argmax(chunk, onet)
+    D.evaluate(); og.set_training(False)
+    assert_close(D.forward(x), og.forward(x), TOL, "D(x) (evaluate)")

@@ -105,7 +105,12 @@ def test_synth_is_deterministic_and_sane():
 
 def test_unsupported_geometries_raise():
     with pytest.raises(L.GanrevError):
-        nn.SpatialConvolution(3, 8, 5, 5, 1, 1, 2, 2)
+        nn.SpatialConvolution(3, 8, 7, 7, 1, 1, 3, 3)
+    with pytest.raises(L.GanrevError):
+        nn.SpatialConvolution(3, 8, 5, 5, 1, 1, 1, 1)          # 5x5 only with the D network's padding (models.lua:275)
+    with pytest.raises(L.GanrevError):
+        nn.SpatialFullConvolution(3, 8, 5, 5, 1, 1, 2, 2)
+    assert nn.SpatialConvolution(3, 8, 5, 5, 1, 1, 2, 2).weight.shape == (8, 3, 5, 5)
     with pytest.raises(L.GanrevError):
         nn.SpatialMaxPooling(3, 3)
     with pytest.raises(L.GanrevError):

@@ -27,6 +27,23 @@ def test_conv3_ops(oracle, B, Cin, Cout, H, W):
     assert_close(ogb, gb.numpy(), 1e-4 * max(1, np.abs(gb.numpy()).max()), "conv backward-bias")
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,K", [(2, 3, 5, 6, 7, 5), (2, 16, 8, 16, 16, 5), (1, 4, 3, 9, 8, 7), (2, 3, 4, 5, 5, 3)])
+def test_convk_ops(oracle, B, Cin, Cout, H, W, K):
+    """nn.SpatialConvolution(.., K, K, 1, 1, (K-1)/2, (K-1)/2): the D network's 5x5 layer (models.lua:290)."""
+    x, w, b = synth.normal((B, Cin, H, W), 1), synth.uniform((Cout, Cin, K, K), 2, -0.3, 0.3), synth.uniform((Cout,), 3)
+    gy = synth.normal((B, Cout, H, W), 4)
+    xt, wt, bt = T(x).requires_grad_(True), T(w).requires_grad_(True), T(b).requires_grad_(True)
+    y = F.conv2d(xt, wt, bt, padding=(K - 1) // 2)
+    gx, gw, gb = torch.autograd.grad(y, (xt, wt, bt), T(gy))
+    assert_close(oracle.convk_forward(x, w, b), y.detach().numpy(), 5e-5, "KxK conv forward")
+    assert_close(oracle.convk_backward_data(gy, w), gx.numpy(), 5e-5, "KxK conv backward-data")
+    ogw, ogb = oracle.convk_backward_weight(x, gy, K)
+    assert_close(ogw, gw.numpy(), 1e-4 * max(1, np.abs(gw.numpy()).max()), "KxK conv backward-weight")
+    assert_close(ogb, gb.numpy(), 1e-4 * max(1, np.abs(gb.numpy()).max()), "KxK conv backward-bias")
+    if K == 3:      # the window-size-generic loops agree with the 3x3 functions the golden fixtures pin
+        assert np.array_equal(oracle.convk_forward(x, w, b), oracle.conv3_forward(x, w, b))
+
+
 def test_conv3_known_answer(oracle):
     # identity kernel (centre tap = 1) reproduces the input; a shifted delta reproduces a zero-padded shift
     x = synth.normal((1, 1, 5, 5), 7)
@@ -121,6 +138,30 @@ def test_fullconv_and_leakyrelu_extras(oracle):
     gy = synth.normal(out.shape, 5)
     onet.zero_grads(); onet.backward(x, gy)
     assert_close(onet.grads, twin.backward(gy), 1e-4, "SpatialFullConvolution gradients")
+
+
+def test_prelu_and_5x5_net(oracle):
+    """The D network's module types in one chain (models.lua:275-276,290): conv3 + PReLU + 5x5 conv + PReLU + SpatialDropout +
+    MaxPool + Linear + PReLU + Sigmoid, against float64 autograd - including the gradient of each PReLU's one shared slope."""
+    from ganrev import nn
+    m = (nn.Sequential().add(nn.SpatialConvolution(2, 6, 3, 3, 1, 1, 1, 1)).add(nn.PReLU())
+         .add(nn.SpatialConvolution(6, 4, 5, 5, 1, 1, 2, 2)).add(nn.PReLU()).add(nn.SpatialDropout(0.25)).add(nn.SpatialMaxPooling(2, 2))
+         .add(nn.View(4 * 4 * 4)).add(nn.Linear(64, 5)).add(nn.PReLU()).add(nn.Linear(5, 1)).add(nn.Sigmoid()))
+    synth.init_params(m, 6)
+    slopes = [mod for mod in m.leaves() if mod.typename == "nn.PReLU"]
+    assert all(float(mod.weight[0]) == 0.25 for mod in slopes)           # nn.PReLU's initial slope survives the init
+    for k, mod in enumerate(slopes):
+        mod.weight[0] = np.float32(0.25 + 0.1 * k)
+    onet, twin = _twin_and_oracle(oracle, m, (2, 8, 8), 3, True, 2)
+    x = synth.normal((3, 2, 8, 8), 3)
+    out = onet.forward(x)
+    assert_close(out, twin.forward(x), 1e-5, "conv + PReLU + 5x5 conv forward")
+    gy = synth.normal(out.shape, 5)
+    onet.zero_grads(); gin = onet.backward(x, gy)
+    ref = twin.backward(gy)
+    assert_close(onet.grads, ref, 1e-4 * max(1.0, np.abs(ref).max()), "gradients incl. the PReLU slopes")
+    off = 2 * 6 * 9 + 6
+    assert abs(ref[off]) > 1e-3 and abs(onet.grads[off] - ref[off]) <= 1e-4 * max(1.0, abs(ref[off]))     # first PReLU's slope
 
 
 def test_mse_and_adam(oracle):

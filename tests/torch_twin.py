@@ -6,6 +6,7 @@ import torch
 import torch.nn.functional as F
 
 CONV3, BN, ELU, RELU, LEAKYRELU, SIGMOID, TANH, DROPOUT, SPATIAL_DROPOUT, MAXPOOL2, UPSAMPLE2, VIEW, LINEAR, FULLCONV3 = range(1, 15)
+CONVK, PRELU = 15, 16
 
 
 class Twin:
@@ -24,6 +25,14 @@ class Twin:
                 wt = flat[off:off + a * b * 9].reshape(shape).clone().requires_grad_(True); off += a * b * 9
                 bs = flat[off:off + b].clone().requires_grad_(True); off += b
                 self.params.append((wt, bs))
+            elif k == CONVK:
+                kk = d[3]
+                wt = flat[off:off + a * b * kk * kk].reshape(b, a, kk, kk).clone().requires_grad_(True); off += a * b * kk * kk
+                bs = flat[off:off + b].clone().requires_grad_(True); off += b
+                self.params.append((wt, bs))
+            elif k == PRELU:
+                wt = flat[off:off + 1].clone().requires_grad_(True); off += 1
+                self.params.append((wt,))
             elif k == LINEAR:
                 wt = flat[off:off + a * b].reshape(b, a).clone().requires_grad_(True); off += a * b
                 bs = flat[off:off + b].clone().requires_grad_(True); off += b
@@ -47,6 +56,10 @@ class Twin:
                 x = F.conv2d(x, p[0], p[1], padding=1)
             elif k == FULLCONV3:
                 x = F.conv_transpose2d(x, p[0], p[1], stride=1, padding=1)
+            elif k == CONVK:
+                x = F.conv2d(x, p[0], p[1], padding=(d[3] - 1) // 2)
+            elif k == PRELU:
+                x = F.prelu(x, p[0])
             elif k == LINEAR:
                 x = F.linear(x.reshape(B, -1), p[0], p[1])
             elif k == BN:
