@@ -1,0 +1,171 @@
+"""Mirror of the reference's GAN game, adversarial.lua:1-205 (driven by train.lua:125-330) - SURVEY.md 8f rank 4.
+
+adversarial.train(env, trainData) plays one epoch: per batch, D is updated on half a batch of real and half a batch of
+generated images (fevalD, adversarial.lua:66-100), then G is updated through D (fevalG_on_D, adversarial.lua:104-133: G forward,
+D forward, BCE against "real", D backward to the images, G backward from D's gradInput).  The reference keeps its state in Lua
+globals (OPT, MODEL_D, MODEL_G, CRITERION, PARAMETERS_*, GRAD_PARAMETERS_*, OPTSTATE, CONFUSION, EPOCH ...); here the same
+names live on one `env` object (make_env builds it the way train.lua:125-200 does).
+
+Everything numeric runs on the GPU through libganrev.so: G and the compiled parts of D (ganrev.nn), nn.BCECriterion
+(gr_bce_host), optim.adam (gr_adam_step).  The penalty / clamp lines are host numpy on the flat vectors, as they are Torch
+tensor ops on the host-visible flat vectors in the reference.
+"""
+import types
+
+import numpy as np
+
+from . import _lib as L
+from . import nn, nn_utils, optim
+
+Y_GENERATOR = 0          # train.lua:67-68
+Y_NOT_GENERATOR = 1
+
+
+def clamp(gradParameters, clampValue):
+    """adversarial.lua:8-12"""
+    if clampValue != 0:
+        np.clip(gradParameters, -clampValue, clampValue, out=gradParameters)
+
+
+def l1(parameters, gradParameters, lossValue, l1weight):
+    """adversarial.lua:14-20.  The reference misspells its own argument in the gradient line (`l1Weight`, a nil global), so a
+    non-zero weight raises there; every shipped configuration has L1 = 0 (train.lua:29,31).  Implemented as evidently meant."""
+    if l1weight != 0:
+        lossValue = lossValue + l1weight * float(np.abs(parameters).sum(dtype=np.float64))
+        gradParameters += np.sign(parameters) * np.float32(l1weight)
+    return lossValue
+
+
+def l2(parameters, gradParameters, lossValue, l2weight):
+    """adversarial.lua:22-28"""
+    if l2weight != 0:
+        lossValue = lossValue + l2weight * float(np.dot(parameters.astype(np.float64), parameters.astype(np.float64))) / 2
+        gradParameters += parameters * np.float32(l2weight)
+    return lossValue
+
+
+def make_env(MODEL_G, MODEL_D, IMG_DIMENSIONS, **opt):
+    """The globals train.lua:125-200 sets up, with its option defaults (train.lua:27-38)."""
+    OPT = types.SimpleNamespace(batchSize=32, N_epoch=30, noiseDim=100, noiseMethod="normal", G_L1=0.0, G_L2=0.0, D_L1=0.0, D_L2=1e-4,
+                                D_iterations=1, G_iterations=1, D_clamp=1.0, G_clamp=5.0, D_optmethod="adam", G_optmethod="adam", seed=1)
+    for k, v in opt.items():
+        if not hasattr(OPT, k):
+            raise L.GanrevError(f"unknown option '{k}'")
+        setattr(OPT, k, v)
+    env = types.SimpleNamespace(OPT=OPT, MODEL_G=MODEL_G, MODEL_D=MODEL_D, IMG_DIMENSIONS=tuple(IMG_DIMENSIONS), EPOCH=1,
+                                Y_GENERATOR=Y_GENERATOR, Y_NOT_GENERATOR=Y_NOT_GENERATOR)
+    env.CRITERION = nn.BCECriterion()                                           # train.lua:173
+    env.PARAMETERS_D, env.GRAD_PARAMETERS_D = MODEL_D.getParameters()           # train.lua:176-177
+    env.PARAMETERS_G, env.GRAD_PARAMETERS_G = MODEL_G.getParameters()
+    env.CONFUSION = np.zeros((2, 2), np.int64)                                  # train.lua:180 optim.ConfusionMatrix: [predicted][target]
+    env.OPTSTATE = {"adam": {"D": {}, "G": {}}}                                 # train.lua:183-193
+    env.noise_counter = 0
+    MODEL_D.training(); MODEL_G.training()                                      # train.lua:133-134
+    return env
+
+
+def _noise(env, N):
+    env.noise_counter += 1
+    return nn_utils.createNoiseInputs(N, env.OPT.noiseDim, env.OPT.noiseMethod, seed=env.OPT.seed * 100003 + env.noise_counter)
+
+
+def createImages(env, N):
+    """NN_UTILS.createImages(N, false) (utils/nn_utils.lua:57-89): MODEL_G:forward on fresh noise, OPT.batchSize rows at a time."""
+    noise = _noise(env, N)
+    out = None
+    for lo in range(0, N, env.OPT.batchSize):
+        gen = env.MODEL_G.forward(noise[lo:lo + env.OPT.batchSize]).copy()
+        if out is None:
+            out = np.empty((N,) + gen.shape[1:], np.float32)
+        out[lo:lo + gen.shape[0]] = gen
+    return out
+
+
+def make_fevalD(env, inputs, targets):
+    """adversarial.lua:66-100: f(X) and df/dX of the discriminator on the batch (inputs, targets)."""
+    def fevalD(x):
+        if x is not env.PARAMETERS_D:
+            env.PARAMETERS_D[...] = x
+        env.GRAD_PARAMETERS_D[...] = 0                                          # :74
+        outputs = env.MODEL_D.forward(inputs)                                   # :79
+        f = env.CRITERION.forward(outputs, targets.reshape(outputs.shape))      # :80
+        df_do = env.CRITERION.backward(outputs, targets.reshape(outputs.shape)) # :83
+        env.MODEL_D.backward(inputs, df_do)                                     # :84
+        f = l1(env.PARAMETERS_D, env.GRAD_PARAMETERS_D, f, env.OPT.D_L1)        # :86-88
+        f = l2(env.PARAMETERS_D, env.GRAD_PARAMETERS_D, f, env.OPT.D_L2)
+        clamp(env.GRAD_PARAMETERS_D, env.OPT.D_clamp)
+        for i in range(outputs.shape[0]):                                       # :91-96
+            c = 1 if outputs[i][0] > 0.5 else 0
+            env.CONFUSION[c, int(targets[i])] += 1
+        return f, env.GRAD_PARAMETERS_D
+    return fevalD
+
+
+def make_fevalG_on_D(env, noiseInputs, targets):
+    """adversarial.lua:104-133: f(X) and df/dX of the generator, rated by D."""
+    def fevalG_on_D(x):
+        if x is not env.PARAMETERS_G:
+            env.PARAMETERS_G[...] = x
+        env.GRAD_PARAMETERS_G[...] = 0                                          # :110
+        samples = env.MODEL_G.forward(noiseInputs).copy()                       # :113
+        outputs = env.MODEL_D.forward(samples)                                  # :114
+        f = env.CRITERION.forward(outputs, targets.reshape(outputs.shape))      # :115
+        df_samples = env.CRITERION.backward(outputs, targets.reshape(outputs.shape))   # :119
+        env.MODEL_D.backward(samples, df_samples)                               # :120
+        df_do = env.MODEL_D.gradInput                                           # :121  MODEL_D.modules[1].gradInput
+        env.MODEL_G.backward(noiseInputs, df_do)                                # :124
+        f = l1(env.PARAMETERS_G, env.GRAD_PARAMETERS_G, f, env.OPT.G_L1)        # :126-128
+        f = l2(env.PARAMETERS_G, env.GRAD_PARAMETERS_G, f, env.OPT.G_L2)
+        clamp(env.GRAD_PARAMETERS_G, env.OPT.G_clamp)
+        return f, env.GRAD_PARAMETERS_G
+    return fevalG_on_D
+
+
+def _optimize(env, which, feval, params, model):
+    method = getattr(env.OPT, which + "_optmethod")
+    if method != "adam":         # adversarial.lua:156-171 / 183-198 list sgd|adagrad|adadelta|adamax|adam|rmsprop; adam is the default and the one with a kernel
+        raise L.GanrevError(f"Unknown optimizer method '{method}' chosen for {which}." if method not in
+                            ("sgd", "adagrad", "adadelta", "adamax", "rmsprop") else
+                            f"optimizer method '{method}' for {which}: only 'adam' (the default, train.lua:37-38) is implemented")
+    return optim.adam(feval, params, env.OPTSTATE["adam"][which], model=model)
+
+
+def train(env, trainData, quiet=True):
+    """adversarial.lua:37-205.  trainData: [N x C x H x W] real images; N >= N_epoch * batchSize/2 * D_iterations (train.lua:214)."""
+    OPT = env.OPT
+    batchSize, batchesPerEpoch = OPT.batchSize, OPT.N_epoch
+    if batchesPerEpoch <= 0:
+        batchesPerEpoch = 100                                                   # :42
+    exampleForDIdx = 0
+    nbExamplesD = nbExamplesG = 0
+    losses = {"D": [], "G": []}
+    if not quiet:
+        print("<trainer> Epoch #%d [batchSize = %d]" % (env.EPOCH, batchSize))
+    for batchIdx in range(1, batchesPerEpoch + 1):
+        inputs = np.empty((batchSize,) + env.IMG_DIMENSIONS, np.float32)        # :54-56
+        targets = np.empty(batchSize, np.float32)
+        for _ in range(OPT.D_iterations):                                       # (1) update D  :139-174
+            half = batchSize // 2
+            if exampleForDIdx + half > len(trainData):
+                raise IndexError("trainData exhausted (adversarial.lua:146 indexes past the loaded examples)")
+            inputs[:half] = trainData[exampleForDIdx:exampleForDIdx + half]     # :141-149
+            targets[:half] = env.Y_NOT_GENERATOR
+            exampleForDIdx += half
+            inputs[half:2 * half] = createImages(env, half)                     # :152-157
+            targets[half:2 * half] = env.Y_GENERATOR
+            _, fs = _optimize(env, "D", make_fevalD(env, inputs, targets), env.PARAMETERS_D, env.MODEL_D)
+            losses["D"].append(fs[0])
+            nbExamplesD += inputs.shape[0]
+        for _ in range(OPT.G_iterations):                                       # (2) update G  :178-201
+            noiseInputs = _noise(env, batchSize)
+            targets[...] = env.Y_NOT_GENERATOR
+            _, fs = _optimize(env, "G", make_fevalG_on_D(env, noiseInputs, targets), env.PARAMETERS_G, env.MODEL_G)
+            losses["G"].append(fs[0])
+            nbExamplesG += noiseInputs.shape[0]
+    if not quiet:
+        print("Trained G on: %d | Trained D on: %d" % (nbExamplesG, nbExamplesD))
+        print(env.CONFUSION)
+    tV = float(np.trace(env.CONFUSION)) / max(1, int(env.CONFUSION.sum()))     # :201 CONFUSION.totalValid
+    env.CONFUSION[...] = 0
+    env.last_losses = losses
+    return tV

@@ -118,7 +118,7 @@ def adopt_device_kinks(model, onet, B, max_flips):
     leaves = model.leaves()
     flips = []
     for i, m in enumerate(leaves):
-        if m.typename not in ("nn.ReLU", "nn.LeakyReLU", "nn.PReLU"):
+        if m.typename not in ("nn.ReLU", "cudnn.ReLU", "nn.LeakyReLU", "nn.PReLU"):      # cudnn.ReLU: G's activations (models.lua:117)
             continue
         li = onet.layer_index[id(m)]
         z = onet.layer_output(li - 1)
@@ -131,7 +131,7 @@ def adopt_device_kinks(model, onet, B, max_flips):
             dev = model._net.layer_output(lj, (z.size,))
         except L.GanrevError:
             continue
-        side = np.where(dev != 0, dev > 0, own if m.typename != "nn.ReLU" or lj != li else False)
+        side = np.where(dev != 0, dev > 0, own if not m.typename.endswith(".ReLU") or lj != li else False)
         diff = np.nonzero(side != own)[0]
         if diff.size:
             assert np.abs(z[diff]).max() < NEAR_TIE, (f"activation layer {li}: {diff.size} inputs on the other side of zero, "

@@ -1270,6 +1270,8 @@ def test_5x5_convolution_and_prelu_vs_oracle(oracle, conv_mode, kind, B):
     out = net.forward(x)
     assert_close(out, ref, TOL * max(1.0, float(np.abs(ref).max())), "forward (training)")
     adopt_device_argmax(net, onet, B, 8)
+    ref = onet.forward(x)                        # the oracle again, on the argmax the device took
+    assert_close(out, ref, TOL * max(1.0, float(np.abs(ref).max())), "forward vs the argmax-forced oracle")
     adopt_device_kinks(net, onet, B, 8)
     gy = synth.normal(ref.shape, 9) * np.float32(0.5)
     grads[...] = 0; onet.zero_grads()
@@ -1280,6 +1282,10 @@ def test_5x5_convolution_and_prelu_vs_oracle(oracle, conv_mode, kind, B):
     slopes = [(lo, m) for m, nm, lo, hi in __import__("helpers").param_segments(net) if m.typename == "nn.PReLU"]
     assert slopes and max(abs(float(onet.grads[lo])) for lo, _ in slopes) > 1e-3, "no PReLU slope gradient large enough for the bar to see"
     __import__("helpers").release_argmax(net, onet)
+    net.pull_params()                            # running statistics: the oracle's saw one more training forward than the device's
+    for bi, m in enumerate(m for m in net.leaves() if hasattr(m, "running_mean")):
+        rm, rv = onet.bn_running(bi)
+        rm[...] = m.running_mean; rv[...] = m.running_var
     net.evaluate(); onet.set_training(False)
     ref_e = onet.forward(x)
     assert_close(net.forward(x), ref_e, TOL * max(1.0, float(np.abs(ref_e).max())), "forward (evaluate)")
@@ -1307,15 +1313,109 @@ def test_D2_forward_backward_vs_oracle(oracle, conv_mode, dims, B):
     assert_close(out, ref, TOL, "D(x) (training)")
     for chunk, onet in og.pairs:
         adopt_device_argmax(chunk, onet, B, 16)
+    ref = og.forward(x)                          # the oracle again, on the argmax the device took
+    assert_close(out, ref, TOL, "D(x) vs the argmax-forced oracle")
+    for chunk, onet in og.pairs:
         adopt_device_kinks(chunk, onet, B, 16)
     gy = synth.normal(ref.shape, 9)
     grads[...] = 0; og.zero_grads()
     gin = D.backward(x, gy)
     ref_gin = og.backward(x, gy)
     assert gin.shape == x.shape
-    assert_close(gin, ref_gin, TOL * max(1.0, float(np.abs(ref_gin).max())), "gradInput w.r.t. the images")
+    assert_close(gin, ref_gin, TOL * float(np.abs(ref_gin).max()), "gradInput w.r.t. the images")
     assert_grads_close(D, grads, og.grads, 1e-4, 1e-3)
     for chunk, onet in og.pairs:
         __import__("helpers").release_argmax(chunk, onet)
     D.evaluate(); og.set_training(False)
     assert_close(D.forward(x), og.forward(x), TOL, "D(x) (evaluate)")
+
+
+def test_adversarial_step_vs_oracle(oracle, conv_mode):
+    """adversarial.lua:66-133, the two closures of the GAN game, each from the oracle's state: fevalD (D forward, BCE, D backward,
+    L2 + clamp) and fevalG_on_D (G forward in training mode, D forward, BCE against "real", D backward to the images, G backward
+    from D's gradInput, clamp) - loss and the whole flat gradient of D resp. G; then optim.adam on the four-part D (stepped
+    slice by slice) bit-exact against the oracle's Adam, and one epoch of adversarial.train end to end."""
+    from ganrev import adversarial, models, synth
+    from helpers import OracleGraph, adopt_device_argmax, adopt_device_kinks, assert_grads_close
+    dims, nd, B = (1, 32, 32), 16, 8
+    G = models.create_G(dims, nd, seed=1); synth.init_params(G, 2)
+    D = models.create_D2(dims, seed=2); synth.init_params(D, 3)
+    env = adversarial.make_env(G, D, dims, batchSize=B, noiseDim=nd, N_epoch=2)
+    oG = oracle.from_model(G, (nd, 1, 1)); oG.set_training(True)
+    og = OracleGraph(oracle, D, dims); og.set_training(True)
+    theta_d = np.concatenate([o.params for _, o in og.pairs])
+    assert np.array_equal(theta_d, env.PARAMETERS_D)
+
+    def inject(seed):
+        for chunk, onet in og.pairs:
+            inject_noise(chunk, onet, B, seed)
+
+    def adopt(x):
+        """the device's pool argmax onto the oracle, the oracle's forward again on it, then the device's side of every kink"""
+        for chunk, onet in og.pairs:
+            adopt_device_argmax(chunk, onet, B, 16)
+        ref = og.forward(x)
+        for chunk, onet in og.pairs:
+            adopt_device_kinks(chunk, onet, B, 16)
+        return ref
+
+    # ---- fevalD on half real, half generated images
+    inputs = np.concatenate([synth.uniform((B // 2,) + dims, 7, 0, 1), oG.forward(synth.normal((B // 2, nd), 8))]).astype(np.float32)
+    targets = np.concatenate([np.ones(B // 2, np.float32), np.zeros(B // 2, np.float32)])
+    inject(21)
+    ref_out = og.forward(inputs)
+    assert_close(D.forward(inputs), ref_out, TOL, "D(inputs)")
+    ref_out = adopt(inputs)
+    inject(21)
+    f, g = adversarial.make_fevalD(env, inputs, targets)(env.PARAMETERS_D)
+    rf, rdf = oracle.bce(ref_out.reshape(-1), targets)
+    og.zero_grads(); og.backward(inputs, rdf.reshape(ref_out.shape))
+    rg = og.grads + theta_d * np.float32(env.OPT.D_L2)
+    np.clip(rg, -env.OPT.D_clamp, env.OPT.D_clamp, out=rg)
+    rf += env.OPT.D_L2 * float(np.dot(theta_d.astype(np.float64), theta_d.astype(np.float64))) / 2
+    assert abs(f - rf) <= 1e-5 * max(1.0, abs(rf)), f"fevalD loss {f} vs {rf}"
+    assert_grads_close(D, g, rg, 1e-4, 1e-3, "fevalD")
+    assert env.CONFUSION.sum() == B
+
+    # ---- optim.adam on a model that runs as several gr_nets: slice-by-slice update == one Adam over the flat vector
+    theta0, g0 = env.PARAMETERS_D.copy(), g.copy()
+    state = {}
+    from ganrev import optim
+    optim.adam(lambda x: (f, g0), env.PARAMETERS_D, state, model=D)
+    m, v = np.zeros_like(theta0), np.zeros_like(theta0)
+    rtheta, rgc = theta0.copy(), g0.copy()
+    oracle.penalty_clamp_adam(rtheta, rgc, m, v, oracle.GoHyper(l1=0.0, l2=0.0, clamp=0.0), 1)
+    assert np.array_equal(env.PARAMETERS_D, rtheta) and np.array_equal(state["m"], m) and np.array_equal(state["v"], v)
+    env.PARAMETERS_D[...] = theta0
+
+    # ---- fevalG_on_D
+    for chunk, onet in og.pairs:
+        __import__("helpers").release_argmax(chunk, onet)
+    noise = synth.normal((B, nd), 31)
+    ones = np.ones(B, np.float32)
+    inject(22)
+    rimg = oG.forward(noise)
+    img = G.forward(noise).copy()
+    assert_close(img, rimg, TOL, "G(noise) in training mode")
+    ref_out = og.forward(rimg)
+    assert_close(D.forward(img), ref_out, TOL, "D(G(noise))")
+    ref_out = adopt(rimg); adopt_device_kinks(G, oG, B, 16)
+    inject(22)
+    f, g = adversarial.make_fevalG_on_D(env, noise, ones)(env.PARAMETERS_G)
+    rf, rdf = oracle.bce(ref_out.reshape(-1), ones)
+    og.zero_grads(); rgin = og.backward(rimg, rdf.reshape(ref_out.shape))
+    assert_close(D.gradInput, rgin, TOL * float(np.abs(rgin).max()), "D's gradInput w.r.t. the generated images")
+    oG.zero_grads(); oG.backward(noise, rgin)
+    rg = oG.grads.copy()
+    np.clip(rg, -env.OPT.G_clamp, env.OPT.G_clamp, out=rg)
+    assert abs(f - rf) <= 1e-5 * max(1.0, abs(rf)), f"fevalG_on_D loss {f} vs {rf}"
+    assert_grads_close(G, g, rg, 1e-4, 1e-6, "fevalG_on_D")
+
+    # ---- one epoch end to end (Philox dropout noise, two batches): finite losses, both parameter vectors move, CONFUSION is reset
+    pd, pg = env.PARAMETERS_D.copy(), env.PARAMETERS_G.copy()
+    tv = adversarial.train(env, synth.uniform((B,) + dims, 40, 0, 1))
+    assert 0.0 <= tv <= 1.0 and env.CONFUSION.sum() == 0
+    assert len(env.last_losses["D"]) == 2 and len(env.last_losses["G"]) == 2 and np.all(np.isfinite(env.last_losses["D"] + env.last_losses["G"]))
+    assert 1e-4 < np.abs(env.PARAMETERS_D - pd).max() <= 2.1e-3 and 1e-4 < np.abs(env.PARAMETERS_G - pg).max() <= 2.1e-3
+    with pytest.raises(IndexError):
+        adversarial.train(env, synth.uniform((B // 2,) + dims, 41, 0, 1))     # trainData shorter than the epoch needs
