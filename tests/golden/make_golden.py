@@ -44,5 +44,34 @@ def main():
     print("wrote", os.path.join(HERE, "golden_v1.npz"), os.path.getsize(os.path.join(HERE, "golden_v1.npz")), "bytes")
 
 
+def main_dnet():
+    """tests/golden/golden_v2_dnet.npz: the D network's module types (golden_cases.DCASES).  The sequential chain is checked
+    against float64 autograd here; the four-part D2 is the same per-part arithmetic composed by helpers.OracleGraph (its parts'
+    operators are pinned by tests/test_oracle_vs_torch.py)."""
+    from golden_cases import DCASES, run_oracle_dcase
+    out = {}
+    for name, case in DCASES.items():
+        res, twin, model, pairs = run_oracle_dcase(oracle, case)
+        if case["kind"] == "chain":
+            descs, index = model._descs(tuple(case["dims"]))
+            masks = {index[id(m)]: synth.bernoulli_keep((pairs[0][1].mask_size(index[id(m)], case["B"]),), case["seed"] * 131 + index[id(m)], m.p)
+                     for m in model.leaves() if m.typename in ("nn.Dropout", "nn.SpatialDropout")}      # what helpers.inject_noise drew
+            tw = Twin(descs, case["dims"], model._flat_host(), [], True, masks)
+            x = synth.uniform((case["B"],) + tuple(case["dims"]), case["seed"] + 1, 0, 1)
+            ref = tw.forward(x)
+            assert np.abs(ref - res["out"]).max() < 5e-6, (name, np.abs(ref - res["out"]).max())
+            g = tw.backward(synth.normal(ref.shape, case["seed"] + 9))
+            assert np.abs(g - res["grads"]).max() < 1e-4 * max(1, np.abs(g).max()), name
+        for k, v in res.items():
+            out[f"{name}/{k}"] = v
+        print(name, {k: getattr(v, "shape", v) for k, v in res.items()})
+    path = os.path.join(HERE, "golden_v2_dnet.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--dnet" in sys.argv:
+        main_dnet()
+    else:
+        main()

@@ -91,3 +91,54 @@ def run_oracle_case(oracle, case):
         idx, sc = oracle.cosine_topk(emb, case["needles"], case["k"])
         return dict(idx=idx, scores=sc)
     raise ValueError(kind)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# D-network cases (tests/golden/golden_v2_dnet.npz): the module types models.lua:272-337 adds
+DCASES = {
+    "Dchain_small": dict(kind="chain", dims=(2, 8, 8), B=3, seed=51),          # conv3 + PReLU + 5x5 conv + PReLU + SpatialDropout + MaxPool + Linear + PReLU + Linear + Sigmoid
+    "D2_gray16": dict(kind="D2", dims=(1, 16, 16), B=2, seed=52),              # models.create_D2: nn.Concat(2) of the 5x5 and the 3x3 tower
+}
+
+
+def build_dcase(case):
+    from ganrev import nn
+    dims, seed = case["dims"], case["seed"]
+    if case["kind"] == "chain":
+        model = (nn.Sequential().add(nn.SpatialConvolution(2, 6, 3, 3, 1, 1, 1, 1)).add(nn.PReLU())
+                 .add(nn.SpatialConvolution(6, 4, 5, 5, 1, 1, 2, 2)).add(nn.PReLU()).add(nn.SpatialDropout(0.25)).add(nn.SpatialMaxPooling(2, 2))
+                 .add(nn.View(4 * 4 * 4)).add(nn.Linear(64, 5)).add(nn.PReLU()).add(nn.Linear(5, 1)).add(nn.Sigmoid()))
+    else:
+        model = models.create_D2(dims, seed=seed)
+    synth.init_params(model, seed)
+    for k, m in enumerate(m for m in model.leaves() if m.typename == "nn.PReLU"):
+        m.weight[0] = np.float32(0.25 + 0.03125 * k)
+    x = synth.uniform((case["B"],) + tuple(dims), seed + 1, 0, 1)
+    return model, x
+
+
+def run_oracle_dcase(oracle, case, model=None):
+    """Training-mode forward + backward of the oracle twin (one oracle net per compiled part, helpers.OracleGraph) with seeded
+    dropout noise.  -> (results, twin, model)"""
+    from helpers import OracleGraph, inject_noise
+    if model is None:
+        model, x = build_dcase(case)
+    else:
+        _, x = build_dcase(case)
+    B = case["B"]
+    model.training()
+    og = OracleGraph(oracle, model, case["dims"]) if model._is_graph() else None
+    pairs = og.pairs if og else [(model, oracle.from_model(model, case["dims"]))]
+    for chunk, onet in pairs:
+        onet.set_training(True)
+        inject_noise(chunk, onet, B, case["seed"])
+    twin = og if og else pairs[0][1]
+    out = twin.forward(x)
+    gy = synth.normal(out.shape, case["seed"] + 9)
+    twin.zero_grads()
+    gin = twin.backward(x, gy)
+    grads = np.concatenate([o.grads for _, o in pairs])
+    res = dict(out=np.array(out), gin=np.array(gin), **summarize_grads(grads))
+    if grads.size < 4096:
+        res["grads"] = grads.copy()
+    return res, twin, model, pairs

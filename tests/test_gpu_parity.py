@@ -1419,3 +1419,51 @@ def test_adversarial_step_vs_oracle(oracle, conv_mode):
     assert 1e-4 < np.abs(env.PARAMETERS_D - pd).max() <= 2.1e-3 and 1e-4 < np.abs(env.PARAMETERS_G - pg).max() <= 2.1e-3
     with pytest.raises(IndexError):
         adversarial.train(env, synth.uniform((B // 2,) + dims, 41, 0, 1))     # trainData shorter than the epoch needs
+
+
+from golden_cases import DCASES as _DCASES, build_dcase as _build_dcase  # noqa: E402
+
+_GOLD_D = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "golden_v2_dnet.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(_DCASES))
+def test_dnet_vs_golden(conv_mode, name):
+    """The D network's module types against the committed vectors (tests/golden/golden_v2_dnet.npz): no oracle in the loop."""
+    from ganrev import synth
+    case = _DCASES[name]
+    model, x = _build_dcase(case)
+    model.training()
+    flat, grads = model.getParameters()
+    # the dropout noise helpers.inject_noise drew for the oracle: seed * 131 + layer index inside the compiled part
+    dims = tuple(case["dims"])
+
+    def inject(part, d):
+        from ganrev import nn
+        if isinstance(part, nn.Concat):
+            outs = [inject(b, d) for b in part.modules]
+            od = list(outs[0]); od[part.dimension - 2] = sum(o[part.dimension - 2] for o in outs)
+            return tuple(od)
+        if part._is_graph():
+            for p in part.parts():
+                d = inject(p, d)
+            return d
+        index = part._descs(d)[1]
+        for m in part.leaves():
+            ds, nd_ = m.desc(d)
+            if m.typename in ("nn.Dropout", "nn.SpatialDropout"):
+                n = case["B"] * (int(np.prod(d)) if m.typename == "nn.Dropout" else d[0])
+                part.setNoise(m, synth.bernoulli_keep((n,), case["seed"] * 131 + index[id(m)], m.p))
+            d = nd_
+        return d
+    inject(model, dims)
+    out = model.forward(x)
+    assert_close(out, _GOLD_D[f"{name}/out"], TOL, f"{name} forward")
+    gy = synth.normal(out.shape, case["seed"] + 9)
+    grads[...] = 0
+    gin = model.backward(x, gy)
+    ggin = _GOLD_D[f"{name}/gin"]
+    assert_close(gin, ggin, TOL * max(1.0, float(np.abs(ggin).max())), f"{name} gradInput")
+    gs = _GOLD_D[f"{name}/grads_sample"]
+    assert_close(grads[::_STRIDE], gs, 2 * TOL * max(1.0, float(np.abs(gs).max())), f"{name} gradient sample")
+    rel = abs(float(np.abs(grads.astype(np.float64)).sum()) - float(_GOLD_D[f"{name}/grads_abs"])) / float(_GOLD_D[f"{name}/grads_abs"])
+    assert rel < 1e-4, f"{name} |grad| checksum off by {rel:.2e}"
