@@ -1,6 +1,6 @@
 // convk.hip — nn.SpatialConvolution(Cin, Cout, K, K, 1, 1, (K-1)/2, (K-1)/2) for odd K other than 3, and nn.PReLU's slope
 // gradient: the module types the D network adds to the path (reference models.lua:272-337 create_D2: createNxN(128, 64, 5, ..)
-// at :290 and nn.PReLU at :276; trained by adversarial.lua:37-205).  SURVEY.md 8f rank 4.
+// at :297 and nn.PReLU at :276; trained by adversarial.lua:37-205).  SURVEY.md 8f rank 4.
 //
 // fp32 VALU kernels (no arithmetic modes): one K x K layer sits in D next to six 3x3 layers that run on the MFMA kernels of
 // conv.hip, so these only have to be far from the critical path, not at a roofline:

@@ -1018,6 +1018,16 @@ void launch_bce(const float* x, const float* t, long n, double* loss_dev, float*
   hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, s, x, t, n, loss_dev, grad);
 }
 
+// y += x : nn.Concat:updateGradInput sums the gradInputs of its branches (models.lua:293-321, device-resident GAN step)
+__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = y[i] + x[i];
+}
+void launch_add_inplace(float* y, const float* x, long n, hipStream_t s) {
+  if (n <= 0) return;
+  const long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, y, x, n);
+}
+
 // ------------------------------------------------------------------ penalty + clamp + Adam, one pass over (theta, g, m, v)
 __device__ __forceinline__ void adam_one(float& th, float& gv, float& mv, float& vv, const AdamConsts& c) {
   if (c.use_penalty) {

@@ -276,6 +276,7 @@ void launch_prelu_grad(const float* g, const float* z, long n, double* part, flo
 
 // ---------------------------------------------------------------- criterion / optimiser / misc
 void launch_mse(const float* x, const float* t, long n, long n_global, double* loss_dev, float* grad, hipStream_t s);
+void launch_add_inplace(float* y, const float* x, long n, hipStream_t s);        // y += x
 void launch_bce(const float* x, const float* t, long n, double* loss_dev, float* grad, hipStream_t s);      // nn.BCECriterion (sizeAverage)
 struct AdamConsts { float b1, b2, c1, c2, eps, step, l1, l2, clamp; int use_penalty, use_clamp; };
 void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long n, const AdamConsts& c, hipStream_t s);

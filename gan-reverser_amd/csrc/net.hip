@@ -1332,6 +1332,23 @@ extern "C" int gr_bce_host(gr_ctx* c, const float* x, const float* t, int64_t n,
   return GR_OK;
 }
 
+// ------------------------------------------------------------------ nn.Concat on device-resident tensors (models.lua:293-321)
+// The container stays on the host (it is a module that calls its children, not an operator); these two move its data
+// without leaving the GPU: rows of one matrix into a column range of another (join the branch outputs / slice gradOutput),
+// and the sum of the branches' gradInputs.
+extern "C" int gr_copy2d_dev(gr_ctx* c, float* dst, int64_t dst_pitch, const float* src, int64_t src_pitch, int64_t rows, int64_t cols) {
+  if (!c || !dst || !src || rows <= 0 || cols <= 0 || dst_pitch < cols || src_pitch < cols) return GR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy2DAsync(dst, sizeof(float) * (size_t)dst_pitch, src, sizeof(float) * (size_t)src_pitch, sizeof(float) * (size_t)cols, (size_t)rows,
+                             hipMemcpyDeviceToDevice, c->stream));
+  return GR_OK;
+}
+extern "C" int gr_add_dev(gr_ctx* c, float* y, const float* x, int64_t n) {
+  if (!c || !y || !x || n <= 0) return GR_ERR_INVALID;
+  launch_add_inplace(y, x, (long)n, c->stream); LAUNCHCHK(c);
+  return GR_OK;
+}
+
 // ------------------------------------------------------------------ optimiser
 static AdamConsts adam_consts(const gr_hyper* h, int t) {
   AdamConsts k{};

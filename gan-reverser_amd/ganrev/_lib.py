@@ -124,6 +124,8 @@ _SIGS = {
     "gr_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_int64]),
     "gr_fill_normal_dev": (C.c_int, [_P, _P, C.c_int64, C.c_uint64]),
     "gr_fill_uniform_dev": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, C.c_uint64]),
+    "gr_copy2d_dev": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64]),
+    "gr_add_dev": (C.c_int, [_P, _P, _P, C.c_int64]),
     "gr_conv3_forward_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gr_conv3_backward_data_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gr_conv3_backward_weight_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -222,6 +224,16 @@ class Context:
 
     def fill_uniform(self, dptr, n, seed, lo=-1.0, hi=1.0):
         self.check(self.lib.gr_fill_uniform_dev(self.h, _ptr(dptr), int(n), float(lo), float(hi), int(seed)), "gr_fill_uniform_dev")
+
+    def copy2d(self, dst, dst_pitch, src, src_pitch, rows, cols):
+        """rows x cols floats between two row-major device matrices (pitches in floats): nn.Concat's join / slice"""
+        self.check(self.lib.gr_copy2d_dev(self.h, _ptr(dst), int(dst_pitch), _ptr(src), int(src_pitch), int(rows), int(cols)), "gr_copy2d_dev")
+
+    def add(self, y, x, n):
+        self.check(self.lib.gr_add_dev(self.h, _ptr(y), _ptr(x), int(n)), "gr_add_dev")
+
+    def bce_dev(self, x, t, n, loss_dev, grad_dev=None):
+        self.check(self.lib.gr_bce_dev(self.h, _ptr(x), _ptr(t), int(n), _ptr(loss_dev), _ptr(grad_dev)), "gr_bce_dev")
 
     # ---- criterion / search
     def mse(self, x, t, n_global=None, want_grad=True):

@@ -169,3 +169,190 @@ def train(env, trainData, quiet=True):
     env.CONFUSION[...] = 0
     env.last_losses = losses
     return tV
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fast mode: the same game with images, gradients, parameters and the Adam state resident on the GPU (what ganrev.train_r's
+# DeviceTrainer / gr_train_r_step is to train_r.lua:138-170).  The containers stay host code that enqueues work: every compiled
+# part runs through gr_net_forward_dev / gr_net_backward_dev, nn.Concat joins / slices / sums with gr_copy2d_dev / gr_add_dev,
+# nn.BCECriterion is gr_bce_dev, and adversarial.l1 / l2 / clamp + optim.adam are the fused gr_adam_step of each part.  Nothing
+# is copied to the host inside a batch except, on request, the two loss values.
+class _DevGraph:
+    """Device-resident executor of a ganrev model that runs as compiled parts (nn.Sequential.parts(), nn.Concat)."""
+
+    def __init__(self, ctx, model):
+        self.ctx, self.model, self.bufs = ctx, model, {}
+        self.nets = [ch._net for ch, _, _ in model._param_chunks()]
+        self.plan = self._plan(model)
+
+    def _plan(self, node):
+        if isinstance(node, nn.Concat):
+            if node.dimension != 2:
+                raise L.GanrevError("device-resident nn.Concat: only nn.Concat(2) of [batch x features] outputs (models.lua:293)")
+            return ("concat", [self._plan(b) for b in node.modules])
+        if node._is_graph():
+            return ("seq", [self._plan(p) for p in node.parts()])
+        if node._net is None:
+            raise L.GanrevError("compile the model first (one forward)")
+        return ("net", node._net)
+
+    def _buf(self, key, n_floats):
+        cur = self.bufs.get(key)
+        if cur is None or cur[1] < n_floats:
+            if cur is not None:
+                self.ctx.free(cur[0])
+            cur = (self.ctx.malloc(4 * int(n_floats)), int(n_floats))
+            self.bufs[key] = cur
+        return cur[0]
+
+    @staticmethod
+    def _vol(d):
+        return int(d[0]) * int(d[1]) * int(d[2])
+
+    def out_features(self, plan=None):
+        plan = plan or self.plan
+        if plan[0] == "net":
+            return self._vol(plan[1].out_dims)
+        if plan[0] == "seq":
+            return self.out_features(plan[1][-1])
+        return sum(self.out_features(p) for p in plan[1])
+
+    def in_features(self, plan=None):
+        plan = plan or self.plan
+        if plan[0] == "net":
+            return self._vol(plan[1].in_dims)
+        return self.in_features(plan[1][0])
+
+    def forward(self, x_dev, B, plan=None):
+        plan = plan or self.plan
+        self.bufs[(id(plan), "x")] = x_dev
+        if plan[0] == "net":
+            return plan[1].forward_dev(x_dev, B)
+        if plan[0] == "seq":
+            for p in plan[1]:
+                x_dev = self.forward(x_dev, B, p)
+            return x_dev
+        total = self.out_features(plan)
+        cat = self._buf((id(plan), "cat"), B * total)
+        lo = 0
+        for p in plan[1]:
+            o, k = self.forward(x_dev, B, p), self.out_features(p)
+            self.ctx.copy2d(cat + 4 * lo, total, o, k, B, k)
+            lo += k
+        return cat
+
+    def backward(self, g_dev, B, want_gin, plan=None):
+        """gradOutput (device) -> gradInput (device pointer, or None when not wanted); accumulates every part's parameter gradient"""
+        plan = plan or self.plan
+        x_dev = self.bufs[(id(plan), "x")]
+        if plan[0] == "net":
+            gin = self._buf((id(plan), "gin"), B * self._vol(plan[1].in_dims)) if want_gin else None
+            plan[1].backward_dev(x_dev, g_dev, B, gin)
+            return gin
+        if plan[0] == "seq":
+            for i in range(len(plan[1]) - 1, -1, -1):
+                g_dev = self.backward(g_dev, B, want_gin or i > 0, plan[1][i])
+            return g_dev
+        total, lo, acc = self.out_features(plan), 0, None
+        nin = B * self.in_features(plan)
+        for j, p in enumerate(plan[1]):
+            k = self.out_features(p)
+            gs = self._buf((id(plan), "gslice", j), B * k)
+            self.ctx.copy2d(gs, k, g_dev + 4 * lo, total, B, k)
+            gi = self.backward(gs, B, want_gin, p)
+            if want_gin:
+                if acc is None:
+                    acc = gi                      # the first branch's own gradInput buffer holds the sum
+                else:
+                    self.ctx.add(acc, gi, nin)
+            lo += k
+        return acc
+
+    def zero_grads(self):
+        for n in self.nets:
+            n.zero_grads()
+
+    def adam_step(self, hyper, t):
+        for n in self.nets:
+            n.adam_step(hyper, t)
+
+
+class DeviceGame:
+    """adversarial.lua:139-201 per batch, device-resident.  game = DeviceGame(env); game.batch(real_half_batch) per batch;
+    game.sync_to_host() before anything reads env.PARAMETERS_* or the host-side modules again (save, evaluate, compat mode)."""
+
+    def __init__(self, env):
+        self.env = env
+        OPT, G, D = env.OPT, env.MODEL_G, env.MODEL_D
+        if OPT.D_optmethod != "adam" or OPT.G_optmethod != "adam":
+            raise L.GanrevError("DeviceGame: only the default optimizer 'adam' (train.lua:37-38)")
+        self.ctx = G._context()
+        B = OPT.batchSize
+        img = G.forward(nn_utils.createNoiseInputs(2, OPT.noiseDim, OPT.noiseMethod, seed=1))       # compile every net (parameters uploaded)
+        D.forward(img)
+        self.gnet = G._net
+        self.dg = _DevGraph(self.ctx, D)
+        for n in [self.gnet] + self.dg.nets:
+            n.set_training(True)
+            n.adam_reset()
+        self.t = {"D": 0, "G": 0}
+        self.npix = int(np.prod(env.IMG_DIMENSIONS))
+        m = self.ctx.malloc
+        self.inputs, self.targets, self.ones = m(4 * B * self.npix), m(4 * B), m(4 * B)
+        self.noise, self.df, self.loss = m(4 * B * OPT.noiseDim), m(4 * B), m(16)
+        half = B // 2
+        self.ctx.upload(np.concatenate([np.full(half, Y_NOT_GENERATOR, np.float32), np.full(B - half, Y_GENERATOR, np.float32)]), self.targets)
+        self.ctx.upload(np.full(B, Y_NOT_GENERATOR, np.float32), self.ones)
+        self.hyper_d = L.Hyper(l1=OPT.D_L1, l2=OPT.D_L2, clamp=OPT.D_clamp)
+        self.hyper_g = L.Hyper(l1=OPT.G_L1, l2=OPT.G_L2, clamp=OPT.G_clamp)
+        self.noise_counter = 0
+
+    def _fill_noise(self, N, host=None):
+        nd = self.env.OPT.noiseDim
+        if host is not None:
+            self.ctx.upload(np.ascontiguousarray(host, np.float32), self.noise)
+            return
+        self.noise_counter += 1
+        seed = self.env.OPT.seed * 100003 + self.noise_counter
+        if self.env.OPT.noiseMethod == "uniform":
+            self.ctx.fill_uniform(self.noise, N * nd, seed)
+        else:
+            self.ctx.fill_normal(self.noise, N * nd, seed)
+
+    def _read_loss(self):
+        return float(self.ctx.download(self.loss, (1,), np.float64)[0])
+
+    def batch(self, real_half, noise_d=None, noise_g=None, want_loss=False):
+        """One batch of adversarial.lua:139-201 (D_iterations = G_iterations = 1).  real_half: [batchSize/2 x C x H x W] host array
+        (the one unavoidable upload).  noise_*: host noise to use instead of device-generated noise (parity tests)."""
+        OPT, B = self.env.OPT, self.env.OPT.batchSize
+        half = B // 2
+        ctx = self.ctx
+        # (1) D on half real, half generated (adversarial.lua:141-157, fevalD :66-100)
+        ctx.upload(np.ascontiguousarray(real_half, np.float32).reshape(half, -1), self.inputs)
+        self._fill_noise(half, noise_d)
+        fake = self.gnet.forward_dev(self.noise, half)
+        ctx.copy2d(self.inputs + 4 * half * self.npix, self.npix, fake, self.npix, half, self.npix)
+        self.dg.zero_grads()
+        out = self.dg.forward(self.inputs, B)
+        ctx.bce_dev(out, self.targets, B, self.loss, self.df)
+        self.dg.backward(self.df, B, False)
+        self.t["D"] += 1
+        self.dg.adam_step(self.hyper_d, self.t["D"])
+        loss_d = self._read_loss() if want_loss else None
+        # (2) G through D (adversarial.lua:178-201, fevalG_on_D :104-133)
+        self._fill_noise(B, noise_g)
+        self.gnet.zero_grads()
+        samples = self.gnet.forward_dev(self.noise, B)
+        out = self.dg.forward(samples, B)
+        ctx.bce_dev(out, self.ones, B, self.loss, self.df)
+        df_do = self.dg.backward(self.df, B, True)
+        self.gnet.backward_dev(self.noise, df_do, B, None)
+        self.t["G"] += 1
+        self.gnet.adam_step(self.hyper_g, self.t["G"])
+        loss_g = self._read_loss() if want_loss else None
+        return loss_d, loss_g
+
+    def sync_to_host(self):
+        self.env.MODEL_D.pull_params()
+        self.env.MODEL_G.pull_params()

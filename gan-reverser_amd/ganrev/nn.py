@@ -298,7 +298,7 @@ class Sequential(Module):
             out.extend(m.leaves())
         return out
 
-    # ---- a Sequential that holds an nn.Concat (models.lua:285-315, the D network) cannot be one gr_net: it runs as a chain
+    # ---- a Sequential that holds an nn.Concat (models.lua:293-321, the D network) cannot be one gr_net: it runs as a chain
     # of PARTS - every run of plain modules is compiled into one gr_net (a chunk), a branching container runs its branches.
     # Host arrays travel between the parts, as Torch7 tensors travel between the modules of the reference's containers.
     def _is_graph(self):
@@ -420,7 +420,7 @@ class Sequential(Module):
 
 class Concat(Module):
     """nn.Concat(dimension): every branch gets the same input, the outputs are joined along `dimension` (1-based, the batch
-    is dimension 1): the D network's two convolution towers (models.lua:285-315, `nn.Concat(2)` of two [B x 512] feature
+    is dimension 1): the D network's two convolution towers (models.lua:293-321, `nn.Concat(2)` of two [B x 512] feature
     vectors).  backward hands each branch its slice of gradOutput and sums the branches' gradInputs."""
     TYPENAME = "nn.Concat"
 
@@ -555,7 +555,7 @@ class _Param(Module):
 
 class SpatialConvolution(_Param):
     """nn.SpatialConvolution(nInputPlane, nOutputPlane, kW, kH, dW, dH, padW, padH) — 3x3 s1 p1 (the one geometry
-    models.lua uses on the G/R path) and 5x5 s1 p2 (the D network's createNxN(128, 64, 5, ..), models.lua:275,290)."""
+    models.lua uses on the G/R path) and 5x5 s1 p2 (the D network's createNxN(128, 64, 5, ..), models.lua:275,297)."""
     TYPENAME = "nn.SpatialConvolution"
     KIND = L.CONV3
 
@@ -563,7 +563,7 @@ class SpatialConvolution(_Param):
         super().__init__()
         padH = padW if padH is None else padH
         if (kW, kH, dW, dH, padW, padH) not in ((3, 3, 1, 1, 1, 1), (5, 5, 1, 1, 2, 2)) or (kW != 3 and self.KIND != L.CONV3):
-            raise L.GanrevError("only 3x3 stride-1 pad-1 (models.lua:409-436) and 5x5 stride-1 pad-2 (models.lua:290) "
+            raise L.GanrevError("only 3x3 stride-1 pad-1 (models.lua:409-436) and 5x5 stride-1 pad-2 (models.lua:297) "
                                 "convolutions have a gfx950 kernel")
         self.nInputPlane, self.nOutputPlane, self.kW, self.kH = nInputPlane, nOutputPlane, kW, kH
         self.weight = np.zeros(self._wshape(), np.float32)

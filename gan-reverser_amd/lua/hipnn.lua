@@ -74,7 +74,7 @@ local function check(rc, what) if rc ~= 0 then error(what .. ': ' .. ffi.string(
 
 -- kind numbers of include/ganrev.h
 local K = {CONV3=1, BN=2, ELU=3, RELU=4, LEAKYRELU=5, SIGMOID=6, TANH=7, DROPOUT=8, SPATIAL_DROPOUT=9,
-           MAXPOOL2=10, UPSAMPLE2=11, VIEW=12, LINEAR=13, FULLCONV3=14}
+           MAXPOOL2=10, UPSAMPLE2=11, VIEW=12, LINEAR=13, FULLCONV3=14, CONVK=15, PRELU=16}
 
 -- nn module -> descriptor rows, in nn.Sequential order (models.lua:104-143, 389-464)
 local function describe(m, out, leaves)
@@ -83,13 +83,17 @@ local function describe(m, out, leaves)
    if t == 'nn.Copy' then return end
    local d = {kind=0, a=0, b=0, c=0, p=0, flags=0}
    if t == 'nn.SpatialConvolution' or t == 'cudnn.SpatialConvolution' or t == 'nn.SpatialConvolutionMM' then
-      assert(m.kW == 3 and m.kH == 3 and m.dW == 1 and m.dH == 1 and m.padW == 1, 'hipnn: only 3x3 s1 p1')
-      d.kind, d.a, d.b = K.CONV3, m.nInputPlane, m.nOutputPlane
+      assert(m.kW == m.kH and (m.kW == 3 or m.kW == 5) and m.dW == 1 and m.dH == 1 and m.padW == (m.kW - 1) / 2,
+             'hipnn: only 3x3 s1 p1 and 5x5 s1 p2 (models.lua:275)')
+      if m.kW == 3 then d.kind, d.a, d.b = K.CONV3, m.nInputPlane, m.nOutputPlane
+      else d.kind, d.a, d.b, d.c = K.CONVK, m.nInputPlane, m.nOutputPlane, m.kW end
    elseif t == 'nn.SpatialFullConvolution' then d.kind, d.a, d.b = K.FULLCONV3, m.nInputPlane, m.nOutputPlane
    elseif t == 'nn.SpatialBatchNormalization' or t == 'nn.BatchNormalization' then d.kind, d.a = K.BN, m.running_mean:size(1)
    elseif t == 'nn.ELU' then d.kind = K.ELU
    elseif t == 'nn.ReLU' or t == 'cudnn.ReLU' then d.kind = K.RELU
    elseif t == 'nn.LeakyReLU' then d.kind, d.p = K.LEAKYRELU, m.negval
+   elseif t == 'nn.PReLU' then       -- models.lua:276: nn.PReLU() = one shared slope, a parameter (weight[1]) in getParameters() order
+      assert(m.nOutputPlane == 0, 'hipnn: only nn.PReLU() with one shared slope'); d.kind = K.PRELU
    elseif t == 'nn.Sigmoid' or t == 'cudnn.Sigmoid' then d.kind = K.SIGMOID
    elseif t == 'nn.Tanh' or t == 'cudnn.Tanh' then d.kind = K.TANH
    elseif t == 'nn.Dropout' then

@@ -49,7 +49,7 @@ enum {
   GR_LINEAR = 13,          /* nn.Linear(a=in, b=out)                                             models.lua:115,447,451 */
   GR_FULLCONV3 = 14,       /* nn.SpatialFullConvolution(a,b,3,3,1,1,1,1) (north_star names it; absent from the reference) */
   /* the module types the D network adds (models.lua:272-337 create_D2, trained by adversarial.lua:37-205) */
-  GR_CONVK = 15,           /* nn.SpatialConvolution(a, b, c=K, K, 1, 1, (K-1)/2, (K-1)/2), K = 5           models.lua:275,290 */
+  GR_CONVK = 15,           /* nn.SpatialConvolution(a, b, c=K, K, 1, 1, (K-1)/2, (K-1)/2), K = 5           models.lua:275,297 */
   GR_PRELU = 16            /* nn.PReLU(): one learnable slope (nOutputPlane 0) in the flat vector; the host mirror starts it at 0.25  models.lua:276 */
 };
 #define GR_DROPOUT_V2 1         /* nn.Dropout default: train-time scale 1/(1-p), identity in evaluate() */
@@ -217,6 +217,14 @@ int gr_memcpy_d2h(gr_ctx* ctx, void* dst_host, const void* src_dev, int64_t byte
 int gr_fill_normal_dev(gr_ctx* ctx, float* dst_dev, int64_t n, uint64_t seed);
 /* the other noise method of createNoiseInputs (utils/nn_utils.lua:44-45): uniform(lo, hi), lo = -1, hi = 1 in the reference */
 int gr_fill_uniform_dev(gr_ctx* ctx, float* dst_dev, int64_t n, float lo, float hi, uint64_t seed);
+
+/* ---- nn.Concat (models.lua:293-321, the D network) on device-resident tensors.  The container itself stays host code: it calls
+ * its branches' gr_net_forward_dev / gr_net_backward_dev; these move its data without leaving the GPU (ctx stream, asynchronous).
+ * gr_copy2d_dev: `rows` rows of `cols` floats between two row-major matrices (pitches in floats): a branch output [B x k] into
+ * columns of the joined [B x sum k] output, or a column range of gradOutput into a contiguous [B x k] slice.
+ * gr_add_dev: y += x, the sum of the branches' gradInputs (nn.Concat:updateGradInput). */
+int gr_copy2d_dev(gr_ctx* ctx, float* dst_dev, int64_t dst_pitch, const float* src_dev, int64_t src_pitch, int64_t rows, int64_t cols);
+int gr_add_dev(gr_ctx* ctx, float* y_dev, const float* x_dev, int64_t n);
 
 /* ---- single-kernel entry points used by bench.py's roofline leg and by kernel-level parity tests ---- */
 int gr_conv3_forward_dev(gr_ctx* ctx, const float* in_dev, const float* w_dev, const float* bias_dev, float* out_dev,

@@ -114,7 +114,7 @@ void go_conv3_backward_weight(const float* in, const float* gout, float* gw, flo
   }
 }
 
-/* ---- nn.SpatialConvolution(Cin, Cout, K, K, 1, 1, (K-1)/2, (K-1)/2), K odd: the D network's 5x5 layer (models.lua:275,290 createNxN;
+/* ---- nn.SpatialConvolution(Cin, Cout, K, K, 1, 1, (K-1)/2, (K-1)/2), K odd: the D network's 5x5 layer (models.lua:275,297 createNxN;
  * SURVEY.md 8f rank 4).  Same loops as the 3x3 functions above with the window size a parameter; THNN evaluates it as im2col +
  * sgemm per sample (SpatialConvolutionMM), so parity is tolerance-based here too. ---- */
 void go_convk_forward(const float* in, const float* w, const float* bias, float* out,

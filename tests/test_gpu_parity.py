@@ -1244,7 +1244,7 @@ def _d_chain(kind):
         return (nn.Sequential().add(nn.SpatialConvolution(3, 16, 5, 5, 1, 1, 2, 2)).add(nn.SpatialBatchNormalization(16)).add(nn.PReLU())
                 .add(nn.Dropout(0.5)).add(nn.SpatialConvolution(16, 8, 3, 3, 1, 1, 1, 1)).add(nn.PReLU()).add(nn.SpatialMaxPooling(2, 2))
                 .add(nn.View(8 * 12 * 10)).add(nn.Linear(8 * 12 * 10, 3))), (3, 24, 20)
-    # the D network's own 5x5 layer (models.lua:290) at 32x32 images: createNxN(128, 64, 5, 0.2) on 16x16 planes
+    # the D network's own 5x5 layer (models.lua:297) at 32x32 images: createNxN(128, 64, 5, 0.2) on 16x16 planes
     return (nn.Sequential().add(nn.SpatialConvolution(16, 128, 3, 3, 1, 1, 1, 1)).add(nn.PReLU())
             .add(nn.SpatialConvolution(128, 64, 5, 5, 1, 1, 2, 2)).add(nn.PReLU()).add(nn.SpatialDropout(0.25)).add(nn.SpatialMaxPooling(2, 2))
             .add(nn.View(64 * 8 * 8)).add(nn.Linear(64 * 8 * 8, 32)).add(nn.PReLU()).add(nn.Dropout(0.25)).add(nn.Linear(32, 1)).add(nn.Sigmoid())), (16, 16, 16)
@@ -1467,3 +1467,39 @@ def test_dnet_vs_golden(conv_mode, name):
     assert_close(grads[::_STRIDE], gs, 2 * TOL * max(1.0, float(np.abs(gs).max())), f"{name} gradient sample")
     rel = abs(float(np.abs(grads.astype(np.float64)).sum()) - float(_GOLD_D[f"{name}/grads_abs"])) / float(_GOLD_D[f"{name}/grads_abs"])
     assert rel < 1e-4, f"{name} |grad| checksum off by {rel:.2e}"
+
+
+def test_device_resident_gan_batch_matches_the_host_mirror(conv_mode):
+    """ganrev.adversarial.DeviceGame (images, gradients, parameters and Adam state on the GPU; nn.Concat through gr_copy2d_dev /
+    gr_add_dev; penalty + clamp + Adam fused per part) against adversarial.train, the line-by-line mirror whose closures the
+    oracle test above pins: one batch from identical state, identical noise and (same seeds, same forward counts) identical
+    Philox dropout masks.  Same kernels on both sides, so the losses agree to rounding and the parameters differ only where
+    Adam's normalised update amplifies the last-bit difference between g + l2 * theta evaluated on the host and on the device."""
+    from ganrev import adversarial, models, nn_utils, synth
+    dims, nd, B = (1, 32, 32), 16, 8
+    envs = []
+    for _ in range(2):
+        G = models.create_G(dims, nd, seed=1); synth.init_params(G, 2)
+        D = models.create_D2(dims, seed=2); synth.init_params(D, 3)
+        envs.append(adversarial.make_env(G, D, dims, batchSize=B, noiseDim=nd, N_epoch=1, seed=5))
+    host, dev = envs
+    assert np.array_equal(host.PARAMETERS_D, dev.PARAMETERS_D) and np.array_equal(host.PARAMETERS_G, dev.PARAMETERS_G)
+    game = adversarial.DeviceGame(dev)                       # compiles with one forward of G and D ...
+    host.MODEL_D.forward(host.MODEL_G.forward(nn_utils.createNoiseInputs(2, nd, "normal", seed=1)))     # ... so the mirror does the same
+    real = synth.uniform((B // 2,) + dims, 40, 0, 1)
+    noise_d = nn_utils.createNoiseInputs(B // 2, nd, "normal", seed=5 * 100003 + 1)     # what adversarial._noise will draw
+    noise_g = nn_utils.createNoiseInputs(B, nd, "normal", seed=5 * 100003 + 2)
+    pd0, pg0 = host.PARAMETERS_D.copy(), host.PARAMETERS_G.copy()
+    adversarial.train(host, real)
+    ld, lg = game.batch(real, noise_d, noise_g, want_loss=True)
+    game.sync_to_host()
+    # the mirror's f includes the L2 penalty term (adversarial.lua:86-88); the device loss word is the criterion alone
+    pen = host.OPT.D_L2 * float(np.dot(pd0.astype(np.float64), pd0.astype(np.float64))) / 2
+    assert abs(ld + pen - host.last_losses["D"][0]) <= 1e-5 * max(1.0, abs(ld)), (ld, pen, host.last_losses["D"][0])
+    assert abs(lg - host.last_losses["G"][0]) <= 1e-5 * max(1.0, abs(lg)), (lg, host.last_losses["G"][0])
+    for name, a, b, p0 in (("D", dev.PARAMETERS_D, host.PARAMETERS_D, pd0), ("G", dev.PARAMETERS_G, host.PARAMETERS_G, pg0)):
+        d = np.abs(a.astype(np.float64) - b)
+        moved = np.abs(b.astype(np.float64) - p0)
+        assert moved.max() > 5e-4, f"{name}: the batch did not move the parameters"
+        assert np.median(d) <= 1e-7 and (d > 1e-5).mean() <= 2e-3 and d.max() <= 2.1e-3, \
+            f"{name}: median {np.median(d):.2e}, share above 1e-5 {(d > 1e-5).mean():.2e}, max {d.max():.2e}"

@@ -29,7 +29,7 @@ def test_conv3_ops(oracle, B, Cin, Cout, H, W):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,K", [(2, 3, 5, 6, 7, 5), (2, 16, 8, 16, 16, 5), (1, 4, 3, 9, 8, 7), (2, 3, 4, 5, 5, 3)])
 def test_convk_ops(oracle, B, Cin, Cout, H, W, K):
-    """nn.SpatialConvolution(.., K, K, 1, 1, (K-1)/2, (K-1)/2): the D network's 5x5 layer (models.lua:290)."""
+    """nn.SpatialConvolution(.., K, K, 1, 1, (K-1)/2, (K-1)/2): the D network's 5x5 layer (models.lua:297)."""
     x, w, b = synth.normal((B, Cin, H, W), 1), synth.uniform((Cout, Cin, K, K), 2, -0.3, 0.3), synth.uniform((Cout,), 3)
     gy = synth.normal((B, Cout, H, W), 4)
     xt, wt, bt = T(x).requires_grad_(True), T(w).requires_grad_(True), T(b).requires_grad_(True)
