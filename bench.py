@@ -247,6 +247,88 @@ def search_cfg5(ctx):
                 note="ms includes the D2H copy of the 5 x 50 results and one host sync per search (gr_cosine_topk_dev)")
 
 
+def gan_step(ctx, with_cpu=True):
+    """one batch of the GAN game (adversarial.lua:139-201: D on half real / half generated images, then G
+    through D) with models.create_G / create_D2 at 32x32 gray, device-resident (ganrev.adversarial.DeviceGame), timed with HIP
+    events; at train.lua's default batch (32) and at cfg2's batch (256).  Beside it the same batch on the CPU oracle, composed
+    part by part.  Not the headline metric: a measured row for the component next to the path."""
+    import numpy as np
+    from ganrev import adversarial, models, synth
+    dims, nd = (1, 32, 32), 100                                              # train.lua:26 noiseDim default
+    rows = {}
+    for B in (32, 256):
+        G = models.create_G(dims, nd, seed=1); synth.init_params(G, 2)
+        D = models.create_D2(dims, seed=2); synth.init_params(D, 3)
+        env = adversarial.make_env(G, D, dims, batchSize=B, noiseDim=nd)
+        game = adversarial.DeviceGame(env)
+        real = synth.uniform((B // 2,) + dims, 40, 0, 1)
+        for _ in range(3):
+            game.batch(real)
+        reps = 20
+        ctx.event_record(61000)
+        for _ in range(reps):
+            game.batch(real)
+        ctx.event_record(61001)
+        ms = ctx.event_elapsed_ms(61000, 61001) / reps
+        ld, lg = game.batch(real, want_loss=True)
+        ctx.set_timing(2)
+        game.batch(real)
+        ctx.synchronize()
+        kt = ctx.kernel_times()
+        ctx.set_timing(0)
+        by = {}
+        for k in kt:
+            a = by.setdefault(k["kernel"], dict(kernel=k["kernel"], launches=0, total_ms=0.0, flops=0.0))
+            a["launches"] += k["launches"]; a["total_ms"] += k["total_ms"]; a["flops"] += k["flops"]
+        top = sorted(by.values(), key=lambda r: -r["total_ms"])[:8]
+        rows[f"batch{B}"] = dict(ms_per_batch=round(ms, 4), generated_images_per_sec=round(B / ms * 1e3, 1), loss_d=round(ld, 5), loss_g=round(lg, 5),
+                                 kernel_ms_sum=round(sum(r["total_ms"] for r in by.values()), 4), launches=int(sum(r["launches"] for r in by.values())),
+                                 top_kernels=[dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["total_ms"], 4),
+                                                   tflops=round(r["flops"] / r["total_ms"] / 1e9, 2) if r["flops"] else None) for r in top])
+        for m in (G, D):
+            for ch, _, _ in m._param_chunks():
+                ch._net.close(); ch._net = None
+    out = dict(config=dict(G="models.create_G3", D="models.create_D2", dims=list(dims), noiseDim=nd, optimizer="adam", D_L2=1e-4, D_clamp=1, G_clamp=5),
+               **rows, note="device-resident batch (ganrev.adversarial.DeviceGame): the only host traffic is the upload of the real half batch")
+    if with_cpu:
+        from oracle import oracle
+        B = 32
+        oracle.set_threads(min(8, os.cpu_count() or 1))
+        G = models.create_G(dims, nd, seed=1); synth.init_params(G, 2)
+        D = models.create_D2(dims, seed=2); synth.init_params(D, 3)
+        oG = oracle.from_model(G, (nd, 1, 1)); oG.set_training(True)
+        trunk, concat, head = D.parts()
+        shapes = [dims, (128, 16, 16), (128, 16, 16), (1024, 1, 1)]
+        ons = [oracle.from_model(pt, sh) for pt, sh in zip([trunk, concat.modules[0], concat.modules[1], head], shapes)]
+        for o, pt in zip(ons, [trunk, concat.modules[0], concat.modules[1], head]):
+            o.set_training(True)
+            for m in pt.leaves():
+                if m.typename in ("nn.Dropout", "nn.SpatialDropout"):
+                    li = o.layer_index[id(m)]
+                    o.set_mask(li, synth.bernoulli_keep((o.mask_size(li, B),), 7 + li, m.p))
+
+        def d_fwd_bwd(x, want_gin):
+            t_out = ons[0].forward(x)
+            l, r = ons[1].forward(t_out), ons[2].forward(t_out)
+            cat = np.concatenate([l, r], axis=1)
+            out_ = ons[3].forward(cat)
+            _, df = oracle.bce(out_.reshape(-1), np.ones(B, np.float32))
+            gcat = ons[3].backward(cat, df.reshape(out_.shape))
+            gt = ons[1].backward(t_out, np.ascontiguousarray(gcat[:, :512])) + ons[2].backward(t_out, np.ascontiguousarray(gcat[:, 512:]))
+            return ons[0].backward(x, gt, want_gin=want_gin)
+        noise = synth.normal((B, nd), 3)
+        t0 = time.perf_counter()
+        x = np.concatenate([synth.uniform((B // 2,) + dims, 40, 0, 1), oG.forward(noise[:B // 2])])
+        d_fwd_bwd(x, False)
+        img = oG.forward(noise)
+        gin = d_fwd_bwd(img, True)
+        oG.backward(noise, gin)
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(ms_per_batch=round(t_cpu * 1e3, 1), batch=B, cores=min(8, os.cpu_count() or 1), kind="port",
+                                   sample="one batch of 32 (both network passes of the D step and of the G step; the Adam sweeps, ~10 ms, not included)")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def kernel_report(kt, nprof, dims, nd, B, traffic=None):
     """Per-kernel table + the roofline object of the dominant MFMA kernel + R's convolutions / element-wise shares."""
@@ -323,6 +405,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the cfg5 (1M x 100, top-50) search leg")
+    ap.add_argument("--no-gan", action="store_true", help="skip the GAN-game leg (SURVEY.md 8f rank 4: G + D2, one adversarial batch)")
     ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "f16x3"), choices=list(MODES),
                     help="arithmetic of the headline line (all meet the 1e-4 parity bar; see DESIGN.md)")
     ap.add_argument("--modes", default=",".join(MODES), help="arithmetic modes timed in this invocation (the headline mode is always run)")
@@ -503,6 +586,8 @@ def main():
         }
         if world == 1 and not args.no_search:
             out["search_cfg5"] = search_cfg5(ctx)
+        if world == 1 and not args.no_gan:
+            out["gan_step"] = gan_step(ctx, with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(WORKLOADS["cfg2"]["dims"], WORKLOADS["cfg2"]["nd"], ctx)
         else:

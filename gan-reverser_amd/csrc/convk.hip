@@ -38,28 +38,31 @@ __global__ void convk_weight_image_kernel(const float* __restrict__ w, float* __
   }
 }
 
-template <int K, int COT>
+template <int K, int COT, int NI>
 __global__ __launch_bounds__(256) void convk_direct_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                            const float* __restrict__ bias, float* __restrict__ y,
-                                                           int Cin, int Cout, int CoP, int H, int W, int tiles_x) {
+                                                           int B, int Cin, int Cout, int CoP, int H, int W, int tiles_x) {
+  // NI images per workgroup share every weight load (NI = 2: see the launcher - measured slower)
   constexpr int P = (K - 1) / 2, TW = KC_TILE + K - 1, TWS = TW + 1;
-  __shared__ float xt[KC_CI][TW][TWS];
+  __shared__ float xt[NI][KC_CI][TW][TWS];
   const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
   const int tile = blockIdx.x, y0 = (tile / tiles_x) * KC_TILE, x0 = (tile % tiles_x) * KC_TILE;
-  const int co0 = blockIdx.y * COT, b = blockIdx.z;
+  const int co0 = blockIdx.y * COT, b0 = blockIdx.z * NI;
   const long HW = (long)H * W;
-  float acc[COT];
+  float acc[NI][COT];
 #pragma unroll
-  for (int o = 0; o < COT; ++o) acc[o] = 0.f;
-  const float* xb = x + (long)b * Cin * HW;
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int o = 0; o < COT; ++o) acc[i][o] = 0.f;
   for (int c0 = 0; c0 < Cin; c0 += KC_CI) {
     __syncthreads();
-    for (int e = t; e < KC_CI * TW * TW; e += 256) {
-      const int ci = e / (TW * TW), r = (e / TW) % TW, c = e % TW;
+    for (int e = t; e < NI * KC_CI * TW * TW; e += 256) {
+      const int i = e / (KC_CI * TW * TW), r0 = e % (KC_CI * TW * TW);
+      const int ci = r0 / (TW * TW), r = (r0 / TW) % TW, c = r0 % TW;
       const int gy = y0 + r - P, gx = x0 + c - P;
       float v = 0.f;
-      if (c0 + ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = xb[(long)(c0 + ci) * HW + (long)gy * W + gx];
-      xt[ci][r][c] = v;
+      if (b0 + i < B && c0 + ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[((long)(b0 + i) * Cin + c0 + ci) * HW + (long)gy * W + gx];
+      xt[i][ci][r][c] = v;
     }
     __syncthreads();
     for (int ci = 0; ci < KC_CI; ++ci) {
@@ -68,18 +71,25 @@ __global__ __launch_bounds__(256) void convk_direct_kernel(const float* __restri
       for (int ky = 0; ky < K; ++ky)
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-          const float v = xt[ci][ty + ky][tx + kx];
           const float* wp = wrow + (ky * K + kx) * CoP;
 #pragma unroll
-          for (int o = 0; o < COT; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
+          for (int i = 0; i < NI; ++i) {
+            const float v = xt[i][ci][ty + ky][tx + kx];
+#pragma unroll
+            for (int o = 0; o < COT; ++o) acc[i][o] = fmaf(v, wp[o], acc[i][o]);
+          }
         }
     }
   }
   const int py = y0 + ty, px = x0 + tx;
   if (py < H && px < W) {
 #pragma unroll
-    for (int o = 0; o < COT; ++o)
-      if (co0 + o < Cout) y[((long)b * Cout + co0 + o) * HW + (long)py * W + px] = acc[o] + (bias ? bias[co0 + o] : 0.f);
+    for (int i = 0; i < NI; ++i)
+      if (b0 + i < B) {
+#pragma unroll
+        for (int o = 0; o < COT; ++o)
+          if (co0 + o < Cout) y[((long)(b0 + i) * Cout + co0 + o) * HW + (long)py * W + px] = acc[i][o] + (bias ? bias[co0 + o] : 0.f);
+      }
   }
 }
 
@@ -164,7 +174,7 @@ __global__ void convk_wgrad_reduce_kernel(const float* __restrict__ part, float*
 }
 
 bool convk_supported(int K) { return K == 5; }       // the one window size models.lua instantiates besides 3
-static int convk_splits(int B) { return B < 32 ? B : 32; }
+static int convk_splits(int B) { return B < 64 ? B : 64; }       // x 8 input-channel groups at Cin = 128: two workgroups per CU
 size_t convk_workspace_bytes(int B, int Cin, int Cout, int K) {
   size_t img = convk_image_floats(Cin, Cout, K), img_b = convk_image_floats(Cout, Cin, K);
   size_t parts = (size_t)convk_splits(B) * Cin * Cout * K * K;
@@ -186,8 +196,16 @@ static void convk_direct(const float* in, const float* w, const float* bias, flo
   KtScope kt(bwd ? "convk_direct_kernel(dgrad)" : "convk_direct_kernel", 2.0 * B * H * W * (double)Cin * Cout * K * K,
              4.0 * B * H * W * (Cin + Cout), s);
   constexpr int COT = 16;
-  dim3 grid(tiles_x * tiles_y, CoP / COT, B);
-  convk_direct_kernel<K, COT><<<grid, 256, 0, s>>>(in, wt, bias, out, cin_eff, cout_eff, CoP, H, W, tiles_x);
+  // two images per workgroup (each weight load used twice) measured SLOWER at the D network's shape, 430 vs 364 us (84 instead
+  // of 50 VGPRs, twice the LDS): the scalar cache is not what bounds the one-image kernel.  Kept behind a switch.
+  static const bool two_images = getenv("GR_CONVK_NI2") != nullptr;
+  if (two_images && (long)tiles_x * tiles_y * (CoP / COT) * ((B + 1) / 2) >= 512) {
+    dim3 grid(tiles_x * tiles_y, CoP / COT, (B + 1) / 2);
+    convk_direct_kernel<K, COT, 2><<<grid, 256, 0, s>>>(in, wt, bias, out, B, cin_eff, cout_eff, CoP, H, W, tiles_x);
+  } else {
+    dim3 grid(tiles_x * tiles_y, CoP / COT, B);
+    convk_direct_kernel<K, COT, 1><<<grid, 256, 0, s>>>(in, wt, bias, out, B, cin_eff, cout_eff, CoP, H, W, tiles_x);
+  }
 }
 
 // out[b,o,y,x] = bias[o] + sum w[o,i,ky,kx] in[b,i,y+ky-P,x+kx-P]        (ws: convk_workspace_bytes)
@@ -215,11 +233,21 @@ void launch_convk_backward_weight(const float* in, const float* gout, float* gw,
 // ---------------------------------------------------------------- nn.PReLU() (one shared slope): gradWeight[0] += sum_{z <= 0} g * z
 // (THNN PReLU.c accGradParameters, nOutputPlane == 0).  Products in fp32, sums in fp64: per-thread, per-workgroup, then the
 // workgroups' partials in index order by the last kernel (deterministic).
-constexpr int PRELU_BLOCKS = 256;
+constexpr int PRELU_BLOCKS = 2048;         // 8 workgroups per CU: the two streams are read at HBM speed (256 workgroups of scalar loads reached 2.3 TB/s)
 __global__ __launch_bounds__(256) void prelu_grad_partial_kernel(const float* __restrict__ g, const float* __restrict__ z, long n, double* __restrict__ part) {
   __shared__ double sh[256];
   double s = 0;
-  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += 256L * PRELU_BLOCKS) {
+  const long n4 = (((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(z)) & 15) == 0) ? n >> 2 : 0;    // 16-byte loads when both streams allow them
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  const float4* z4 = reinterpret_cast<const float4*>(z);
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n4; e += 256L * PRELU_BLOCKS) {
+    const float4 zv = z4[e], gv = g4[e];
+    if (!(zv.x > 0.f)) s += (double)(gv.x * zv.x);
+    if (!(zv.y > 0.f)) s += (double)(gv.y * zv.y);
+    if (!(zv.z > 0.f)) s += (double)(gv.z * zv.z);
+    if (!(zv.w > 0.f)) s += (double)(gv.w * zv.w);
+  }
+  for (long e = (n4 << 2) + blockIdx.x * 256L + threadIdx.x; e < n; e += 256L * PRELU_BLOCKS) {      // tail / unaligned streams
     const float zv = z[e];
     if (!(zv > 0.f)) s += (double)(g[e] * zv);
   }
@@ -228,18 +256,20 @@ __global__ __launch_bounds__(256) void prelu_grad_partial_kernel(const float* __
   for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
-__global__ void prelu_grad_final_kernel(const double* __restrict__ part, float* __restrict__ gslope) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0;
-    for (int k = 0; k < PRELU_BLOCKS; ++k) s += part[k];
-    gslope[0] += (float)s;
-  }
+__global__ __launch_bounds__(256) void prelu_grad_final_kernel(const double* __restrict__ part, float* __restrict__ gslope) {
+  __shared__ double sh[256];
+  double s = 0;
+  for (int k = threadIdx.x; k < PRELU_BLOCKS; k += 256) s += part[k];      // fixed assignment and tree: deterministic
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) gslope[0] += (float)sh[0];
 }
 size_t prelu_grad_workspace_bytes() { return sizeof(double) * PRELU_BLOCKS; }
 void launch_prelu_grad(const float* g, const float* z, long n, double* part, float* gslope, hipStream_t s) {
   KtScope kt("prelu_grad_kernel", 2.0 * n, 8.0 * n, s);
   prelu_grad_partial_kernel<<<PRELU_BLOCKS, 256, 0, s>>>(g, z, n, part);
-  prelu_grad_final_kernel<<<1, 64, 0, s>>>(part, gslope);
+  prelu_grad_final_kernel<<<1, 256, 0, s>>>(part, gslope);
 }
 
 }  // namespace gr
