@@ -20,7 +20,8 @@ constexpr int KC_CI = 8;          // input channels staged per round (direct ker
 constexpr int KC_TILE = 16;       // 16 x 16 output pixels per workgroup
 
 
-size_t convk_image_floats(int cin_eff, int cout_eff, int K) { return (size_t)round_up(cin_eff, KC_CI) * K * K * round_up(cout_eff, 32); }
+constexpr int KC_KS = 4;         // channel slices of the sliced direct kernel
+size_t convk_image_floats(int cin_eff, int cout_eff, int K) { return (size_t)round_up(cin_eff, KC_CI * KC_KS) * K * K * round_up(cout_eff, 32); }
 
 // wt[ci][ky][kx][co], zero rows / columns up to the padded extents.  bwd = 0: ci = input plane i, co = output plane o,
 // wt = w[o][i][ky][kx].  bwd = 1 (data gradient; the kernel's input is dy): ci = o, co = i, wt = w[o][i][K-1-ky][K-1-kx].
@@ -90,6 +91,69 @@ __global__ __launch_bounds__(256) void convk_direct_kernel(const float* __restri
         for (int o = 0; o < COT; ++o)
           if (co0 + o < Cout) y[((long)(b0 + i) * Cout + co0 + o) * HW + (long)py * W + px] = acc[i][o] + (bias ? bias[co0 + o] : 0.f);
       }
+  }
+}
+
+// The same convolution with the input channels of a round split over KS groups of four waves (1024 threads at KS = 4): every use
+// of a scalar-loaded weight waits for ALL outstanding scalar loads (SMEM returns out of order: lgkmcnt 0), ~250 cycles per
+// three taps = 24 v_pk_fma, so a SIMD needs several waves to keep its VALU busy - and a small batch gives the one-image kernel
+// one wave per SIMD (290 us per launch at batch 32, 364 at 256).  The groups' partial sums meet in LDS, added in group order.
+template <int K, int COT, int KS>
+__global__ __launch_bounds__(256 * KS) void convk_direct_sliced_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                                       int Cin, int Cout, int CoP, int H, int W, int tiles_x) {
+  constexpr int P = (K - 1) / 2, TW = KC_TILE + K - 1, TWS = TW + 1, XT = KC_CI * TW * TWS;
+  static_assert(KS * XT >= (KS - 1) * COT * 256, "the reduction reuses the staging buffer");
+  __shared__ float lds[KS * XT];
+  const int t = threadIdx.x, tx = t & 15, ty = (t >> 4) & 15;
+  const int ks = __builtin_amdgcn_readfirstlane(t >> 8);         // uniform in a wave (four waves per group): keeps the weight loads scalar
+  const int tile = blockIdx.x, y0 = (tile / tiles_x) * KC_TILE, x0 = (tile % tiles_x) * KC_TILE;
+  const int co0 = blockIdx.y * COT, b = blockIdx.z;
+  const long HW = (long)H * W;
+  float acc[COT];
+#pragma unroll
+  for (int o = 0; o < COT; ++o) acc[o] = 0.f;
+  const float* xb = x + (long)b * Cin * HW;
+  float (*xt)[TW][TWS] = reinterpret_cast<float (*)[TW][TWS]>(lds + ks * XT);
+  for (int c0 = 0; c0 < Cin; c0 += KC_CI * KS) {
+    __syncthreads();
+    for (int e = t; e < KS * KC_CI * TW * TW; e += 256 * KS) {
+      const int cc = e / (TW * TW), r = (e / TW) % TW, c = e % TW;       // cc = slice * KC_CI + channel in the slice
+      const int gy = y0 + r - P, gx = x0 + c - P;
+      float v = 0.f;
+      if (c0 + cc < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = xb[(long)(c0 + cc) * HW + (long)gy * W + gx];
+      lds[(cc * TW + r) * TWS + c] = v;
+    }
+    __syncthreads();
+    for (int ci = 0; ci < KC_CI; ++ci) {
+      const float* wrow = wt + (long)(c0 + ks * KC_CI + ci) * K * K * CoP + co0;       // uniform per wave: scalar loads (rows past Cin: the image is padded to a multiple of KC_CI * 4)
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const float v = xt[ci][ty + ky][tx + kx];
+          const float* wp = wrow + (ky * K + kx) * CoP;
+#pragma unroll
+          for (int o = 0; o < COT; ++o) acc[o] = fmaf(v, wp[o], acc[o]);
+        }
+    }
+  }
+  __syncthreads();
+  const int pix = t & 255;
+  if (ks > 0) {
+#pragma unroll
+    for (int o = 0; o < COT; ++o) lds[((ks - 1) * COT + o) * 256 + pix] = acc[o];
+  }
+  __syncthreads();
+  const int py = y0 + ty, px = x0 + tx;
+  if (ks == 0 && py < H && px < W) {
+#pragma unroll
+    for (int o = 0; o < COT; ++o) {
+      float v = acc[o];
+#pragma unroll
+      for (int g = 1; g < KS; ++g) v += lds[((g - 1) * COT + o) * 256 + pix];
+      if (co0 + o < Cout) y[((long)b * Cout + co0 + o) * HW + (long)py * W + px] = v + (bias ? bias[co0 + o] : 0.f);
+    }
   }
 }
 
@@ -186,7 +250,7 @@ template <int K>
 static void convk_direct(const float* in, const float* w, const float* bias, float* out, void* ws, int B, int cin_eff, int cout_eff, int Cin, int Cout,
                          int H, int W, bool bwd, hipStream_t s) {
   float* wt = static_cast<float*>(ws);
-  const int CiP = round_up(cin_eff, KC_CI), CoP = round_up(cout_eff, 32);
+  const int CiP = round_up(cin_eff, KC_CI * KC_KS), CoP = round_up(cout_eff, 32);
   {
     KtScope kt("convk_weight_image_kernel", 0, 8.0 * Cin * Cout * K * K, s);
     const long total = (long)CiP * K * K * CoP;
@@ -198,6 +262,14 @@ static void convk_direct(const float* in, const float* w, const float* bias, flo
   constexpr int COT = 16;
   // two images per workgroup (each weight load used twice) measured SLOWER at the D network's shape, 430 vs 364 us (84 instead
   // of 50 VGPRs, twice the LDS): the scalar cache is not what bounds the one-image kernel.  Kept behind a switch.
+  // measured (GAN batch, D network's shape): batch 32 - 290 -> 83 us per launch sliced; batch 256 (1024+ workgroups) - 364 us either way
+  static const int sliced_env = getenv("GR_CONVK_SLICED") ? atoi(getenv("GR_CONVK_SLICED")) : -1;
+  const bool sliced = sliced_env >= 0 ? sliced_env != 0 : (long)tiles_x * tiles_y * (CoP / COT) * B < 1024;
+  if (sliced) {
+    dim3 grid(tiles_x * tiles_y, CoP / COT, B);
+    convk_direct_sliced_kernel<K, COT, KC_KS><<<grid, 256 * KC_KS, 0, s>>>(in, wt, bias, out, cin_eff, cout_eff, CoP, H, W, tiles_x);
+    return;
+  }
   static const bool two_images = getenv("GR_CONVK_NI2") != nullptr;
   if (two_images && (long)tiles_x * tiles_y * (CoP / COT) * ((B + 1) / 2) >= 512) {
     dim3 grid(tiles_x * tiles_y, CoP / COT, (B + 1) / 2);
