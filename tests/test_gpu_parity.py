@@ -1291,7 +1291,7 @@ def test_5x5_convolution_and_prelu_vs_oracle(oracle, conv_mode, kind, B):
     assert_close(net.forward(x), ref_e, TOL * max(1.0, float(np.abs(ref_e).max())), "forward (evaluate)")
 
 
-@pytest.mark.parametrize("dims,B", [((1, 32, 32), 6), ((3, 32, 32), 4)])
+@pytest.mark.parametrize("dims,B", [((1, 32, 32), 6), ((3, 32, 32), 4), ((3, 64, 64), 2)])
 def test_D2_forward_backward_vs_oracle(oracle, conv_mode, dims, B):
     """MODEL_D = models.create_D2 (models.lua:272-337): nn.Concat(2) of the 5x5 tower and the deeper 3x3 tower, run as four
     compiled parts chained on the host.  Output, gradInput w.r.t. the images (what adversarial.lua:113-118 hands to G) and the
