@@ -259,6 +259,17 @@ def to_model(obj):
         return seq
     if t == "nn.Copy":
         return None
+    if t == "nn.Concat":                     # the D network (models.lua:293-321; train.lua:256 saves D next to G)
+        cat = nn.Concat(int(f["dimension"]))
+        for m in f.get("modules", []):
+            sub = to_model(m)
+            if sub is not None:
+                cat.add(sub)
+        return cat
+    if t == "nn.PReLU":
+        m = nn.PReLU(int(f.get("nOutputPlane", 0)))
+        m.weight[...] = np.asarray(f["weight"], np.float32).reshape(m.weight.shape)
+        return m
     if t in ("nn.SpatialConvolution", "cudnn.SpatialConvolution", "nn.SpatialConvolutionMM"):
         m = nn.SpatialConvolution(f["nInputPlane"], f["nOutputPlane"], f["kW"], f["kH"], f.get("dW", 1), f.get("dH", 1), f.get("padW", 0), f.get("padH", f.get("padW", 0)))
         m.weight[...] = np.asarray(f["weight"], np.float32).reshape(m.weight.shape)      # SpatialConvolutionMM stores it 2-D
@@ -318,9 +329,14 @@ def from_model(model):
     t = model.typename
     if isinstance(model, nn.Sequential):
         return TorchObject("nn.Sequential", dict(base, modules=[from_model(m) for m in model.modules]))
+    if isinstance(model, nn.Concat):
+        return TorchObject("nn.Concat", dict(base, dimension=model.dimension, size=np.zeros(0, np.int64), modules=[from_model(m) for m in model.modules]))
     f = dict(base)
-    if isinstance(model, nn.SpatialConvolution):
-        f.update(nInputPlane=model.nInputPlane, nOutputPlane=model.nOutputPlane, kW=3, kH=3, dW=1, dH=1, padW=1, padH=1,
+    if isinstance(model, nn.PReLU):
+        f.update(nOutputPlane=0, weight=model.weight, gradWeight=empty, gradWeightBuf=empty, gradWeightBuf2=empty)
+    elif isinstance(model, nn.SpatialConvolution):
+        pad = (model.kW - 1) // 2
+        f.update(nInputPlane=model.nInputPlane, nOutputPlane=model.nOutputPlane, kW=model.kW, kH=model.kH, dW=1, dH=1, padW=pad, padH=pad,
                  weight=model.weight, bias=model.bias, gradWeight=empty, gradBias=empty, finput=empty, fgradInput=empty)
         if isinstance(model, nn.SpatialFullConvolution):
             f.update(adjW=0, adjH=0)

@@ -168,6 +168,42 @@ def test_t7_checkpoint_round_trip():
             assert np.array_equal(a.running_mean, b.running_mean) and np.array_equal(a.running_var, b.running_var)
 
 
+def test_D_network_structure_parts_and_checkpoint_round_trip():
+    """models.create_D2 (models.lua:272-337): layer list, the compiled parts an nn.Concat splits it into, getParameters() views
+    across the parts, top-level-only weight-init (weight-init.lua:52: the nested towers keep their constructor draw), and the
+    train.lua:256 checkpoint round trip with nn.Concat / nn.PReLU / the 5x5 convolution."""
+    from ganrev import t7
+    D = models.create_D2((1, 32, 32), seed=4)
+    names = [m.typename for m in D.modules]
+    assert names == ["nn.Copy", "nn.Sequential", "nn.Sequential", "nn.SpatialMaxPooling", "nn.Concat", "nn.Linear", "nn.PReLU", "nn.Dropout",
+                     "nn.Linear", "nn.Sigmoid", "nn.Copy"]
+    concat = D.modules[4]
+    assert concat.dimension == 2 and concat.size() == 2
+    left = [m.typename for m in concat.get(1).leaves()]
+    assert left == ["nn.SpatialConvolution", "nn.PReLU", "nn.SpatialDropout", "nn.SpatialMaxPooling", "nn.View", "nn.Linear", "nn.PReLU", "nn.Dropout"]
+    conv5 = concat.get(1).leaves()[0]
+    assert conv5.weight.shape == (64, 128, 5, 5) and conv5._wshape() == (64, 128, 5, 5)
+    assert sum(1 for m in D.leaves() if m.typename == "nn.PReLU") == 9 and all(float(m.weight[0]) == 0.25 for m in D.leaves() if m.typename == "nn.PReLU")
+    assert D._is_graph() and [type(p).__name__ for p in D.parts()] == ["Sequential", "Concat", "Sequential"]
+    chunks = D._param_chunks()
+    assert len(chunks) == 4 and chunks[0][1] == 0 and all(a[2] == b[1] for a, b in zip(chunks, chunks[1:])) and chunks[-1][2] == D._param_count()
+    # 1->128 3x3 (+1 slope), 128->128 3x3 (+1): the trunk's share of the flat vector
+    assert chunks[0][2] == (128 * 9 + 128 + 1) + (128 * 128 * 9 + 128 + 1)
+    flat, grads = D.getParameters()
+    conv5.weight[0, 0, 0, 0] = 77.0
+    assert flat[chunks[1][1]] == 77.0                      # the 5x5 weights open the second part's slice
+    head_linear = D.modules[5]
+    assert np.all(head_linear.bias == 0)                   # weight-init reaches the top-level Linear ...
+    assert np.abs(conv5.bias).max() > 0                    # ... not the modules nested in the towers (weight-init.lua:52 walks net.modules only)
+    descs = D.parts()[1].modules[0]._descs((128, 16, 16))[0]
+    assert descs[0][:4] == (L.CONVK, 128, 64, 5) and descs[1][0] == L.PRELU
+    back = t7.to_model(t7.load(t7.dumps({"D": t7.from_model(D)}))["D"])
+    assert [m.typename for m in back.leaves()] == [m.typename for m in D.leaves()]
+    assert np.array_equal(back._flat_host(), flat) and back.modules[3].dimension == 2
+    with pytest.raises(L.GanrevError):
+        nn.PReLU(16)                                       # per-channel slopes: not what models.lua builds
+
+
 def test_module_initialisation_draws_from_one_stream():
     """Torch draws every module's initial parameters from one process-wide generator: equal-shaped modules must not start
     out identical, create_*(seed=...) must reach the modules weight-init.lua does not touch (BatchNorm gammas, G's
