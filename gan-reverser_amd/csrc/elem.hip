@@ -26,6 +26,9 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sh) {
   return r;  // valid on thread 0
 }
 
+// x / d for the plane-size divisors of the pipeline kernels (d > 0, uniform): a shift when d is a power of two - every shape of
+// the path - instead of the ~20 VALU instructions of a 32-bit division per float4 (these kernels are VALU-bound, ~37 per element)
+__device__ __forceinline__ unsigned udivp(unsigned x, unsigned d) { return (d & (d - 1)) == 0 ? x >> (__ffs(d) - 1) : x / d; }
 __device__ __forceinline__ float post_slope(const PostArgs& a) { return a.act == ACT_PRELU ? *a.slope_dev : a.slope; }
 __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
   switch (act) {
@@ -136,13 +139,13 @@ __global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
   const unsigned n4 = (unsigned)a.B * a.C * q_per_plane;
   float omax = 0.f;
   for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
-    const unsigned bc = i4 / q_per_plane, within = i4 - bc * q_per_plane, c = bc % (unsigned)a.C;
+    const unsigned bc = udivp(i4, q_per_plane), within = i4 - bc * q_per_plane, c = bc - udivp(bc, (unsigned)a.C) * (unsigned)a.C;
     float mean = 0.f, invstd = 1.f, g = 1.f, bt = 0.f;
     if (a.has_bn) { mean = a.mean[c]; invstd = a.invstd[c]; g = a.gamma[c]; bt = a.beta[c]; }
     const unsigned eo = bc * HWo + within * 4;
     float4 r;
     if (a.pool) {
-      const unsigned yo = within / wq, xo = (within - yo * wq) * 4;
+      const unsigned yo = udivp(within, wq), xo = (within - yo * wq) * 4;
       const unsigned e0 = bc * HW + (2 * yo) * W + 2 * xo, e1 = e0 + W;
       const float4 t0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0), mean, invstd, g, bt), mask4(a.m1, e0, bc));
       const float4 t1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0 + 4), mean, invstd, g, bt), mask4(a.m1, e0 + 4, bc));
@@ -239,14 +242,14 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
   for (unsigned u = blockIdx.x; u < units; u += gridDim.x) {
     const unsigned bg = u / tiles, tile = u - bg * tiles, b = bg / G, g = bg - b * G;
     for (unsigned task = threadIdx.x; task < 8 * qpt; task += 256) {
-      const unsigned j = task / qpt, within = tile * qpt + (task - j * qpt);       // channel 8g + j, quad `within` of the plane
+      const unsigned j = udivp(task, qpt), within = tile * qpt + (task - j * qpt);       // channel 8g + j, quad `within` of the plane
       const unsigned c = 8 * g + j, bc = b * (unsigned)a.C + c;
       float mean = 0.f, invstd = 1.f, gm = 1.f, bt = 0.f;
       if (a.has_bn) { mean = a.mean[c]; invstd = a.invstd[c]; gm = a.gamma[c]; bt = a.beta[c]; }
       const unsigned eo = bc * HWo + within * 4;
       float4 r;
       if constexpr (POOL) {
-        const unsigned yo = within / wq, xo = (within - yo * wq) * 4;
+        const unsigned yo = udivp(within, wq), xo = (within - yo * wq) * 4;
         const unsigned e0 = bc * HW + (2 * yo) * W + 2 * xo, e1 = e0 + W;
         const float4 t0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0), mean, invstd, gm, bt), mask4(a.m1, e0, bc));
         const float4 t1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0 + 4), mean, invstd, gm, bt), mask4(a.m1, e0 + 4, bc));
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_vec_kernel(const float* 
   double s = 0, q = 0;
   const unsigned tot = b1 > b0 ? (unsigned)(b1 - b0) * q4 : 0u;     // an empty slice contributes zeros
   for (unsigned j = threadIdx.x; j < tot; j += 256) {
-    const unsigned bb = j / (unsigned)q4, i = j - bb * q4;
+    const unsigned bb = udivp(j, (unsigned)q4), i = j - bb * q4;
     const float4 v = reinterpret_cast<const float4*>(y + ((size_t)(b0 + bb) * C + c) * HW)[i];
     s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
     q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
@@ -551,7 +554,7 @@ __device__ __forceinline__ BwdRaw post_bwd_load4(const PostBwdArgs& a, unsigned 
   const PostArgs& f = a.f;
   BwdRaw r;
   if (f.pool) {
-    const unsigned yy = i / wq, xx = (i - yy * wq) * 4, eo = obase + (yy >> 1) * Wo + (xx >> 1);
+    const unsigned yy = udivp(i, wq), xx = (i - yy * wq) * 4, eo = obase + (yy >> 1) * Wo + (xx >> 1);
     const float2 go = *reinterpret_cast<const float2*>(a.gout + eo);
     r.g = make_float4(go.x, go.y, 0.f, 0.f);
     r.id2 = *reinterpret_cast<const uint16_t*>(f.pool_idx + eo);
@@ -599,7 +602,7 @@ __device__ __forceinline__ float4 post_bwd_dz4(const PostBwdArgs& a, unsigned bc
   const PostArgs& f = a.f;
   float4 g;
   if (f.pool) {
-    const unsigned yy = i / wq, xx = (i - yy * wq) * 4, eo = obase + (yy >> 1) * Wo + (xx >> 1);
+    const unsigned yy = udivp(i, wq), xx = (i - yy * wq) * 4, eo = obase + (yy >> 1) * Wo + (xx >> 1);
     const float2 go = *reinterpret_cast<const float2*>(a.gout + eo);
     const uint32_t id2 = *reinterpret_cast<const uint16_t*>(f.pool_idx + eo);
     const float m20 = mask_mul(f.m2, eo, bc), m21 = mask_mul(f.m2, eo + 1, bc);
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
   const unsigned tot = b1 > b0 ? (unsigned)(b1 - b0) * q4 : 0u;     // an empty slice contributes zeros
   {
     for (unsigned j = threadIdx.x; j < tot; j += 256) {
-      const unsigned bb = j / q4, i = j - bb * q4;
+      const unsigned bb = udivp(j, q4), i = j - bb * q4;
       const unsigned bc = (unsigned)(b0 + bb) * f.C + c, pbase = bc * HW, obase = bc * HWo;
       const unsigned e = pbase + i * 4;
       float4 yv;
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
   const unsigned tot = b1 > b0 ? (unsigned)(b1 - b0) * q4 : 0u;     // an empty slice contributes zeros
   {
     for (unsigned j = threadIdx.x; j < tot; j += 256) {
-      const unsigned bb = j / q4, i = j - bb * q4;
+      const unsigned bb = udivp(j, q4), i = j - bb * q4;
       const unsigned bc = (unsigned)(b0 + bb) * f.C + c;
       const size_t base = (size_t)bc * HW;
       float4* dyp = reinterpret_cast<float4*>(a.dy + base);
