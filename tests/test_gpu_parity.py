@@ -1503,3 +1503,25 @@ def test_device_resident_gan_batch_matches_the_host_mirror(conv_mode):
         assert moved.max() > 5e-4, f"{name}: the batch did not move the parameters"
         assert np.median(d) <= 1e-7 and (d > 1e-5).mean() <= 2e-3 and d.max() <= 2.1e-3, \
             f"{name}: median {np.median(d):.2e}, share above 1e-5 {(d > 1e-5).mean():.2e}, max {d.max():.2e}"
+
+
+@pytest.mark.parametrize("compat", [False, True])
+def test_train_loop_saves_a_loadable_checkpoint(tmp_path, compat):
+    """ganrev.train (train.lua:125-257 around adversarial.train): two epochs of two batches on synthetic images in the fast
+    (device-resident) and the --compat loop, then the Torch7 checkpoint {D, G, opt, epoch} it wrote reads back into the same
+    layers and parameters, the four-part D included, and the loop continues from it (--network)."""
+    from ganrev import t7, train
+    argv = ["--epochs", "2", "--N_epoch", "2", "--batchSize", "8", "--noiseDim", "16", "--save", str(tmp_path), "--saveFreq", "1", "--quiet"]
+    res = train.main(argv + (["--compat"] if compat else []))
+    assert res["epoch"] == 2 and np.all(np.isfinite(res["last_losses"]))
+    env = res["env"]
+    assert _os.path.isfile(res["path"]) and _os.path.isfile(res["path"] + ".old")          # train.lua:247-249 keeps the previous file
+    ck = t7.load_checkpoint(res["path"])
+    assert "_unconverted" not in ck and ck["epoch"] == 2 and ck["opt"]["batchSize"] == 8
+    for key, model in (("D", env.MODEL_D), ("G", env.MODEL_G)):
+        assert [m.typename.split(".")[-1] for m in ck[key].leaves()] == [m.typename.split(".")[-1] for m in model.leaves()]
+        assert np.array_equal(ck[key]._flat_host(), model.getParameters()[0])
+    g_bn = [m for m in ck["G"].leaves() if hasattr(m, "running_mean")][0]
+    assert float(np.abs(g_bn.running_mean).max()) > 0                                      # G trained in training mode: its statistics moved and were saved
+    res2 = train.main(argv[:1] + ["1"] + argv[2:] + ["--network", res["path"]] + (["--compat"] if compat else []))
+    assert res2["epoch"] == 2 and np.all(np.isfinite(res2["last_losses"]))                 # epoch counter continues from the file (2 -> plays epoch 2 again as train.lua:202 does)
