@@ -285,6 +285,8 @@ def gan_step(ctx, with_cpu=True):
                                  kernel_ms_sum=round(sum(r["total_ms"] for r in by.values()), 4), launches=int(sum(r["launches"] for r in by.values())),
                                  top_kernels=[dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["total_ms"], 4),
                                                    tflops=round(r["flops"] / r["total_ms"] / 1e9, 2) if r["flops"] else None) for r in top])
+        ctx.synchronize()
+        game.close()
         for m in (G, D):
             for ch, _, _ in m._param_chunks():
                 ch._net.close(); ch._net = None

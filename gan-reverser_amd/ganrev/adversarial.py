@@ -272,6 +272,12 @@ class _DevGraph:
         for n in self.nets:
             n.zero_grads()
 
+    def close(self):
+        for key, v in list(self.bufs.items()):
+            if isinstance(v, tuple):           # (pointer, size): a buffer this executor allocated ("x" entries are borrowed pointers)
+                self.ctx.free(v[0])
+            del self.bufs[key]
+
     def adam_step(self, hyper, t):
         for n in self.nets:
             n.adam_step(hyper, t)
@@ -356,3 +362,10 @@ class DeviceGame:
     def sync_to_host(self):
         self.env.MODEL_D.pull_params()
         self.env.MODEL_G.pull_params()
+
+    def close(self):
+        """Release the device buffers of the game (the nets stay with their models)."""
+        self.dg.close()
+        for p in (self.inputs, self.targets, self.ones, self.noise, self.df, self.loss):
+            self.ctx.free(p)
+        self.inputs = self.targets = self.ones = self.noise = self.df = self.loss = None

@@ -278,6 +278,7 @@ class Sequential(Module):
 
     def add(self, m):
         self.modules.append(m)
+        self._parts = None             # the execution plan of a model with an nn.Concat is rebuilt on the next use
         return self
 
     def get(self, i):
