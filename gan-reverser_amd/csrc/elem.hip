@@ -888,6 +888,7 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
     hipLaunchKernelGGL(post_backward_a_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
   }
   if (!f.has_bn) {      // no BatchNorm: pass A's dz is dy; only the bias gradient is left to sum
+    if (!a.gbias) return;         // ... and an element-wise stage (dropout / pooling behind a PReLU: the D network) has no bias either
     hipLaunchKernelGGL(post_backward_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a, splits, (double)n);
     return;
   }
