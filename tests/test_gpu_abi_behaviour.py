@@ -108,3 +108,37 @@ def test_layer_output_and_module_level_calls(ctx, oracle):
     with pytest.raises(L.GanrevError):
         seq._net.layer_output(1, (3, 6, 8, 8))                               # BN output is fused away
     assert np.array_equal(seq._net.layer_output(2, (3, 6, 8, 8)), out)
+
+
+def test_concat_helpers_and_new_layer_kinds_error_paths(ctx):
+    """gr_copy2d_dev / gr_add_dev (nn.Concat's data movement, models.lua:293-321) on device buffers against numpy, their argument
+    checks, and gr_net_create's answers for the D network's layer kinds: a 7x7 window is UNSUPPORTED (no kernel), a 5x5
+    convolution with the wrong plane count INVALID, UpSampling in front of a 5x5 convolution UNSUPPORTED."""
+    import ganrev._lib as L
+    lib = ctx.lib
+    a = np.arange(6 * 5, dtype=np.float32).reshape(6, 5)
+    b = -np.arange(6 * 3, dtype=np.float32).reshape(6, 3)
+    da, db, dcat = ctx.upload(a), ctx.upload(b), ctx.malloc(4 * 6 * 8)
+    ctx.copy2d(dcat, 8, da, 5, 6, 5)                      # join: [6 x 5] and [6 x 3] side by side
+    ctx.copy2d(dcat + 4 * 5, 8, db, 3, 6, 3)
+    assert np.array_equal(ctx.download(dcat, (6, 8)), np.concatenate([a, b], axis=1))
+    dsl = ctx.malloc(4 * 6 * 3)
+    ctx.copy2d(dsl, 3, dcat + 4 * 5, 8, 6, 3)             # slice the second block back out
+    assert np.array_equal(ctx.download(dsl, (6, 3)), b)
+    ctx.add(dsl, db, 18)
+    assert np.array_equal(ctx.download(dsl, (6, 3)), 2 * b)
+    assert lib.gr_copy2d_dev(ctx.h, C.c_void_p(dcat), 4, C.c_void_p(da), 5, 6, 5) == -1        # destination pitch shorter than a row
+    assert lib.gr_add_dev(ctx.h, C.c_void_p(dsl), None, 18) == -1
+    for p in (da, db, dcat, dsl):
+        ctx.free(p)
+    net = C.c_void_p()
+    k7 = (L.LayerDesc * 1)(L.LayerDesc(L.CONVK, 3, 8, 7, 0.0, 0))
+    assert lib.gr_net_create(ctx.h, k7, 1, 3, 16, 16, C.byref(net)) == -2 and b"7x7" in lib.gr_last_error(ctx.h)
+    k5 = (L.LayerDesc * 1)(L.LayerDesc(L.CONVK, 4, 8, 5, 0.0, 0))
+    assert lib.gr_net_create(ctx.h, k5, 1, 3, 16, 16, C.byref(net)) == -1 and b"expects 4 input planes" in lib.gr_last_error(ctx.h)
+    up5 = (L.LayerDesc * 2)(L.LayerDesc(L.UPSAMPLE2, 0, 0, 0, 0.0, 0), L.LayerDesc(L.CONVK, 3, 8, 5, 0.0, 0))
+    assert lib.gr_net_create(ctx.h, up5, 2, 3, 8, 8, C.byref(net)) == -2
+    ok = (L.LayerDesc * 2)(L.LayerDesc(L.CONVK, 3, 8, 5, 0.0, 0), L.LayerDesc(L.PRELU, 0, 0, 0, 0.0, 0))
+    assert lib.gr_net_create(ctx.h, ok, 2, 3, 16, 16, C.byref(net)) == 0
+    assert lib.gr_net_param_count(net) == 3 * 8 * 25 + 8 + 1                                   # weight, bias, the PReLU slope
+    assert lib.gr_net_destroy(net) == 0

@@ -311,3 +311,36 @@ def test_oracle_bce_matches_float64_formula():
     gref = (-(td - xd) / ((1 - xd + 1e-12) * (xd + 1e-12)) / x.size).astype(np.float32)
     assert abs(loss - ref) <= 1e-12 * max(1.0, abs(ref))
     assert np.array_equal(g, gref)
+
+
+def test_adversarial_host_pieces():
+    """ganrev.adversarial without a GPU: the penalty / clamp helpers (adversarial.lua:8-28), the option table of train.lua:27-38,
+    the optimiser dispatch's error for a method the reference lists but this build has no kernel for, and the unknown-method
+    error text of adversarial.lua:170."""
+    from ganrev import adversarial
+    theta = np.array([1.0, -2.0, 0.0, 0.5], np.float32)
+    g = np.array([0.3, -7.0, 9.0, -0.1], np.float32)
+    f = adversarial.l2(theta, g, 1.0, 0.1)                               # f + l2 * ||theta||^2 / 2 ; g += l2 * theta
+    assert abs(f - (1.0 + 0.1 * 5.25 / 2)) < 1e-7 and np.allclose(g, [0.4, -7.2, 9.0, -0.05])
+    f = adversarial.l1(theta, g, f, 0.5)                                 # f + l1 * |theta|_1 ; g += l1 * sign(theta)
+    assert abs(f - (1.0 + 0.2625 + 0.5 * 3.5)) < 1e-6 and np.allclose(g, [0.9, -7.7, 9.0, 0.45])
+    adversarial.clamp(g, 5.0)
+    assert np.allclose(g, [0.9, -5.0, 5.0, 0.45])
+    g0 = g.copy(); adversarial.clamp(g, 0); assert np.array_equal(g, g0)      # clampValue 0: untouched (adversarial.lua:9)
+    assert adversarial.l2(theta, g, 2.0, 0) == 2.0 and np.array_equal(g, g0)
+    G, D = models.create_G((1, 16, 16), 8), models.create_D2((1, 16, 16))
+    env = adversarial.make_env(G, D, (1, 16, 16), batchSize=8, noiseDim=8)
+    assert (env.OPT.D_L2, env.OPT.D_clamp, env.OPT.G_clamp, env.OPT.G_L2, env.OPT.D_optmethod) == (1e-4, 1.0, 5.0, 0.0, "adam")   # train.lua:27-38
+    assert env.PARAMETERS_D.size == D._param_count() and env.PARAMETERS_G.size == G._param_count() and env.CONFUSION.shape == (2, 2)
+    assert all(m.train for m in D.listModules()) and all(m.train for m in G.listModules())                                      # train.lua:133-134
+    with pytest.raises(L.GanrevError):
+        adversarial.make_env(G, D, (1, 16, 16), batchsize=8)
+    env.OPT.D_optmethod = "sgd"
+    with pytest.raises(L.GanrevError, match="only 'adam'"):
+        adversarial._optimize(env, "D", lambda x: (0.0, x), env.PARAMETERS_D, D)
+    env.OPT.D_optmethod = "lbfgs"
+    with pytest.raises(L.GanrevError, match="Unknown optimizer method 'lbfgs' chosen for D."):
+        adversarial._optimize(env, "D", lambda x: (0.0, x), env.PARAMETERS_D, D)
+    from ganrev import train
+    imgs = train.synthetic_images(6, (3, 16, 16), 5)
+    assert imgs.shape == (6, 3, 16, 16) and imgs.dtype == np.float32 and 0 <= imgs.min() and imgs.max() <= 1 and not np.array_equal(imgs[0], imgs[1])
