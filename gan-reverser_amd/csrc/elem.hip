@@ -9,6 +9,7 @@
 //   nn.MSECriterion                                        train_r.lua:119,147,150
 //   fevalR penalty+clamp and optim.adam                    train_r.lua:153-165,170
 #include "kernels.h"
+#include <type_traits>
 
 namespace gr {
 
@@ -30,6 +31,34 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* sh) {
 // the path - instead of the ~20 VALU instructions of a 32-bit division per float4 (these kernels are VALU-bound, ~37 per element)
 __device__ __forceinline__ unsigned udivp(unsigned x, unsigned d) { return (d & (d - 1)) == 0 ? x >> (__ffs(d) - 1) : x / d; }
 __device__ __forceinline__ float post_slope(const PostArgs& a) { return a.act == ACT_PRELU ? *a.slope_dev : a.slope; }
+// The pipeline kernels read their stage description (activation, mask kinds, pooling, BatchNorm) from the argument block and
+// branch on it per element - uniform branches, but ~25 of them per float4 and every taken one a fetch bubble.  The three
+// descriptions R's training step consists of (models.lua:409-440: conv-SBN-ELU-Dropout; ...-ELU-MaxPool-Dropout;
+// ...-ELU-SpatialDropout-MaxPool) are instantiated with those fields as compile-time constants: same code, same arithmetic,
+// the switches folded.  CB = 0 is the generic kernel.
+template <int CB>
+__device__ __forceinline__ void post_specialize(PostArgs& f) {
+  if (CB == 1) { f.act = ACT_ELU; f.has_bn = 1; f.m1.kind = MASK_ELEM; f.pool = 0; f.m2.kind = MASK_NONE; }
+  if (CB == 2) { f.act = ACT_ELU; f.has_bn = 1; f.m1.kind = MASK_NONE; f.pool = 1; f.m2.kind = MASK_ELEM; }
+  if (CB == 3) { f.act = ACT_ELU; f.has_bn = 1; f.m1.kind = MASK_SPATIAL; f.pool = 1; f.m2.kind = MASK_NONE; }
+}
+inline int post_combo(const PostArgs& f) {
+  static const bool on = !getenv("GR_POST_GENERIC");
+  if (!on || f.act != ACT_ELU || !f.has_bn) return 0;
+  if (f.m1.kind == MASK_ELEM && !f.pool && f.m2.kind == MASK_NONE) return 1;
+  if (f.m1.kind == MASK_NONE && f.pool && f.m2.kind == MASK_ELEM) return 2;
+  if (f.m1.kind == MASK_SPATIAL && f.pool && f.m2.kind == MASK_NONE) return 3;
+  return 0;
+}
+template <typename F>
+static void with_combo(int cb, F&& f) {          // f(std::integral_constant<int, CB>)
+  switch (cb) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    default: f(std::integral_constant<int, 0>{});
+  }
+}
 __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
   switch (act) {
     // ELU on the hardware exponential (v_exp_f32 of z * log2 e: 2 instructions instead of expf's ~15; these pipelines are
@@ -133,7 +162,9 @@ __device__ __forceinline__ float4 bn_act4(const PostArgs& a, float4 v, float mea
 }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
+template <int CB>
 __global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
+  post_specialize<CB>(a);
   const unsigned H = a.H, W = a.W, Ho = a.pool ? H >> 1 : H, Wo = a.pool ? W >> 1 : W;
   const unsigned HW = H * W, HWo = Ho * Wo, q_per_plane = HWo >> 2, wq = Wo >> 2;
   const unsigned n4 = (unsigned)a.B * a.C * q_per_plane;
@@ -229,8 +260,9 @@ __device__ __forceinline__ void t8_emit(const unsigned char* img, int npx, uint4
 }
 // PXT = pixels per tile: 1024, or 256 for planes of 256 output pixels (a 34 KB image for 1024 pixels limits a CU to four
 // workgroups; 16x16 planes need 9 KB and fit eight)
-template <bool POOL, int PXT>
+template <bool POOL, int PXT, int CB>
 __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
+  post_specialize<CB>(a);
   constexpr int RSB = PXT * 2 + 64;                          // bytes per (term, channel) row: 64 (mod 256)
   __shared__ __attribute__((aligned(16))) unsigned char img[16 * RSB];
   const unsigned H = a.H, W = a.W, Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
@@ -328,19 +360,19 @@ void launch_post_forward(const PostArgs& a, hipStream_t s) {
     KtScope kt("post_forward_g8_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + (a.out ? 2.0 : 1.0) * (double)n), s);
     if (hwo <= 256) {
       if (blocks > 8192) blocks = 8192;
-      if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((post_forward_g8_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      if (a.pool) with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<true, 256, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
+      else with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<false, 256, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
     } else if (g8_half_tiles() == 2) {
       blocks *= 4; if (blocks > 8192) blocks = 8192;
-      if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((post_forward_g8_kernel<false, 256>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      if (a.pool) with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<true, 256, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
+      else with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<false, 256, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
     } else if (g8_half_tiles() && hwo % 512 == 0) {
       blocks *= 2; if (blocks > 8192) blocks = 8192;
-      if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 512>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((post_forward_g8_kernel<false, 512>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      if (a.pool) with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<true, 512, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
+      else with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<false, 512, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
     } else {
-      if (a.pool) hipLaunchKernelGGL((post_forward_g8_kernel<true, 1024>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((post_forward_g8_kernel<false, 1024>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      if (a.pool) with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<true, 1024, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
+      else with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<false, 1024, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
     }
     return;
   }
@@ -350,7 +382,7 @@ void launch_post_forward(const PostArgs& a, hipStream_t s) {
   if (blocks < 1) blocks = 1;
   if (vec) {
     KtScope kt("post_forward_vec_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + (double)n), s);
-    hipLaunchKernelGGL(post_forward_vec_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL(post_forward_vec_kernel<decltype(cb)::value>, dim3((unsigned)blocks), dim3(256), 0, s, a); });
     return;
   }
   KtScope kt("post_forward_kernel", 0.0, 4.0 * ((double)a.B * a.C * a.H * a.W + (double)n), s);
@@ -630,8 +662,10 @@ __device__ __forceinline__ float4 post_bwd_dz4(const PostBwdArgs& a, unsigned bc
 }
 
 // float4 variants of pass A / pass B: block (c, split) walks its images, threads take consecutive pre-pool float4s.
+template <int CB>
 __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a, int splits) {
   __shared__ double sh[8];
+  post_specialize<CB>(a.f);
   const PostArgs& f = a.f;
   const int c = blockIdx.x, sp = blockIdx.y;
   const unsigned H = f.H, W = f.W, Wo = f.pool ? W >> 1 : W, HW = H * W, HWo = f.pool ? (H >> 1) * Wo : HW;
@@ -681,9 +715,11 @@ __device__ __forceinline__ void post_bwd_coef(const PostBwdArgs& a, int c, int s
   __syncthreads();
 }
 
+template <int CB>
 __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a, int splits, double n) {
   __shared__ double sh[8];
   __shared__ float sh_coef[2];
+  post_specialize<CB>(a.f);
   const PostArgs& f = a.f;
   const int c = blockIdx.x, sp = blockIdx.y;
   post_bwd_coef(a, c, sp, splits, n, sh_coef);
@@ -718,8 +754,9 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
 // the LDS transpose of the forward kernel (t8_pack / t8_emit).  Writes dy as the data- / weight-gradient convolutions' image
 // dy_p16[b][g][term][pixel], scaled by the power of two of the bound K * max|dz| (K from the forward's statistics, max|dz| from
 // pass A) that it also leaves in amax_dy, and as fp32 only when a consumer still needs that (a.dy != null).
-template <int PXT>
+template <int PXT, int CB>
 __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, int splits, int slices, double n, int dbg) {
+  post_specialize<CB>(a.f);
   constexpr int RSB = PXT * 2 + 64;
   __shared__ __attribute__((aligned(16))) unsigned char img[16 * RSB];
   __shared__ double sh_part[16];
@@ -882,7 +919,12 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
   if (vec) {
     splits = batch_splits(n, f.B);
     KtScope kt("post_backward_a_vec_kernel", 0.0, 4.0 * ((f.has_bn ? 1.0 : 2.0) * pre + post), s);   // with BN: dz is not stored
-    hipLaunchKernelGGL(post_backward_a_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+    switch (post_combo(f)) {
+      case 1: hipLaunchKernelGGL(post_backward_a_vec_kernel<1>, dim3(f.C, splits), dim3(256), 0, s, a, splits); break;
+      case 2: hipLaunchKernelGGL(post_backward_a_vec_kernel<2>, dim3(f.C, splits), dim3(256), 0, s, a, splits); break;
+      case 3: hipLaunchKernelGGL(post_backward_a_vec_kernel<3>, dim3(f.C, splits), dim3(256), 0, s, a, splits); break;
+      default: hipLaunchKernelGGL(post_backward_a_vec_kernel<0>, dim3(f.C, splits), dim3(256), 0, s, a, splits);
+    }
   } else {
     KtScope kt("post_backward_a_kernel", 0.0, 4.0 * (2.0 * pre + post), s);
     hipLaunchKernelGGL(post_backward_a_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
@@ -898,10 +940,10 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
     // 35 for the per-channel kernel): the batch is sliced down to single images instead, up to PB_SPLITS slices
     int slices = f.B < PB_SPLITS ? f.B : PB_SPLITS;
     { const int per = (f.B + slices - 1) / slices; slices = (f.B + per - 1) / per; }
-    if (f.H * f.W <= 256) hipLaunchKernelGGL(post_backward_b_g8_kernel<256>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
-    else if (g8_half_tiles() == 2) hipLaunchKernelGGL(post_backward_b_g8_kernel<256>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
-    else if (g8_half_tiles() && (f.H * f.W) % 512 == 0) hipLaunchKernelGGL(post_backward_b_g8_kernel<512>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
-    else hipLaunchKernelGGL(post_backward_b_g8_kernel<1024>, dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug);
+    if (f.H * f.W <= 256) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug); });
+    else if (g8_half_tiles() == 2) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug); });
+    else if (g8_half_tiles() && (f.H * f.W) % 512 == 0) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<512, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug); });
+    else with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<1024, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug); });
     if (a.gbias) {
       BiasJobs one{}; one.n = 0;
       BiasJobs* q = defer ? defer : &one;
@@ -912,7 +954,7 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
     return;
   } else if (vec) {
     KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);                      // reads g and y, writes dy
-    hipLaunchKernelGGL(post_backward_b_vec_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits, (double)n);
+    with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL(post_backward_b_vec_kernel<decltype(cb)::value>, dim3(f.C, splits), dim3(256), 0, s, a, splits, (double)n); });
   } else {
     KtScope kt("post_backward_b_kernel", 0.0, 4.0 * 3.0 * pre, s);
     hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits, (double)n);
