@@ -41,10 +41,22 @@ __device__ __forceinline__ void post_specialize(PostArgs& f) {
   if (CB == 1) { f.act = ACT_ELU; f.has_bn = 1; f.m1.kind = MASK_ELEM; f.pool = 0; f.m2.kind = MASK_NONE; }
   if (CB == 2) { f.act = ACT_ELU; f.has_bn = 1; f.m1.kind = MASK_NONE; f.pool = 1; f.m2.kind = MASK_ELEM; }
   if (CB == 3) { f.act = ACT_ELU; f.has_bn = 1; f.m1.kind = MASK_SPATIAL; f.pool = 1; f.m2.kind = MASK_NONE; }
+  // the D network's stages (models.lua:272-337: no BatchNorm; a PReLU closes its stage, dropout / pooling follow element-wise)
+  if (CB == 4) { f.act = ACT_PRELU; f.has_bn = 0; f.m1.kind = MASK_NONE; f.pool = 0; f.m2.kind = MASK_NONE; }
+  if (CB == 5) { f.act = ACT_NONE; f.has_bn = 0; f.m1.kind = MASK_SPATIAL; f.pool = 1; f.m2.kind = MASK_NONE; }
+  if (CB == 6) { f.act = ACT_NONE; f.has_bn = 0; f.m1.kind = MASK_NONE; f.pool = 1; f.m2.kind = MASK_NONE; }
+  if (CB == 7) { f.act = ACT_NONE; f.has_bn = 0; f.m1.kind = MASK_SPATIAL; f.pool = 0; f.m2.kind = MASK_NONE; }
 }
 inline int post_combo(const PostArgs& f) {
   static const bool on = !getenv("GR_POST_GENERIC");
-  if (!on || f.act != ACT_ELU || !f.has_bn) return 0;
+  if (!on) return 0;
+  if (!f.has_bn && f.m2.kind == MASK_NONE) {
+    if (f.act == ACT_PRELU && f.m1.kind == MASK_NONE && !f.pool) return 4;
+    if (f.act == ACT_NONE && f.m1.kind == MASK_SPATIAL && f.pool) return 5;
+    if (f.act == ACT_NONE && f.m1.kind == MASK_NONE && f.pool) return 6;
+    if (f.act == ACT_NONE && f.m1.kind == MASK_SPATIAL && !f.pool) return 7;
+  }
+  if (f.act != ACT_ELU || !f.has_bn) return 0;
   if (f.m1.kind == MASK_ELEM && !f.pool && f.m2.kind == MASK_NONE) return 1;
   if (f.m1.kind == MASK_NONE && f.pool && f.m2.kind == MASK_ELEM) return 2;
   if (f.m1.kind == MASK_SPATIAL && f.pool && f.m2.kind == MASK_NONE) return 3;
@@ -56,6 +68,10 @@ static void with_combo(int cb, F&& f) {          // f(std::integral_constant<int
     case 1: f(std::integral_constant<int, 1>{}); break;
     case 2: f(std::integral_constant<int, 2>{}); break;
     case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 5: f(std::integral_constant<int, 5>{}); break;
+    case 6: f(std::integral_constant<int, 6>{}); break;
+    case 7: f(std::integral_constant<int, 7>{}); break;
     default: f(std::integral_constant<int, 0>{});
   }
 }
@@ -919,12 +935,7 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
   if (vec) {
     splits = batch_splits(n, f.B);
     KtScope kt("post_backward_a_vec_kernel", 0.0, 4.0 * ((f.has_bn ? 1.0 : 2.0) * pre + post), s);   // with BN: dz is not stored
-    switch (post_combo(f)) {
-      case 1: hipLaunchKernelGGL(post_backward_a_vec_kernel<1>, dim3(f.C, splits), dim3(256), 0, s, a, splits); break;
-      case 2: hipLaunchKernelGGL(post_backward_a_vec_kernel<2>, dim3(f.C, splits), dim3(256), 0, s, a, splits); break;
-      case 3: hipLaunchKernelGGL(post_backward_a_vec_kernel<3>, dim3(f.C, splits), dim3(256), 0, s, a, splits); break;
-      default: hipLaunchKernelGGL(post_backward_a_vec_kernel<0>, dim3(f.C, splits), dim3(256), 0, s, a, splits);
-    }
+    with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL(post_backward_a_vec_kernel<decltype(cb)::value>, dim3(f.C, splits), dim3(256), 0, s, a, splits); });
   } else {
     KtScope kt("post_backward_a_kernel", 0.0, 4.0 * (2.0 * pre + post), s);
     hipLaunchKernelGGL(post_backward_a_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits);
