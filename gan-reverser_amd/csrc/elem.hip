@@ -693,17 +693,33 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
   float dmax = 0.f;
   const unsigned tot = b1 > b0 ? (unsigned)(b1 - b0) * q4 : 0u;     // an empty slice contributes zeros
   {
-    for (unsigned j = threadIdx.x; j < tot; j += 256) {
-      const unsigned bb = udivp(j, q4), i = j - bb * q4;
-      const unsigned bc = (unsigned)(b0 + bb) * f.C + c, pbase = bc * HW, obase = bc * HWo;
-      const unsigned e = pbase + i * 4;
-      float4 yv;
-      const float4 dz = post_bwd_dz4(a, bc, e, i, obase, wq, Wo, mean, invstd, gm, bt, yv);
-      if (!f.has_bn) *reinterpret_cast<float4*>(a.dy + e) = dz;     // with BatchNorm pass B recomputes dz: nothing stored here
-      dmax = absmax4(dmax, dz);
-      s += (double)dz.x + (double)dz.y + (double)dz.z + (double)dz.w;
-      q += (double)(yv.x - mean) * (double)dz.x + (double)(yv.y - mean) * (double)dz.y +
-           (double)(yv.z - mean) * (double)dz.z + (double)(yv.w - mean) * (double)dz.w;
+    // four float4 groups per thread and round: all their loads are issued before the first is used (a block owns only ~1024
+    // groups - four per thread - so without this every thread waits out one memory round trip per group); post_bwd_load4 /
+    // post_bwd_dz_of are the two halves of post_bwd_dz4, same operations in the same order
+    for (unsigned j0 = threadIdx.x; j0 < tot; j0 += 1024) {
+      BwdRaw r[4]; unsigned ee[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned j = j0 + 256u * u;
+        if (j < tot) {
+          const unsigned bb = udivp(j, q4), i = j - bb * q4;
+          const unsigned bc = (unsigned)(b0 + bb) * f.C + c, pbase = bc * HW, obase = bc * HWo;
+          ee[u] = pbase + i * 4;
+          r[u] = post_bwd_load4(a, bc, ee[u], i, obase, wq, Wo);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j0 + 256u * u < tot) {
+          const float4 dz = post_bwd_dz_of(a, r[u], mean, invstd, gm, bt);
+          const float4 yv = r[u].y;
+          if (!f.has_bn) *reinterpret_cast<float4*>(a.dy + ee[u]) = dz;     // with BatchNorm pass B recomputes dz: nothing stored here
+          dmax = absmax4(dmax, dz);
+          s += (double)dz.x + (double)dz.y + (double)dz.z + (double)dz.w;
+          q += (double)(yv.x - mean) * (double)dz.x + (double)(yv.y - mean) * (double)dz.y +
+               (double)(yv.z - mean) * (double)dz.z + (double)(yv.w - mean) * (double)dz.w;
+        }
+      }
     }
   }
   if (a.amax_dy && !f.has_bn) absmax_commit(dmax, a.amax_dy);      // without BN pass A's dz is the final dy
