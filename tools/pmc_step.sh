@@ -5,7 +5,7 @@ F=${1:-conv3x3}
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmcs_$tag
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_$tag -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-search --modes f16x3 --traffic off > $R/gpurun_out/pmcs_$tag.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_$tag -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-search --no-gan --modes f16x3 --traffic off > $R/gpurun_out/pmcs_$tag.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
@@ -25,5 +25,6 @@ for k in sorted(agg):
     clock = g("GRBM_GUI_ACTIVE") / 8 / t
     print(f"{k:46s} avg {t*1e6:7.1f} us  clock {clock/1e9:4.2f} GHz  MFMA busy {100*g('SQ_VALU_MFMA_BUSY_CYCLES')/(1024*t*clock):5.1f}%  waiting {100*g('SQ_WAIT_INST_ANY')/g('SQ_WAVE_CYCLES'):5.1f}%  "
           f"wait-LDS {100*g('SQ_WAIT_INST_LDS')/g('SQ_WAVE_CYCLES'):5.1f}%  VALU/MFMA {g('SQ_INSTS_VALU')/max(g('SQ_INSTS_MFMA'),1):5.2f}  LDS/MFMA {g('SQ_INSTS_LDS')/max(g('SQ_INSTS_MFMA'),1):5.2f}  "
-          f"bank-conflict {100*g('SQ_LDS_BANK_CONFLICT')/max(g('SQ_LDS_IDX_ACTIVE'),1):5.1f}% of LDS cycles  LDS active {100*g('SQ_ACTIVE_INST_LDS')/max(g('SQ_BUSY_CYCLES'),1):5.1f}%")
+          f"bank-conflict {100*g('SQ_LDS_BANK_CONFLICT')/max(g('SQ_LDS_IDX_ACTIVE'),1):5.1f}% of LDS cycles  LDS active {100*g('SQ_ACTIVE_INST_LDS')/max(g('SQ_BUSY_CYCLES'),1):5.1f}%  "
+          f"wave instructions per dispatch: VALU {g('SQ_INSTS_VALU'):.3g} SALU {g('SQ_INSTS_SALU'):.3g} VMEM-read {g('SQ_INSTS_VMEM_RD'):.3g}")
 PY
