@@ -46,6 +46,9 @@ __device__ __forceinline__ void post_specialize(PostArgs& f) {
   if (CB == 5) { f.act = ACT_NONE; f.has_bn = 0; f.m1.kind = MASK_SPATIAL; f.pool = 1; f.m2.kind = MASK_NONE; }
   if (CB == 6) { f.act = ACT_NONE; f.has_bn = 0; f.m1.kind = MASK_NONE; f.pool = 1; f.m2.kind = MASK_NONE; }
   if (CB == 7) { f.act = ACT_NONE; f.has_bn = 0; f.m1.kind = MASK_SPATIAL; f.pool = 0; f.m2.kind = MASK_NONE; }
+  // G in training mode (the GAN game trains it: models.lua:115-133): Linear/conv - BatchNorm - ReLU, and the Sigmoid of its last layer
+  if (CB == 8) { f.act = ACT_RELU; f.has_bn = 1; f.m1.kind = MASK_NONE; f.pool = 0; f.m2.kind = MASK_NONE; }
+  if (CB == 9) { f.act = ACT_SIGMOID; f.has_bn = 0; f.m1.kind = MASK_NONE; f.pool = 0; f.m2.kind = MASK_NONE; }
 }
 inline int post_combo(const PostArgs& f) {
   static const bool on = !getenv("GR_POST_GENERIC");
@@ -55,7 +58,9 @@ inline int post_combo(const PostArgs& f) {
     if (f.act == ACT_NONE && f.m1.kind == MASK_SPATIAL && f.pool) return 5;
     if (f.act == ACT_NONE && f.m1.kind == MASK_NONE && f.pool) return 6;
     if (f.act == ACT_NONE && f.m1.kind == MASK_SPATIAL && !f.pool) return 7;
+    if (f.act == ACT_SIGMOID && f.m1.kind == MASK_NONE && !f.pool) return 9;
   }
+  if (f.act == ACT_RELU && f.has_bn && f.m1.kind == MASK_NONE && !f.pool && f.m2.kind == MASK_NONE) return 8;
   if (f.act != ACT_ELU || !f.has_bn) return 0;
   if (f.m1.kind == MASK_ELEM && !f.pool && f.m2.kind == MASK_NONE) return 1;
   if (f.m1.kind == MASK_NONE && f.pool && f.m2.kind == MASK_ELEM) return 2;
@@ -72,6 +77,8 @@ static void with_combo(int cb, F&& f) {          // f(std::integral_constant<int
     case 5: f(std::integral_constant<int, 5>{}); break;
     case 6: f(std::integral_constant<int, 6>{}); break;
     case 7: f(std::integral_constant<int, 7>{}); break;
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    case 9: f(std::integral_constant<int, 9>{}); break;
     default: f(std::integral_constant<int, 0>{});
   }
 }
