@@ -49,6 +49,10 @@ __device__ __forceinline__ void post_specialize(PostArgs& f) {
   // G in training mode (the GAN game trains it: models.lua:115-133): Linear/conv - BatchNorm - ReLU, and the Sigmoid of its last layer
   if (CB == 8) { f.act = ACT_RELU; f.has_bn = 1; f.m1.kind = MASK_NONE; f.pool = 0; f.m2.kind = MASK_NONE; }
   if (CB == 9) { f.act = ACT_SIGMOID; f.has_bn = 0; f.m1.kind = MASK_NONE; f.pool = 0; f.m2.kind = MASK_NONE; }
+  // R in evaluate() mode (apply_r.lua's embedding): the two pooling stages (the other four ride in their convolutions' epilogues);
+  // Dropout is the identity there, SpatialDropout a multiplication by 1 - p
+  if (CB == 10) { f.act = ACT_ELU; f.has_bn = 1; f.m1.kind = MASK_NONE; f.pool = 1; f.m2.kind = MASK_NONE; }
+  if (CB == 11) { f.act = ACT_ELU; f.has_bn = 1; f.m1.kind = MASK_SCALE; f.pool = 1; f.m2.kind = MASK_NONE; }
 }
 inline int post_combo(const PostArgs& f) {
   static const bool on = !getenv("GR_POST_GENERIC");
@@ -65,6 +69,8 @@ inline int post_combo(const PostArgs& f) {
   if (f.m1.kind == MASK_ELEM && !f.pool && f.m2.kind == MASK_NONE) return 1;
   if (f.m1.kind == MASK_NONE && f.pool && f.m2.kind == MASK_ELEM) return 2;
   if (f.m1.kind == MASK_SPATIAL && f.pool && f.m2.kind == MASK_NONE) return 3;
+  if (f.m1.kind == MASK_NONE && f.pool && f.m2.kind == MASK_NONE) return 10;
+  if (f.m1.kind == MASK_SCALE && f.pool && f.m2.kind == MASK_NONE) return 11;
   return 0;
 }
 template <typename F>
@@ -79,6 +85,8 @@ static void with_combo(int cb, F&& f) {          // f(std::integral_constant<int
     case 7: f(std::integral_constant<int, 7>{}); break;
     case 8: f(std::integral_constant<int, 8>{}); break;
     case 9: f(std::integral_constant<int, 9>{}); break;
+    case 10: f(std::integral_constant<int, 10>{}); break;
+    case 11: f(std::integral_constant<int, 11>{}); break;
     default: f(std::integral_constant<int, 0>{});
   }
 }
