@@ -374,7 +374,7 @@ def load_checkpoint(path):
         if isinstance(v, TorchObject) and v.typename == "nn.Sequential":
             try:
                 out[k] = to_model(v)
-            except Exception as e:          # D networks use layers this path has no kernels for: keep the raw tree
+            except Exception as e:          # a layer this path has no kernel for (e.g. SpatialAveragePooling of create_D_default): keep the raw tree
                 out[k] = v
                 out.setdefault("_unconverted", {})[k] = str(e)
         else:
