@@ -225,9 +225,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 // M = Cout <= 4 would waste 7/8 of a 32-row MFMA block and the layer is HBM-bound anyway (reads 128 planes to emit 1-3), so
 // this is a VALU kernel: one thread = 4 consecutive output pixels x all CO channels; input channels stream through LDS in
 // chunks of 8 (register-prefetched float4 rows + scalar halo columns), weights come in through the scalar cache.
-// KS = 2: the tile is 16 rows and the two halves of the workgroup take the even / odd half of every chunk's channels for the
-// same pixels, added through LDS at the end - twice the workgroups (a batch-256 layer on 32x32 planes has one 32-row tile per
-// CU: 4 waves per CU, every chunk's load latency exposed; 57 -> 40 us at cfg2).
+// KS = 2 / 4: the tile is 16 / 8 rows and the KS groups of the workgroup each take 1/KS of every chunk's channels for the
+// same pixels, added through LDS (in group order) at the end - KS times the workgroups (a batch-256 layer on 32x32 planes
+// has one 32-row tile per CU: 4 waves per CU, every chunk's load latency exposed; cfg2: 57 -> 47.5 us with two groups, 38.8
+// with four, 3.5 TB/s).
 template <int CO, int KS = 1>
 __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, const float* __restrict__ w_native) {
   constexpr int TW = 32, TRr = 32 / KS, CK = 8, PR = TRr + 2, PCS = 40, PS = PR * PCS;   // interior columns at [4, 36), halo at 3 and 36
@@ -246,8 +247,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
   const int y0 = ty * TRr, x0 = tx * TW, H = a.H, W = a.W;
   const size_t HW = (size_t)H * W;
   const float* in_base = a.in + (size_t)b * a.Cin * HW;
-  const int kg = KS == 1 ? 0 : tid >> 7;                   // channel half of this thread (KS = 2)
-  const int row = (KS == 1 ? tid : tid & 127) >> 3, strip = tid & 7;               // this thread's 4 output pixels: (y0+row, x0+4*strip ..+3)
+  constexpr int TPG = 256 / KS;                            // threads per channel group: TRr rows x 8 strips
+  const int kg = tid / TPG;                                // channel group of this thread (KS groups share the chunk's 8 channels)
+  const int row = (tid % TPG) >> 3, strip = tid & 7;       // this thread's 4 output pixels: (y0+row, x0+4*strip ..+3)
   static_assert(CK * WS <= 512, "two weight words per thread");
   const int wl_c = tid / WS, wl_e = tid % WS, wl_c2 = (tid + 256) / WS, wl_e2 = (tid + 256) % WS;
   float wreg[2];
@@ -327,20 +329,23 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
     __syncthreads();
   }
 #undef GR_FO_LOAD
-  if (KS == 2) {           // the upper half hands its partial sums over (the patch is dead: every thread is past the last chunk's barrier)
+  if (KS > 1) {            // groups 1 .. KS-1 hand their partial sums over (the patch is dead: every thread is past the last chunk's barrier)
+    static_assert((KS - 1) * CO * 4 * TPG <= CK * PS, "the hand-over reuses the patch");
     float* red = patch;
-    if (kg == 1) {
+    if (kg > 0) {
 #pragma unroll
       for (int o = 0; o < CO; ++o)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[(o * 4 + j) * 128 + (tid & 127)] = acc[o][j];
+        for (int j = 0; j < 4; ++j) red[((kg - 1) * CO * 4 + o * 4 + j) * TPG + (tid % TPG)] = acc[o][j];
     }
     __syncthreads();
-    if (kg == 1) return;
+    if (kg > 0) return;
 #pragma unroll
-    for (int o = 0; o < CO; ++o)
+    for (int g = 1; g < KS; ++g)          // added in group order: the same bits on every run
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[o][j] += red[(o * 4 + j) * 128 + tid];
+      for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] += red[((g - 1) * CO * 4 + o * 4 + j) * TPG + tid];
   }
   const int y = y0 + row, x = x0 + 4 * strip;
   if (y < H && x < W) {
@@ -484,15 +489,21 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
   a.nchunks = L.cin_pad / CONV_CK; a.cout_pad = L.cout_pad;
   if (w_native && Cout <= 4 && !up && W % 4 == 0 && W >= 16) {
-    static const int fo_split = getenv("GR_FEWOUT_SPLIT") ? atoi(getenv("GR_FEWOUT_SPLIT")) : 1;
+    static const int fo_split = getenv("GR_FEWOUT_SPLIT") ? atoi(getenv("GR_FEWOUT_SPLIT")) : 4;     // 0: 32-row tiles, 1: two channel groups on 16-row tiles, 4: four on 8-row tiles
     // (decided by the plane alone, not by the batch: a row must get the same bits whatever batch it travels in)
     const bool ks2 = fo_split && H % 16 == 0 && ((W + 31) / 32) * ((H + 31) / 32) < 4;      // small planes: too few 32-row tiles per image to fill the chip
-    a.tiles_x = (W + 31) / 32; a.tiles_y = ks2 ? H / 16 : (H + 31) / 32; a.n_otiles = 1;
+    const bool ks4 = fo_split == 4 && ks2 && H % 8 == 0;
+    a.tiles_x = (W + 31) / 32; a.tiles_y = ks4 ? H / 8 : (ks2 ? H / 16 : (H + 31) / 32); a.n_otiles = 1;
     const int grid = B * a.tiles_x * a.tiles_y;
     const double px = (double)B * H * W;
     const std::string fo_name = "conv3x3_fewout_kernel<" + std::to_string(Cout <= 3 ? Cout : 4) + ">";
     KtScope kt(fo_name.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
-    if (ks2) switch (Cout) {
+    if (ks4) switch (Cout) {
+      case 1: hipLaunchKernelGGL((conv3x3_fewout_kernel<1, 4>), dim3(grid), dim3(256), 0, s, a, w_native); break;
+      case 2: hipLaunchKernelGGL((conv3x3_fewout_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a, w_native); break;
+      case 3: hipLaunchKernelGGL((conv3x3_fewout_kernel<3, 4>), dim3(grid), dim3(256), 0, s, a, w_native); break;
+      default: hipLaunchKernelGGL((conv3x3_fewout_kernel<4, 4>), dim3(grid), dim3(256), 0, s, a, w_native); break;
+    } else if (ks2) switch (Cout) {
       case 1: hipLaunchKernelGGL((conv3x3_fewout_kernel<1, 2>), dim3(grid), dim3(256), 0, s, a, w_native); break;
       case 2: hipLaunchKernelGGL((conv3x3_fewout_kernel<2, 2>), dim3(grid), dim3(256), 0, s, a, w_native); break;
       case 3: hipLaunchKernelGGL((conv3x3_fewout_kernel<3, 2>), dim3(grid), dim3(256), 0, s, a, w_native); break;
