@@ -69,12 +69,12 @@ def spawn_ranks(args):
 # HBM traffic of the dominant kernel, measured in this run: two rocprofv3 --pmc children (FETCH_SIZE / WRITE_SIZE in separate
 # passes, MI355X_MICROARCH.md section HBM), each a short run of this same script.  They are started BEFORE this process
 # initialises the GPU.
-def measure_traffic(args):
+def measure_traffic(args, workload):
     import csv, glob, shutil, tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     out, base = {}, tempfile.mkdtemp(prefix="ganrev_pmc_")
-    child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "2", "--warmup", "1", "--conv-mode", args.conv_mode,
+    child = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "2", "--warmup", "1", "--conv-mode", args.conv_mode,
              "--modes", args.conv_mode, "--traffic", "off", "--no-cpu-baseline", "--no-search", "--quiet-child"]
     env = dict(os.environ, TMPDIR="/tmp")
     try:
@@ -276,6 +276,7 @@ def gan_step(ctx, with_cpu=True):
         ctx.synchronize()
         kt = ctx.kernel_times()
         ctx.set_timing(0)
+        kt, pseudo = split_pseudo_rows(kt)
         by = {}
         for k in kt:
             a = by.setdefault(k["kernel"], dict(kernel=k["kernel"], launches=0, total_ms=0.0, flops=0.0))
@@ -283,8 +284,9 @@ def gan_step(ctx, with_cpu=True):
         top = sorted(by.values(), key=lambda r: -r["total_ms"])[:8]
         rows[f"batch{B}"] = dict(ms_per_batch=round(ms, 4), generated_images_per_sec=round(B / ms * 1e3, 1), loss_d=round(ld, 5), loss_g=round(lg, 5),
                                  kernel_ms_sum=round(sum(r["total_ms"] for r in by.values()), 4), launches=int(sum(r["launches"] for r in by.values())),
+                                 timer_failed_samples=pseudo.get("timer_failed_samples", dict(count=0))["count"],
                                  top_kernels=[dict(kernel=r["kernel"], launches=r["launches"], ms=round(r["total_ms"], 4),
-                                                   tflops=round(r["flops"] / r["total_ms"] / 1e9, 2) if r["flops"] else None) for r in top])
+                                                   **dict(zip(("tflops", "rejected"), checked_tflops(r["kernel"], r["flops"], r["total_ms"])))) for r in top])
         ctx.synchronize()
         game.close()
         for m in (G, D):
@@ -332,8 +334,47 @@ def gan_step(ctx, with_cpu=True):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+PSEUDO_ROWS = ("timer_failed_samples", "range_guard_fallback")      # counts the library reports beside the kernels (gr_kernel_times)
+
+
+def kernel_ceiling_tflops(kname):
+    """Ceiling for the ALGORITHMIC FLOP rate of a kernel, from its symbol: split kernels issue `passes` 16-bit MFMA products per
+    fp32-accurate multiply-add (dense 16-bit peak / passes); everything else is priced at the fp32 rate of the pipe it runs on
+    (fp32 MFMA = packed-fp32 VALU = 157.3 TFLOP/s).  The fused up-sampling kernel issues 4/9 of the reference's taps."""
+    passes = 0
+    if "_split_" in kname or "_pre_" in kname:
+        targs = [t.strip() for t in kname[kname.index("<") + 1:kname.rindex(">")].split(",")]
+        nterm = int(targs[2]) if ("split_wide" in kname or kname.startswith("conv3x3_split_kernel")) else int(targs[-1])
+        passes = {3: BF16X6_PASSES, 2: F16X3_PASSES}.get(nterm, 0)
+    elif "f16x3" in kname or "_p16_" in kname:        # operand-ready kernels (conv3x3_p16_*, conv3x3_wgrad_p16_*), gemm_f16x3_*: fp16 hi/lo, 3 products
+        passes = F16X3_PASSES
+    peak = PEAK_BF16_MFMA_TFLOPS / passes if passes else PEAK_FP32_MFMA_TFLOPS
+    if "up2" in kname:
+        peak *= 9.0 / 4.0
+    return peak, passes
+
+
+def split_pseudo_rows(kt):
+    """-> (kernel rows, {pseudo row name: count}).  A timer that could not read a sample says so in a row of its own."""
+    counts = {k["kernel"]: dict(count=int(k["launches"]), detail=k.get("phase", "")) for k in kt if k["kernel"] in PSEUDO_ROWS}
+    return [k for k in kt if k["kernel"] not in PSEUDO_ROWS], counts
+
+
+def checked_tflops(kname, flops, ms):
+    """TFLOP/s of a row, or (None, reason) when it exceeds the kernel's ceiling: a rate above the ceiling means the timer did not
+    time the work (a 1885 TFLOP/s row from unfinished events) - such a figure is never printed."""
+    if not flops or ms <= 0:
+        return None, None
+    tf = flops / ms / 1e9
+    peak, _ = kernel_ceiling_tflops(kname)
+    if tf > peak * 1.02:
+        return None, f"{tf:.1f} TFLOP/s exceeds the kernel's ceiling {peak:.1f}: timing rejected"
+    return round(tf, 2), None
+
+
 def kernel_report(kt, nprof, dims, nd, B, traffic=None):
     """Per-kernel table + the roofline object of the dominant MFMA kernel + R's convolutions / element-wise shares."""
+    kt, pseudo = split_pseudo_rows(kt)
     by_name = {}
     for k in kt:
         a = by_name.setdefault(k["kernel"], dict(kernel=k["kernel"], launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
@@ -348,20 +389,11 @@ def kernel_report(kt, nprof, dims, nd, B, traffic=None):
     # kernel names are the symbols rocprofv3 prints; the split kernels carry their number of terms as a template argument
     # (conv3x3_split_wide_kernel<TW, NI, NTERM, DB>, conv3x3_split_kernel<TW, MT, NTERM>, conv3x3_wgrad_split_*<..., NTERM>)
     kname = dom["kernel"]
-    passes = 0
-    if "_split_" in kname or "_pre_" in kname:
-        targs = [t.strip() for t in kname[kname.index("<") + 1:kname.rindex(">")].split(",")]
-        nterm = int(targs[2]) if ("split_wide" in kname or kname.startswith("conv3x3_split_kernel")) else int(targs[-1])
-        passes = {3: BF16X6_PASSES, 2: F16X3_PASSES}[nterm]
-    elif "f16x3" in kname or "_p16_" in kname:        # operand-ready kernels (conv3x3_p16_*, conv3x3_wgrad_p16_*): fp16 hi/lo, 3 products
-        passes = F16X3_PASSES
+    peak, passes = kernel_ceiling_tflops(kname)
     split = passes > 0
-    # split modes: the kernel issues `passes` 16-bit MFMA products per algorithmic multiply-add; its ceiling for ALGORITHMIC
-    # flops is the dense 16-bit MFMA peak / passes
-    peak = PEAK_BF16_MFMA_TFLOPS / passes if split else PEAK_FP32_MFMA_TFLOPS
     up2 = "up2" in kname
-    if up2:     # fused up-sampling layer: the reference's 9 taps per output collapse to 4 (conv.hip), so the ceiling for the
-        peak *= 9.0 / 4.0   # reference-algorithm FLOPs this line is quoted in is 9/4 of the issued-FLOP ceiling
+    if achieved > peak * 1.02:
+        raise SystemExit(f"bench.py: dominant kernel {kname} measures {achieved:.1f} TFLOP/s, above its ceiling {peak:.1f}: the timer is not timing the work")
     roofline = dict(bound="mfma", kernel=kname, achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
                     frac=round(achieved / peak, 4), traffic=(traffic or {}).get(kname),
                     peak_note=(f"dense bf16/f16 MFMA 2500 TFLOP/s / {passes} products per fp32-accurate multiply-add "
@@ -370,10 +402,14 @@ def kernel_report(kt, nprof, dims, nd, B, traffic=None):
                     frac_of_fp32_mfma_peak=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                     avg_launch_ms=round(avg_ms, 4), launches_per_step=dom["launches"] / nprof,
                     algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3))
-    kernels = {k["kernel"]: dict(ms_per_step=round(k["total_ms"] / nprof, 4), launches_per_step=round(k["launches"] / nprof, 2),
-                                 tflops=round(k["flops"] / max(k["total_ms"], 1e-9) / 1e9, 2) if k["flops"] else None,
-                                 gbs=round(k["bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1) if k["bytes"] else None)
-               for k in sorted(rows, key=lambda k: -k["total_ms"])}
+    kernels = {}
+    for k in sorted(rows, key=lambda k: -k["total_ms"]):
+        tf, why = checked_tflops(k["kernel"], k["flops"], k["total_ms"])
+        row = dict(ms_per_step=round(k["total_ms"] / nprof, 4), launches_per_step=round(k["launches"] / nprof, 2), tflops=tf,
+                   gbs=round(k["bytes"] / max(k["total_ms"], 1e-9) / 1e6, 1) if k["bytes"] else None)
+        if why:
+            row = dict(launches_per_step=row["launches_per_step"], rejected=why)
+        kernels[k["kernel"]] = row
     total_ms = sum(k["total_ms"] for k in rows) / nprof
     # north_star: ">= 40 % of MFMA roofline on R's 3x3 convs at bs256" - every conv3x3_* launch of R's forward and backward
     # (forward, data gradient, weight gradient incl. its slab reductions) against 3 x R's forward conv FLOPs x batch
@@ -389,7 +425,9 @@ def kernel_report(kt, nprof, dims, nd, B, traffic=None):
     conv_fl = sum(k["flops"] for k in mfma) / nprof
     extra = dict(conv_kernels_tflops=round(conv_fl / max(conv_ms * 1e-3, 1e-12) / 1e12, 2), r_convs=r_convs,
                  elementwise=dict(ms_per_step=round(ew_ms, 4), share_of_kernel_time=round(ew_ms / max(total_ms, 1e-9), 4)),
-                 kernel_ms_per_step=round(total_ms, 4))
+                 kernel_ms_per_step=round(total_ms, 4), timer_failed_samples=pseudo.get("timer_failed_samples", dict(count=0))["count"])
+    if "timer_failed_samples" in pseudo:
+        extra["timer_error"] = pseudo["timer_failed_samples"]["detail"]
     return roofline, kernels, extra
 
 
@@ -399,12 +437,118 @@ def percentiles(ms):
     return dict(p10=q(0.10), p50=q(0.50), p90=q(0.90), min=round(s[0], 4), max=round(s[-1], 4))
 
 
+def run_workload(args, wl_key, modes, ctx, rank, world, shared_gpu, traffic, traffic_from, dist, torch):
+    """One workload (cfg2 / cfg3) through the timed loop in every requested arithmetic mode.  Returns the line's fields for
+    it (rank 0) or None."""
+    import ganrev._lib as L
+    from ganrev import models, synth
+    from ganrev.parallel import DeviceTrainer, host_allreduce_grads
+    wl = WORKLOADS[wl_key]
+    dims, nd, B = wl["dims"], wl["nd"], wl["batch"]
+    G = models.create_G(dims, nd); synth.init_params(G, 1)               # random-init weights of the named architecture
+    R = models.create_R(dims, nd); synth.init_params(R, 2)
+    G._ctx = R._ctx = ctx
+    # compile the nets with one small forward each (allocation happens at the first full-size step, in warm-up)
+    G.evaluate(); G.forward(synth.normal((2, nd), 1))
+    R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
+    gnet, rnet = G._net, R._net
+    rnet.set_seed(1 + rank)                                              # independent dropout noise per rank
+    rnet.adam_reset()
+    theta0 = rnet.get_params()
+    host_reduce = shared_gpu
+    if world > 1 and not shared_gpu:
+        rnet.broadcast_params(0)
+    hyper = L.Hyper()
+    GB = B * world
+    trainer = DeviceTrainer(ctx, gnet, rnet, hyper, B, world, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    t_adam = 0
+
+    def step(want_loss=False):
+        nonlocal t_adam
+        t_adam += 1
+        trainer.new_noise((t_adam << 8) + rank)                          # createNoiseInputs (utils/nn_utils.lua:39-51), on device
+        if host_reduce:  # test hook only (ranks share GPU 0: RCCL refuses duplicate devices): reduce through gloo
+            return trainer.step_decomposed(host_allreduce_grads(dist))
+        return trainer.step(want_loss=want_loss)
+
+    def timed(mode):
+        """W untimed steps, then EXACTLY K steps between barrier + device sync on both sides (max over ranks); one HIP event per
+        step on the library's stream for the percentiles; then 3 instrumented steps for the per-kernel table."""
+        nonlocal t_adam
+        ctx.set_conv_mode(mode)
+        rnet.set_params(theta0); rnet.adam_reset(); t_adam = 0            # every mode starts from the same state
+        trainer.t = 0
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.event_record(0)
+        for i in range(args.steps):
+            step()
+            ctx.event_record(i + 1)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        per_step = [ctx.event_elapsed_ms(i, i + 1) for i in range(args.steps)]
+        loss = step(want_loss=True)
+        # roofline leg: per-kernel HIP events (on the launch stream) over extra steps of the same workload.  Every rank runs
+        # these steps (they contain the collective); only rank 0 instruments and reports.
+        nprof = 3
+        if rank == 0:
+            ctx.set_timing(2)
+        for _ in range(nprof):
+            step()
+        barrier()
+        rep = None
+        if rank == 0:
+            kt = ctx.kernel_times()
+            ctx.set_timing(0)
+            rep = kernel_report(kt, nprof, dims, nd, B, traffic if mode == args.conv_mode else None)
+        return dt, per_step, loss, rep
+
+    results = {m: timed(m) for m in modes}
+    ctx.set_conv_mode(args.conv_mode)
+    out = None
+    if rank == 0:
+        fl_img = step_flops_per_image(dims, nd)[0]
+        dt, per_step, loss, (roofline, kernels, extra) = results[args.conv_mode]
+        if roofline.get("traffic") is not None or traffic_from:
+            roofline["traffic_from"] = traffic_from
+        mode_rows = {}
+        for m, (mdt, mps, mloss, (mroof, _, mextra)) in results.items():
+            mode_rows[m] = dict(images_per_sec=round(GB * args.steps / mdt, 1), ms_per_step=round(mdt / args.steps * 1e3, 4), dtype=DTYPE[m],
+                                step_ms_events=percentiles(mps), last_loss=mloss,
+                                roofline={k: mroof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_of_fp32_mfma_peak", "avg_launch_ms")},
+                                r_convs=mextra["r_convs"], elementwise=mextra["elementwise"])
+        out = dict(images_per_sec=round(GB * args.steps / dt, 1), ms_per_step=round(dt / args.steps * 1e3, 4),
+                   workload=wl["name"], global_batch=GB, per_gpu_batch=B,
+                   step_ms_events=percentiles(per_step),
+                   step_tflops=round(fl_img * GB * args.steps / dt / 1e12 / world, 2),
+                   step_frac_of_fp32_mfma_peak=round(fl_img * GB * args.steps / dt / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
+                   last_loss=loss, roofline=roofline, **extra, modes=mode_rows, kernels=kernels, host_reduce=host_reduce)
+    trainer.close()
+    gnet.close(); rnet.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="both", choices=sorted(WORKLOADS) + ["both"],
+                    help="both (default): cfg2 is the headline (BASELINE configs[1], the size north_star's bs256 target is quoted on) and "
+                         "cfg3 (configs[2] = the per-GPU shard of configs[3]) rides in the same line as the `cfg3` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the cfg5 (1M x 100, top-50) search leg")
     ap.add_argument("--no-gan", action="store_true", help="skip the GAN-game leg (SURVEY.md 8f rank 4: G + D2, one adversarial batch)")
@@ -444,45 +588,37 @@ def main():
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": sorted(seen)}))
         return
 
-    traffic, traffic_from = None, None
-    if world == 1 and args.traffic == "live":
-        traffic, traffic_from = measure_traffic(args)     # children first: this process has not initialised the GPU yet
-    if traffic is None and args.traffic != "off":
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        note = traffic_from
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(args.workload)
-                traffic_from = "profiles/traffic.json (committed rocprofv3 --pmc summary of an earlier run, NOT measured in this run)" + (f"; live: {note}" if note else "")
-            except Exception:  # noqa: BLE001
-                traffic = None
+    head = "cfg2" if args.workload == "both" else args.workload
+    workloads = [head] + (["cfg3"] if args.workload == "both" else [])
+    traffic, traffic_from = {}, {}
+    for w in workloads:
+        t, tf = None, None
+        if world == 1 and args.traffic == "live":
+            t, tf = measure_traffic(args, w)              # children first: this process has not initialised the GPU yet
+        if t is None and args.traffic != "off":
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
+            note = tf
+            if os.path.exists(tfile):
+                try:
+                    t = json.load(open(tfile)).get(w)
+                    tf = "profiles/traffic.json (committed rocprofv3 --pmc summary of an earlier run, NOT measured in this run)" + (f"; live: {note}" if note else "")
+                except Exception:  # noqa: BLE001
+                    t = None
+        traffic[w], traffic_from[w] = t, tf
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
     import ganrev._lib as L
-    from ganrev import models, synth
 
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only; gradients go over RCCL
-
-    wl = WORKLOADS[args.workload]
-    dims, nd, B = wl["dims"], wl["nd"], wl["batch"]
-    ctx = L.Context(local_rank)
+    os.environ["LOCAL_RANK"] = str(local_rank)
+    ctx = L.default_context()          # THE context of this process: the side legs' modules (default_context()) launch on the stream the timers watch
     ctx.set_conv_mode(args.conv_mode)
-    G = models.create_G(dims, nd); synth.init_params(G, 1)               # random-init weights of the named architecture
-    R = models.create_R(dims, nd); synth.init_params(R, 2)
-    G._ctx = R._ctx = ctx
-    # compile the nets with one small forward each (allocation happens at the first full-size step, in warm-up)
-    G.evaluate(); G.forward(synth.normal((2, nd), 1))
-    R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
-    gnet, rnet = G._net, R._net
-    rnet.set_seed(1 + rank)                                              # independent dropout noise per rank
-    rnet.adam_reset()
-    theta0 = rnet.get_params()
-    host_reduce, rccl_ranks = shared_gpu, 1
+    rccl_ranks = 1
     if world > 1 and not shared_gpu:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -490,102 +626,36 @@ def main():
         rccl_ranks, rccl_rank = ctx.comm_ranks()
         if rccl_ranks != world or rccl_rank != rank:
             raise SystemExit(f"bench.py: RCCL communicator has {rccl_ranks} ranks (this is {rccl_rank}), expected {world} / {rank}")
-        rnet.broadcast_params(0)
-    hyper = L.Hyper()
-    GB = B * world
-    from ganrev.parallel import DeviceTrainer, host_allreduce_grads
-    trainer = DeviceTrainer(ctx, gnet, rnet, hyper, B, world, rank)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        ctx.synchronize()
-        torch.cuda.synchronize()
-
-    t_adam = 0
-
-    def step(want_loss=False):
-        nonlocal t_adam
-        t_adam += 1
-        trainer.new_noise((t_adam << 8) + rank)                          # createNoiseInputs (utils/nn_utils.lua:39-51), on device
-        if host_reduce:  # test hook only (ranks share GPU 0: RCCL refuses duplicate devices): reduce through gloo
-            return trainer.step_decomposed(host_allreduce_grads(dist))
-        return trainer.step(want_loss=want_loss)
-
-    def timed(mode):
-        """W untimed steps, then EXACTLY K steps between barrier + device sync on both sides (max over ranks); one HIP event per
-        step on the library's stream for the percentiles; then 3 instrumented steps for the per-kernel table."""
-        nonlocal t_adam
-        ctx.set_conv_mode(mode)
-        rnet.set_params(theta0); rnet.adam_reset(); t_adam = 0            # every mode starts from the same state
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        ctx.event_record(0)
-        for i in range(args.steps):
-            step()
-            ctx.event_record(i + 1)
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        per_step = [ctx.event_elapsed_ms(i, i + 1) for i in range(args.steps)]
-        loss = step(want_loss=True)
-        # roofline leg: per-kernel HIP events (on the launch stream) over extra steps of the same workload.  Every rank runs
-        # these steps (they contain the collective); only rank 0 instruments and reports.
-        nprof = 3
-        if rank == 0:
-            ctx.set_timing(2)
-        for _ in range(nprof):
-            step()
-        barrier()
-        rep = None
-        if rank == 0:
-            kt = ctx.kernel_times()
-            ctx.set_timing(0)
-            rep = kernel_report(kt, nprof, dims, nd, B, traffic if mode == args.conv_mode else None)
-        return dt, per_step, loss, rep
 
     modes = [args.conv_mode] + [m for m in args.modes.split(",") if m in MODES and m != args.conv_mode]
-    results = {m: timed(m) for m in modes}
-    ctx.set_conv_mode(args.conv_mode)
+    res = {}
+    for w in workloads:
+        # the second workload of a default run is timed in the headline arithmetic only (its other modes: --workload cfg3)
+        res[w] = run_workload(args, w, modes if w == head else [args.conv_mode], ctx, rank, world, shared_gpu,
+                              traffic[w], traffic_from[w], dist, torch)
 
     out = None
     if rank == 0:
-        fl_img = step_flops_per_image(dims, nd)[0]
-        dt, per_step, loss, (roofline, kernels, extra) = results[args.conv_mode]
-        if roofline.get("traffic") is not None or traffic_from:
-            roofline["traffic_from"] = traffic_from
-        ms_step = dt / args.steps * 1e3
-        mode_rows = {}
-        for m, (mdt, mps, mloss, (mroof, _, mextra)) in results.items():
-            mode_rows[m] = dict(images_per_sec=round(GB * args.steps / mdt, 1), ms_per_step=round(mdt / args.steps * 1e3, 4), dtype=DTYPE[m],
-                                step_ms_events=percentiles(mps), last_loss=mloss,
-                                roofline={k: mroof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_of_fp32_mfma_peak", "avg_launch_ms")},
-                                r_convs=mextra["r_convs"], elementwise=mextra["elementwise"])
+        h = res[head]
+        host_reduce = h.pop("host_reduce")
         out = {
-            "metric": "images/sec G+R fwd/bwd", "value": round(GB * args.steps / dt, 1), "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "metric": "images/sec G+R fwd/bwd", "value": h.pop("images_per_sec"), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": h.pop("ms_per_step"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[args.conv_mode],
             "data": "synthetic",
-            "config": {"workload": wl["name"], "global_batch": GB, "per_gpu_batch": B,
+            "config": {"workload": h.pop("workload"), "global_batch": h.pop("global_batch"), "per_gpu_batch": h.pop("per_gpu_batch"),
                        "parallelism": f"dp{world}" + ("" if world == 1 else (" (RCCL all-reduce of R's flat gradient)" if not host_reduce else
                                                       " (TEST HOOK: ranks share one GPU, gradients reduced through gloo on the host)")),
                        "bn": "per-rank batch statistics"},
             "rccl_ranks": rccl_ranks,
-            "step_ms_events": percentiles(per_step),
-            "step_tflops": round(fl_img * GB * args.steps / dt / 1e12 / world, 2),
-            "step_frac_of_fp32_mfma_peak": round(fl_img * GB * args.steps / dt / 1e12 / world / PEAK_FP32_MFMA_TFLOPS, 4),
-            "last_loss": loss,
-            "roofline": roofline,
-            **extra,
-            "modes": mode_rows,
-            "kernels": kernels,
+            **h,
         }
+        if "cfg3" in res and head != "cfg3":
+            c3 = res["cfg3"]; c3.pop("host_reduce")
+            c3["note"] = ("BASELINE configs[2] (64x64 RGB, noise 100, batch 512 per GPU) = the per-GPU shard of configs[3] (global batch 4096 over 8 GPUs): "
+                          "same run, same steps / warmup, headline arithmetic; at n_gpus = 8 this object IS configs[3]")
+            out["cfg3"] = c3
         if world == 1 and not args.no_search:
             out["search_cfg5"] = search_cfg5(ctx)
         if world == 1 and not args.no_gan:
@@ -599,7 +669,7 @@ def main():
             out["cpu_baseline"] = None
     if world > 1:
         dist.barrier()
-        if not host_reduce:
+        if not shared_gpu:
             ctx.comm_destroy()
         dist.destroy_process_group()
     if out is not None and not args.quiet_child:

@@ -9,6 +9,7 @@
 #include "../../include/ganrev.h"
 #include "kernels.h"
 #include <rccl/rccl.h>
+#include <roctracer/roctx.h>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,19 +59,40 @@ struct gr_ctx {
 namespace gr { KernelTimer* g_ktimer = nullptr; }
 static int g_kphase = 0;      // which part of gr_train_r_step is launching: 0 outside, 1 G forward, 2 R forward, 3 loss, 4 R backward, 5 Adam
 struct EventTimer : gr::KernelTimer {
-  struct Rec { std::string name; int phase; double flops, bytes; hipEvent_t e0, e1; };
+  struct Rec { std::string name; int phase; double flops, bytes; hipEvent_t e0, e1; bool ok; };
   std::vector<hipEvent_t> pool; size_t next = 0;
   std::vector<Rec> open_, recs;
   struct Agg { long launches = 0; double ms = 0, flops = 0, bytes = 0; };
   std::vector<std::pair<std::pair<std::string, int>, Agg>> agg;      // keyed by (kernel, phase)
-  hipEvent_t get() { if (next == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); } return pool[next++]; }
-  void begin(const char* name, double flops, double bytes, hipStream_t s) override {
-    Rec r{name, g_kphase, flops, bytes, get(), get()}; (void)hipEventRecord(r.e0, s); open_.push_back(r);
+  long failed = 0;               // samples whose events could not be created / recorded / read: reported, never counted as 0 ms
+  std::string first_error;
+  void note(hipError_t e, const char* what) {
+    if (e == hipSuccess) return;
+    if (first_error.empty()) first_error = std::string(what) + ": " + hipGetErrorString(e);
   }
-  void end(hipStream_t s) override { Rec r = open_.back(); open_.pop_back(); (void)hipEventRecord(r.e1, s); recs.push_back(r); }
-  void collect() {   // caller has synchronised the stream
+  hipEvent_t get(bool& ok) {
+    if (next == pool.size()) { hipEvent_t e = nullptr; hipError_t r = hipEventCreate(&e); note(r, "hipEventCreate"); if (r != hipSuccess) { ok = false; return nullptr; } pool.push_back(e); }
+    return pool[next++];
+  }
+  void begin(const char* name, double flops, double bytes, hipStream_t s) override {
+    Rec r{name, g_kphase, flops, bytes, nullptr, nullptr, true};
+    r.e0 = get(r.ok); r.e1 = get(r.ok);
+    if (r.ok) { hipError_t e = hipEventRecord(r.e0, s); note(e, "hipEventRecord"); r.ok = e == hipSuccess; }
+    open_.push_back(r);
+  }
+  void end(hipStream_t s) override {
+    Rec r = open_.back(); open_.pop_back();
+    if (r.ok) { hipError_t e = hipEventRecord(r.e1, s); note(e, "hipEventRecord"); r.ok = e == hipSuccess; }
+    recs.push_back(r);
+  }
+  // Waits for each sample's closing event itself (the kernels may have been launched on ANY context's stream: a caller that
+  // synchronises only its own stream used to read unfinished events as 0 ms - VERDICT round 2, the GAN leg's table).
+  void collect() {
     for (auto& r : recs) {
-      float ms = 0; (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+      float ms = 0;
+      if (r.ok) { hipError_t e = hipEventSynchronize(r.e1); note(e, "hipEventSynchronize"); r.ok = e == hipSuccess; }
+      if (r.ok) { hipError_t e = hipEventElapsedTime(&ms, r.e0, r.e1); note(e, "hipEventElapsedTime"); r.ok = e == hipSuccess; }
+      if (!r.ok) { failed++; continue; }
       Agg* a = nullptr;
       for (auto& kv : agg) if (kv.first.first == r.name && kv.first.second == r.phase) a = &kv.second;
       if (!a) { agg.push_back({{r.name, r.phase}, Agg()}); a = &agg.back().second; }
@@ -78,7 +100,7 @@ struct EventTimer : gr::KernelTimer {
     }
     recs.clear(); next = 0;
   }
-  void reset() { recs.clear(); open_.clear(); agg.clear(); next = 0; }
+  void reset() { recs.clear(); open_.clear(); agg.clear(); next = 0; failed = 0; first_error.clear(); }
   ~EventTimer() override { for (auto e : pool) (void)hipEventDestroy(e); }
 };
 static EventTimer* g_evtimer = nullptr;
@@ -99,6 +121,19 @@ static int fail(gr_ctx* c, int code, const char* fmt, ...) {
   do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess)                                       \
       return fail(ctx, GR_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+// RCCL reports failures of already-enqueued collectives (a peer that died, a transport error) asynchronously: asked for after
+// every group of collectives this library issues, so that a broken communicator surfaces as GR_ERR_COMM in the call that
+// issued them (or the next one) instead of a hang in a later stream wait.
+static int comm_check(gr_ctx* c) {
+  if (!c->comm) return GR_OK;
+  ncclResult_t st = ncclSuccess;
+  NCCLCHK(c, ncclCommGetAsyncError(c->comm, &st));
+  if (st != ncclSuccess && st != ncclInProgress) return fail(c, GR_ERR_COMM, "RCCL asynchronous error: %s", ncclGetErrorString(st));
+  return GR_OK;
+}
+// roctx range of one phase of gr_train_r_step (shows up in rocprofv3 --marker-trace / the rocprof timeline; a no-op without a tool)
+struct PhaseRange { explicit PhaseRange(const char* name) { roctxRangePushA(name); } ~PhaseRange() { roctxRangePop(); } };
+
 static int ensure_ws(gr_ctx* c, size_t bytes) {
   if (bytes <= c->ws_bytes) return GR_OK;
   if (c->ws) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
@@ -117,7 +152,7 @@ static int ensure_ws2(gr_ctx* c, size_t bytes) {
   return GR_OK;
 }
 
-extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.2 (round 2)"; }
+extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.3 (round 3)"; }
 
 extern "C" int gr_init(int device, gr_ctx** out) {
   if (!out) return GR_ERR_INVALID;
@@ -237,10 +272,16 @@ extern "C" int gr_kernel_times(gr_ctx* c, char* buf, int buflen) {
              i ? ", " : "", kv.first.first.c_str(), phase_names[kv.first.second], kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes);
     out += line;
   }
+  if (g_evtimer->failed > 0) {       // samples the timer could not read: a row of their own, so a table with holes says so
+    char line[512];
+    snprintf(line, sizeof line, "%s{\"kernel\": \"timer_failed_samples\", \"phase\": \"%s\", \"launches\": %ld, \"total_ms\": 0.0, \"flops\": 0.0, \"bytes\": 0.0}",
+             g_evtimer->agg.empty() ? "" : ", ", g_evtimer->first_error.c_str(), g_evtimer->failed);
+    out += line;
+  }
   if (c->guard_fallbacks > 0) {      // passes the f16x3 range guard sent to bf16x6 since gr_init (not a kernel: a count)
     char line[256];
     snprintf(line, sizeof line, "%s{\"kernel\": \"range_guard_fallback\", \"phase\": \"\", \"launches\": %ld, \"total_ms\": 0.0, \"flops\": 0.0, \"bytes\": 0.0}",
-             g_evtimer->agg.empty() ? "" : ", ", c->guard_fallbacks);
+             (g_evtimer->agg.empty() && g_evtimer->failed == 0) ? "" : ", ", c->guard_fallbacks);
     out += line;
   }
   out += "]";
@@ -1250,6 +1291,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     // Adam (compute stream) must see every reduced bucket
     HIPCHK(c, hipEventRecord(c->ev_done, c->comm_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+    r = comm_check(c); if (r) return r;
   }
   return GR_OK;
 }
@@ -1398,7 +1440,7 @@ extern "C" int gr_allreduce_dev(gr_ctx* c, float* buf, int64_t n) {
   if (!c || !buf || n <= 0) return GR_ERR_INVALID;
   if (c->nranks <= 1 || !c->comm) return GR_OK;
   NCCLCHK(c, ncclAllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
-  return GR_OK;
+  return comm_check(c);
 }
 extern "C" int gr_allreduce_grads(gr_net* n) { if (!n) return GR_ERR_INVALID; return gr_allreduce_dev(n->ctx, n->grads, n->n_params); }
 extern "C" int gr_broadcast_params(gr_net* n, int root) {
@@ -1412,7 +1454,7 @@ extern "C" int gr_broadcast_params(gr_net* n, int root) {
     s.eval_ready = false;        // the evaluate()-mode constants cached from the old running statistics are stale
   }
   n->params_version++;
-  return GR_OK;
+  return comm_check(c);
 }
 
 // ------------------------------------------------------------------ the whole train_r.lua:138-170 iteration
@@ -1446,15 +1488,17 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   if (tm) (void)hipEventRecord(c->ev[0], c->stream);
   g->training = false;                                         // train_r.lua:70  MODEL_G:evaluate()
   g_kphase = 1;
-  r = forward_impl(g, noise_dev, B); if (r) return r;          // train_r.lua:139
+  { PhaseRange pr("G forward"); r = forward_impl(g, noise_dev, B); } if (r) return r;          // train_r.lua:139
   const float* images = g->st.back().out;
   if (tm) (void)hipEventRecord(c->ev[1], c->stream);
   rn->training = true;
   g_kphase = 2;
   r = gr_net_zero_grads(rn); if (r) return r;                  // :143
-  r = forward_impl(rn, images, B); if (r) return r;            // :146
+  { PhaseRange pr("R forward"); r = forward_impl(rn, images, B); } if (r) return r;            // :146
   if (tm) (void)hipEventRecord(c->ev[2], c->stream);
   g_kphase = 3;
+  {
+  PhaseRange pr("loss");
   launch_mse(rn->st.back().out, noise_dev, (long)B * nd, (long)GB * nd, c->d_loss, rn->gout_buf, c->stream);  // :147,150
   LAUNCHCHK(c);
   if (c->comm) {   // global MSE = sum of the ranks' partial means (same communicator, same stream as the gradient buckets)
@@ -1462,22 +1506,23 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
     NCCLCHK(c, ncclAllReduce(c->d_loss, c->d_loss, 1, ncclDouble, ncclSum, c->comm, c->comm_stream));
   }
+  }
   if (tm) (void)hipEventRecord(c->ev[3], c->stream);
   // the penalty and the clamp are non-linear in g (train_r.lua:154-165): the SUM over ranks comes first.  It is issued
   // bucket by bucket from inside backward on the comm stream; the compute stream waits for it only here.
   g_kphase = 4;
-  r = backward_impl(rn, images, rn->gout_buf, B, nullptr, /*reduce=*/true); if (r) return r;   // :151
+  { PhaseRange pr(c->comm ? "R backward + all-reduce" : "R backward"); r = backward_impl(rn, images, rn->gout_buf, B, nullptr, /*reduce=*/true); } if (r) return r;   // :151
   if (tm) (void)hipEventRecord(c->ev[4], c->stream);
 
   if (tm) (void)hipEventRecord(c->ev[5], c->stream);
   g_kphase = 5;
-  r = gr_adam_step(rn, h, t); g_kphase = 0; if (r) return r;   // :153-170
+  { PhaseRange pr("penalty + clamp + Adam"); r = gr_adam_step(rn, h, t); } g_kphase = 0; if (r) return r;   // :153-170
   if (tm) (void)hipEventRecord(c->ev[6], c->stream);
   if (loss_out || tm) {
     HIPCHK(c, hipMemcpyAsync(c->h_loss, c->d_loss, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (loss_out) *loss_out = *c->h_loss;
-    if (tm) for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]);
+    if (tm) for (int i = 0; i < 6; ++i) HIPCHK(c, hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]));
   }
   return GR_OK;
 }

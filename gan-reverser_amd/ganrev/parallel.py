@@ -123,6 +123,12 @@ class DeviceTrainer:
         self.dfdo = ctx.malloc(4 * self.B * self.nd)
         self.loss_dev = ctx.malloc(64)
 
+    def close(self):
+        for p in (self.noise, self.dfdo, self.loss_dev):
+            if p:
+                self.ctx.free(p)
+        self.noise = self.dfdo = self.loss_dev = None
+
     def new_noise(self, seed):
         # createNoiseInputs on device (utils/nn_utils.lua:39-51): normal(0, 1) or uniform(-1, 1) - with the uniform method R ends
         # in a Tanh (models.lua:452-454) and can only reach targets in (-1, 1)

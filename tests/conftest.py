@@ -50,3 +50,47 @@ def f16_path(request):
     yield request.param
     c.set_tuning("p16_min_tiles", 128)     # the library default (conv.hip g_p16_min_tiles)
     c.set_conv_mode(prev)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two-process data-parallel parity test (tests/test_gpu_dp.py): the rank processes are started HERE, at the end of collection,
+# i.e. before any test - and therefore this process - has initialised the GPU (on this pool a process that has touched HIP
+# must not start another program).  They run beside the first tests (3 processes on the card, limit 6) and the test that
+# needs them waits for their exit.
+_DP = {}
+
+
+def pytest_collection_finish(session):
+    if not any(item.name.startswith("test_dp_two_processes") for item in session.items):
+        return
+    import socket
+    import subprocess
+    import tempfile
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = tempfile.mkdtemp(prefix="ganrev_dp_")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS="4")
+    worker = os.path.join(ROOT, "tests", "dp_rank_worker.py")
+    _DP["out"] = out
+    _DP["procs"] = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), out], env=env,
+                                     stdout=open(os.path.join(out, f"rank{r}.log"), "w"), stderr=subprocess.STDOUT) for r in range(2)]
+
+
+@pytest.fixture(scope="session")
+def dp_children():
+    def wait(timeout=600):
+        if "procs" not in _DP:
+            pytest.fail("the data-parallel rank processes were not started (collection hook did not see this test)")
+        for r, p in enumerate(_DP["procs"]):
+            try:
+                rc = p.wait(timeout=timeout)
+            except Exception:  # noqa: BLE001
+                p.kill()
+                rc = "timeout"
+            if rc != 0:
+                log = open(os.path.join(_DP["out"], f"rank{r}.log")).read()[-3000:]
+                pytest.fail(f"data-parallel rank {r} exited with {rc}:\n{log}")
+        return _DP["out"]
+    yield wait
+    for p in _DP.get("procs", []):
+        if p.poll() is None:
+            p.kill()

@@ -75,7 +75,7 @@ def pools_well_conditioned(model, onet, B, gap=2e-6):
 # tests (1) read the argmax both sides took (gr_net_get_pool_index / go_net_get_pool_index), (2) require the windows where
 # they differ to be FEW and each to be a genuine near-tie in the oracle's own forward, and (3) re-run the oracle with the
 # device's argmax forced, after which every gradient tensor is held to the strict bar.
-NEAR_TIE = TOL       # the forward bar itself: two pool inputs closer than the tolerance either side is held to may legitimately swap (measured gaps: up to 4e-5)
+NEAR_TIE = TOL       # (kink adoption of the small GAN cases only; the pool argmax uses near_tie_bar(mode) below)
 
 
 def pool_layers(model, onet):
@@ -84,25 +84,98 @@ def pool_layers(model, onet):
             for m in model.leaves() if m.typename == "nn.SpatialMaxPooling"]
 
 
-def adopt_device_argmax(model, onet, B, max_flips):
+def current_mode():
+    import ganrev._lib as L
+    return L.default_context().conv_mode()
+
+
+def _stage_before_pool(model, pool_module):
+    """(conv, bn, elu) modules of the stage a nn.SpatialMaxPooling closes (models.lua:419-422, 436-440)."""
+    leaves = model.leaves()
+    i = leaves.index(pool_module)
+    conv = bn = act = None
+    for m in reversed(leaves[:i]):
+        t = m.typename
+        if t == "nn.ELU" and act is None: act = m
+        elif t.endswith("BatchNormalization") and bn is None: bn = m
+        elif t.endswith("SpatialConvolution"):
+            conv = m
+            break
+    if conv is None or bn is None or act is None:
+        return None            # not R's conv-SBN-ELU-[SpatialDropout]-MaxPool stage (the D network's BatchNorm-free PReLU stages)
+    return conv, bn, act
+
+
+def pool_input_error(model, onet, B, pool_module, y_dev, groups=1):
+    """max |device - oracle| at the inputs of a max-pool, measured in THIS run: the device keeps the raw convolution output y of
+    the stage (gr_net_layer_output of the conv layer) but never materialises BN -> ELU of it (fused into the pipeline kernel), so
+    the device's pool input is rebuilt here from ITS y - batch-statistics BatchNorm (per data-parallel group) and ELU in float64 -
+    and compared with the oracle's ELU output.  (A SpatialDropout between ELU and pool multiplies by 0 / 1: it cannot enlarge
+    the error.)  The rebuild leaves out the device's own fp32 rounding of BN + ELU (~1e-7 relative)."""
+    conv, bn, act = _stage_before_pool(model, pool_module)
+    segs = {(id(m), nm): (lo, hi) for m, nm, lo, hi in param_segments(model)}
+    gamma = onet.params[slice(*segs[(id(bn), "weight")])].astype(np.float64)
+    beta = onet.params[slice(*segs[(id(bn), "bias")])].astype(np.float64)
+    ref = onet.layer_output(onet.layer_index[id(act)])
+    C = gamma.size
+    y = np.asarray(y_dev).reshape(B, C, -1)
+    ref = ref.reshape(B, C, -1)
+    per, err = B // groups, 0.0
+    for g in range(groups):
+        yg = y[g * per:(g + 1) * per].astype(np.float64)
+        mean = yg.mean(axis=(0, 2), keepdims=True)
+        var = yg.var(axis=(0, 2), keepdims=True)
+        z = (yg - mean) / np.sqrt(var + 1e-5) * gamma[None, :, None] + beta[None, :, None]
+        z = np.where(z > 0, z, np.expm1(np.minimum(z, 0)))
+        err = max(err, float(np.abs(z - ref[g * per:(g + 1) * per]).max()))
+    return err
+
+
+# documented argmax flips per full-size step (DESIGN.md section 1): windows that differ, summed over both pool layers;
+# the full-size tests allow 4 x these
+DOCUMENTED_FLIPS = {"cfg2": 5, "cfg3": 110}
+
+
+def adopt_device_argmax(model, onet, B, max_flips, dev_index=None, dev_y=None, groups=1, mode=None, report=None):
     """Compare the pool argmax of the device's and the oracle's last forward, assert the differences are few genuine
-    near-ties, force the device's argmax onto the oracle.  Returns the number of differing windows per pool layer."""
-    flips = []
+    near-ties, force the device's argmax onto the oracle.
+    The near-tie bar is DERIVED, per run and arithmetic, from the forward error measured at that pool's inputs
+    (pool_input_error): two inputs can swap order when they are closer than the two sides' errors; the bar is 8 x the measured
+    error (floor 1e-6: an fp32 ulp at the activations' magnitude), capped by the 1e-4 output tolerance.
+    dev_index / dev_y: {layer: array} when the device ran the batch in several pieces (data-parallel shards: per-shard arrays
+    concatenated by the caller), else read from model._net.  Returns the number of differing windows per pool layer and prints
+    them with the gaps (pytest -rP shows the line): a regression from "1-5 flips" to "30 flips" is visible in the log."""
+    mode = mode or current_mode()
+    flips, gaps, bars = [], [], []
     for m, li, (c, h, w) in pool_layers(model, onet):
         n = B * c * (h // 2) * (w // 2)
-        dev = model._net.pool_index(li, n)
+        dev = dev_index[li] if dev_index is not None else model._net.pool_index(li, n)
         ora = onet.pool_index(li)
-        assert dev.max() <= 3
+        assert dev.size == n and dev.max() <= 3
+        stage = _stage_before_pool(model, m)
+        if stage is not None:
+            cli = onet.layer_index[id(stage[0])]
+            y = dev_y[cli] if dev_y is not None else model._net.layer_output(cli, (B * c * h * w,))
+            ferr = pool_input_error(model, onet, B, m, y, groups)
+            assert ferr <= 0.25 * TOL, f"pool layer {li} [{mode}]: forward error at the pool inputs {ferr:.3e} (bar {0.25 * TOL:g})"
+            bar = min(TOL, 8.0 * max(ferr, 1e-6))
+        else:                  # the D network's small cases (SURVEY 8f rank 4): no rebuildable pool input, the output tolerance is the bar
+            ferr, bar = float("nan"), NEAR_TIE
         diff = np.nonzero(dev != ora)[0]
+        gmax = 0.0
         if diff.size:
             x = onet.layer_output(li - 1).reshape(B * c, h // 2, 2, w // 2, 2).transpose(0, 1, 3, 2, 4).reshape(-1, 4)
             gap = x[diff, ora[diff]].astype(np.float64) - x[diff, dev[diff]].astype(np.float64)
             assert np.all(gap >= 0), "the oracle's argmax is not the maximum of its own window"
-            assert gap.max() < NEAR_TIE, (f"pool layer {li}: {diff.size} windows with a different argmax, largest gap "
-                                          f"{gap.max():.3e}: not a rounding-level near-tie")
-        assert diff.size <= max_flips, f"pool layer {li}: {diff.size} of {n} windows differ in argmax (allowed {max_flips})"
+            gmax = float(gap.max())
+            assert gmax < bar, (f"pool layer {li} [{mode}]: {diff.size} windows with a different argmax, largest gap {gmax:.3e} >= "
+                                f"{bar:.2e} (8 x the forward error {ferr:.2e} measured at this pool's inputs): not a rounding-level near-tie")
+        assert diff.size <= max_flips, f"pool layer {li} [{mode}]: {diff.size} of {n} windows differ in argmax (allowed {max_flips})"
         onet.force_pool_index(li, dev)
-        flips.append(int(diff.size))
+        flips.append(int(diff.size)); gaps.append(gmax); bars.append(bar)
+    print(f"[argmax] mode={mode} B={B} flips per pool layer {flips}, largest gaps {['%.2e' % g for g in gaps]}, bars {['%.2e' % b for b in bars]}")
+    if report is not None:
+        report.update(flips=flips, gaps=gaps, bars=bars)
     return flips
 
 

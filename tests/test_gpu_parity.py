@@ -636,7 +636,9 @@ def _full_size_case(oracle, dims, nd, B):
     return _FULL_CACHE[key]
 
 
-FULL_STEP_SIZES = [pytest.param((1, 32, 32), 32, 256, 32, id="cfg2"), pytest.param((3, 64, 64), 100, 512, 256, id="cfg3")]
+# allowed argmax flips per pool layer: 4 x the documented counts (helpers.DOCUMENTED_FLIPS: 1-5 at cfg2, 100-110 at cfg3), and
+# never more than round 2 allowed (256 at cfg3)
+FULL_STEP_SIZES = [pytest.param((1, 32, 32), 32, 256, 20, id="cfg2"), pytest.param((3, 64, 64), 100, 512, 256, id="cfg3")]
 
 
 @pytest.mark.parametrize("dims,nd,B,max_flips", FULL_STEP_SIZES)
@@ -646,8 +648,9 @@ def test_full_size_step_vs_oracle(ctx, oracle, conv_mode, dims, nd, B, max_flips
     recovered noise and loss at the north-star tolerance against the oracle's own forward.  The gradient - ALL of R's
     parameter tensors - at 2e-4 of its module's largest entry: the pool argmax the device took is read back
     (gr_net_get_pool_index), the windows where it differs from the oracle's must be a handful of rounding-level near-ties
-    (gap < the 1e-4 forward tolerance in the oracle's own activations; 6.5M / 52M windows: measured 1-5 / 100-110), and the oracle's backward is
-    run with the device's argmax (helpers.adopt_device_argmax).
+    (gap below 8 x the forward error MEASURED in this run at that pool's inputs - helpers.pool_input_error - capped at the 1e-4
+    forward tolerance; 6.5M / 52M windows: measured 1-5 / 100-110 flips, at most 4 x that is accepted and the counts are printed),
+    and the oracle's backward is run with the device's argmax (helpers.adopt_device_argmax).
     Why 2e-4 and not 1e-4 at this size (the small cases hold 1e-4): BatchNorm's backward makes sum(dy) vanish per channel in
     exact arithmetic; in fp32 a residue of ~1e-7 |dy| per element survives on either side, and the first convolution's weight
     gradient multiplies it with NON-NEGATIVE pixels summed over B*H*W = 2.1M positions, where the signal itself (random signs)
