@@ -106,7 +106,8 @@ def measure_traffic(args, workload):
 def cpu_baseline(dims, nd, ctx=None):
     """The oracle (CPU restatement of the Torch7 nn path, OpenMP) timed on this box's host cores at BASELINE.json configs[0]
     (32x32 grayscale, noise 32, batch 16 - train_r.lua's own CPU case) on a bounded sample: with the reference's default thread
-    count (8, train_r.lua:21) and with the thread count that measured fastest on this box class."""
+    count (8, train_r.lua:21) and with the thread count that measured fastest on this box class; convolutions as im2col +
+    blocked sgemm (the reported value) and as the parity oracle's direct loops (beside it)."""
     import numpy as np
     from ganrev import models, synth
     from oracle import oracle
@@ -121,7 +122,8 @@ def cpu_baseline(dims, nd, ctx=None):
     mm = np.zeros(oR.n_params, np.float32); vv = np.zeros_like(mm)
     noise = synth.normal((B, nd), 9)
 
-    def run(threads, budget):
+    def run(threads, budget, impl):
+        oracle.set_conv_impl(impl)
         threads = oracle.set_threads(threads)      # libgomp is already initialised (torch): the env var would be ignored
         oracle.train_r_step(oG, oR, noise, oracle.GoHyper(), mm, vv, 1)          # warm-up (page-in, thread pool)
         t0 = time.perf_counter(); n = 0
@@ -129,16 +131,26 @@ def cpu_baseline(dims, nd, ctx=None):
             oracle.train_r_step(oG, oR, noise, oracle.GoHyper(), mm, vv, 2 + n)
             n += 1
             dt = time.perf_counter() - t0
-            if dt > budget or n >= 40:
+            if dt > budget or n >= 60:
                 break
         return threads, n, dt
-    t8, n8, dt8 = run(8, 6.0)
-    # 16-32 OpenMP threads measured fastest for the oracle on the 2x64-core box (tools/cpu_baseline_sweep.py)
-    tb, nb, dtb = run(min(32, os.cpu_count() or 1), 6.0)
+    best = min(32, os.cpu_count() or 1)    # 16-32 OpenMP threads measured fastest for the oracle on the 2x64-core box (tools/cpu_baseline_sweep.py)
+    try:
+        # "mm": im2col + blocked sgemm per sample (oracle/oracle_mm.c) - the structure of THNN's SpatialConvolutionMM, which is what
+        # SURVEY.md 8d specifies for this column; "direct": the parity oracle's 9-tap loop nests, kept beside it
+        t8, n8, dt8 = run(8, 5.0, "mm")
+        tb, nb, dtb = run(best, 5.0, "mm")
+        d8, dn8, ddt8 = run(8, 4.0, "direct")
+        db, dnb, ddtb = run(best, 4.0, "direct")
+    finally:
+        oracle.set_conv_impl("direct")
     out = dict(value=round(B * nb / dtb, 2), unit="images/sec", cores=tb, kind="port",
                sample=f"{nb} steps of the same step at batch {B} = BASELINE configs[0] ({dtb:.1f} s); oracle = C restatement of the Torch7 nn CPU "
-                      "path (direct-loop convolutions, OpenMP), not Torch7 itself",
-               reference_default_threads=dict(value=round(B * n8 / dt8, 2), cores=t8, sample=f"{n8} steps ({dt8:.1f} s), --threads 8 = train_r.lua:21"))
+                      "path with im2col + blocked-sgemm convolutions per sample (THNN SpatialConvolutionMM's structure; plain C, OpenMP over samples), "
+                      "not Torch7 itself",
+               reference_default_threads=dict(value=round(B * n8 / dt8, 2), cores=t8, sample=f"{n8} steps ({dt8:.1f} s), --threads 8 = train_r.lua:21"),
+               direct_loop_convolutions=dict(value=round(B * dnb / ddtb, 2), cores=db, at_8_threads=round(B * dn8 / ddt8, 2),
+                                             note="the parity oracle's own 9-tap loop nests (oracle_blas.c): what every parity test compares with; slower than the im2col path"))
     out["torch_cpu"] = torch_cpu_column(dims, nd, B)
     if ctx is not None:
         # second half of BASELINE.json's metric - "cosine top-50 exact-match vs ref" - at the size north_star names (10k x 32-d

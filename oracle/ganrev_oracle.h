@@ -51,6 +51,13 @@ typedef struct { int32_t kind, a, b, c; float p; int32_t flags; } go_layer;
 typedef struct go_net go_net;
 
 /* ---- single operators (exported so tests can check each against PyTorch-CPU) ---- */
+/* convolution implementation of the three go_conv3_* calls: 0 = direct loops (the parity oracle), 1 = im2col + blocked sgemm
+ * per sample (oracle_mm.c; THNN SpatialConvolutionMM's structure; the CPU baseline bench.py reports) */
+void go_set_conv_impl(int impl);
+int go_get_conv_impl(void);
+void go_conv3_forward_mm(const float* in, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int H, int W);
+void go_conv3_backward_data_mm(const float* gout, const float* w, float* gin, int B, int Cin, int Cout, int H, int W);
+void go_conv3_backward_weight_mm(const float* in, const float* gout, float* gw, float* gb, int B, int Cin, int Cout, int H, int W);
 void go_conv3_forward(const float* in, const float* w, const float* bias, float* out,
                       int B, int Cin, int Cout, int H, int W);
 void go_conv3_backward_data(const float* gout, const float* w, float* gin,

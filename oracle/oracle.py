@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libganrev_oracle.so")
+# GANREV_ORACLE_SO: load another build of the same sources instead (tests/test_sanitizers.py: the ASan + UBSan build)
+_SO = os.environ.get("GANREV_ORACLE_SO") or os.path.join(_HERE, "libganrev_oracle.so")
 
 
 def build(force=False):
@@ -79,6 +80,7 @@ def lib():
         L.go_l2_distance_rows.argtypes = [_P, _P, C.c_int64, C.c_int64, _P]
         L.go_kmeans.argtypes = [_P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, _P]
         L.go_cosine_assign.argtypes = [_P, C.c_int64, C.c_int, _P, C.c_int, C.c_int, _P, _P]
+        L.go_set_conv_impl.argtypes = [C.c_int]
         L.go_conv3_forward.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
         L.go_conv3_backward_data.argtypes = [_P, _P, _P] + [C.c_int] * 5
         L.go_conv3_backward_weight.argtypes = [_P, _P, _P, _P] + [C.c_int] * 5
@@ -211,6 +213,15 @@ class Net:
 def set_threads(n):
     lib().go_set_threads(int(n))
     return lib().go_get_max_threads()
+
+
+def set_conv_impl(impl):
+    """3x3 convolutions of every later call: "direct" (0; the parity oracle's loop nests, oracle_blas.c) or "mm" (1; im2col +
+    blocked sgemm per sample, oracle_mm.c: the structure of THNN's SpatialConvolutionMM - the CPU BASELINE bench.py reports).
+    Returns the previous setting."""
+    prev = lib().go_get_conv_impl()
+    lib().go_set_conv_impl({"direct": 0, "mm": 1}.get(impl, impl))
+    return prev
 
 
 def mse(x, t, n_global=None):

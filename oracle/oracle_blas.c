@@ -10,9 +10,16 @@
 #include "ganrev_oracle.h"
 #include <string.h>
 
+/* 0 (default): the direct 9-tap loop nests below - the parity oracle, pinned by tests/golden.  1: im2col + blocked sgemm per
+ * sample (oracle_mm.c: the structure of THNN's SpatialConvolutionMM, SURVEY.md 8d's CPU-baseline structure). */
+static int g_conv_impl = 0;
+void go_set_conv_impl(int impl) { g_conv_impl = impl ? 1 : 0; }
+int go_get_conv_impl(void) { return g_conv_impl; }
+
 /* out[b,o,y,x] = bias[o] + sum_{i,ky,kx} w[o,i,ky,kx] * in[b,i,y+ky-1,x+kx-1]   (cross-correlation, zero pad) */
 void go_conv3_forward(const float* in, const float* w, const float* bias, float* out,
                       int B, int Cin, int Cout, int H, int W) {
+  if (g_conv_impl) { go_conv3_forward_mm(in, w, bias, out, B, Cin, Cout, H, W); return; }
   const long HW = (long)H * W;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < B; ++b)
@@ -43,6 +50,7 @@ void go_conv3_forward(const float* in, const float* w, const float* bias, float*
 /* gin[b,i,y+ky-1,x+kx-1] += w[o,i,ky,kx] * gout[b,o,y,x]   (updateGradInput; gin is overwritten) */
 void go_conv3_backward_data(const float* gout, const float* w, float* gin,
                             int B, int Cin, int Cout, int H, int W) {
+  if (g_conv_impl) { go_conv3_backward_data_mm(gout, w, gin, B, Cin, Cout, H, W); return; }
   const long HW = (long)H * W;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < B; ++b)
@@ -72,6 +80,7 @@ void go_conv3_backward_data(const float* gout, const float* w, float* gin,
 /* gw[o,i,ky,kx] += sum_{b,y,x} gout[b,o,y,x]*in[b,i,y+ky-1,x+kx-1] ; gb[o] += sum gout   (accGradParameters, scale 1) */
 void go_conv3_backward_weight(const float* in, const float* gout, float* gw, float* gb,
                               int B, int Cin, int Cout, int H, int W) {
+  if (g_conv_impl) { go_conv3_backward_weight_mm(in, gout, gw, gb, B, Cin, Cout, H, W); return; }
   const long HW = (long)H * W;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int o = 0; o < Cout; ++o)

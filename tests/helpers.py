@@ -139,9 +139,11 @@ DOCUMENTED_FLIPS = {"cfg2": 5, "cfg3": 110}
 def adopt_device_argmax(model, onet, B, max_flips, dev_index=None, dev_y=None, groups=1, mode=None, report=None):
     """Compare the pool argmax of the device's and the oracle's last forward, assert the differences are few genuine
     near-ties, force the device's argmax onto the oracle.
-    The near-tie bar is DERIVED, per run and arithmetic, from the forward error measured at that pool's inputs
-    (pool_input_error): two inputs can swap order when they are closer than the two sides' errors; the bar is 8 x the measured
-    error (floor 1e-6: an fp32 ulp at the activations' magnitude), capped by the 1e-4 output tolerance.
+    The near-tie bar is DERIVED, per run, layer and arithmetic, from the forward error MEASURED at that pool's inputs
+    (pool_input_error): the device takes j where the oracle takes i only if o_i - o_j <= e_j - e_i <= 2 max|e|, so a legitimate
+    flip has a gap of at most twice the measured error (+1e-6 for the device's own fp32 rounding of BN + ELU, which the rebuild
+    leaves out), capped by the 1e-4 forward tolerance the error itself is held to (measured on MI355X:
+    errors 5e-6..2.7e-5 at the pool inputs - six convolutions deep, normalised by BatchNorm - and gaps up to 9.2e-6).
     dev_index / dev_y: {layer: array} when the device ran the batch in several pieces (data-parallel shards: per-shard arrays
     concatenated by the caller), else read from model._net.  Returns the number of differing windows per pool layer and prints
     them with the gaps (pytest -rP shows the line): a regression from "1-5 flips" to "30 flips" is visible in the log."""
@@ -157,8 +159,8 @@ def adopt_device_argmax(model, onet, B, max_flips, dev_index=None, dev_y=None, g
             cli = onet.layer_index[id(stage[0])]
             y = dev_y[cli] if dev_y is not None else model._net.layer_output(cli, (B * c * h * w,))
             ferr = pool_input_error(model, onet, B, m, y, groups)
-            assert ferr <= 0.25 * TOL, f"pool layer {li} [{mode}]: forward error at the pool inputs {ferr:.3e} (bar {0.25 * TOL:g})"
-            bar = min(TOL, 8.0 * max(ferr, 1e-6))
+            assert ferr <= TOL, f"pool layer {li} [{mode}]: forward error at the pool inputs {ferr:.3e} exceeds the forward bar {TOL:g}"
+            bar = min(TOL, 2.0 * ferr + 1e-6)
         else:                  # the D network's small cases: no rebuildable pool input, the output tolerance is the bar
             ferr, bar = float("nan"), NEAR_TIE
         diff = np.nonzero(dev != ora)[0]
@@ -169,7 +171,7 @@ def adopt_device_argmax(model, onet, B, max_flips, dev_index=None, dev_y=None, g
             assert np.all(gap >= 0), "the oracle's argmax is not the maximum of its own window"
             gmax = float(gap.max())
             assert gmax < bar, (f"pool layer {li} [{mode}]: {diff.size} windows with a different argmax, largest gap {gmax:.3e} >= "
-                                f"{bar:.2e} (8 x the forward error {ferr:.2e} measured at this pool's inputs): not a rounding-level near-tie")
+                                f"{bar:.2e} (2 x the forward error {ferr:.2e} measured at this pool's inputs): not a rounding-level near-tie")
         assert diff.size <= max_flips, f"pool layer {li} [{mode}]: {diff.size} of {n} windows differ in argmax (allowed {max_flips})"
         onet.force_pool_index(li, dev)
         flips.append(int(diff.size)); gaps.append(gmax); bars.append(bar)

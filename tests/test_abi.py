@@ -47,3 +47,64 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".lua")):
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert "ganrev_oracle" not in src and "from oracle" not in src and "import oracle" not in src, os.path.join(dp, f)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# lua/hipnn.lua declares its share of the ABI by hand in an ffi.cdef block.  There is no Lua runtime here or on the GPU box, so
+# a text-level comparison with include/ganrev.h is the only guard against the two drifting apart:
+# every prototype of the cdef must exist in the header with the same return type and the same parameter TYPES in the same order
+# (parameter names are free, and may be absent, on either side).
+def _strip_comments(txt):
+    return re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+
+
+_C_TYPE_WORDS = {"const", "unsigned", "signed", "struct", "int", "float", "double", "char", "void", "long", "short",
+                 "int32_t", "int64_t", "uint8_t", "uint64_t", "uint32_t", "size_t", "gr_ctx", "gr_net", "gr_layer_desc", "gr_hyper"}
+
+
+def _param_type(p):
+    """'const float* in_host' -> 'const float*'; 'gr_net*' -> 'gr_net*'; 'int' -> 'int' (the identifier, if any, is dropped)"""
+    p = p.strip()
+    stars = p.count("*")
+    words = re.findall(r"[A-Za-z_][A-Za-z0-9_]*", p)
+    if len(words) > 1 and words[-1] not in _C_TYPE_WORDS:
+        words = words[:-1]                         # trailing parameter name
+    assert all(w in _C_TYPE_WORDS for w in words), f"unknown type word in parameter {p!r}"
+    return " ".join(words) + "*" * stars
+
+
+def prototypes(txt):
+    """{name: (return type, [parameter types])} of every `type gr_xxx(params);` in a piece of C."""
+    txt = _strip_comments(txt)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(gr_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
+        ret, name, params = m.group(1), m.group(2), m.group(3)
+        ret = " ".join(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", ret)) + "*" * ret.count("*")
+        plist = [] if params.strip() in ("", "void") else [_param_type(p) for p in params.split(",")]
+        assert name not in out, f"{name} declared twice"
+        out[name] = (ret, plist)
+    return out
+
+
+def test_lua_ffi_cdef_matches_the_header():
+    lua = open(os.path.join(ROOT, "gan-reverser_amd", "lua", "hipnn.lua")).read()
+    m = re.search(r"ffi\.cdef\[\[(.*?)\]\]", lua, flags=re.S)
+    assert m, "no ffi.cdef block in hipnn.lua"
+    cdef = m.group(1)
+    hdr = open(os.path.join(ROOT, "include", "ganrev.h")).read()
+    lp, hp = prototypes(cdef), prototypes(hdr)
+    assert len(lp) >= 40 and len(hp) >= 60, (len(lp), len(hp))
+    for name, sig in sorted(lp.items()):
+        assert name in hp, f"hipnn.lua declares {name}, which include/ganrev.h does not"
+        assert sig == hp[name], f"{name}: hipnn.lua {sig} != ganrev.h {hp[name]}"
+    # every C function the Lua code calls through the library handle is declared in its cdef
+    called = set(re.findall(r"\bC\.(gr_[a-z0-9_]+)", lua))
+    assert called and called <= set(lp), f"called but not declared in the cdef: {sorted(called - set(lp))}"
+    # and the structs the cdef restates have the header's layout
+    norm = lambda s: re.sub(r"\s+", " ", _strip_comments(s)).strip()
+    for struct in ("gr_layer_desc", "gr_hyper"):
+        a = re.search(r"typedef struct \{([^}]*)\}\s*" + struct, norm(cdef)).group(1)
+        b = re.search(r"typedef struct \{([^}]*)\}\s*" + struct, norm(hdr)).group(1)
+        fields = lambda body: [(_param_type(d.split(",")[0]).replace("*", ""), len(d.split(","))) for d in body.split(";") if d.strip()]
+        flat = lambda body: [t for t, n in fields(body) for _ in range(n)]
+        assert flat(a) == flat(b), f"{struct}: {flat(a)} != {flat(b)}"

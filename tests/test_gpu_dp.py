@@ -140,7 +140,7 @@ def test_dp_two_processes_share_the_gpu_vs_grouped_oracle(oracle, dp_children):
             dev_index = {li: np.concatenate([rk[f"pool{li}"] for rk in ranks]) for li in pooled}
             dev_y = {cl: np.concatenate([rk[f"y{cl}"] for rk in ranks]) for cl in pooled.values()}
             rep = {}
-            ref = D.oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, oracle.GoHyper(), dev_index, dev_y, R, max_flips=16, report=rep)
+            ref = D.oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, oracle.GoHyper(), dev_index, dev_y, R, max_flips=16, report=rep, mode=mode)
             assert_close(np.concatenate([rk["preds"] for rk in ranks]), ref["preds"], TOL, f"{name} {mode}: recovered noise")
             rk = ranks[0]
             _check_against_oracle(oracle, R, ref, float(rk["loss"]), rk["raw_sum"], rk["grads"], rk["theta"], rk["m"], rk["v"],
