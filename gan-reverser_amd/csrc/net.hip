@@ -854,6 +854,23 @@ static bool guard_applies(gr_net* n) {
   for (auto& s : n->st) if (f16_consumer(n, s)) return true;
   return false;
 }
+// Synchronous parameter scan for host loops built from the *_dev calls (ganrev.adversarial.DeviceGame: gr_net_forward_dev /
+// gr_net_backward_dev are unguarded - their activations never pass through host memory): scans this net's weights and BatchNorm
+// scales, waits for the verdict, and on a hostile spread keeps the CONTEXT on bf16x6 exactly as gr_train_r_step's sampled
+// guard does.  *tripped (nullable) reports the state of the context's guard.
+extern "C" int gr_range_guard_scan_params(gr_net* n, int* tripped) {
+  if (!n) return GR_ERR_INVALID;
+  gr_ctx* c = n->ctx;
+  if (c->guard_tripped && c->conv_mode == 2) c->conv_mode = 1;
+  if (guard_applies(n)) {
+    int r = guard_scan_params(n); if (r) return r;
+    unsigned top2 = 0;
+    r = guard_verdict(c, &top2); if (r) return r;
+    if (guard_over_budget(top2) && !c->guard_tripped) { c->guard_tripped = true; c->guard_fallbacks++; c->conv_mode = 1; }
+  }
+  if (tripped) *tripped = c->guard_tripped ? 1 : 0;
+  return GR_OK;
+}
 // view of a per-sample [C][H][W] tensor as channels: a flat feature vector (H = W = 1 behind a Linear) has C "channels" of one element
 static int guard_scan_activation(gr_ctx* c, const float* t, int B, int C, int H, int W) {
   const long hw = (long)H * W;
@@ -1438,8 +1455,19 @@ extern "C" int gr_comm_destroy(gr_ctx* c) {
 extern "C" int gr_comm_ranks(gr_ctx* c, int* nr, int* r) { if (!c) return GR_ERR_INVALID; if (nr) *nr = c->nranks; if (r) *r = c->rank; return GR_OK; }
 extern "C" int gr_allreduce_dev(gr_ctx* c, float* buf, int64_t n) {
   if (!c || !buf || n <= 0) return GR_ERR_INVALID;
-  if (c->nranks <= 1 || !c->comm) return GR_OK;
+  if (!c->comm) return GR_OK;          // (a one-rank communicator still goes through RCCL: the path a 1-GPU box can exercise)
   NCCLCHK(c, ncclAllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
+  return comm_check(c);
+}
+// ncclAllGather of `bytes` bytes per rank (the sharded search's candidate exchange, SURVEY.md 8e: Q * k * 12 bytes per rank);
+// with one rank (or no communicator) the rank's own block is copied to slot 0.
+extern "C" int gr_allgather_dev(gr_ctx* c, const void* send, void* recv, int64_t bytes) {
+  if (!c || !send || !recv || bytes <= 0) return GR_ERR_INVALID;
+  if (!c->comm) {
+    if (send != recv) HIPCHK(c, hipMemcpyAsync(recv, send, (size_t)bytes, hipMemcpyDeviceToDevice, c->stream));
+    return GR_OK;
+  }
+  NCCLCHK(c, ncclAllGather(send, recv, (size_t)bytes, ncclChar, c->comm, c->stream));
   return comm_check(c);
 }
 extern "C" int gr_allreduce_grads(gr_net* n) { if (!n) return GR_ERR_INVALID; return gr_allreduce_dev(n->ctx, n->grads, n->n_params); }

@@ -291,8 +291,11 @@ __global__ void topk_decode_kernel(const unsigned long long* __restrict__ keys, 
 // for 1024 needles over 10^6 x 100).  The batched path (north_star: "one MFMA GEMM + top-k") keeps the RESULT exact and uses the
 // matrix pipe only to decide which rows can matter:
 //   1. approximate cosines  emb x needles^T  on v_mfma_f32_32x32x16_bf16 (both operands rounded to bf16 while staged, row norms
-//      from the bf16 values): |approximate - exact| <= BERR = 2^-7 for every pair (2^-8 |a||b| from the two roundings by
-//      Cauchy-Schwarz, 2^-9 from the norm, fp32 accumulation far below);
+//      from the bf16 values): the approximate score is the cosine of the ROUNDED vectors a^ = a + da, |da| <= u |a| with
+//      u = 2^-8 (bf16 keeps 8 significant bits, round to nearest), so each vector turns by at most asin(u) and
+//      |approximate - exact| <= 2 u + O(u^2) = 2^-7 (1 + 2^-9 ..) - SLIGHTLY ABOVE 2^-7 - plus the fp32
+//      accumulation of d <= 128 products (< 1e-5) and the 1e-12 in the denominators.  BERR = 2^-7 + 2^-10 bounds all of it
+//      with a margin of 9.8e-4, so the two cuts below are proven, not merely comfortable in practice;
 //   2. a strided sample of SAMPLE_ROWS rows first: tau_q = (k-th largest approximate sample score) - 2 BERR is a lower bound
 //      of every approximate score whose exact score can reach the true k-th largest one;
 //   3. the pass over the table keeps (row, approximate score) pairs >= tau_q, each workgroup in its own BSLOT entries per needle;
@@ -305,7 +308,7 @@ constexpr int BATCH_MIN_Q = 32;
 constexpr int BQ_MAX = 2048;          // needles per call of the batched path (LDS counters)
 constexpr int BSLOT = 16;             // (row, score) entries per workgroup (256 rows) and needle: expected 1.2 at cfg5, P(> 16) ~ 1e-14
 constexpr int BD_MAX = 128;           // widest row the batched kernel stages whole
-#define GR_BERR 0.0078125f
+#define GR_BERR 0.0087890625f      /* 2^-7 + 2^-10: see the bound above */
 typedef short bf16x8s __attribute__((ext_vector_type(8)));
 typedef float f32x16s __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ unsigned short to_bf16(float x) { const __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }

@@ -99,12 +99,14 @@ _SIGS = {
     "gr_comm_ranks": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gr_allreduce_grads": (C.c_int, [_P]),
     "gr_allreduce_dev": (C.c_int, [_P, _P, C.c_int64]),
+    "gr_allgather_dev": (C.c_int, [_P, _P, _P, C.c_int64]),
     "gr_broadcast_params": (C.c_int, [_P, C.c_int]),
     "gr_train_r_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(Hyper), C.c_int, C.POINTER(C.c_double)]),
     "gr_set_conv_mode": (C.c_int, [_P, C.c_int]),
     "gr_get_conv_mode": (C.c_int, [_P]),
     "gr_set_tuning": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "gr_range_guard_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gr_range_guard_scan_params": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "gr_search_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "gr_debug_stamps": (C.c_int, [_P, _P]),
     "gr_set_timing": (C.c_int, [_P, C.c_int]),
@@ -317,6 +319,9 @@ class Context:
     def allreduce(self, dptr, n):
         self.check(self.lib.gr_allreduce_dev(self.h, _ptr(dptr), int(n)), "gr_allreduce_dev")
 
+    def allgather(self, send_dev, recv_dev, nbytes):
+        self.check(self.lib.gr_allgather_dev(self.h, _ptr(send_dev), _ptr(recv_dev), int(nbytes)), "gr_allgather_dev")
+
     def set_conv_mode(self, mode):
         """0 / "f32": exact fp32 MFMA; 1 / "bf16x6": fp32-accurate 3-term bf16 split on the bf16 MFMA (6 products);
         2 / "f16x3": fp32-accurate 2-term fp16 split of power-of-two-scaled operands on the f16 MFMA (3 products)."""
@@ -509,6 +514,13 @@ class Net:
     def set_adam_state(self, m, v):
         m, v = f32(m), f32(v)
         self._c(self.lib.gr_adam_set_state(self.h, _ptr(m), _ptr(v)), "gr_adam_set_state")
+
+    def range_guard_scan(self):
+        """f16x3 range guard for loops built from the *_dev calls: synchronous scan of this net's weights / BatchNorm scales; True
+        when the context's guard has tripped (it then stays on bf16x6)."""
+        t = C.c_int(0)
+        self._c(self.lib.gr_range_guard_scan_params(self.h, C.byref(t)), "gr_range_guard_scan_params")
+        return bool(t.value)
 
     def allreduce_grads(self):
         self._c(self.lib.gr_allreduce_grads(self.h), "gr_allreduce_grads")

@@ -294,10 +294,20 @@ class DeviceGame:
             raise L.GanrevError("DeviceGame: only the default optimizer 'adam' (train.lua:37-38)")
         self.ctx = G._context()
         B = OPT.batchSize
-        img = G.forward(nn_utils.createNoiseInputs(2, OPT.noiseDim, OPT.noiseMethod, seed=1))       # compile every net (parameters uploaded)
+        # Compile every net with one small forward (parameters uploaded) WITHOUT side effects on the models: the
+        # reference has no such step, so the BatchNorm running statistics a training-mode forward of two samples would write - and
+        # which evaluate()-mode users of G (train_r, apply_r) and the saved checkpoint would then carry - are put back afterwards.
+        img = G.forward(nn_utils.createNoiseInputs(2, OPT.noiseDim, OPT.noiseMethod, seed=1))
         D.forward(img)
         self.gnet = G._net
         self.dg = _DevGraph(self.ctx, D)
+        for model in (G, D):
+            for chunk, _, _ in model._param_chunks():
+                bi = 0
+                for mod in chunk.leaves():
+                    if hasattr(mod, "running_mean"):
+                        chunk._net.set_bn_running(bi, mod.running_mean, mod.running_var)     # the modules still hold the pre-compile values
+                        bi += 1
         for n in [self.gnet] + self.dg.nets:
             n.set_training(True)
             n.adam_reset()
@@ -328,35 +338,52 @@ class DeviceGame:
     def _read_loss(self):
         return float(self.ctx.download(self.loss, (1,), np.float64)[0])
 
-    def batch(self, real_half, noise_d=None, noise_g=None, want_loss=False):
-        """One batch of adversarial.lua:139-201 (D_iterations = G_iterations = 1).  real_half: [batchSize/2 x C x H x W] host array
-        (the one unavoidable upload).  noise_*: host noise to use instead of device-generated noise (parity tests)."""
+    GUARD_PERIOD = 64       # batches between two f16x3 range-guard scans of the parameters (gr_range_guard_scan_params)
+
+    def batch(self, real, noise_d=None, noise_g=None, want_loss=False):
+        """One batch of adversarial.lua:139-201: OPT.D_iterations updates of D, each on batchSize/2 fresh real images + batchSize/2
+        generated ones, then OPT.G_iterations updates of G through D.  real: [D_iterations * batchSize/2 x C x H x W] host array (the
+        one unavoidable upload).  noise_*: host noise to use instead of device-generated noise (parity tests): arrays of
+        [D_iterations * batchSize/2 x noiseDim] / [G_iterations * batchSize x noiseDim].  Returns the LAST (loss_D, loss_G)."""
         OPT, B = self.env.OPT, self.env.OPT.batchSize
         half = B // 2
         ctx = self.ctx
-        # (1) D on half real, half generated (adversarial.lua:141-157, fevalD :66-100)
-        ctx.upload(np.ascontiguousarray(real_half, np.float32).reshape(half, -1), self.inputs)
-        self._fill_noise(half, noise_d)
-        fake = self.gnet.forward_dev(self.noise, half)
-        ctx.copy2d(self.inputs + 4 * half * self.npix, self.npix, fake, self.npix, half, self.npix)
-        self.dg.zero_grads()
-        out = self.dg.forward(self.inputs, B)
-        ctx.bce_dev(out, self.targets, B, self.loss, self.df)
-        self.dg.backward(self.df, B, False)
-        self.t["D"] += 1
-        self.dg.adam_step(self.hyper_d, self.t["D"])
-        loss_d = self._read_loss() if want_loss else None
-        # (2) G through D (adversarial.lua:178-201, fevalG_on_D :104-133)
-        self._fill_noise(B, noise_g)
-        self.gnet.zero_grads()
-        samples = self.gnet.forward_dev(self.noise, B)
-        out = self.dg.forward(samples, B)
-        ctx.bce_dev(out, self.ones, B, self.loss, self.df)
-        df_do = self.dg.backward(self.df, B, True)
-        self.gnet.backward_dev(self.noise, df_do, B, None)
-        self.t["G"] += 1
-        self.gnet.adam_step(self.hyper_g, self.t["G"])
-        loss_g = self._read_loss() if want_loss else None
+        nD, nG = max(1, int(OPT.D_iterations)), max(1, int(OPT.G_iterations))
+        real = np.ascontiguousarray(real, np.float32).reshape(-1, self.npix)
+        if real.shape[0] < nD * half:
+            raise IndexError("trainData exhausted (adversarial.lua:146 indexes past the loaded examples): "
+                             f"{real.shape[0]} images for {nD} D iterations of {half}")
+        if self.ctx.conv_mode() == "f16x3" and (self.t["D"] // nD) % self.GUARD_PERIOD == 0:
+            for n in [self.gnet] + self.dg.nets:      # the *_dev calls below are unguarded: sampled parameter scan, as gr_train_r_step does
+                n.range_guard_scan()
+        loss_d = loss_g = None
+        for k in range(nD):
+            # (1) D on half real, half generated (adversarial.lua:141-157, fevalD :66-100)
+            ctx.upload(real[k * half:(k + 1) * half], self.inputs)
+            self._fill_noise(half, None if noise_d is None else np.asarray(noise_d).reshape(nD, half, -1)[k])
+            fake = self.gnet.forward_dev(self.noise, half)
+            ctx.copy2d(self.inputs + 4 * half * self.npix, self.npix, fake, self.npix, half, self.npix)
+            self.dg.zero_grads()
+            out = self.dg.forward(self.inputs, B)
+            ctx.bce_dev(out, self.targets, B, self.loss, self.df)
+            self.dg.backward(self.df, B, False)
+            self.t["D"] += 1
+            self.dg.adam_step(self.hyper_d, self.t["D"])
+            if want_loss and k == nD - 1:
+                loss_d = self._read_loss()
+        for k in range(nG):
+            # (2) G through D (adversarial.lua:178-201, fevalG_on_D :104-133)
+            self._fill_noise(B, None if noise_g is None else np.asarray(noise_g).reshape(nG, B, -1)[k])
+            self.gnet.zero_grads()
+            samples = self.gnet.forward_dev(self.noise, B)
+            out = self.dg.forward(samples, B)
+            ctx.bce_dev(out, self.ones, B, self.loss, self.df)
+            df_do = self.dg.backward(self.df, B, True)
+            self.gnet.backward_dev(self.noise, df_do, B, None)
+            self.t["G"] += 1
+            self.gnet.adam_step(self.hyper_g, self.t["G"])
+            if want_loss and k == nG - 1:
+                loss_g = self._read_loss()
         return loss_d, loss_g
 
     def sync_to_host(self):

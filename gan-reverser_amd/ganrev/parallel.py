@@ -82,6 +82,34 @@ class RcclCommunicator:
     def close(self):
         self.ctx.comm_destroy()
 
+    # The collectives of the sharded search (gather_needles / sharded_cosine_topk below) on the RCCL communicator: host arrays
+    # are staged through device buffers (they are Q x d and Q x k values), the exchange itself is ncclAllReduce / ncclAllGather
+    # over xGMI (SURVEY.md 8e names the all-gather of Q * k * 12 bytes per rank).
+    def _staged(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return arr, self.ctx.upload(arr)
+
+    def allreduce_sum(self, arr):
+        arr, d = self._staged(np.asarray(arr, np.float32))
+        try:
+            self.ctx.allreduce(d, arr.size)
+            return self.ctx.download(d, arr.shape, np.float32)
+        finally:
+            self.ctx.free(d)
+
+    def allreduce_scalar(self, x):
+        return float(self.allreduce_sum(np.array([x], np.float32))[0])       # (control values only: fp32 on the wire)
+
+    def allgather(self, arr):
+        arr, d = self._staged(arr)
+        out = self.ctx.malloc(arr.nbytes * self.world)
+        try:
+            self.ctx.allgather(d, out, arr.nbytes)
+            full = self.ctx.download(out, (self.world,) + arr.shape, arr.dtype)
+            return [full[r] for r in range(self.world)]
+        finally:
+            self.ctx.free(d); self.ctx.free(out)
+
 
 def train_r_step_decomposed(g_forward, r_forward_backward, penalty_clamp_adam, comm, noise_global, t):
     """One iteration of train_r.lua:138-170 over `comm`, phase by phase.

@@ -121,13 +121,13 @@ class Reader:
             if storage is None or nd == 0:
                 arr = np.zeros(size if nd else (0,), _DTYPES[kind[:-6]])
             else:
-                arr = np.lib.stride_tricks.as_strided(storage[off:], shape=size, strides=[s * storage.itemsize for s in stride]).copy()
+                arr = np.lib.stride_tricks.as_strided(np.asarray(storage)[off:], shape=size, strides=[s * storage.itemsize for s in stride]).copy()
             self.memo[idx] = arr
             return arr
         if kind.endswith("Storage") and kind[:-7] in _DTYPES:
             n = self.long()
             dt = np.dtype(_DTYPES[kind[:-7]])
-            arr = np.frombuffer(self._take(n * dt.itemsize), dtype=dt.newbyteorder("<")).astype(dt)
+            arr = np.frombuffer(self._take(n * dt.itemsize), dtype=dt.newbyteorder("<")).astype(dt).view(Storage)
             self.memo[idx] = arr
             return arr
         o = TorchObject(cls)
@@ -135,6 +135,17 @@ class Reader:
         fields = self.obj()
         o.fields = fields if isinstance(fields, dict) else ({} if fields is None else {i + 1: v for i, v in enumerate(fields)})
         return o
+
+
+class Storage(np.ndarray):
+    """A torch.XStorage (flat, typed, no shape) as opposed to a torch.XTensor: the reader returns storages that appear as OBJECTS
+    (nn.Concat.size and nn.View.size are torch.LongStorage in Torch7's nn: `self.size:resize(...):copy(outs[1]:size())` needs a
+    storage, a LongTensor there breaks the reference's first forward of a loaded D) as this ndarray view, and the writer emits a
+    Storage as torch.XStorage.  Use storage(values, dtype) to make one."""
+
+
+def storage(values, dtype=np.int64):
+    return np.ascontiguousarray(values, dtype=dtype).reshape(-1).view(Storage)
 
 
 def _listify(d):
@@ -186,6 +197,8 @@ class Writer:
             self.int(TYPE_NUMBER); self.out += struct.pack("<d", float(o))
         elif isinstance(o, str):
             self.int(TYPE_STRING); self.string(o)
+        elif isinstance(o, Storage):
+            self._storage(o)
         elif isinstance(o, np.ndarray):
             self._tensor(o)
         elif isinstance(o, (list, tuple)):
@@ -207,6 +220,18 @@ class Writer:
                 self.obj(o.fields)
         else:
             raise TypeError(f"cannot serialise {type(o).__name__}")
+
+    _NAMES = {np.dtype(np.float32): "Float", np.dtype(np.float64): "Double", np.dtype(np.int64): "Long", np.dtype(np.int32): "Int",
+              np.dtype(np.uint8): "Byte"}
+
+    def _storage(self, a):
+        """a torch.XStorage object of its own (not the storage behind a tensor): int64 n, n raw elements"""
+        self.int(TYPE_TORCH)
+        if not self._index(a):
+            return
+        self.string("V 1"); self.string(f"torch.{self._NAMES[a.dtype]}Storage")
+        self.long(a.size)
+        self.out += np.asarray(a).astype(a.dtype.newbyteorder("<")).tobytes()
 
     def _tensor(self, a):
         name = {np.dtype(np.float32): "Float", np.dtype(np.float64): "Double", np.dtype(np.int64): "Long", np.dtype(np.int32): "Int",
@@ -330,7 +355,7 @@ def from_model(model):
     if isinstance(model, nn.Sequential):
         return TorchObject("nn.Sequential", dict(base, modules=[from_model(m) for m in model.modules]))
     if isinstance(model, nn.Concat):
-        return TorchObject("nn.Concat", dict(base, dimension=model.dimension, size=np.zeros(0, np.int64), modules=[from_model(m) for m in model.modules]))
+        return TorchObject("nn.Concat", dict(base, dimension=model.dimension, size=storage([]), modules=[from_model(m) for m in model.modules]))
     f = dict(base)
     if isinstance(model, nn.PReLU):
         f.update(nOutputPlane=0, weight=model.weight, gradWeight=empty, gradWeightBuf=empty, gradWeightBuf2=empty)
@@ -359,7 +384,7 @@ def from_model(model):
     elif isinstance(model, nn.SpatialUpSamplingNearest):
         f.update(scale_factor=2, inputSize=np.zeros(4, np.int64), outputSize=np.zeros(4, np.int64))
     elif isinstance(model, nn.View):
-        f.update(size=np.asarray(model.sizes, np.int64), numElements=int(np.prod(model.sizes)))
+        f.update(size=storage(model.sizes), numElements=int(np.prod(model.sizes)))            # nn.View keeps a torch.LongStorage
     elif isinstance(model, nn.ELU):
         f.update(alpha=1, inplace=False)
     return TorchObject(t if t.startswith("nn.") else "nn." + t.split(".")[-1], f)

@@ -88,7 +88,7 @@ def main(argv=None):
         ck = t7.load_checkpoint(OPT.network)
         if "_unconverted" in ck:
             raise L.GanrevError(f"{OPT.network}: {ck['_unconverted']}")
-        MODEL_D, MODEL_G, epoch0 = ck["D"], ck["G"], int(ck.get("epoch", 1))
+        MODEL_D, MODEL_G, epoch0 = ck["D"], ck["G"], int(ck.get("epoch", 0)) + 1      # train.lua:113  EPOCH = tmp.epoch + 1
     else:                                                             # train.lua:143,160
         MODEL_D = models.create_D(dims, True, OPT.seed)
         MODEL_G = models.create_G(dims, OPT.noiseDim, True, OPT.seed + 1)
@@ -98,8 +98,16 @@ def main(argv=None):
     env.EPOCH = epoch0
     data = np.load(OPT.data).astype(np.float32) if OPT.data else None
     game = None if OPT.compat else adversarial.DeviceGame(env)
-    nbLoad = (OPT.N_epoch * OPT.batchSize // 2) * OPT.D_iterations    # train.lua:214
-    cursor, last, t0, images = 0, None, time.perf_counter(), 0
+    N_epoch = OPT.N_epoch if OPT.N_epoch > 0 else 100                 # adversarial.lua:42-45: N_epoch <= 0 means 100 batches
+    D_it, G_it = max(1, OPT.D_iterations), max(1, OPT.G_iterations)
+    # a continued run must not replay the first epochs' noise: the counters start where epoch0 - 1 finished epochs left them
+    # (the reference's Torch RNG is not restored from a checkpoint either; Adam's state restarts empty, as train.lua does)
+    done = (epoch0 - 1) * N_epoch * (D_it + G_it)
+    env.noise_counter = getattr(env, "noise_counter", 0) + done
+    if game is not None:
+        game.noise_counter += done
+    nbLoad = (N_epoch * OPT.batchSize // 2) * D_it                    # train.lua:214
+    cursor, last, t0, images = (epoch0 - 1) * nbLoad, None, time.perf_counter(), 0
     for _ in range(OPT.epochs):
         if data is not None:
             idx = (cursor + np.arange(nbLoad)) % len(data); cursor += nbLoad
@@ -110,13 +118,13 @@ def main(argv=None):
             adversarial.train(env, TRAIN_DATA, quiet=OPT.quiet)       # train.lua:229
             last = (env.last_losses["D"][-1], env.last_losses["G"][-1])
         else:
-            half = OPT.batchSize // 2
-            for b in range(OPT.N_epoch):
-                want = b == OPT.N_epoch - 1
-                res = game.batch(TRAIN_DATA[b * half:(b + 1) * half], want_loss=want)
+            per = (OPT.batchSize // 2) * D_it                         # real images one batch consumes: batchSize/2 per D iteration (adversarial.lua:139-149)
+            for b in range(N_epoch):
+                want = b == N_epoch - 1
+                res = game.batch(TRAIN_DATA[b * per:(b + 1) * per], want_loss=want)
                 if want:
                     last = res
-        images += OPT.N_epoch * OPT.batchSize
+        images += N_epoch * OPT.batchSize * G_it
         if not OPT.quiet:
             print("<trainer> epoch %d: loss D=%.4f G=%.4f" % (env.EPOCH, last[0], last[1]))
         if env.EPOCH % OPT.saveFreq == 0:                             # train.lua:232-234

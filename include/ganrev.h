@@ -135,6 +135,9 @@ int gr_comm_destroy(gr_ctx* ctx);
 int gr_comm_ranks(gr_ctx* ctx, int* nranks, int* rank);
 int gr_allreduce_grads(gr_net* net);                        /* SUM over ranks of the flat gradient; no-op when nranks == 1 */
 int gr_allreduce_dev(gr_ctx* ctx, float* buf_dev, int64_t n);
+/* all-gather of bytes_per_rank bytes from every rank into recv_dev [nranks x bytes_per_rank], rank order (the sharded search's
+ * candidate exchange: apply_r.lua:266-282 over a corpus split across GPUs; one ncclAllGather).  One rank: a copy. */
+int gr_allgather_dev(gr_ctx* ctx, const void* send_dev, void* recv_dev, int64_t bytes_per_rank);
 int gr_broadcast_params(gr_net* net, int root);             /* make replicas identical before the first step */
 
 /* ---- one whole iteration of train_r.lua:138-170:  images = G:forward(noise) ; R fwd ; MSE ; R bwd ;
@@ -164,6 +167,11 @@ int gr_set_tuning(gr_ctx* ctx, const char* key, int value);
  * switches the context to bf16x6 when a scan trips.  Counters: scan launches and passes sent to bf16x6 since gr_init (the
  * latter also in gr_kernel_times as "range_guard_fallback"). */
 int gr_range_guard_stats(gr_ctx* ctx, int64_t* scans, int64_t* fallbacks);
+/* The device-pointer calls (gr_net_forward_dev / gr_net_backward_dev) are NOT guarded: host loops built from them (the GAN game,
+ * adversarial.lua:139-201 mirrored by ganrev.adversarial.DeviceGame) call this every few dozen batches per net: synchronous scan of
+ * the net's weights and BatchNorm scales; a hostile spread keeps the context on bf16x6 (as gr_train_r_step's sampled scan does).
+ * tripped_out (nullable): 1 when the context's guard has tripped. */
+int gr_range_guard_scan_params(gr_net* net, int* tripped_out);
 int gr_debug_stamps(gr_ctx* ctx, void* dev_buf);   /* diagnostic builds: device buffer for in-kernel time stamps (tools/stamps_p16.py) */
 int gr_set_timing(gr_ctx* ctx, int mode /*0 off, 1 per-phase events in gr_train_r_step, 2 per-kernel events*/);
 /* mode 2: JSON array of {kernel, phase, launches, total_ms, flops, bytes} (algorithmic flops/bytes) accumulated since it was
@@ -186,8 +194,8 @@ int gr_cosine_topk_dev(gr_ctx* ctx, const float* emb_dev, int64_t n, int d, cons
 int gr_cosine_similarity_host(gr_ctx* ctx, const float* a_host, const float* b_host, int d, float* out);
 /* Tables of 2^17 rows or more are searched through a bound taken from a strided 16384-row sample (only keys at or above the
  * sample's k-th largest key are kept: same result, bit for bit, without writing n x q keys).  With 32 or more needles (d <= 128)
- * the candidates come from ONE bf16 MFMA GEMM of the table against all needles (approximate cosines, error bound 2^-7, two
- * cuts with a 2^-6 margin) and only they are scored in the exact op order: the result is still bit-identical.  When a table's
+ * the candidates come from ONE bf16 MFMA GEMM of the table against all needles (approximate cosines, error bound 2^-7 + 2^-10, two
+ * cuts with twice that margin) and only they are scored in the exact op order: the result is still bit-identical.  When a table's
  * order defeats the sample (a candidate list overflows) the search runs again on every key.  reruns = how often that
  * happened since gr_init. */
 int gr_search_stats(gr_ctx* ctx, int64_t* reruns);

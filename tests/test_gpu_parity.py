@@ -403,6 +403,74 @@ def test_range_guard_trips_in_the_device_resident_loop(ctx):
         ctx.set_conv_mode(prev)
 
 
+def test_dead_channels_between_two_guard_scans_in_the_device_loop(ctx, oracle):
+    """the device-resident loop scans the parameters only every 64th gr_train_r_step and never the
+    activations.  The case that could slip through between two scans is a TRAINED-LOOKING weight tensor with dead channels: a few
+    output channels (and one input channel's column) of R's convolutions at |w| ~ 1e-7 next to channels at ~1 - 23 bits of
+    spread, over the 20-bit budget.  f16x3 then keeps only ~17 bits of the dead channels' weights.  What saves the result is the
+    reference's own BatchNorm: var + 1e-5 in the denominator caps the gain of a channel whose outputs are ~1e-7 at 316, so a dead
+    channel's error enters the next layer below 1e-10.  Asserted here: (1) a step that runs on f16x3 with such weights between two
+    scans (t = 2: no scan due, the context stays on f16x3) still meets every parity bar against the oracle - images, loss, all of
+    R's gradients, Adam's step; (2) the next scan (t = 65) sees the spread and moves the context to bf16x6, counted once."""
+    import ganrev._lib as L
+    from ganrev import synth
+    from helpers import adopt_device_argmax, assert_grads_close, release_argmax
+    dims, nd, B = (1, 32, 32), 32, 8
+    prev = ctx.conv_mode(); ctx.set_conv_mode("f16x3")
+    try:
+        G, R, oG, oR = _make_pair(oracle, dims, nd, 9)
+        convs = [m for m in R.leaves() if m.typename == "nn.SpatialConvolution"]
+        for conv, dead_out, dead_in in ((convs[1], (3, 17, 40), 5), (convs[4], (0, 64, 127), 77)):
+            conv.weight[list(dead_out)] *= np.float32(1e-7)          # output channels that died in training
+            conv.weight[:, dead_in] *= np.float32(1e-7)              # an input channel nothing listens to any more
+        oR = oracle.from_model(R, dims)
+        G.evaluate(); G.forward(synth.normal((2, nd), 1))
+        R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
+        R._pending_masks = {}
+        gnet, rnet = G._net, R._net
+        theta0 = oR.params.copy()
+        zeros = np.zeros_like(theta0)
+        noise = synth.normal((B, nd), 321)
+        inject_noise(R, oR, B, 322)
+        for module, keep in R._pending_masks.values():
+            rnet.set_mask(R._leaf_layer(module), keep)
+        R._pending_masks = {}
+        rnet.set_params(theta0); rnet.set_adam_state(zeros, zeros)
+        _, falls0 = ctx.range_guard_stats()
+        dn = ctx.upload(noise)
+        t = 2                                                          # t % 64 != 1: no parameter scan is due in this call
+        loss = L.train_r_step(gnet, rnet, dn, B, B, L.Hyper(), t)
+        assert ctx.conv_mode() == "f16x3" and ctx.range_guard_stats()[1] == falls0, "the step under test did not run on f16x3"
+        img = ctx.download(gnet.lib.gr_net_output_dev(gnet.h), (B,) + dims)
+        rec = ctx.download(rnet.lib.gr_net_output_dev(rnet.h), (B, nd))
+        g, theta = rnet.get_grads(), rnet.get_params()
+        # the oracle on the same state (argmax adopted as everywhere else)
+        oG.set_training(False); rimg = oG.forward(noise)
+        oR.set_training(True); oR.zero_grads()
+        preds = np.array(oR.forward(rimg), copy=True)
+        assert_close(img, rimg, TOL, "G images"); assert_close(rec, preds, TOL, "recovered noise with dead channels (f16x3, between scans)")
+        flips = adopt_device_argmax(R, oR, B, 8)
+        inject_noise(R, oR, B, 322); R._pending_masks = {}
+        oR.zero_grads(); preds = np.array(oR.forward(rimg), copy=True)
+        rloss, dfdo = oracle.mse(preds, noise)
+        oR.backward(rimg, dfdo, want_gin=False); release_argmax(R, oR)
+        assert abs(loss - rloss) <= 1e-5 * max(1.0, abs(rloss))
+        rg, rtheta, rm, rv = oR.grads.copy(), theta0.copy(), zeros.copy(), zeros.copy()
+        oracle.penalty_clamp_adam(rtheta, rg, rm, rv, oracle.GoHyper(), t)
+        assert_grads_close(R, g, rg, 1e-4, 1e-3, f"(dead channels, argmax flips {flips})")
+        well = np.abs(rg) > 1e-4
+        assert_close(theta[well], rtheta[well], TOL, "parameters after Adam")
+        # (2) the next due scan catches it
+        rnet.set_params(theta0)
+        for t2 in (65, 66, 67):
+            L.train_r_step(gnet, rnet, dn, B, B, L.Hyper(), t2); ctx.synchronize()
+        assert ctx.conv_mode() == "bf16x6" and ctx.range_guard_stats()[1] - falls0 == 1, (ctx.conv_mode(), ctx.range_guard_stats())
+        ctx.free(dn)
+    finally:
+        ctx.set_tuning("range_guard", 0); ctx.set_tuning("range_guard", 1)     # clears the tripped state
+        ctx.set_conv_mode(prev)
+
+
 def test_side_stream_weight_gradients_change_nothing(ctx):
     """gr_set_tuning "side_wgrad" 1 runs R's convolution weight gradients on a second stream beside the rest of backward (dy
     double-buffered, events both ways).  Same kernels, same operands, same order inside each kernel: three training steps
@@ -921,6 +989,29 @@ def test_rccl_single_rank_allreduce(ctx):
         assert np.array_equal(ctx.download(d, a.shape), a)
     finally:
         ctx.comm_destroy()
+
+
+def test_sharded_search_over_the_rccl_communicator(ctx):
+    """the sharded search's two exchanges - the needle vectors (sum all-reduce) and the candidates (ONE
+    ncclAllGather of Q * k * 12 bytes per rank) - through ganrev.parallel.RcclCommunicator, i.e. through libganrev.so's RCCL
+    communicator instead of host arrays.  A 1-GPU box can only form a one-rank communicator: the
+    collectives still run through RCCL (gr_allreduce_dev / gr_allgather_dev do not bypass it), and the result must equal the
+    plain search bit for bit."""
+    from ganrev import synth
+    from ganrev.parallel import RcclCommunicator, sharded_cosine_topk
+    N, d, k = 20011, 100, 50
+    emb = synth.normal((N, d), 91); emb[12345] = emb[150]
+    needles = [100, 150, N - 1]
+    comm = RcclCommunicator(ctx, world=1, rank=0)
+    try:
+        assert ctx.comm_ranks() == (1, 0)
+        got = comm.allgather(np.arange(12, dtype=np.int64).reshape(3, 4))
+        assert len(got) == 1 and np.array_equal(got[0], np.arange(12).reshape(3, 4))
+        idx, sc = sharded_cosine_topk(ctx.cosine_topk, emb, 0, needles, k, comm)
+    finally:
+        comm.close()
+    ridx, rsc = ctx.cosine_topk(emb, needles, k)
+    assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
 
 
 # ------------------------------------------------------------------ committed golden vectors (tests/golden/golden_v1.npz)

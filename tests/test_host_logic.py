@@ -197,7 +197,21 @@ def test_D_network_structure_parts_and_checkpoint_round_trip():
     assert np.abs(conv5.bias).max() > 0                    # ... not the modules nested in the towers (weight-init.lua:52 walks net.modules only)
     descs = D.parts()[1].modules[0]._descs((128, 16, 16))[0]
     assert descs[0][:4] == (L.CONVK, 128, 64, 5) and descs[1][0] == L.PRELU
-    back = t7.to_model(t7.load(t7.dumps({"D": t7.from_model(D)}))["D"])
+    raw = t7.load(t7.dumps({"D": t7.from_model(D)}))["D"]
+    back = t7.to_model(raw)
+    # nn.Concat.size and nn.View.size are torch.LongStorage objects in Torch7's nn (a LongTensor there breaks the reference's
+    # first forward of a loaded D: `self.size:resize(...):copy(outs[1]:size())`): the bytes must say so, not merely round-trip
+    blob = t7.dumps({"D": t7.from_model(D)})
+    cat = [m for m in raw.fields["modules"] if getattr(m, "typename", "") == "nn.Concat"][0]
+    assert isinstance(cat.fields["size"], t7.Storage) and cat.fields["size"].dtype == np.int64 and cat.fields["size"].size == 0
+    i = blob.index(b"nn.Concat")
+    assert blob.index(b"torch.LongStorage", i) < blob.index(b"nn.Sequential", i), "nn.Concat.size is not written as a torch.LongStorage"
+    def walk(o):
+        yield o
+        for m in (o.fields.get("modules") or []):
+            yield from walk(m)
+    views = [m for m in walk(t7.from_model(D)) if m.typename == "nn.View"]
+    assert views and all(isinstance(v.fields["size"], t7.Storage) for v in views)
     assert [m.typename for m in back.leaves()] == [m.typename for m in D.leaves()]
     assert np.array_equal(back._flat_host(), flat) and back.modules[3].dimension == 2
     with pytest.raises(L.GanrevError):
