@@ -1536,6 +1536,22 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_kernel(
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
+// Epilogue stores of the up-sampling kernels.  A lane ends with the 2x2 outputs of its source pixel (x, y): two float2 per channel,
+// 8 bytes per lane - store-issue-bound (MI355X_MICROARCH.md: a dwordx2-per-lane store tail runs at ~7 B/clk/CU, dwordx4 halves it;
+// ablation round 3: the stores are 34-39 us of G.convB's 246 at cfg2), and rocprofv3's WRITE_SIZE reads 2.4x the bytes for them.
+// Lanes l and l ^ 1 hold horizontally adjacent source pixels (tile_pixel: pc = lane & (TW - 1)), so they swap half of their values
+// through DPP (quad_perm [1,0,3,2]: a VALU move, no LDS): the even lane ends with output row 2y, columns 2x .. 2x+3, the odd
+// lane with row 2y+1 of the same four columns - ONE 16-byte store per lane and channel.
+__device__ __forceinline__ float dpp_swap1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+// v = {out(2y, 2x), out(2y, 2x+1), out(2y+1, 2x), out(2y+1, 2x+1)} of this lane's source pixel; returns the lane's float4 and the output
+// row phase (0 / 1) and source column (x or x - 1) it belongs to
+__device__ __forceinline__ float4 up2_pair_rows(const float* v, bool odd) {
+  const float s0 = odd ? v[0] : v[2], s1 = odd ? v[1] : v[3];          // what the partner needs: my other row
+  const float r0 = dpp_swap1(s0), r1 = dpp_swap1(s1);
+  return odd ? make_float4(r0, r1, v[2], v[3]) : make_float4(v[0], v[1], r0, r1);
+}
 // ---------------------------------------------------------------- nearest x2 up-sampling + 3x3 convolution as four 2x2 convolutions
 // nn.SpatialUpSamplingNearest(2) followed by the 3x3 convolution (G: models.lua:121-122,127-128) reads every source pixel
 // through several taps: for output pixel (2y+a, 2x+b) the three tap rows 2y+a-1 .. 2y+a+1 of the up-sampled plane are only
@@ -1798,17 +1814,208 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
       }
     }
     conv_act_block<64>(a.ep, v);
-    if (pin) {
+    {
+      // (both lanes of a pair share the row and the image: `pin` is the same for them, Ws is even)
+      const bool odd = (pc & 1) != 0;
+      float* orow = a.out + ((size_t)(b + img) * a.Cout * a.H + 2 * y + (odd ? 1 : 0)) * a.W + 2 * (x - (odd ? 1 : 0));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (o < a.Cout) {
+        const float4 res = up2_pair_rows(v + r * 4, odd);            // every lane takes part in the exchange
+        if (pin && o < a.Cout) {
+          *reinterpret_cast<float4*>(orow + (size_t)o * a.H * a.W) = res;
+          omax = absmax4(omax, res);
+        }
+      }
+    }
+  }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+
+// ---------------------------------------------------------------- the same layer as TWO independent four-wave workgroups per CU
+// conv3x3_up2_f16x3_kernel keeps two operand images (144-148 KB): one eight-wave workgroup per CU whose waves move through
+// staging, multiply and epilogue in lock-step - the structure conv3x3_p16_quad_kernel left behind for R's layers (+35 % there).
+// PMC in the real step: matrix pipe busy 37 % (P16 kernels: 44-49 %), and making the workgroups persistent so that a tile's
+// epilogue overlaps the next tile's loads changed nothing (round 3, measured): the loss is in the steady state, not at the tile
+// boundaries.  Here a workgroup is FOUR waves (one per SIMD) on 256 source pixels x 32 output channels x the four output
+// phases, ONE operand image of ~54 KB, so two workgroups share a CU and run out of phase by themselves: while one converts
+// its next chunk, waits for its weights or stores its tile, the other one has the matrix pipe.  The activations still arrive as
+// fp32 (G's stages run in evaluate() mode, their producers cannot know the tensor's maximum before it exists, so there is no
+// operand-ready image to read) and are split on the VALU: they are prefetched into registers behind the MFMAs of the chunk
+// before.  The weights are pre-split by the prep kernel, so they go HBM/L2 -> LDS by DMA (no registers, no ds_write).
+// Per chunk and wave: 96 MFMAs, 62 ds_read_b128, ~60 VALU, 6 ds_write_b128, 8 DMA instructions.
+template <int TW, int NI>
+__global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, const uint4* __restrict__ wup) {
+  constexpr int NW = 4, NT = 64 * NW, NG = 2, PT = 64 * NW, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
+  static_assert(NI == 1 && (TW == 16 || TW == 32), "one image (16x16) or 8 rows of a 32-wide plane per tile");
+  constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;            // (position, half) pairs staged per thread
+  constexpr int PV = 2 * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;
+  constexpr int WV = 2 * 2 * 8 * 2 * 32, NWI = WV / 64, NWS = NWI / NW;   // weight vectors per chunk; DMA instructions; per wave
+  static_assert(2 * (PVP + WV) * 16 <= 160 * 1024, "two workgroups per CU");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [2 terms][2 halves][PS]
+  uint4* wts = patch + PVP;                                       // [2 terms][2 a][8 slots][2 halves][32 o]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * 32;
+  const int Hs = a.H >> 1, Ws = a.W >> 1;                        // source plane
+  const size_t HWs = (size_t)Hs * Ws;
+  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
+  const size_t in_left = (size_t)(a.B - b) * a.Cin * HWs * sizeof(float);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
+      (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
+  const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wup), 0,
+      (int)((size_t)nchunks * 64 * a.cout_pad * 16), 0x00020000);
+  const int kin = f16_scale_exp(absmax_read(a.amax_in));
+  const int ktot = kin + f16_scale_exp(absmax_read(a.amax_w)) - 2;   // summed weights: up to 4 max|w|
+  const float sc_in = pow2f(kin);
+  const int dbg = a.up >> 1;            // diagnostic ablations (gr_set_tuning "up2_debug"; outputs are then wrong by design): 1 no stores, 2 no MFMA, 4 no activation staging, 8 no weight DMA
+  int voff[NSL], eoff[NSL];
 #pragma unroll
-          for (int pa = 0; pa < 2; ++pa) {
-            const float2 res = make_float2(v[r * 4 + pa * 2], v[r * 4 + pa * 2 + 1]);
-            *reinterpret_cast<float2*>(a.out + (((size_t)(b + img) * a.Cout + o) * a.H + 2 * y + pa) * a.W + 2 * x) = res;
-            omax = fmaxf(omax, fmaxf(fabsf(res.x), fabsf(res.y)));
+  for (int s = 0; s < NSL; ++s) {
+    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
+    const int yy = y0 + rr - 1, xx = x0 + c - 1;
+    const bool inb = eh < NEH && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws && b < a.B;
+    const int so = yy * Ws + xx + (8 * hh) * (int)HWs;
+    voff[s] = inb ? so * 4 : (int)0x7FFFF000;
+    eoff[s] = eh < NEH ? eh : -1;
+  }
+  // weight DMA: instruction i = wave + NW * j covers LDS vectors 64 i .. 64 i + 63 = rows 2 i, 2 i + 1 of the chunk's 64 rows
+  const int woff0 = ((2 * wave + (lane >> 5)) * a.cout_pad + o0 + (lane & 31)) * 16, wstep = 2 * NW * a.cout_pad * 16;
+  float pv[NSL][8];
+#define GR_UQ_LOAD(ch_)                                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
+      const int soff_ = (int)(((ch_) * BF_CK + j) * HWs * 4);                                             \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
+        pv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
+    }                                                                                                     \
+  }
+#define GR_UQ_DMAW(ch_)                                                                                   \
+  {                                                                                                       \
+    const int wsoff_ = (ch_) * 64 * a.cout_pad * 16;                                                      \
+    _Pragma("unroll") for (int j = 0; j < NWS; ++j) lds_dma16(rwt, wts + 64 * (wave + NW * j), woff0 + j * wstep, wsoff_); \
+  }
+#define GR_UQ_STORE(ch_)                                                                                  \
+  {                                                                                                       \
+    if (((ch_) + 1) * BF_CK > a.Cin) {                                                                    \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                   \
+        const int clim_ = a.Cin - ((tid + NT * s) >= PS ? 8 : 0);                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) if ((ch_) * BF_CK + j >= clim_) pv[s][j] = 0.f;     \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
+      if (eoff[s] >= 0) {                                                                                 \
+        uint4 t0, t1;                                                                                     \
+        split8_f16(pv[s], sc_in, t0, t1);                                                                 \
+        patch[eoff[s]] = t0; patch[2 * PS + eoff[s]] = t1;                                                \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+  f32x16 acc[2][2][NG];                                            // [row phase a][column phase b][pixel group]
+#pragma unroll
+  for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pa][pb][ng][r] = 0.f;
+  int pix[NG];
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    pix[ng] = h * PS + prr * PC + pc;                              // patch row prr = source row y - 1
+  }
+  // The two workgroups of a CU run the same program from (almost) the same start: left alone they stay IN phase - both convert,
+  // both multiply (sharing the matrix pipe), both store - and the phases add up instead of overlapping (ablation, round 3:
+  // skeleton 38 + MFMA 122 + staging 62 + stores 34 = 256 us against 246 measured on G.convB at cfg2).  The workgroup whose waves
+  // sit in the odd wave slots of their SIMDs (HW_ID.wave_id: the one that arrived second, whatever its block index) starts late
+  // by a.nchunks x 512 clocks (gr_set_tuning "up2_stagger"), about half a chunk iteration.
+  if (a.nchunks > 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));     // HW_REG_HW_ID bits [3:0] = wave slot on its SIMD
+    if (hwid & 1) {
+#pragma unroll 1
+      for (int i = 0; i < a.nchunks; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (!(dbg & 4)) GR_UQ_LOAD(0)
+  if (!(dbg & 8)) GR_UQ_DMAW(0)
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (!(dbg & 4)) GR_UQ_STORE(ch)                                // the image is free: every wave passed the barrier below
+    dma_publish_barrier();                                         // this chunk's weights have landed, every wave's patch stores are visible
+    if (ch + 1 < nchunks && !(dbg & 4)) GR_UQ_LOAD(ch + 1)         // lands behind the MFMAs
+    if (!(dbg & 2))
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) {                               // source rows y-1, y, y+1
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3) {                             // source columns x-1, x, x+1: one column's operands at a time
+        uint4 bv[NG][2];
+#pragma unroll
+        for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) bv[ng][t] = patch[t * 2 * PS + pix[ng] + r3 * PC + c3];
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+          const int dy = r3 - pa;                                  // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
+          if (dy < 0 || dy > 1) continue;
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb) {
+            const int dx = c3 - pb;                                // column phase b reads source columns x-1+b (dx 0) and x+b (dx 1)
+            if (dx < 0 || dx > 1) continue;
+            uint4 av[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) av[t] = wts[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
+#pragma unroll
+            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[ng], acc[pa][pb][ng]);
           }
+        }
+      }
+    }
+    __syncthreads();                                               // every wave is past the image
+    if (ch + 1 < nchunks && !(dbg & 8)) GR_UQ_DMAW(ch + 1)
+  }
+#undef GR_UQ_LOAD
+#undef GR_UQ_DMAW
+#undef GR_UQ_STORE
+  // epilogue: scale back + bias (+ evaluate()-mode BatchNorm) per channel, one activation switch per block, then two output
+  // rows x float2 per lane
+  float omax = 0.f;
+  const bool has_bn = a.ep.mean != nullptr;
+#pragma unroll
+  for (int ng = 0; ng < NG; ++ng) {
+    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    const int y = y0 + prr, x = x0 + pc;
+    const bool pin = y < Hs && x < Ws && b < a.B && !(dbg & 1);
+    float v[64];                                                   // [r][pa][pb]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = min(o0 + (r & 3) + 8 * (r >> 2) + 4 * h, a.Cout - 1);
+      const float bvv = a.bias ? a.bias[o] : 0.f;
+      float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
+      if (has_bn) { mean = a.ep.mean[o]; invstd = a.ep.invstd[o]; gam = a.ep.gamma[o]; bet = a.ep.beta[o]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = ldexpf(acc[q >> 1][q & 1][ng][r], -ktot) + bvv;
+        if (has_bn) t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t, mean), invstd), gam), bet);   // same order as conv_epilogue
+        v[r * 4 + q] = t;
+      }
+    }
+    conv_act_block<64>(a.ep, v);
+    {
+      const bool odd = (pc & 1) != 0;
+      float* orow = a.out + ((size_t)b * a.Cout * a.H + 2 * y + (odd ? 1 : 0)) * a.W + 2 * (x - (odd ? 1 : 0));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float4 res = up2_pair_rows(v + r * 4, odd);
+        if (pin && o < a.Cout) {
+          *reinterpret_cast<float4*>(orow + (size_t)o * a.H * a.W) = res;
+          omax = absmax4(omax, res);
         }
       }
     }
@@ -1857,7 +2064,7 @@ __global__ void conv_weight_up2_split_kernel(const float* __restrict__ w, unsign
 size_t conv_weight_up2_bytes(int cin, int cout) { return (size_t)(round_up(cin, BF_CK) / BF_CK) * 64 * round_up(cout, 32) * 16; }
 bool conv_up2_supported(int Cin, int Cout, int H, int W) {
   const int Hs = H / 2, Ws = W / 2;
-  if (H % 2 || W % 2 || Cout <= 4) return false;
+  if (H % 2 || W % 4 || Cout <= 4) return false;          // W % 4: the epilogue pairs horizontally adjacent source pixels into 16-byte stores
   return (Hs == 8 && Ws == 8) || (Hs == 16 && Ws == 16) || Ws >= 17;
 }
 void launch_conv_weight_up2_split(const float* w_native, void* dst, int cin, int cout, hipStream_t s, unsigned* amax_w, bool take_absmax) {
@@ -1891,17 +2098,37 @@ static void launch_conv_up2_t(const ConvArgs& a, const void* wup, hipStream_t s)
   if (FITS && db) launch_conv_up2_db<TW, NI, FITS>(a, wup, s);
   else launch_conv_up2_db<TW, NI, false>(a, wup, s);
 }
+template <int TW, int NI>
+static void launch_conv_up2q(ConvArgs a, const void* wup, hipStream_t s) {
+  constexpr int PT = 256, TR = PT / TW, IH = PT / (NI * TW), PS = NI * (IH + 2) * (TW + 2), PV = 2 * 2 * PS, PVP = (PV + 63) / 64 * 64;
+  const int Hs = a.H / 2, Ws = a.W / 2;
+  a.tiles_x = (Ws + TW - 1) / TW; a.tiles_y = (Hs + TR - 1) / TR;
+  a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / 32;
+  a.nchunks = g_up2_stagger;
+  const size_t lds = 16 * (size_t)(PVP + 2 * 2 * 8 * 2 * 32);
+  const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2q_f16x3_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = "conv3x3_up2q_f16x3_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";   // as rocprofv3 prints it
+  const double px = (double)a.B * a.H * a.W;
+  KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+  hipLaunchKernelGGL((conv3x3_up2q_f16x3_kernel<TW, NI>), dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wup));
+}
 // in: [B, Cin, H/2, W/2]; out: [B, Cout, H, W] = conv3x3(nearest-upsample x2 (in)); wup from launch_conv_weight_up2_split
 void launch_conv3x3_up2_f16x3(const float* in, const void* wup, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                               hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out) {
   ConvArgs a{};
   if (ep) a.ep = *ep;
-  a.in = in; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = 1;
+  a.in = in; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = 1 | (g_up2_debug << 1);
   a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
-  const int Ws = W / 2;
+  const int Ws = W / 2, Hs = H / 2;
+  const int quad = g_up2_quad;                                       // 0: the eight-wave kernels everywhere (A/B runs: gr_set_tuning "up2_quad", GR_UP2_QUAD)
   if (Ws == 8) launch_conv_up2_t<8, 8>(a, wup, s);
-  else if (Ws == 16) launch_conv_up2_t<16, 2>(a, wup, s);
-  else launch_conv_up2_t<32, 1>(a, wup, s);
+  // four-wave kernel: measured (round 3, same process, interleaved): 32-wide source tiles 1591 us against 1689 (G.convB at cfg3), 16x16
+  // source planes 1499 against 1464 (G.convA at cfg3) and 210 against 203 (G.convB at cfg2) - so only the 32-wide tiles take it
+  // (quad = 2 forces it onto the 16x16 planes too: tools/ablate_up2.py)
+  else if (Ws == 16) { if (quad >= 2 && Hs == 16) launch_conv_up2q<16, 1>(a, wup, s); else launch_conv_up2_t<16, 2>(a, wup, s); }
+  else { if (quad) launch_conv_up2q<32, 1>(a, wup, s); else launch_conv_up2_t<32, 1>(a, wup, s); }
 }
 
 // ---------------------------------------------------------------- max|x| of a tensor (f16x3 scale tracking)
@@ -2056,6 +2283,9 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
 
 // f16x3 convolution on an operand-ready (P16) activation: see conv3x3_p16_wide_kernel
 int g_p16_debug = 0;
+int g_up2_quad = getenv("GR_UP2_QUAD") ? atoi(getenv("GR_UP2_QUAD")) : 1;
+int g_up2_stagger = getenv("GR_UP2_STAGGER") ? atoi(getenv("GR_UP2_STAGGER")) : 0;
+int g_up2_debug = 0;       // diagnostic ablations of conv3x3_up2q_f16x3_kernel (gr_set_tuning "up2_debug")
 void* g_p16_stamps = nullptr;     // diagnostic: device buffer of 32 x 8 bytes per workgroup (gr_debug_stamps)
 int g_p16_min_tiles = 128;      // below half a workgroup per CU the 256-pixel-tile kernels fill the chip better (gr_set_tuning("p16_min_tiles"): tests force the path)
 bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {

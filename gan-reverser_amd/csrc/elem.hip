@@ -114,6 +114,14 @@ __device__ __forceinline__ float act_bwd(float g, float z, float a, int act, flo
     default: return g;
   }
 }
+// dz of one element from gradOutput g and the activation's INPUT z, the forward recomputed: act_bwd(g, z, act_fwd(z)).  ELU is
+// spelled out: for z <= 0 the forward value a = e^z - 1 is <= 0 as well, so the two selects of the composition (z <= 0 in the
+// forward, a <= 0 in the backward) are one - same operations on the same operands, bit-identical result, one compare and one
+// select less per element in kernels that are VALU-bound.
+__device__ __forceinline__ float act_bwd_z(float g, float z, int act, float slope) {
+  if (act == ACT_ELU) return z <= 0.f ? g * (((__expf(z) - 1.f) * 1.f) + 1.f) : g;
+  return act_bwd(g, z, act_fwd(z, act, slope), act, slope);
+}
 __device__ __forceinline__ float mask_mul(const MaskRef& m, long e, long bc) {
   switch (m.kind) {
     case MASK_ELEM: return ((m.bits[e >> 5] >> (e & 31)) & 1u) ? m.scale : 0.f;
@@ -519,17 +527,27 @@ __device__ __forceinline__ void amax_fold(unsigned* slot, int entry, float v) {
   unsigned* e = slot + (entry % AMAX_ENTRIES) * AMAX_STRIDE;
   atomicMax(e, __float_as_uint(v));
 }
-__global__ __launch_bounds__(256) void bn_stats_finalize_tiles_kernel(const double* __restrict__ part, int tiles, double n,
+// One WAVE per channel (four channels per workgroup): every lane adds its share of the channel's per-tile (sum, sum of squares)
+// pairs - all its loads issued before the first add - and the 64 lane sums meet in a fixed shuffle tree.  No LDS, no barrier:
+// the kernel sits on the forward critical path between a convolution and its pipeline kernel six times per step, and the
+// workgroup-per-channel version spent most of its 7.8 us in two barrier-separated block reductions (round 3: VERDICT item 4a).
+__global__ __launch_bounds__(256) void bn_stats_finalize_tiles_kernel(const double* __restrict__ part, int tiles, double n, int C,
                                                                        float* mean, float* invstd, float* run_mean, float* run_var, BnBounds bd) {
-  __shared__ double sh[8];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;                                            // (whole waves leave together)
   const unsigned ymax_bits = bd.amax_y ? absmax_read(bd.amax_y) : 0u;
+  const double2* row = reinterpret_cast<const double2*>(part) + (size_t)c * tiles;
   double s = 0, q = 0;
-#pragma unroll 4
-  for (int t = threadIdx.x; t < tiles; t += 256) { s += part[((size_t)c * tiles + t) * 2]; q += part[((size_t)c * tiles + t) * 2 + 1]; }
-  s = block_reduce_sum(s, sh);
-  q = block_reduce_sum(q, sh);
-  if (threadIdx.x == 0) {
+  for (int t0 = lane; t0 < tiles; t0 += 64 * 8) {
+    double2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int t = t0 + 64 * u; v[u] = t < tiles ? row[t] : make_double2(0.0, 0.0); }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+  if (lane == 0) {
     const double m = s / n;
     double vs = q - s * m;               // sum (x-mean)^2
     if (vs < 0) vs = 0;
@@ -556,7 +574,7 @@ void launch_bn_stats_from_tiles(const double* stat_part, int tiles, int C, doubl
                                 float* run_mean, float* run_var, hipStream_t s, const BnBounds* bounds) {
   KtScope kt("bn_stats_finalize_tiles_kernel", 0.0, 16.0 * tiles * C, s);
   BnBounds bd{}; if (bounds) bd = *bounds;
-  hipLaunchKernelGGL(bn_stats_finalize_tiles_kernel, dim3(C), dim3(256), 0, s, stat_part, tiles, n, mean, invstd, run_mean, run_var, bd);
+  hipLaunchKernelGGL(bn_stats_finalize_tiles_kernel, dim3((C + 3) / 4), dim3(256), 0, s, stat_part, tiles, n, C, mean, invstd, run_mean, run_var, bd);
 }
 void launch_bn_eval_prepare(const float* rm, const float* rv, float* mean, float* invstd, int C, hipStream_t s) {
   hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, s, rm, rv, mean, invstd, C);
@@ -653,10 +671,8 @@ __device__ __forceinline__ float4 post_bwd_dz_of(const PostBwdArgs& a, const Bwd
     z.z = ((yv.z - mean) * invstd) * gm + bt; z.w = ((yv.w - mean) * invstd) * gm + bt;
   }
   float4 dz;
-  dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, post_slope(f)), f.act, post_slope(f));
-  dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, post_slope(f)), f.act, post_slope(f));
-  dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, post_slope(f)), f.act, post_slope(f));
-  dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, post_slope(f)), f.act, post_slope(f));
+  dz.x = act_bwd_z(g.x, z.x, f.act, post_slope(f)); dz.y = act_bwd_z(g.y, z.y, f.act, post_slope(f));
+  dz.z = act_bwd_z(g.z, z.z, f.act, post_slope(f)); dz.w = act_bwd_z(g.w, z.w, f.act, post_slope(f));
   return dz;
 }
 
@@ -685,10 +701,8 @@ __device__ __forceinline__ float4 post_bwd_dz4(const PostBwdArgs& a, unsigned bc
     z.z = ((yv.z - mean) * invstd) * gm + bt; z.w = ((yv.w - mean) * invstd) * gm + bt;
   }
   float4 dz;
-  dz.x = act_bwd(g.x, z.x, act_fwd(z.x, f.act, post_slope(f)), f.act, post_slope(f));
-  dz.y = act_bwd(g.y, z.y, act_fwd(z.y, f.act, post_slope(f)), f.act, post_slope(f));
-  dz.z = act_bwd(g.z, z.z, act_fwd(z.z, f.act, post_slope(f)), f.act, post_slope(f));
-  dz.w = act_bwd(g.w, z.w, act_fwd(z.w, f.act, post_slope(f)), f.act, post_slope(f));
+  dz.x = act_bwd_z(g.x, z.x, f.act, post_slope(f)); dz.y = act_bwd_z(g.y, z.y, f.act, post_slope(f));
+  dz.z = act_bwd_z(g.z, z.z, f.act, post_slope(f)); dz.w = act_bwd_z(g.w, z.w, f.act, post_slope(f));
   return dz;
 }
 
@@ -730,9 +744,11 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
           const float4 yv = r[u].y;
           if (!f.has_bn) *reinterpret_cast<float4*>(a.dy + ee[u]) = dz;     // with BatchNorm pass B recomputes dz: nothing stored here
           dmax = absmax4(dmax, dz);
-          s += (double)dz.x + (double)dz.y + (double)dz.z + (double)dz.w;
-          q += (double)(yv.x - mean) * (double)dz.x + (double)(yv.y - mean) * (double)dz.y +
-               (double)(yv.z - mean) * (double)dz.z + (double)(yv.w - mean) * (double)dz.w;
+          // the four elements of a group are added in fp32 (pairwise), the groups in fp64: 2 conversions + 2 fp64 adds per
+          // group instead of 20 fp64-class instructions (half rate on gfx950, and these kernels are VALU-bound); the partial's
+          // rounding is 2 ulp of a 4-term sum, far inside the 1e-4 bar
+          s += (double)((dz.x + dz.y) + (dz.z + dz.w));
+          q += (double)(((yv.x - mean) * dz.x + (yv.y - mean) * dz.y) + ((yv.z - mean) * dz.z + (yv.w - mean) * dz.w));
         }
       }
     }
@@ -789,7 +805,7 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
       d.z = ((dz.z - gm) - (yv.z - mean) * k) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * k) * invstd * w;
       dyp[i] = d;
       dmax = absmax4(dmax, d);
-      s += (double)d.x + (double)d.y + (double)d.z + (double)d.w;
+      s += (double)((d.x + d.y) + (d.z + d.w));
     }
   }
   if (a.amax_dy) absmax_commit(dmax, a.amax_dy);
@@ -872,7 +888,7 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
             d.x = ((dz.x - gm) - (yv.x - mean) * kk) * invstd * w; d.y = ((dz.y - gm) - (yv.y - mean) * kk) * invstd * w;
             d.z = ((dz.z - gm) - (yv.z - mean) * kk) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * kk) * invstd * w;
             if (a.dy) reinterpret_cast<float4*>(a.dy + (size_t)bcj * HW)[i] = d;     // (null: both gradient kernels take the operand-ready image)
-            csum += (double)d.x + (double)d.y + (double)d.z + (double)d.w;
+            csum += (double)((d.x + d.y) + (d.z + d.w));
             uint2 hi, lo;
             t8_pack(d, sc, hi, lo);
             *reinterpret_cast<uint2*>(img + (size_t)jc * RSB + qi * 8) = hi;

@@ -403,20 +403,22 @@ def test_range_guard_trips_in_the_device_resident_loop(ctx):
         ctx.set_conv_mode(prev)
 
 
-def test_dead_channels_between_two_guard_scans_in_the_device_loop(ctx, oracle):
+def test_dead_channels_between_two_guard_scans_in_the_device_loop(ctx, oracle, conv_mode):
     """the device-resident loop scans the parameters only every 64th gr_train_r_step and never the
     activations.  The case that could slip through between two scans is a TRAINED-LOOKING weight tensor with dead channels: a few
     output channels (and one input channel's column) of R's convolutions at |w| ~ 1e-7 next to channels at ~1 - 23 bits of
-    spread, over the 20-bit budget.  f16x3 then keeps only ~17 bits of the dead channels' weights.  What saves the result is the
-    reference's own BatchNorm: var + 1e-5 in the denominator caps the gain of a channel whose outputs are ~1e-7 at 316, so a dead
-    channel's error enters the next layer below 1e-10.  Asserted here: (1) a step that runs on f16x3 with such weights between two
-    scans (t = 2: no scan due, the context stays on f16x3) still meets every parity bar against the oracle - images, loss, all of
-    R's gradients, Adam's step; (2) the next scan (t = 65) sees the spread and moves the context to bf16x6, counted once."""
+    spread, over the 20-bit budget; f16x3 then keeps only ~17 bits of the dead channels' weights.  What saves the result is the
+    reference's own BatchNorm: var + 1e-5 in the denominator caps the gain of a channel whose outputs are ~1e-7 at 316, so what a
+    dead channel's lost bits change downstream is below 1e-10.  Asserted: (1) a step that runs with such weights BETWEEN two scans
+    (t = 2: no scan due; in f16x3 mode the context must still be on f16x3 afterwards) meets every parity bar against the oracle -
+    images, recovered noise, loss, and every RAW gradient tensor at 1e-4 of its module's largest entry (measured on MI355X: 4-7e-6
+    in f32, bf16x6 and f16x3 alike - tools/debug_dead.py; the dead channels' own gradients are ~35, amplified by that 316, so the
+    comparison is made before the clamp, which would otherwise hide them all at +-1); (2) f16x3 only: the next due scan (t = 65)
+    sees the spread and moves the context to bf16x6, counted once."""
     import ganrev._lib as L
     from ganrev import synth
     from helpers import adopt_device_argmax, assert_grads_close, release_argmax
     dims, nd, B = (1, 32, 32), 32, 8
-    prev = ctx.conv_mode(); ctx.set_conv_mode("f16x3")
     try:
         G, R, oG, oR = _make_pair(oracle, dims, nd, 9)
         convs = [m for m in R.leaves() if m.typename == "nn.SpatialConvolution"]
@@ -427,6 +429,7 @@ def test_dead_channels_between_two_guard_scans_in_the_device_loop(ctx, oracle):
         G.evaluate(); G.forward(synth.normal((2, nd), 1))
         R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
         R._pending_masks = {}
+        ctx.set_tuning("range_guard", 0); ctx.set_tuning("range_guard", 1); ctx.set_conv_mode(conv_mode)   # (the compile forwards above were host calls: guarded)
         gnet, rnet = G._net, R._net
         theta0 = oR.params.copy()
         zeros = np.zeros_like(theta0)
@@ -439,36 +442,31 @@ def test_dead_channels_between_two_guard_scans_in_the_device_loop(ctx, oracle):
         _, falls0 = ctx.range_guard_stats()
         dn = ctx.upload(noise)
         t = 2                                                          # t % 64 != 1: no parameter scan is due in this call
-        loss = L.train_r_step(gnet, rnet, dn, B, B, L.Hyper(), t)
-        assert ctx.conv_mode() == "f16x3" and ctx.range_guard_stats()[1] == falls0, "the step under test did not run on f16x3"
+        free = L.Hyper(l1=0.0, l2=0.0, clamp=0.0)                      # the step leaves the raw gradient readable
+        loss = L.train_r_step(gnet, rnet, dn, B, B, free, t)
+        assert ctx.conv_mode() == conv_mode and ctx.range_guard_stats()[1] == falls0, "the step under test changed arithmetic"
         img = ctx.download(gnet.lib.gr_net_output_dev(gnet.h), (B,) + dims)
         rec = ctx.download(rnet.lib.gr_net_output_dev(rnet.h), (B, nd))
-        g, theta = rnet.get_grads(), rnet.get_params()
+        g = rnet.get_grads()
         # the oracle on the same state (argmax adopted as everywhere else)
         oG.set_training(False); rimg = oG.forward(noise)
         oR.set_training(True); oR.zero_grads()
         preds = np.array(oR.forward(rimg), copy=True)
-        assert_close(img, rimg, TOL, "G images"); assert_close(rec, preds, TOL, "recovered noise with dead channels (f16x3, between scans)")
+        assert_close(img, rimg, TOL, "G images"); assert_close(rec, preds, TOL, "recovered noise with dead channels, between scans")
         flips = adopt_device_argmax(R, oR, B, 8)
-        inject_noise(R, oR, B, 322); R._pending_masks = {}
         oR.zero_grads(); preds = np.array(oR.forward(rimg), copy=True)
         rloss, dfdo = oracle.mse(preds, noise)
         oR.backward(rimg, dfdo, want_gin=False); release_argmax(R, oR)
         assert abs(loss - rloss) <= 1e-5 * max(1.0, abs(rloss))
-        rg, rtheta, rm, rv = oR.grads.copy(), theta0.copy(), zeros.copy(), zeros.copy()
-        oracle.penalty_clamp_adam(rtheta, rg, rm, rv, oracle.GoHyper(), t)
-        assert_grads_close(R, g, rg, 1e-4, 1e-3, f"(dead channels, argmax flips {flips})")
-        well = np.abs(rg) > 1e-4
-        assert_close(theta[well], rtheta[well], TOL, "parameters after Adam")
-        # (2) the next due scan catches it
-        rnet.set_params(theta0)
-        for t2 in (65, 66, 67):
-            L.train_r_step(gnet, rnet, dn, B, B, L.Hyper(), t2); ctx.synchronize()
-        assert ctx.conv_mode() == "bf16x6" and ctx.range_guard_stats()[1] - falls0 == 1, (ctx.conv_mode(), ctx.range_guard_stats())
+        assert_grads_close(R, g, oR.grads, 1e-4, 1e-3, f"(dead channels, {conv_mode}, argmax flips {flips})")
+        if conv_mode == "f16x3":                                       # (2) the next due scan catches it
+            rnet.set_params(theta0)
+            for t2 in (65, 66, 67):
+                L.train_r_step(gnet, rnet, dn, B, B, L.Hyper(), t2); ctx.synchronize()
+            assert ctx.conv_mode() == "bf16x6" and ctx.range_guard_stats()[1] - falls0 == 1, (ctx.conv_mode(), ctx.range_guard_stats())
         ctx.free(dn)
     finally:
         ctx.set_tuning("range_guard", 0); ctx.set_tuning("range_guard", 1)     # clears the tripped state
-        ctx.set_conv_mode(prev)
 
 
 def test_side_stream_weight_gradients_change_nothing(ctx):
