@@ -531,6 +531,18 @@ def run_workload(args, wl_key, modes, ctx, rank, world, shared_gpu, traffic, tra
     results = {m: timed(m) for m in modes}
     ctx.set_conv_mode(args.conv_mode)
     out = None
+    if rank == 0 and "f16x3" in results:
+        # What the chip's clock under MFMA load leaves of the spec ceiling, on THIS device in THIS run: the bare f16x3 inner loop
+        # (LDS reads + three fp16 MFMA products per accumulate, two waves per SIMD, random data; csrc/mfmaloop.hip) right after the
+        # timed steps.  `peak` and `frac` stay priced at the guide's dense peak; the sustained figure is reported beside them.
+        roof = results["f16x3"][3][0]
+        s32, s16 = ctx.bench_mfma_loop(0, 100), ctx.bench_mfma_loop(1, 100)
+        up2 = 9.0 / 4.0 if "up2" in roof["kernel"] else 1.0
+        roof["sustained"] = dict(bare_loop_tflops_32x32x16=round(s32 * up2, 1), bare_loop_tflops_16x16x32=round(s16 * up2, 1),
+                                 frac_of_bare_loop=round(roof["achieved"] / (s32 * up2), 4),
+                                 note="fp32-accurate TFLOP/s of a bare LDS-read + f16x3 MFMA loop (no staging, no epilogue) on this device after a warm-up under load, "
+                                      "same units as `peak`: the chip does not hold 2.4 GHz under MFMA load on random data (MI355X_MICROARCH.md, DVFS give-back); "
+                                      "32x32x16 is the instruction the convolution kernels issue, 16x16x32 the shape the chip clocks higher on")
     if rank == 0:
         fl_img = step_flops_per_image(dims, nd)[0]
         dt, per_step, loss, (roofline, kernels, extra) = results[args.conv_mode]
@@ -540,7 +552,7 @@ def run_workload(args, wl_key, modes, ctx, rank, world, shared_gpu, traffic, tra
         for m, (mdt, mps, mloss, (mroof, _, mextra)) in results.items():
             mode_rows[m] = dict(images_per_sec=round(GB * args.steps / mdt, 1), ms_per_step=round(mdt / args.steps * 1e3, 4), dtype=DTYPE[m],
                                 step_ms_events=percentiles(mps), last_loss=mloss,
-                                roofline={k: mroof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_of_fp32_mfma_peak", "avg_launch_ms")},
+                                roofline={k: mroof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_of_fp32_mfma_peak", "avg_launch_ms", "sustained") if k in mroof},
                                 r_convs=mextra["r_convs"], elementwise=mextra["elementwise"])
         out = dict(images_per_sec=round(GB * args.steps / dt, 1), ms_per_step=round(dt / args.steps * 1e3, 4),
                    workload=wl["name"], global_batch=GB, per_gpu_batch=B,

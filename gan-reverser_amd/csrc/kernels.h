@@ -323,4 +323,9 @@ int launch_kmeans(const float* x, long N, int d, int k, int niter, float* cent, 
 int launch_cosine_assign(const float* x, long N, int d, const float* cent, int k, int take_min, float* w32_scratch,
                          int* labels, float* sims, hipStream_t s);
 
+// mfmaloop.hip: the bare LDS-read + f16x3 MFMA loop (sustained ceiling of the convolution inner loop on this device; diagnostic)
+size_t mfma_loop_workspace_bytes();
+double mfma_loop_flops(int iters);
+void launch_mfma_loop_fill(void* workspace, hipStream_t s);
+void launch_mfma_loop(int shape, void* workspace, int iters, hipStream_t s);
 }  // namespace gr

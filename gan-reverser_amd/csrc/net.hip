@@ -1742,6 +1742,28 @@ extern "C" int gr_conv3_backward_weight_dev(gr_ctx* c, const float* in, const fl
   LAUNCHCHK(c);
   return GR_OK;
 }
+// Sustained rate of the bare f16x3 inner loop (mfmaloop.hip) on this device: `launches` back-to-back launches (>= 0.3 s of them
+// before the timed ones so that the clock settles), HIP events on the ctx stream.  shape 0 = v_mfma_f32_32x32x16_f16 (what the
+// convolution kernels issue), 1 = v_mfma_f32_16x16x32_f16.  tflops_out: fp32-accurate TFLOP/s (f16 MFMA rate / 3 products), the
+// figure comparable with the 833 TFLOP/s ceiling bench.py prices the f16x3 kernels against.
+extern "C" int gr_bench_mfma_loop(gr_ctx* c, int shape, int launches, float* tflops_out) {
+  if (!c || !tflops_out || shape < 0 || shape > 1 || launches < 1) return GR_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = ensure_ws(c, mfma_loop_workspace_bytes()); if (r) return r;
+  launch_mfma_loop_fill(c->ws, c->stream);
+  const int iters = 200;
+  for (int i = 0; i < 300; ++i) launch_mfma_loop(shape, c->ws, iters, c->stream);     // ~0.35 s of warm-up under load
+  LAUNCHCHK(c);
+  hipEvent_t e0, e1; HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int i = 0; i < launches; ++i) launch_mfma_loop(shape, c->ws, iters, c->stream);
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *tflops_out = (float)(mfma_loop_flops(iters) * launches / (ms * 1e-3) / 1e12 / 3.0);
+  return GR_OK;
+}
 extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, int h, int wd, int iters, float* avg_ms) {
   if (!c || iters < 1 || !avg_ms) return GR_ERR_INVALID;
   HIPCHK(c, hipSetDevice(c->device));

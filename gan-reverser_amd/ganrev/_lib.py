@@ -131,6 +131,7 @@ _SIGS = {
     "gr_conv3_forward_dev": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gr_conv3_backward_data_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gr_conv3_backward_weight_dev": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gr_bench_mfma_loop": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "gr_bench_conv3": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
@@ -372,6 +373,12 @@ class Context:
         t = np.zeros(6, dtype=np.float32)
         self.check(self.lib.gr_last_step_times(self.h, _ptr(t)), "gr_last_step_times")
         return dict(zip(("g_fwd", "r_fwd", "loss", "r_bwd", "allreduce", "adam"), t.tolist()))
+
+    def bench_mfma_loop(self, shape=0, launches=100):
+        """fp32-accurate TFLOP/s the bare f16x3 inner loop sustains on this device (0: 32x32x16, 1: 16x16x32 MFMA shape)"""
+        t = C.c_float()
+        self.check(self.lib.gr_bench_mfma_loop(self.h, int(shape), int(launches), C.byref(t)), "gr_bench_mfma_loop")
+        return t.value
 
     def bench_conv3(self, which, batch, cin, cout, h, w, iters):
         ms = C.c_float()

@@ -245,6 +245,11 @@ int gr_conv3_backward_weight_dev(gr_ctx* ctx, const float* in_dev, const float* 
 int gr_bench_conv3(gr_ctx* ctx, int which /*0 fwd,1 bwd-data,2 bwd-weight*/, int batch, int cin, int cout, int h, int w,
                    int iters, float* avg_ms_out);
 
+/* sustained fp32-accurate TFLOP/s of the bare f16x3 inner loop (operands re-read from LDS, three fp16 MFMA products per accumulate, two
+ * waves per SIMD, random data) on this device, after a warm-up under load: what the chip's clock under MFMA load leaves of the 833
+ * TFLOP/s spec ceiling.  shape 0 = v_mfma_f32_32x32x16_f16 (the convolution kernels' instruction), 1 = v_mfma_f32_16x16x32_f16. */
+int gr_bench_mfma_loop(gr_ctx* ctx, int shape, int launches, float* tflops_out);
+
 #ifdef __cplusplus
 }
 #endif

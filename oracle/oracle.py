@@ -429,3 +429,79 @@ def from_model(model, in_dims):
             net.pool_in_dims[index[id(m)]] = d
         d = nd_
     return net
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Noise.  The reference draws createNoiseInputs (utils/nn_utils.lua:39-51: torch.Tensor:normal(0, 1) / :uniform(-1, 1)) and the
+# nn.Dropout / nn.SpatialDropout masks (nn's bernoulli) from Torch7's CPU MT19937 stream, which the device cannot share; the
+# library draws them from a counter-based generator instead (include/ganrev.h: gr_fill_normal_dev, gr_fill_uniform_dev,
+# gr_net_set_seed).  Restated here in numpy integer arithmetic so that the DEVICE's noise is checked value by value, not only
+# statistically: Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as
+# 1, 2, 3", SC'11 - the Random123 library), pinned below by that library's published known-answer vectors
+# (tests/test_oracle_vs_torch.py::test_philox_known_answers), then the same counter / key layout and the same Box-Muller as
+# csrc/elem.hip.
+_PHILOX_M0, _PHILOX_M1, _PHILOX_W0, _PHILOX_W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32 with 10 rounds on arrays of counters (uint32 each); returns the four output words as uint32 arrays."""
+    c = [np.asarray(v, np.uint64) & np.uint64(0xFFFFFFFF) for v in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = np.uint64(int(k0) & 0xFFFFFFFF), np.uint64(int(k1) & 0xFFFFFFFF)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(_PHILOX_M0) * c[0]
+        p1 = np.uint64(_PHILOX_M1) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & mask, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & mask]
+        k0 = (k0 + np.uint64(_PHILOX_W0)) & mask
+        k1 = (k1 + np.uint64(_PHILOX_W1)) & mask
+    return [v.astype(np.uint32) for v in c]
+
+
+def _noise_words(n, seed, tag):
+    """the four Philox words of every group of four outputs: counter (i lo, i hi, tag, 0), key = the 64-bit seed"""
+    i = np.arange((n + 3) // 4, dtype=np.uint64)
+    return philox4x32_10(i & np.uint64(0xFFFFFFFF), i >> np.uint64(32), tag, 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+
+
+def fill_uniform(n, seed, lo=-1.0, hi=1.0):
+    """gr_fill_uniform_dev: lo + (hi - lo) * (top 24 bits of a Philox word) / 2^24 in fp32, element 4 i + k from word k of counter i"""
+    r = _noise_words(n, int(seed), 0x756e6966)
+    u = np.stack(r, axis=1).reshape(-1)[:n]
+    lo, hi = np.float32(lo), np.float32(hi)
+    return lo + (hi - lo) * ((u >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0))
+
+
+def fill_normal(n, seed):
+    """gr_fill_normal_dev: Box-Muller on the words (x, y) and (z, w) of counter i, radius from a uniform in (0, 1], angle from one in
+    [0, 1): elements 4i, 4i+1 = r cos / r sin of the first pair, 4i+2, 4i+3 of the second - fp32 throughout (libm's logf / cosf /
+    sinf here, the device's there: the comparison allows a few ulp)."""
+    x, y, z, w = _noise_words(n, int(seed), 0x6e6f6973)
+    f = np.float32
+    inv = f(1.0 / 16777216.0)
+    u1 = ((x >> np.uint32(8)).astype(f) + f(1)) * inv; u2 = (y >> np.uint32(8)).astype(f) * inv
+    u3 = ((z >> np.uint32(8)).astype(f) + f(1)) * inv; u4 = (w >> np.uint32(8)).astype(f) * inv
+    ra = np.sqrt(f(-2) * np.log(u1)).astype(f); rb = np.sqrt(f(-2) * np.log(u3)).astype(f)
+    tp = f(6.2831853071795864)
+    out = np.stack([ra * np.cos(tp * u2).astype(f), ra * np.sin(tp * u2).astype(f), rb * np.cos(tp * u4).astype(f), rb * np.sin(tp * u4).astype(f)], axis=1)
+    return out.reshape(-1)[:n].astype(f)
+
+
+def dropout_keep(n_elems, p_drop, seed, counter, layer):
+    """Keep flags (0/1 bytes) of one Dropout / SpatialDropout layer as gr_net draws them: keyed by (seed, forward counter - 1 for the
+    first forward after gr_net_set_seed -, layer index of the module, element).  p = 0.5 takes the Philox bits themselves (128 per
+    counter); any other p compares one 32-bit word per element with p * 2^32 (keep when word >= threshold)."""
+    nwords = (n_elems + 31) // 32
+    s0, s1, c0, c1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF
+    if np.float32(p_drop) == np.float32(0.5):
+        i = np.arange((nwords + 3) // 4, dtype=np.uint64)
+        words = np.stack(philox4x32_10(i, layer, c0, c1, s0, s1), axis=1).reshape(-1)[:nwords]
+    else:
+        thresh = np.uint32(min(4294967295.0, float(np.float32(p_drop)) * 4294967296.0))
+        i = np.arange(nwords, dtype=np.uint64)
+        words = np.zeros(nwords, np.uint32)
+        for j in range(8):
+            r = philox4x32_10(i, j | (layer << 8), c0, c1, s0, s1)
+            for k in range(4):
+                words |= (r[k] >= thresh).astype(np.uint32) << np.uint32(j * 4 + k)
+    bits = (words[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & np.uint32(1)
+    return bits.reshape(-1)[:n_elems].astype(np.uint8)

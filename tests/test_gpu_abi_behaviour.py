@@ -88,6 +88,37 @@ def test_fill_normal_statistics(ctx):
     ctx.free(d)
 
 
+def test_device_noise_equals_the_oracle_stream(ctx, oracle):
+    """createNoiseInputs (utils/nn_utils.lua:39-51) and the Dropout noise on the device, value by value against the oracle's
+    restatement of the same counter-based stream (oracle.fill_normal / fill_uniform / dropout_keep: Philox4x32-10 pinned by the
+    Random123 known-answer vectors, test_philox_known_answers).  The reference's own MT19937 stream is not reproduced (by
+    design: DESIGN.md); what is pinned is that the device draws exactly the documented stream - uniform values bit for bit, normal
+    values to a few ulp of the fp32 libm functions in the Box-Muller step, every Dropout / SpatialDropout keep flag."""
+    from ganrev import models, synth
+    for n, seed in ((1 << 16, 9), (1003, 0xDEADBEEF12345), (5, 1)):
+        d = ctx.malloc(4 * n)
+        ctx.fill_uniform(d, n, seed, -1.0, 1.0)
+        assert np.array_equal(ctx.download(d, (n,)), oracle.fill_uniform(n, seed)), f"uniform noise n={n} seed={seed}"
+        ctx.fill_uniform(d, n, seed, 0.0, 16777216.0)                  # the top 24 bits of every Philox word, exactly
+        assert np.array_equal(ctx.download(d, (n,)), oracle.fill_uniform(n, seed, 0.0, 16777216.0))
+        ctx.fill_normal(d, n, seed)
+        got, want = ctx.download(d, (n,)), oracle.fill_normal(n, seed)
+        assert np.max(np.abs(got - want)) <= 4e-6, f"normal noise n={n}: {np.max(np.abs(got - want)):.2e}"
+        ctx.free(d)
+    # the masks of R's Dropout (p = 0.5: 128 Philox bits per counter) and SpatialDropout (p = 0.25: one word per element) layers
+    R = models.create_R((1, 16, 16), 8); synth.init_params(R, 1)
+    R.training(); R.manualSeed(77)
+    B = 6
+    x = synth.uniform((B, 1, 16, 16), 3, 0, 1)
+    for fwd in (1, 2):                                                   # the forward counter starts at 1 after manualSeed
+        R.forward(x)
+        for m in R.leaves():
+            if m.typename in ("nn.Dropout", "nn.SpatialDropout"):
+                keep = R.getNoise(m, B)
+                want = oracle.dropout_keep(keep.size, m.p, 77, fwd, R._leaf_layer(m))
+                assert np.array_equal(keep, want), f"{m.typename}(p={m.p}) forward {fwd}: {int((keep != want).sum())} of {keep.size} keep flags differ"
+
+
 def test_layer_output_and_module_level_calls(ctx, oracle):
     from ganrev import nn, synth
     import ganrev._lib as L

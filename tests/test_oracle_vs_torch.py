@@ -251,3 +251,26 @@ def test_kmeans_and_cosine_assign_vs_float64():
         ref = S.argmin(1) if take_min else S.argmax(1)
         assert np.array_equal(la, ref)
         assert np.abs(si - (S.min(1) if take_min else S.max(1))).max() < 1e-6
+
+
+def test_philox_known_answers(oracle):
+    """The counter-based generator behind gr_fill_normal_dev / gr_fill_uniform_dev / the Dropout masks is Philox4x32-10 (Salmon et al.,
+    SC'11).  The oracle's numpy restatement must reproduce the known-answer vectors published with the Random123 library
+    (kat_vectors: counter words, key words -> output words); the device is then compared with the oracle value by value
+    (tests/test_gpu_abi_behaviour.py::test_device_noise_equals_the_oracle_stream).  Also: distribution sanity of the two fills."""
+    kat = [((0x00000000,) * 4, (0x00000000,) * 2, (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = oracle.philox4x32_10(*[np.array([v]) for v in ctr], *key)
+        assert tuple(int(v[0]) for v in got) == want, (ctr, key)
+    # vectorised call = element-wise calls
+    i = np.arange(1000, dtype=np.uint64)
+    many = oracle.philox4x32_10(i, 7, 0x6e6f6973, 0, 9, 0)
+    one = oracle.philox4x32_10(np.array([123]), 7, 0x6e6f6973, 0, 9, 0)
+    assert all(int(m[123]) == int(o[0]) for m, o in zip(many, one))
+    z = oracle.fill_normal(1 << 18, 9)
+    assert z.dtype == np.float32 and abs(z.mean()) < 1e-2 and abs(z.std() - 1) < 1e-2 and abs(((z ** 3).mean())) < 3e-2 and abs((z ** 4).mean() - 3) < 0.1
+    u = oracle.fill_uniform(1 << 18, 9)
+    assert -1 <= u.min() and u.max() < 1 and abs(u.mean()) < 1e-2 and abs(u.var() - 1 / 3) < 1e-2
+    assert abs(oracle.dropout_keep(1 << 18, 0.5, 5, 1, 3).mean() - 0.5) < 5e-3 and abs(oracle.dropout_keep(1 << 18, 0.25, 5, 1, 3).mean() - 0.75) < 5e-3
