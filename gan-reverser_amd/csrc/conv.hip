@@ -3145,6 +3145,45 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce8_kernel(const float*
   }
 }
 
+// slab [split][tap][ob][cb][wo][wc][q][lane] float4 (the P16 weight-gradient kernels' accumulator order) -> gw[o][ci][tap] += sum
+// over splits, in a fixed order (deterministic).  256 threads = 32 consecutive float4s x 8 split groups; the partial sums meet in LDS.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_tiled_kernel(const float4* __restrict__ slab, float* __restrict__ gw,
+                                                                         int Cin, int Cout, int n_ob, int n_cb, int nsplit) {
+  __shared__ float4 part[8][33];
+  const int l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long n4 = (long)9 * Cout * Cin / 4;
+  const long f = (long)blockIdx.x * 32 + l;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (f < n4) {
+    const float4* p = slab + f;
+    const int per = (nsplit + 7) / 8, k0 = grp * per, k1 = min(nsplit, k0 + per);
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {            // eight loads in flight per lane, added in split order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < k1; ++k) { const float4 v = p[(size_t)k * n4]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  }
+  part[grp][l] = s;
+  __syncthreads();
+  if (grp == 0 && f < n4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { const float4 v = part[g][l]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    const int lane = (int)(f & 63), q = (int)(f >> 6) & 3, wc = (int)(f >> 8) & 1, wo = (int)(f >> 9) & 1;
+    long rest = f >> 10;
+    const int cb = (int)(rest % n_cb); rest /= n_cb;
+    const int ob = (int)(rest % n_ob), tap = (int)(rest / n_ob);
+    const int o = ob * 64 + wo * 32 + 8 * q + 4 * (lane >> 5), ci = cb * 64 + wc * 32 + (lane & 31);
+    float* g0 = gw + ((size_t)o * Cin + ci) * 9 + tap;
+    const size_t so = (size_t)Cin * 9;
+    g0[0] += t.x; g0[so] += t.y; g0[2 * so] += t.z; g0[3 * so] += t.w;
+  }
+}
+
 __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gw,
                                             int Cin, int Cout, int cinp, int coutp, int nsplit) {
   const long n = (long)9 * Cout * cinp;
@@ -3282,13 +3321,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
       }
     }
   }
-  float* slp = a.slab + (size_t)split * 9 * a.coutp * a.cinp;
+  // Slab in the ACCUMULATORS' own order, [split][tap][ob][cb][wo][wc][q = r / 4][lane] float4 = registers 4q .. 4q+3 of a lane (four
+  // output channels of one input channel): 36 16-byte stores per lane, every wave-instruction 1 KB contiguous.  The [tap][o][ci]
+  // order it replaces (round 3) took 144 dword stores per lane - a store-ISSUE-bound tail (MI355X_MICROARCH.md: dword / dwordx2
+  // store tails run at a few bytes per clock per CU) that was most of the kernel's fixed ~23 us.  conv3x3_wgrad_reduce_tiled_kernel
+  // reads the same order back with 16-byte loads and scatters only the final 9 * Cout * Cin values.
+  float4* slp = reinterpret_cast<float4*>(a.slab) + (size_t)split * 9 * a.coutp * a.cinp / 4;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = ob * 64 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, ci = cb * 64 + wc * 32 + l31;
-      slp[((size_t)tap * a.coutp + o) * a.cinp + ci] = ldexpf(acc[tap][r], -ktot);
+    for (int q = 0; q < 4; ++q) {
+      const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + q) * 64 + lane;
+      slp[f] = make_float4(ldexpf(acc[tap][4 * q], -ktot), ldexpf(acc[tap][4 * q + 1], -ktot), ldexpf(acc[tap][4 * q + 2], -ktot), ldexpf(acc[tap][4 * q + 3], -ktot));
     }
 }
 
@@ -3432,13 +3476,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
     __syncthreads();
   }
   if (half == 1) return;
-  float* slp = a.slab + (size_t)split * 9 * a.coutp * a.cinp;
+  // Slab in the ACCUMULATORS' own order, [split][tap][ob][cb][wo][wc][q = r / 4][lane] float4 = registers 4q .. 4q+3 of a lane (four
+  // output channels of one input channel): 36 16-byte stores per lane, every wave-instruction 1 KB contiguous.  The [tap][o][ci]
+  // order it replaces (round 3) took 144 dword stores per lane - a store-ISSUE-bound tail (MI355X_MICROARCH.md: dword / dwordx2
+  // store tails run at a few bytes per clock per CU) that was most of the kernel's fixed ~23 us.  conv3x3_wgrad_reduce_tiled_kernel
+  // reads the same order back with 16-byte loads and scatters only the final 9 * Cout * Cin values.
+  float4* slp = reinterpret_cast<float4*>(a.slab) + (size_t)split * 9 * a.coutp * a.cinp / 4;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = ob * 64 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, ci = cb * 64 + wc * 32 + l31;
-      slp[((size_t)tap * a.coutp + o) * a.cinp + ci] = ldexpf(acc[tap][r], -ktot);
+    for (int q = 0; q < 4; ++q) {
+      const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + q) * 64 + lane;
+      slp[f] = make_float4(ldexpf(acc[tap][4 * q], -ktot), ldexpf(acc[tap][4 * q + 1], -ktot), ldexpf(acc[tap][4 * q + 2], -ktot), ldexpf(acc[tap][4 * q + 3], -ktot));
     }
 }
 // GR_WGRAD_PP: 1 (default) = the ping-pong kernel on 16-wide planes only, 2 = everywhere, 0 = never.  Measured at cfg2 per launch:
@@ -3543,8 +3592,9 @@ void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, 
     if (W == 16) launch_wgrad_p16_t<16>(a, grid, lds, s); else if (W == 32) launch_wgrad_p16_t<32>(a, grid, lds, s); else launch_wgrad_p16_t<64>(a, grid, lds, s);
   }
   const long n_ = (long)9 * Cout * a.cinp;
-  KtScope kt("conv3x3_wgrad_reduce8_kernel", (double)n_ * a.nsplit, 4.0 * n_ * (a.nsplit + 2.0), s);
-  hipLaunchKernelGGL(conv3x3_wgrad_reduce8_kernel, dim3((unsigned)((n_ + 31) / 32)), dim3(256), 0, s, a.slab, gw, Cin, Cout, a.cinp, a.coutp, a.nsplit);
+  KtScope kt("conv3x3_wgrad_reduce_tiled_kernel", (double)n_ * a.nsplit, 4.0 * n_ * (a.nsplit + 2.0), s);
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_tiled_kernel, dim3((unsigned)((n_ / 4 + 31) / 32)), dim3(256), 0, s, reinterpret_cast<const float4*>(a.slab), gw,
+                     Cin, Cout, a.n_ob, a.n_cb, a.nsplit);
 }
 
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,
