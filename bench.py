@@ -75,7 +75,7 @@ def measure_traffic(args, workload):
         return None, "rocprofv3 not on PATH"
     out, base = {}, tempfile.mkdtemp(prefix="ganrev_pmc_")
     child = [sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "2", "--warmup", "1", "--conv-mode", args.conv_mode,
-             "--modes", args.conv_mode, "--traffic", "off", "--no-cpu-baseline", "--no-search", "--quiet-child"]
+             "--modes", args.conv_mode, "--traffic", "off", "--no-cpu-baseline", "--no-search", "--no-gan", "--no-sustained", "--quiet-child"]
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -531,7 +531,7 @@ def run_workload(args, wl_key, modes, ctx, rank, world, shared_gpu, traffic, tra
     results = {m: timed(m) for m in modes}
     ctx.set_conv_mode(args.conv_mode)
     out = None
-    if rank == 0 and "f16x3" in results:
+    if rank == 0 and "f16x3" in results and not args.no_sustained:
         # What the chip's clock under MFMA load leaves of the spec ceiling, on THIS device in THIS run: the bare f16x3 inner loop
         # (LDS reads + three fp16 MFMA products per accumulate, two waves per SIMD, random data; csrc/mfmaloop.hip) right after the
         # timed steps.  `peak` and `frac` stay priced at the guide's dense peak; the sustained figure is reported beside them.
@@ -575,6 +575,7 @@ def main():
                          "cfg3 (configs[2] = the per-GPU shard of configs[3]) rides in the same line as the `cfg3` object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the cfg5 (1M x 100, top-50) search leg")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the bare f16x3 MFMA loop (roofline.sustained): profiling runs, whose kernel statistics it would dominate")
     ap.add_argument("--no-gan", action="store_true", help="skip the GAN-game leg (SURVEY.md 8f rank 4: G + D2, one adversarial batch)")
     ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "f16x3"), choices=list(MODES),
                     help="arithmetic of the headline line (all meet the 1e-4 parity bar; see DESIGN.md)")

@@ -5,7 +5,7 @@ F=${1:-conv3x3}
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmcs_$tag
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_$tag -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-search --no-gan --modes f16x3 --traffic off > $R/gpurun_out/pmcs_$tag.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_$tag -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-search --no-gan --no-sustained --modes f16x3 --traffic off > $R/gpurun_out/pmcs_$tag.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections

@@ -8,7 +8,7 @@
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; WL=${1:-cfg2}; shift
 cd /tmp
 rm -rf $R/gpurun_out/prof_stats $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --traffic off "$@" > $R/gpurun_out/bench_prof.log 2>&1 || exit 1
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --traffic off "$@" > $R/gpurun_out/bench_fetch.log 2>&1 || exit 1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --traffic off "$@" > $R/gpurun_out/bench_write.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_stats -- python3 $R/bench.py --workload $WL --steps 10 --warmup 3 --no-cpu-baseline --no-sustained --traffic off "$@" > $R/gpurun_out/bench_prof.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $R/bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --no-sustained --traffic off "$@" > $R/gpurun_out/bench_fetch.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_write -- python3 $R/bench.py --workload $WL --steps 3 --warmup 2 --no-cpu-baseline --no-sustained --traffic off "$@" > $R/gpurun_out/bench_write.log 2>&1 || exit 1
 tail -1 $R/gpurun_out/bench_prof.log | cut -c1-300
