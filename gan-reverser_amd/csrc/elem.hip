@@ -200,6 +200,19 @@ __device__ __forceinline__ float4 bn_act4(const PostArgs& a, float4 v, float mea
   return v;
 }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+// Streaming loads of the pipeline kernels.  y and gradOutput are read once per pass; when the tensor is far larger than the
+// Infinity Cache (256 MB) nothing of it survives until the next pass anyway, and a non-temporal load keeps it from evicting
+// what does get reused.  Measured in the real step (round 3, same box, interleaved): cfg3 (268 / 537 MB tensors) pass A 1.02-1.04 ->
+// 0.955-0.964 ms, pass B 1.105 -> 0.991 ms; cfg2 (34 / 67 MB tensors, which pass B finds in the cache) pass B 0.168 -> 0.182 ms
+// (slower, and mostly because a non-temporal pass A no longer leaves the tensors in the cache for it).  So: passes A and B above 128 MB
+// only (launchers; GR_POST_NT overrides: bit 0 pass A, 1 pass B, 2 forward).
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_maybe_nt(const float* p, bool nt) {
+  if (nt) { const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+  return *reinterpret_cast<const float4*>(p);
+}
+inline int post_nt_mode() { static const int m = getenv("GR_POST_NT") ? atoi(getenv("GR_POST_NT")) : -1; return m; }   // -1: the size rule; else bit 0 pass A, 1 pass B, 2 forward
+inline bool post_big(const PostArgs& f) { return 4.0 * f.B * f.C * f.H * f.W >= 128.0 * 1024 * 1024; }
 
 template <int CB>
 __global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
@@ -217,10 +230,10 @@ __global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
     if (a.pool) {
       const unsigned yo = udivp(within, wq), xo = (within - yo * wq) * 4;
       const unsigned e0 = bc * HW + (2 * yo) * W + 2 * xo, e1 = e0 + W;
-      const float4 t0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0), mean, invstd, g, bt), mask4(a.m1, e0, bc));
-      const float4 t1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0 + 4), mean, invstd, g, bt), mask4(a.m1, e0 + 4, bc));
-      const float4 b0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1), mean, invstd, g, bt), mask4(a.m1, e1, bc));
-      const float4 b1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1 + 4), mean, invstd, g, bt), mask4(a.m1, e1 + 4, bc));
+      const float4 t0 = mul4(bn_act4(a, ld4_maybe_nt(a.y + e0, a.nt != 0), mean, invstd, g, bt), mask4(a.m1, e0, bc));
+      const float4 t1 = mul4(bn_act4(a, ld4_maybe_nt(a.y + e0 + 4, a.nt != 0), mean, invstd, g, bt), mask4(a.m1, e0 + 4, bc));
+      const float4 b0 = mul4(bn_act4(a, ld4_maybe_nt(a.y + e1, a.nt != 0), mean, invstd, g, bt), mask4(a.m1, e1, bc));
+      const float4 b1 = mul4(bn_act4(a, ld4_maybe_nt(a.y + e1 + 4, a.nt != 0), mean, invstd, g, bt), mask4(a.m1, e1 + 4, bc));
       const float top[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
       const float bot[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       float o[4]; uint32_t idx = 0;
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(256) void post_forward_vec_kernel(PostArgs a) {
       *reinterpret_cast<uint32_t*>(a.pool_idx + eo) = idx;
       r = make_float4(o[0], o[1], o[2], o[3]);
     } else {
-      r = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + eo), mean, invstd, g, bt), mask4(a.m1, eo, bc));
+      r = mul4(bn_act4(a, ld4_maybe_nt(a.y + eo, a.nt != 0), mean, invstd, g, bt), mask4(a.m1, eo, bc));
     }
     const float4 res = mul4(r, mask4(a.m2, eo, bc));
     *reinterpret_cast<float4*>(a.out + eo) = res;
@@ -322,10 +335,10 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
       if constexpr (POOL) {
         const unsigned yo = udivp(within, wq), xo = (within - yo * wq) * 4;
         const unsigned e0 = bc * HW + (2 * yo) * W + 2 * xo, e1 = e0 + W;
-        const float4 t0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0), mean, invstd, gm, bt), mask4(a.m1, e0, bc));
-        const float4 t1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e0 + 4), mean, invstd, gm, bt), mask4(a.m1, e0 + 4, bc));
-        const float4 b0 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1), mean, invstd, gm, bt), mask4(a.m1, e1, bc));
-        const float4 b1 = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + e1 + 4), mean, invstd, gm, bt), mask4(a.m1, e1 + 4, bc));
+        const float4 t0 = mul4(bn_act4(a, ld4_maybe_nt(a.y + e0, a.nt != 0), mean, invstd, gm, bt), mask4(a.m1, e0, bc));
+        const float4 t1 = mul4(bn_act4(a, ld4_maybe_nt(a.y + e0 + 4, a.nt != 0), mean, invstd, gm, bt), mask4(a.m1, e0 + 4, bc));
+        const float4 b0 = mul4(bn_act4(a, ld4_maybe_nt(a.y + e1, a.nt != 0), mean, invstd, gm, bt), mask4(a.m1, e1, bc));
+        const float4 b1 = mul4(bn_act4(a, ld4_maybe_nt(a.y + e1 + 4, a.nt != 0), mean, invstd, gm, bt), mask4(a.m1, e1 + 4, bc));
         const float top[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         const float bot[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float o[4]; uint32_t idx = 0;
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
         *reinterpret_cast<uint32_t*>(a.pool_idx + eo) = idx;
         r = make_float4(o[0], o[1], o[2], o[3]);
       } else {
-        r = mul4(bn_act4(a, *reinterpret_cast<const float4*>(a.y + eo), mean, invstd, gm, bt), mask4(a.m1, eo, bc));
+        r = mul4(bn_act4(a, ld4_maybe_nt(a.y + eo, a.nt != 0), mean, invstd, gm, bt), mask4(a.m1, eo, bc));
       }
       const float4 res = mul4(r, mask4(a.m2, eo, bc));
       if (a.out) *reinterpret_cast<float4*>(a.out + eo) = res;          // (null: every consumer takes the operand-ready image)
@@ -390,7 +403,9 @@ void launch_to_p16(const float* x, void* p16, int B, int C, int HW, const unsign
   hipLaunchKernelGGL(to_p16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, reinterpret_cast<uint4*>(p16), B, C, HW, slot);
 }
 
-void launch_post_forward(const PostArgs& a, hipStream_t s) {
+void launch_post_forward(const PostArgs& a0, hipStream_t s) {
+  PostArgs a = a0;
+  a.nt = post_nt_mode() >= 0 ? (post_nt_mode() >> 2) & 1 : 0;        // forward: measured no gain at either size (0.7356 -> 0.7385 ms at cfg3)
   const long n = (long)a.B * a.C * (a.pool ? (a.H >> 1) * (a.W >> 1) : a.H * a.W);
   if (a.p16) {      // caller checked post_g8_supported
     const long hwo = a.pool ? (long)(a.H >> 1) * (a.W >> 1) : (long)a.H * a.W;
@@ -631,6 +646,7 @@ __global__ __launch_bounds__(256) void post_backward_a_kernel(PostBwdArgs a, int
 // The same in two phases for kernels that work on several channels per thread: all loads of a channel first (so that the loads
 // of eight channels are in flight together), the arithmetic afterwards.  Same operations in the same order as post_bwd_dz4.
 struct BwdRaw { float4 g, y; uint32_t id2, m2w, m1w, t0; };
+
 __device__ __forceinline__ BwdRaw post_bwd_load4(const PostBwdArgs& a, unsigned bc, unsigned e, unsigned i, unsigned obase, unsigned wq, unsigned Wo) {
   const PostArgs& f = a.f;
   BwdRaw r;
@@ -642,12 +658,12 @@ __device__ __forceinline__ BwdRaw post_bwd_load4(const PostBwdArgs& a, unsigned 
     r.m2w = mask_word(f.m2, eo, bc);                  // eo is even: the bits of eo and eo + 1 sit in one word
     r.t0 = (yy & 1) << 1;
   } else {
-    r.g = *reinterpret_cast<const float4*>(a.gout + e);
+    r.g = ld4_maybe_nt(a.gout + e, a.nt != 0);
     r.id2 = 0; r.t0 = 0;
     r.m2w = mask_word(f.m2, e, bc);
   }
   r.m1w = mask_word(f.m1, e, bc);
-  r.y = *reinterpret_cast<const float4*>(f.y + e);
+  r.y = ld4_maybe_nt(f.y + e, a.nt != 0);
   return r;
 }
 __device__ __forceinline__ float4 post_bwd_dz_of(const PostBwdArgs& a, const BwdRaw& r, float mean, float invstd, float gm, float bt) {
@@ -973,7 +989,12 @@ void launch_bias_grad_batch(BiasJobs& jobs, hipStream_t s) {
   jobs.n = 0;
 }
 
-void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) {
+void launch_post_backward(const PostBwdArgs& a0, hipStream_t s, BiasJobs* defer) {
+  PostBwdArgs a = a0, aB = a0;
+  // pass A and the operand-ready pass B: tensors the Infinity Cache cannot hold (at cfg2's 34 / 67 MB a non-temporal pass A takes from
+  // pass B what it would have found in the cache: A 0.169 -> 0.161 ms but B 0.163 -> 0.181); the float4 pass B measured no gain
+  a.nt = post_nt_mode() >= 0 ? post_nt_mode() & 1 : (post_big(a0.f) ? 1 : 0);
+  aB.nt = post_nt_mode() >= 0 ? (post_nt_mode() >> 1) & 1 : ((post_big(a0.f) && a0.dy_p16) ? 1 : 0);
   const PostArgs& f = a.f;
   const long n = (long)f.B * f.H * f.W;
   int splits = stat_splits(n);
@@ -998,10 +1019,10 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
     // 35 for the per-channel kernel): the batch is sliced down to single images instead, up to PB_SPLITS slices
     int slices = f.B < PB_SPLITS ? f.B : PB_SPLITS;
     { const int per = (f.B + slices - 1) / slices; slices = (f.B + per - 1) / per; }
-    if (f.H * f.W <= 256) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug); });
-    else if (g8_half_tiles() == 2) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug); });
-    else if (g8_half_tiles() && (f.H * f.W) % 512 == 0) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<512, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug); });
-    else with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<1024, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, a, splits, slices, (double)n, g_p16_debug); });
+    if (f.H * f.W <= 256) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, splits, slices, (double)n, g_p16_debug); });
+    else if (g8_half_tiles() == 2) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, splits, slices, (double)n, g_p16_debug); });
+    else if (g8_half_tiles() && (f.H * f.W) % 512 == 0) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<512, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, splits, slices, (double)n, g_p16_debug); });
+    else with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<1024, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, splits, slices, (double)n, g_p16_debug); });
     if (a.gbias) {
       BiasJobs one{}; one.n = 0;
       BiasJobs* q = defer ? defer : &one;
@@ -1012,7 +1033,7 @@ void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer) 
     return;
   } else if (vec) {
     KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);                      // reads g and y, writes dy
-    with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL(post_backward_b_vec_kernel<decltype(cb)::value>, dim3(f.C, splits), dim3(256), 0, s, a, splits, (double)n); });
+    with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL(post_backward_b_vec_kernel<decltype(cb)::value>, dim3(f.C, splits), dim3(256), 0, s, aB, splits, (double)n); });
   } else {
     KtScope kt("post_backward_b_kernel", 0.0, 4.0 * 3.0 * pre, s);
     hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits, (double)n);

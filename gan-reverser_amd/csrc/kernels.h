@@ -231,6 +231,7 @@ struct PostArgs {
   // 8-channel-group kernel; p16_scale = the consumer's scale slot, which already holds an UPPER BOUND of max|out| (written by
   // launch_bn_stats_from_tiles from the batch statistics and max|y|) - amax_out must then be null
   void* p16; const unsigned* p16_scale;
+  int nt;                  // non-temporal loads of y (set by the launcher: tensors far larger than the Infinity Cache)
 };
 void launch_post_forward(const PostArgs& a, hipStream_t s);
 
@@ -256,6 +257,7 @@ struct PostBwdArgs {
   // receives max|dz| from pass A; kb holds the forward's factor K (BnBounds); pass B writes the bound K * max|dz| into amax_dy
   // (which then must not be accumulated into) and scales by it.
   void* dy_p16; unsigned* amax_dz; const unsigned* kb;
+  int nt;                  // non-temporal loads of gradOutput and y (set by the launcher, per pass)
 };
 bool post_g8_supported(int C, int H, int W, bool pool, bool backward = false);
 // Bias gradients are summed from partials_b by one batched launch for several stages (launch_bias_grad_batch) when
