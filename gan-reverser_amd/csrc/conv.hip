@@ -41,6 +41,7 @@ struct ConvArgs {
   // nullable: per-channel (sum, sum of squares) of the stored output over this workgroup's pixels, [Cout][stat_tiles][2]
   // (training-mode BatchNorm statistics without a second pass over y; summed in a fixed order by bn_stats_finalize_tiles)
   double* stat_part = nullptr; int stat_tiles = 0;
+  int nt_out = 0;        // non-temporal output stores (kernels.h store4; launchers set it from g_nt_stores)
 };
 
 // out = act(((conv + bias - mean) * invstd) * gamma + beta): the per-channel pipeline of an evaluate()-mode stage
@@ -1071,6 +1072,14 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, uint4* ld
   (void)rsrc; (void)lds_dst; (void)voff; (void)soff;
 #endif
 }
+// the same with the non-temporal cache policy (aux = 2): for streams that one workgroup reads once
+__device__ __forceinline__ void lds_dma16_nt(__amdgpu_buffer_rsrc_t rsrc, uint4* lds_dst, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 2);
+#else
+  (void)rsrc; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
 template <int TW, int NI>
 __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
   constexpr int MT = 2, NTERM = 2;
@@ -1353,7 +1362,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_kernel(
     const int psoff_ = (ch_) * HW * 64;                                                                   \
     _Pragma("unroll") for (int j = 0; j < NPS; ++j) {                                                     \
       const int i_ = wave + NW * j;                                                                       \
-      if (i_ < NPI) lds_dma16(rin, lds + 64 * i_, voff[j], psoff_);                                       \
+      if (i_ < NPI) { if (dbg & 16) lds_dma16_nt(rin, lds + 64 * i_, voff[j], psoff_); else lds_dma16(rin, lds + 64 * i_, voff[j], psoff_); } \
     }                                                                                                     \
     const int wsoff_ = (ch_) * WROWS * a.cout_pad * 16;                                                   \
     _Pragma("unroll") for (int j = 0; j < NWS; ++j) {                                                     \
@@ -1525,7 +1534,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_kernel(
         const int chl = CPI * i + hq, o = o0 + mt * 32 + chl;
         const float4 v = *reinterpret_cast<const float4*>(stg + chl * RS + 4 * kq);
         if (inq && o < a.Cout) {
-          *reinterpret_cast<float4*>(outq + (size_t)o * H * W) = v;
+          store4(outq + (size_t)o * H * W, v, a.nt_out != 0);
           if (want_max) omax = absmax4(omax, v);
         }
       }
@@ -1823,7 +1832,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
         const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float4 res = up2_pair_rows(v + r * 4, odd);            // every lane takes part in the exchange
         if (pin && o < a.Cout) {
-          *reinterpret_cast<float4*>(orow + (size_t)o * a.H * a.W) = res;
+          store4(orow + (size_t)o * a.H * a.W, res, a.nt_out != 0);
           omax = absmax4(omax, res);
         }
       }
@@ -2014,7 +2023,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, 
         const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const float4 res = up2_pair_rows(v + r * 4, odd);
         if (pin && o < a.Cout) {
-          *reinterpret_cast<float4*>(orow + (size_t)o * a.H * a.W) = res;
+          store4(orow + (size_t)o * a.H * a.W, res, a.nt_out != 0);
           omax = absmax4(omax, res);
         }
       }
@@ -2119,7 +2128,7 @@ void launch_conv3x3_up2_f16x3(const float* in, const void* wup, const float* bia
                               hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out) {
   ConvArgs a{};
   if (ep) a.ep = *ep;
-  a.in = in; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = 1 | (g_up2_debug << 1);
+  a.in = in; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = 1 | (g_up2_debug << 1); a.nt_out = (g_nt_stores >> 1) & 1;
   a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
   const int Ws = W / 2, Hs = H / 2;
   const int quad = g_up2_quad;                                       // 0: the eight-wave kernels everywhere (A/B runs: gr_set_tuning "up2_quad", GR_UP2_QUAD)
@@ -2285,6 +2294,7 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
 int g_p16_debug = 0;
 int g_up2_quad = getenv("GR_UP2_QUAD") ? atoi(getenv("GR_UP2_QUAD")) : 1;
 int g_up2_stagger = getenv("GR_UP2_STAGGER") ? atoi(getenv("GR_UP2_STAGGER")) : 0;
+int g_nt_stores = getenv("GR_NT_STORES") ? atoi(getenv("GR_NT_STORES")) : 0;      // kernels.h store4: which kernels store non-temporally (measured: no effect; off)
 int g_up2_debug = 0;       // diagnostic ablations of conv3x3_up2q_f16x3_kernel (gr_set_tuning "up2_debug")
 void* g_p16_stamps = nullptr;     // diagnostic: device buffer of 32 x 8 bytes per workgroup (gr_debug_stamps)
 int g_p16_min_tiles = 128;      // below half a workgroup per CU the 256-pixel-tile kernels fill the chip better (gr_set_tuning("p16_min_tiles"): tests force the path)
@@ -2346,7 +2356,7 @@ void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias
   ConvArgs a{};
   if (ep) a.ep = *ep;
   a.in = nullptr; a.wt = (g_p16_debug & 32) ? reinterpret_cast<const float*>(g_p16_stamps) : nullptr; a.bias = bias; a.out = out;
-  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = g_p16_debug; a.nchunks = g_p16_stagger;
+  a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = g_p16_debug; a.nchunks = g_p16_stagger; a.nt_out = g_nt_stores & 1;
   a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
   a.stat_part = stat_tiles ? stat_part : nullptr;
   // 16x16 planes: two-image tiles when they still give two workgroups per CU, single-image tiles otherwise

@@ -301,13 +301,13 @@ __device__ __forceinline__ void t8_pack(float4 v, float sc, uint2& hi, uint2& lo
 }
 // phase 2: the tile's npx pixels x 2 terms, one vector per lane and step; dst = the image's term-0 plane at the tile's first pixel
 template <int RSB>
-__device__ __forceinline__ void t8_emit(const unsigned char* img, int npx, uint4* dst, size_t term_stride) {
+__device__ __forceinline__ void t8_emit(const unsigned char* img, int npx, uint4* dst, size_t term_stride, bool nt = false) {
   const int lane16 = threadIdx.x & 15, q = lane16 >> 2, pq = lane16 & 3;
   for (int v = threadIdx.x; v < 2 * npx; v += 256) {
     const int t = v / npx, px = v - t * npx, c0 = px & ~15;              // the 16-lane group's block of pixels c0 .. c0 + 15 (t is wave-uniform)
     const unsigned char* row = img + (size_t)(t * 8 + q) * RSB + (c0 + 4 * pq) * 2;
     const uint2 lo4 = t8_tr(row), hi4 = t8_tr(row + 4 * RSB);         // channels 0-3 and 4-7 of pixel px
-    dst[(size_t)t * term_stride + px] = make_uint4(lo4.x, lo4.y, hi4.x, hi4.y);
+    store4(dst + (size_t)t * term_stride + px, make_uint4(lo4.x, lo4.y, hi4.x, hi4.y), nt);
   }
 }
 // PXT = pixels per tile: 1024, or 256 for planes of 256 output pixels (a 34 KB image for 1024 pixels limits a CU to four
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
         r = mul4(bn_act4(a, ld4_maybe_nt(a.y + eo, a.nt != 0), mean, invstd, gm, bt), mask4(a.m1, eo, bc));
       }
       const float4 res = mul4(r, mask4(a.m2, eo, bc));
-      if (a.out) *reinterpret_cast<float4*>(a.out + eo) = res;          // (null: every consumer takes the operand-ready image)
+      if (a.out) store4(a.out + eo, res, a.nt_st != 0);                  // (null: every consumer takes the operand-ready image)
       uint2 hi, lo;
       t8_pack(res, sc, hi, lo);
       const unsigned qi = task - j * qpt;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void post_forward_g8_kernel(PostArgs a) {
       *reinterpret_cast<uint2*>(img + (size_t)(8 + j) * RSB + qi * 8) = lo;
     }
     __syncthreads();
-    t8_emit<RSB>(img, (int)npx, p16 + (size_t)bg * 2 * HWo + (size_t)tile * npx, HWo);
+    t8_emit<RSB>(img, (int)npx, p16 + (size_t)bg * 2 * HWo + (size_t)tile * npx, HWo, a.nt_st != 0);
     __syncthreads();
   }
 }
@@ -405,6 +405,7 @@ void launch_to_p16(const float* x, void* p16, int B, int C, int HW, const unsign
 
 void launch_post_forward(const PostArgs& a0, hipStream_t s) {
   PostArgs a = a0;
+  a.nt_st = (g_nt_stores >> 2) & 1;
   a.nt = post_nt_mode() >= 0 ? (post_nt_mode() >> 2) & 1 : 0;        // forward: measured no gain at either size (0.7356 -> 0.7385 ms at cfg3)
   const long n = (long)a.B * a.C * (a.pool ? (a.H >> 1) * (a.W >> 1) : a.H * a.W);
   if (a.p16) {      // caller checked post_g8_supported
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
             float4 d;
             d.x = ((dz.x - gm) - (yv.x - mean) * kk) * invstd * w; d.y = ((dz.y - gm) - (yv.y - mean) * kk) * invstd * w;
             d.z = ((dz.z - gm) - (yv.z - mean) * kk) * invstd * w; d.w = ((dz.w - gm) - (yv.w - mean) * kk) * invstd * w;
-            if (a.dy) reinterpret_cast<float4*>(a.dy + (size_t)bcj * HW)[i] = d;     // (null: both gradient kernels take the operand-ready image)
+            if (a.dy) store4(a.dy + (size_t)bcj * HW + 4 * (size_t)i, d, f.nt_st != 0);     // (null: both gradient kernels take the operand-ready image)
             csum += (double)((d.x + d.y) + (d.z + d.w));
             uint2 hi, lo;
             t8_pack(d, sc, hi, lo);
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
         }
       }
       __syncthreads();
-      if (!(dbg & 64)) t8_emit<RSB>(img, (int)npx, p16 + ((size_t)b * G + g) * 2 * HW + (size_t)tile * npx, HW);
+      if (!(dbg & 64)) t8_emit<RSB>(img, (int)npx, p16 + ((size_t)b * G + g) * 2 * HW + (size_t)tile * npx, HW, f.nt_st != 0);
       __syncthreads();
     }
   // bias gradient: per-channel sums of dy = the 32 threads of a channel (one half-wave), added in a fixed shuffle tree
@@ -994,6 +995,7 @@ void launch_post_backward(const PostBwdArgs& a0, hipStream_t s, BiasJobs* defer)
   // pass A and the operand-ready pass B: tensors the Infinity Cache cannot hold (at cfg2's 34 / 67 MB a non-temporal pass A takes from
   // pass B what it would have found in the cache: A 0.169 -> 0.161 ms but B 0.163 -> 0.181); the float4 pass B measured no gain
   a.nt = post_nt_mode() >= 0 ? post_nt_mode() & 1 : (post_big(a0.f) ? 1 : 0);
+  aB.f.nt_st = (g_nt_stores >> 3) & 1;
   aB.nt = post_nt_mode() >= 0 ? (post_nt_mode() >> 1) & 1 : ((post_big(a0.f) && a0.dy_p16) ? 1 : 0);
   const PostArgs& f = a.f;
   const long n = (long)f.B * f.H * f.W;

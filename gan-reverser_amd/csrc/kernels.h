@@ -102,6 +102,22 @@ __device__ __forceinline__ void split8_f16(const float* x, float sc, uint4& t0, 
   t0 = make_uint4(a[0] | (unsigned)a[1] << 16, a[2] | (unsigned)a[3] << 16, a[4] | (unsigned)a[5] << 16, a[6] | (unsigned)a[7] << 16);
   t1 = make_uint4(b[0] | (unsigned)b[1] << 16, b[2] | (unsigned)b[3] << 16, b[4] | (unsigned)b[5] << 16, b[6] | (unsigned)b[7] << 16);
 }
+// Streaming stores (an experiment kept as a knob, OFF by default).  A plain store allocates its line in the XCD's L2 and the Infinity
+// Cache; a non-temporal one does not.  Round 3 measured the outputs of the convolutions, the up-sampling convolutions, the forward
+// pipeline and pass B stored non-temporally (g_nt_stores bits 0..3; gr_set_tuning "nt_stores", GR_NT_STORES) in the real step, same
+// box, interleaved: cfg3 12.62-12.86 ms over all masks, cfg2 2.059-2.066 ms - no effect beyond run-to-run noise.  (A first reading
+// of -7 % was an artefact: the diagnostic bit used to switch it on also switched off pass B's operand-ready image.)  Non-temporal
+// LOADS in the backward pipeline passes do pay at cfg3: elem.hip, ld4_maybe_nt.
+typedef float st_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned st_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store4(float* p, const float4& v, bool nt) {
+  if (nt) { const st_f4 t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<st_f4*>(p)); }
+  else *reinterpret_cast<float4*>(p) = v;
+}
+__device__ __forceinline__ void store4(uint4* p, const uint4& v, bool nt) {
+  if (nt) { const st_u4 t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<st_u4*>(p)); }
+  else *p = v;
+}
 __device__ __forceinline__ float absmax4(float m, const float4& v) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
@@ -146,7 +162,7 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
 // Pixels are linear inside a plane: the pipeline kernels assemble the vectors through an LDS transpose (elem.hip, t8_emit), so
 // consecutive lanes hold consecutive pixels and a wave's store is 1 KB contiguous.  (A "quad-major" order - pixel 4q + k at
 // 64k + q, for producers whose threads own 4 pixels x 8 channels - was measured first: those threads were too heavy.)
-extern int g_p16_min_tiles, g_p16_variant, g_p16_stagger, g_up2_debug, g_up2_quad, g_up2_stagger;
+extern int g_p16_min_tiles, g_p16_variant, g_p16_stagger, g_up2_debug, g_up2_quad, g_up2_stagger, g_nt_stores;
 extern void* g_p16_stamps;
 extern int g_p16_debug;       // diagnostic builds only (GR_P16_DEBUG bit mask: 1 no output stores, 2 no statistics, 4 no DMA, 8 no MFMA)
 void launch_to_p16(const float* x, void* p16, int B, int C, int HW, const unsigned* slot, hipStream_t s);   // C % 8 == 0, HW % 4 == 0
@@ -232,6 +248,7 @@ struct PostArgs {
   // launch_bn_stats_from_tiles from the batch statistics and max|y|) - amax_out must then be null
   void* p16; const unsigned* p16_scale;
   int nt;                  // non-temporal loads of y (set by the launcher: tensors far larger than the Infinity Cache)
+  int nt_st;               // non-temporal stores of the outputs (launcher: g_nt_stores)
 };
 void launch_post_forward(const PostArgs& a, hipStream_t s);
 

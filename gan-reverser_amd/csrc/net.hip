@@ -236,6 +236,7 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!strcmp(key, "p16_variant")) { gr::g_p16_variant = value; return GR_OK; }
   if (!strcmp(key, "p16_debug")) { gr::g_p16_debug = value; return GR_OK; }
   if (!strcmp(key, "up2_debug")) { gr::g_up2_debug = value; return GR_OK; }     // diagnostic ablations of the four-wave up-sampling kernel
+  if (!strcmp(key, "nt_stores")) { gr::g_nt_stores = value; return GR_OK; }        // bit mask: which kernels store their outputs non-temporally (kernels.h)
   if (!strcmp(key, "up2_stagger")) { gr::g_up2_stagger = value; return GR_OK; }   // start delay of a CU's second workgroup, x 512 clocks
   if (!strcmp(key, "up2_quad")) { gr::g_up2_quad = value; return GR_OK; }       // 1 (default): four-wave up-sampling kernel where it applies; 0: eight-wave     // diagnostic ablations (outputs are then wrong by design)
   if (!strcmp(key, "side_wgrad")) { c->side_wgrad = value; return GR_OK; }          // weight gradients on the side stream (1) or in line (0, default)
