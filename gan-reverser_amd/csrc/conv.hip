@@ -254,11 +254,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
   static_assert(CK * WS <= 512, "two weight words per thread");
   const int wl_c = tid / WS, wl_e = tid % WS, wl_c2 = (tid + 256) / WS, wl_e2 = (tid + 256) % WS;
   float wreg[2];
-  float acc[CO][4];
+  // accumulators as two float2 per channel: the 9 x CO x 4 multiply-adds of an input channel run as chained PACKED FMAs
+  // (v_pk_fma_f32: two per instruction) - the scalar spelling `acc += w0 v0 + w1 v1 + w2 v2` came out as mul + 2 fma + add, 144
+  // VALU instructions per input channel at CO = 3 where 54 packed ones do (the layer is VALU-bound at CO = 3: round 3)
+  typedef float fo_f2 __attribute__((ext_vector_type(2)));
+  fo_f2 acc2[CO][2];
 #pragma unroll
-  for (int o = 0; o < CO; ++o)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+  for (int o = 0; o < CO; ++o) { acc2[o][0] = fo_f2{0.f, 0.f}; acc2[o][1] = fo_f2{0.f, 0.f}; }
   float4 xv[NV]; float hv[NHL];
 #define GR_FO_LOAD(ch_)                                                                          \
   {                                                                                              \
@@ -317,12 +319,17 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
           // LDS cycles were bank conflicts on the counters.)
           float lf = dpp_take<0x111, 0xF>(m.w), rt = dpp_take<0x101, 0xF>(m.x);      // row_shr:1 / row_shl:1
           if (strip == 0 || strip == 7) { const float hv = pr[strip == 0 ? 3 : 8]; if (strip == 0) lf = hv; else rt = hv; }
-          const float v[6] = {lf, m.x, m.y, m.z, m.w, rt};
+          const fo_f2 p01 = {lf, m.x}, p12 = {m.x, m.y}, p23 = {m.y, m.z}, p34 = {m.z, m.w}, p45 = {m.w, rt};
 #pragma unroll
           for (int o = 0; o < CO; ++o) {
             const float w0 = wr[o * 9 + ky * 3], w1 = wr[o * 9 + ky * 3 + 1], w2 = wr[o * 9 + ky * 3 + 2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[o][j] += w0 * v[j] + w1 * v[j + 1] + w2 * v[j + 2];
+            const fo_f2 s0 = {w0, w0}, s1 = {w1, w1}, s2 = {w2, w2};
+            acc2[o][0] = __builtin_elementwise_fma(s0, p01, acc2[o][0]);      // pixels 0, 1: taps kx = 0, 1, 2
+            acc2[o][0] = __builtin_elementwise_fma(s1, p12, acc2[o][0]);
+            acc2[o][0] = __builtin_elementwise_fma(s2, p23, acc2[o][0]);
+            acc2[o][1] = __builtin_elementwise_fma(s0, p23, acc2[o][1]);      // pixels 2, 3
+            acc2[o][1] = __builtin_elementwise_fma(s1, p34, acc2[o][1]);
+            acc2[o][1] = __builtin_elementwise_fma(s2, p45, acc2[o][1]);
           }
         }
       }
@@ -330,6 +337,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
     __syncthreads();
   }
 #undef GR_FO_LOAD
+  float acc[CO][4];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) { acc[o][0] = acc2[o][0].x; acc[o][1] = acc2[o][0].y; acc[o][2] = acc2[o][1].x; acc[o][3] = acc2[o][1].y; }
   if (KS > 1) {            // groups 1 .. KS-1 hand their partial sums over (the patch is dead: every thread is past the last chunk's barrier)
     static_assert((KS - 1) * CO * 4 * TPG <= CK * PS, "the hand-over reuses the patch");
     float* red = patch;
