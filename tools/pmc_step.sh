@@ -1,11 +1,11 @@
 #!/bin/bash
-# PMC passes over bench.py (run on the GPU box): per-kernel counters of the real training step.  usage: tools/pmc_step.sh [kernel-substring]
+# PMC passes over bench.py (run on the GPU box): per-kernel counters of the real training step.  usage: tools/pmc_step.sh [kernel-substring] [cfg2|cfg3]
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
-F=${1:-conv3x3}
+F=${1:-conv3x3}; WL=${2:-cfg2}
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmcs_$tag
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_$tag -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-search --no-gan --no-sustained --modes f16x3 --traffic off > $R/gpurun_out/pmcs_$tag.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_$tag -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-search --no-gan --no-sustained --workload $WL --modes f16x3 --traffic off > $R/gpurun_out/pmcs_$tag.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
@@ -17,7 +17,7 @@ for f in glob.glob("$R/gpurun_out/pmcs_*/**/*_counter_collection.csv", recursive
         if "$F" not in k: continue
         a = agg[k][r["Counter_Name"]]; a[0]+=1; a[1]+=float(r["Counter_Value"])
         d = dur[k]; d[0]+=1; d[1]+= (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
-print("# rocprofv3 --pmc passes over bench.py (tools/pmc_step.sh): per-dispatch averages inside the real cfg2 step")
+print("# rocprofv3 --pmc passes over bench.py (tools/pmc_step.sh): per-dispatch averages inside the real $WL step")
 print("# clock = GRBM_GUI_ACTIVE / 8 XCDs / time; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x time x clock); waiting = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES")
 for k in sorted(agg):
     g = lambda c: agg[k][c][1] / agg[k][c][0] if c in agg[k] and agg[k][c][0] else float("nan")
