@@ -240,7 +240,9 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!strcmp(key, "up2_stagger")) { gr::g_up2_stagger = value; return GR_OK; }   // start delay of a CU's second workgroup, x 512 clocks
   if (!strcmp(key, "up2_quad")) { gr::g_up2_quad = value; return GR_OK; }       // 1 (default): four-wave up-sampling kernel where it applies; 0: eight-wave     // diagnostic ablations (outputs are then wrong by design)
   if (!strcmp(key, "side_wgrad")) { c->side_wgrad = value; return GR_OK; }          // weight gradients on the side stream (1) or in line (0, default)
-  if (!strcmp(key, "range_guard")) { c->range_guard = value; if (!value) c->guard_tripped = false; return GR_OK; }   // f16x3 range guard on / off (off also clears a tripped trainer guard)
+  // f16x3 range guard on / off.  Off also clears a tripped trainer guard AND drops a verdict still in flight: that verdict is about the
+  // nets scanned by an earlier gr_train_r_step and must not trip the context under whoever trains next on it.
+  if (!strcmp(key, "range_guard")) { c->range_guard = value; if (!value) { c->guard_tripped = false; c->guard_pending = false; } return GR_OK; }
   return fail(c, GR_ERR_INVALID, "gr_set_tuning: unknown key %s", key);
 }
 extern "C" int gr_range_guard_stats(gr_ctx* c, int64_t* scans, int64_t* fallbacks) {

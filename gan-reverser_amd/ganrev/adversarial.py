@@ -47,7 +47,8 @@ def l2(parameters, gradParameters, lossValue, l2weight):
 def make_env(MODEL_G, MODEL_D, IMG_DIMENSIONS, **opt):
     """The globals train.lua:125-200 sets up, with its option defaults (train.lua:27-38)."""
     OPT = types.SimpleNamespace(batchSize=32, N_epoch=30, noiseDim=100, noiseMethod="normal", G_L1=0.0, G_L2=0.0, D_L1=0.0, D_L2=1e-4,
-                                D_iterations=1, G_iterations=1, D_clamp=1.0, G_clamp=5.0, D_optmethod="adam", G_optmethod="adam", seed=1)
+                                D_iterations=1, G_iterations=1, D_clamp=1.0, G_clamp=5.0, D_optmethod="adam", G_optmethod="adam", seed=1,
+                                D_sgd_lr=0.02, G_sgd_lr=0.02, D_sgd_momentum=0.0, G_sgd_momentum=0.0)
     for k, v in opt.items():
         if not hasattr(OPT, k):
             raise L.GanrevError(f"unknown option '{k}'")
@@ -58,7 +59,9 @@ def make_env(MODEL_G, MODEL_D, IMG_DIMENSIONS, **opt):
     env.PARAMETERS_D, env.GRAD_PARAMETERS_D = MODEL_D.getParameters()           # train.lua:176-177
     env.PARAMETERS_G, env.GRAD_PARAMETERS_G = MODEL_G.getParameters()
     env.CONFUSION = np.zeros((2, 2), np.int64)                                  # train.lua:180 optim.ConfusionMatrix: [predicted][target]
-    env.OPTSTATE = {"adam": {"D": {}, "G": {}}}                                 # train.lua:183-193
+    env.OPTSTATE = {k: {"D": {}, "G": {}} for k in ("adagrad", "adadelta", "adamax", "adam", "rmsprop")}      # train.lua:183-193
+    env.OPTSTATE["sgd"] = {"D": {"learningRate": OPT.D_sgd_lr, "momentum": OPT.D_sgd_momentum},
+                           "G": {"learningRate": OPT.G_sgd_lr, "momentum": OPT.G_sgd_momentum}}
     env.noise_counter = 0
     MODEL_D.training(); MODEL_G.training()                                      # train.lua:133-134
     return env
@@ -122,12 +125,14 @@ def make_fevalG_on_D(env, noiseInputs, targets):
 
 
 def _optimize(env, which, feval, params, model):
+    """adversarial.lua:156-171 / 183-198: the optimiser chosen with --D_optmethod / --G_optmethod on the host flat vectors.  adam (the
+    default) updates through the fused device kernel; the other five are host mirrors of the optim rock (ganrev/optim.py)."""
     method = getattr(env.OPT, which + "_optmethod")
-    if method != "adam":         # adversarial.lua:156-171 / 183-198 list sgd|adagrad|adadelta|adamax|adam|rmsprop; adam is the default and the one with a kernel
-        raise L.GanrevError(f"Unknown optimizer method '{method}' chosen for {which}." if method not in
-                            ("sgd", "adagrad", "adadelta", "adamax", "rmsprop") else
-                            f"optimizer method '{method}' for {which}: only 'adam' (the default, train.lua:37-38) is implemented")
-    return optim.adam(feval, params, env.OPTSTATE["adam"][which], model=model)
+    if method == "adam":
+        return optim.adam(feval, params, env.OPTSTATE["adam"][which], model=model)
+    if method not in optim.METHODS:
+        raise L.GanrevError(f"Unknown optimizer method '{method}' chosen for {which}.")        # adversarial.lua:170, 197
+    return optim.METHODS[method](feval, params, env.OPTSTATE[method][which])      # the host vector is authoritative: the next forward uploads it
 
 
 def train(env, trainData, quiet=True):
@@ -291,7 +296,7 @@ class DeviceGame:
         self.env = env
         OPT, G, D = env.OPT, env.MODEL_G, env.MODEL_D
         if OPT.D_optmethod != "adam" or OPT.G_optmethod != "adam":
-            raise L.GanrevError("DeviceGame: only the default optimizer 'adam' (train.lua:37-38)")
+            raise L.GanrevError("DeviceGame: only the default optimizer 'adam' (train.lua:37-38); the other methods run in adversarial.train")
         self.ctx = G._context()
         B = OPT.batchSize
         # Compile every net with one small forward (parameters uploaded) WITHOUT side effects on the models: the

@@ -38,8 +38,12 @@ def parse(argv=None):
     p.add_argument("--G_iterations", type=int, default=1)
     p.add_argument("--D_clamp", type=float, default=1.0)
     p.add_argument("--G_clamp", type=float, default=5.0)
-    p.add_argument("--D_optmethod", default="adam")
+    p.add_argument("--D_optmethod", default="adam", help="sgd|adagrad|adadelta|adamax|adam|rmsprop (anything but adam plays the --compat game)")
     p.add_argument("--G_optmethod", default="adam")
+    p.add_argument("--D_sgd_lr", type=float, default=0.02)
+    p.add_argument("--G_sgd_lr", type=float, default=0.02)
+    p.add_argument("--D_sgd_momentum", type=float, default=0.0)
+    p.add_argument("--G_sgd_momentum", type=float, default=0.0)
     p.add_argument("--noiseDim", type=int, default=100)
     p.add_argument("--noiseMethod", default="normal", choices=["normal", "uniform"])
     p.add_argument("--height", type=int, default=32)
@@ -94,10 +98,11 @@ def main(argv=None):
         MODEL_G = models.create_G(dims, OPT.noiseDim, True, OPT.seed + 1)
     env = adversarial.make_env(MODEL_G, MODEL_D, dims, **{k: getattr(OPT, k) for k in
                                ("batchSize", "N_epoch", "noiseDim", "noiseMethod", "G_L1", "G_L2", "D_L1", "D_L2", "D_iterations", "G_iterations",
-                                "D_clamp", "G_clamp", "D_optmethod", "G_optmethod", "seed")})
+                                "D_clamp", "G_clamp", "D_optmethod", "G_optmethod", "seed", "D_sgd_lr", "G_sgd_lr", "D_sgd_momentum", "G_sgd_momentum")})
     env.EPOCH = epoch0
     data = np.load(OPT.data).astype(np.float32) if OPT.data else None
-    game = None if OPT.compat else adversarial.DeviceGame(env)
+    only_adam = OPT.D_optmethod == "adam" and OPT.G_optmethod == "adam"      # the fused device update is Adam's; the rest are host mirrors
+    game = None if (OPT.compat or not only_adam) else adversarial.DeviceGame(env)
     N_epoch = OPT.N_epoch if OPT.N_epoch > 0 else 100                 # adversarial.lua:42-45: N_epoch <= 0 means 100 batches
     D_it, G_it = max(1, OPT.D_iterations), max(1, OPT.G_iterations)
     # a continued run must not replay the first epochs' noise: the counters start where epoch0 - 1 finished epochs left them

@@ -26,15 +26,37 @@ def ctx():
     return L.default_context()
 
 
+def _reset_guard(c):
+    """The trainer's range guard is context state (a tripped guard keeps the context on bf16x6; a scan's verdict is read by the next
+    gr_train_r_step): no test may inherit it from the one before."""
+    c.set_tuning("range_guard", 0); c.set_tuning("range_guard", 1)
+
+
+@pytest.fixture(autouse=True)
+def _default_arithmetic_between_gpu_tests(request):
+    """Every GPU test starts from the library's defaults on the shared context: f16x3 arithmetic, guard untripped, nothing pending."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import ganrev._lib as L
+    c = L.default_context()
+    _reset_guard(c)
+    first = _DP.setdefault("default_mode", c.conv_mode())         # f16x3 unless GR_CONV_MODE says otherwise
+    assert c.conv_mode() == first, f"a previous test left the context on {c.conv_mode()}"
+    yield
+
+
 @pytest.fixture(params=["f32", "bf16x6", "f16x3"])
 def conv_mode(request):
     """Run the test once per convolution arithmetic: exact fp32 MFMA, the fp32-accurate 3-term bf16 split (bf16x6) and the
     fp32-accurate 2-term fp16 split of scaled operands (f16x3) that bench.py uses by default.  Same tolerances for all three."""
     import ganrev._lib as L
     c = L.default_context()
+    _reset_guard(c)
     prev = c.conv_mode()
     c.set_conv_mode(request.param)
     yield request.param
+    _reset_guard(c)
     c.set_conv_mode(prev)
 
 
@@ -44,6 +66,7 @@ def f16_path(request):
     8-channel-group pipeline kernels) path forced onto shapes with fewer tiles than the chip has CUs."""
     import ganrev._lib as L
     c = L.default_context()
+    _reset_guard(c)
     prev = c.conv_mode()
     c.set_conv_mode("f16x3")
     c.set_tuning("p16_min_tiles", 1 if request.param.endswith("p16") else 128)

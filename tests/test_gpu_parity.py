@@ -1513,6 +1513,33 @@ def test_adversarial_step_vs_oracle(oracle, conv_mode):
         adversarial.train(env, synth.uniform((B // 2,) + dims, 41, 0, 1))     # trainData shorter than the epoch needs
 
 
+@pytest.mark.parametrize("method", ["sgd", "adagrad", "adadelta", "adamax", "rmsprop"])
+def test_adversarial_game_with_the_other_optimisers(method):
+    """adversarial.lua:156-171 / 183-198 with --D_optmethod / --G_optmethod other than adam: the closures run on the GPU, the update is the
+    host mirror of the optim rock on PARAMETERS_D / PARAMETERS_G.  One batch: the step each network took equals the method's rule
+    applied to the gradient its closure left in GRAD_PARAMETERS_* (first step from an empty state), and the next forward sees it."""
+    from ganrev import adversarial, models, synth
+    dims, nd, B = (1, 16, 16), 8, 8
+    G, D = models.create_G(dims, nd, True, 3), models.create_D2(dims, True, 4)
+    env = adversarial.make_env(G, D, dims, batchSize=B, noiseDim=nd, N_epoch=1, D_optmethod=method, G_optmethod=method, D_sgd_momentum=0.5)
+    pd, pg = env.PARAMETERS_D.copy(), env.PARAMETERS_G.copy()
+    adversarial.train(env, synth.uniform((B // 2,) + dims, 40, 0, 1))
+    first = {"sgd": lambda g: 0.02 * g, "adagrad": lambda g: 1e-3 * g / (np.abs(g) + 1e-10),
+             "adadelta": lambda g: np.sqrt(1e-6) / np.sqrt(0.1 * g * g + 1e-6) * g, "adamax": lambda g: 2e-3 * g / (np.abs(g) + 1e-38),
+             "rmsprop": lambda g: 1e-2 * g / (np.sqrt(0.01 * g * g) + 1e-8)}[method]
+    for name, before, after, grad in (("D", pd, env.PARAMETERS_D, env.GRAD_PARAMETERS_D), ("G", pg, env.PARAMETERS_G, env.GRAD_PARAMETERS_G)):
+        g = grad.astype(np.float64)
+        nz = g != 0
+        assert nz.any() and np.all(np.isfinite(after))
+        assert np.allclose((before.astype(np.float64) - after)[nz], first(g[nz]), rtol=1e-3, atol=2e-7), (method, name)
+        assert np.array_equal(before[~nz], after[~nz])
+    assert env.OPTSTATE["adam"]["D"] == {} and len(env.OPTSTATE[method]["D"]) > 0
+    D.evaluate(); x = synth.uniform((2,) + dims, 41, 0, 1)
+    y1 = D.forward(x).copy()
+    env.PARAMETERS_D[:] = pd
+    assert not np.array_equal(D.forward(x), y1)                        # the device ran with the stepped parameters
+
+
 from golden_cases import DCASES as _DCASES, build_dcase as _build_dcase  # noqa: E402
 
 _GOLD_D = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "golden_v2_dnet.npz"))
@@ -1632,4 +1659,5 @@ def test_train_loop_saves_a_loadable_checkpoint(tmp_path, compat):
     g_bn = [m for m in ck["G"].leaves() if hasattr(m, "running_mean")][0]
     assert float(np.abs(g_bn.running_mean).max()) > 0                                      # G trained in training mode: its statistics moved and were saved
     res2 = train.main(argv[:1] + ["1"] + argv[2:] + ["--network", res["path"]] + (["--compat"] if compat else []))
-    assert res2["epoch"] == 2 and np.all(np.isfinite(res2["last_losses"]))                 # epoch counter continues from the file (2 -> plays epoch 2 again as train.lua:202 does)
+    assert res2["epoch"] == 3 and np.all(np.isfinite(res2["last_losses"]))                 # the epoch counter continues behind the file's: EPOCH = tmp.epoch + 1 (train.lua:113)
+    assert t7.load_checkpoint(res2["path"])["epoch"] == 3

@@ -329,7 +329,7 @@ def test_oracle_bce_matches_float64_formula():
 
 def test_adversarial_host_pieces():
     """ganrev.adversarial without a GPU: the penalty / clamp helpers (adversarial.lua:8-28), the option table of train.lua:27-38,
-    the optimiser dispatch's error for a method the reference lists but this build has no kernel for, and the unknown-method
+    the optimiser state tables of train.lua:183-193, and the unknown-method
     error text of adversarial.lua:170."""
     from ganrev import adversarial
     theta = np.array([1.0, -2.0, 0.0, 0.5], np.float32)
@@ -349,12 +349,65 @@ def test_adversarial_host_pieces():
     assert all(m.train for m in D.listModules()) and all(m.train for m in G.listModules())                                      # train.lua:133-134
     with pytest.raises(L.GanrevError):
         adversarial.make_env(G, D, (1, 16, 16), batchsize=8)
-    env.OPT.D_optmethod = "sgd"
-    with pytest.raises(L.GanrevError, match="only 'adam'"):
-        adversarial._optimize(env, "D", lambda x: (0.0, x), env.PARAMETERS_D, D)
+    assert env.OPTSTATE["sgd"]["D"] == {"learningRate": 0.02, "momentum": 0.0} and env.OPTSTATE["rmsprop"]["G"] == {}         # train.lua:183-193
     env.OPT.D_optmethod = "lbfgs"
     with pytest.raises(L.GanrevError, match="Unknown optimizer method 'lbfgs' chosen for D."):
         adversarial._optimize(env, "D", lambda x: (0.0, x), env.PARAMETERS_D, D)
     from ganrev import train
     imgs = train.synthetic_images(6, (3, 16, 16), 5)
     assert imgs.shape == (6, 3, 16, 16) and imgs.dtype == np.float32 and 0 <= imgs.min() and imgs.max() <= 1 and not np.array_equal(imgs[0], imgs[1])
+
+
+def test_host_optimisers_follow_their_update_rules():
+    """ganrev.optim's five host methods (adversarial.lua:156-171 picks among them) on a quadratic f = |x - c|^2 / 2: each step is
+    checked against the update rule spelled out in float64, state carried across calls, and all of them reduce f."""
+    from ganrev import optim
+    rng = np.random.default_rng(3)
+    c = rng.standard_normal(64).astype(np.float32)
+
+    def feval(x):
+        return float(0.5 * np.sum((x - c) ** 2)), (x - c).astype(np.float32)
+
+    def run(name, cfg, ref_step, steps=5):
+        x = np.zeros(64, np.float32); xr = np.zeros(64, np.float64); st = {}; cfg = dict(cfg)
+        f0 = feval(x)[0]
+        for t in range(1, steps + 1):
+            g = xr - c
+            xr = ref_step(xr, g, st, t)
+            xo, fs = optim.METHODS[name](feval, x, cfg)
+            assert xo is x and len(fs) == 1                                # in place, {f(x)} returned like optim.*
+            assert np.allclose(x, xr, rtol=2e-5, atol=2e-6), (name, t, np.abs(x - xr).max())
+        assert feval(x)[0] < f0
+        return cfg
+
+    def sgd_ref(x, g, st, t):
+        st["b"] = g.copy() if "b" not in st else 0.9 * st["b"] + (1 - 0.9) * g           # dampening defaults to the momentum
+        return x - 0.02 / (1 + (t - 1) * 0.1) * st["b"]
+    cfg = run("sgd", {"learningRate": 0.02, "momentum": 0.9, "learningRateDecay": 0.1}, sgd_ref)
+    assert cfg["evalCounter"] == 5 and cfg["dfdx"].shape == (64,)                         # the state lives in the config table (train.lua:189-191)
+    run("sgd", {"learningRate": 0.02, "momentum": 0.0}, lambda x, g, st, t: x - 0.02 * g)
+
+    def adagrad_ref(x, g, st, t):
+        st["v"] = st.get("v", 0) + g * g
+        return x - 1e-3 * g / (np.sqrt(st["v"]) + 1e-10)
+    run("adagrad", {}, adagrad_ref)
+
+    def adadelta_ref(x, g, st, t):
+        st["v"] = 0.9 * st.get("v", 0) + 0.1 * g * g
+        d = np.sqrt(st.get("a", 0) + 1e-6) / np.sqrt(st["v"] + 1e-6) * g
+        st["a"] = 0.9 * st.get("a", 0) + 0.1 * d * d
+        return x - d
+    run("adadelta", {}, adadelta_ref)
+
+    def adamax_ref(x, g, st, t):
+        st["m"] = 0.9 * st.get("m", 0) + 0.1 * g
+        st["u"] = np.maximum(0.999 * st.get("u", 0), np.abs(g) + 1e-38)
+        return x - 2e-3 / (1 - 0.9 ** t) * st["m"] / st["u"]
+    run("adamax", {}, adamax_ref)
+
+    def rmsprop_ref(x, g, st, t):
+        st["m"] = 0.99 * st.get("m", 0) + 0.01 * g * g
+        return x - 1e-2 * g / (np.sqrt(st["m"]) + 1e-8)
+    run("rmsprop", {}, rmsprop_ref)
+    with pytest.raises(ValueError):
+        optim.sgd(feval, np.zeros(64, np.float32), {"nesterov": True})
