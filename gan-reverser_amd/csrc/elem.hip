@@ -1063,9 +1063,10 @@ __global__ __launch_bounds__(256) void channel_absmax_kernel(const float* __rest
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(chmax + c, __float_as_uint(m));
 }
 // one block: fold every thread's (max, smallest non-zero) pair, then thread 0 enters the spread (in bits: exponent of the
-// maximum minus exponent of the smallest non-zero channel maximum, + 1 for the mantissas) into the two largest seen so far -
-// *top2 = first | second << 16.  Kernels of one stream run one after the other, so the read-modify-write needs no atomics.
-__device__ __forceinline__ void spread_enter(float mx, float mn, unsigned* top2) {
+// maximum minus exponent of the smallest non-zero channel maximum, + 1 for the mantissas) into the largest seen so far OF ITS
+// SIDE - *word = activation side (side 0: net input, gradOutput, BatchNorm pairs) | weight side (side 1) << 16.  Kernels of one
+// stream run one after the other, so the read-modify-write needs no atomics.
+__device__ __forceinline__ void spread_enter(float mx, float mn, unsigned* word, int side) {
   __shared__ float tmx[256], tmn[256];
   tmx[threadIdx.x] = mx; tmn[threadIdx.x] = mn;
   __syncthreads();
@@ -1073,28 +1074,28 @@ __device__ __forceinline__ void spread_enter(float mx, float mn, unsigned* top2)
     for (int i = 1; i < 256; ++i) { mx = fmaxf(mx, tmx[i]); mn = fminf(mn, tmn[i]); }
     if (mx > 0.f && mn < mx) {
       const unsigned bits = (unsigned)min(ilogbf(mx) - ilogbf(mn) + 1, 0xffff);
-      const unsigned w = *top2;
+      const unsigned w = *word;
       unsigned a = w & 0xffffu, b = w >> 16;
-      if (bits > a) { b = a; a = bits; } else if (bits > b) b = bits;
-      *top2 = a | b << 16;
+      if (side == 0) a = max(a, bits); else b = max(b, bits);
+      *word = a | b << 16;
     }
   }
 }
-__global__ __launch_bounds__(256) void spread_verdict_kernel(unsigned* chmax, int C, unsigned* top2) {
+__global__ __launch_bounds__(256) void spread_verdict_kernel(unsigned* chmax, int C, unsigned* word, int side) {
   float mx = 0.f, mn = INFINITY;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float v = __uint_as_float(chmax[c]); chmax[c] = 0u;
     mx = fmaxf(mx, v); if (v > 0.f) mn = fminf(mn, v);
   }
-  spread_enter(mx, mn, top2);
+  spread_enter(mx, mn, word, side);
 }
-__global__ __launch_bounds__(256) void pair_spread_kernel(const float* __restrict__ a, const float* __restrict__ b, int C, unsigned* top2) {
+__global__ __launch_bounds__(256) void pair_spread_kernel(const float* __restrict__ a, const float* __restrict__ b, int C, unsigned* word) {
   float mx = 0.f, mn = INFINITY;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float v = fmaxf(fabsf(a[c]), b ? fabsf(b[c]) : 0.f);
     mx = fmaxf(mx, v); if (v > 0.f) mn = fminf(mn, v);
   }
-  spread_enter(mx, mn, top2);
+  spread_enter(mx, mn, word, 0);
 }
 void launch_channel_absmax(const float* t, int B, int C, long HW, long sB, long sC, unsigned* chmax, hipStream_t s) {
   const long n = (long)B * HW;
@@ -1104,8 +1105,8 @@ void launch_channel_absmax(const float* t, int B, int C, long HW, long sB, long 
   KtScope kt("range_guard_scan", 0.0, 4.0 * (double)n * C, s);
   hipLaunchKernelGGL(channel_absmax_kernel, dim3(C, splits), dim3(256), 0, s, t, B, HW, sB, sC, chmax);
 }
-void launch_spread_verdict(unsigned* chmax, int C, unsigned* top2, hipStream_t s) {
-  hipLaunchKernelGGL(spread_verdict_kernel, dim3(1), dim3(256), 0, s, chmax, C, top2);
+void launch_spread_verdict(unsigned* chmax, int C, unsigned* word, int side, hipStream_t s) {
+  hipLaunchKernelGGL(spread_verdict_kernel, dim3(1), dim3(256), 0, s, chmax, C, word, side);
 }
 void launch_pair_spread(const float* a, const float* b, int C, unsigned* top2, hipStream_t s) {
   hipLaunchKernelGGL(pair_spread_kernel, dim3(1), dim3(256), 0, s, a, b, C, top2);

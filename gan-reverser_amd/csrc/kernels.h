@@ -311,16 +311,18 @@ void launch_fill_normal(float* dst, long n, uint64_t seed, hipStream_t s);
 void launch_fill_uniform(float* dst, long n, float lo, float hi, uint64_t seed, hipStream_t s);
 
 // ---- f16x3 range guard.  The f16x3 arithmetic scales a whole tensor by one power of two: an entry 2^k below the tensor's
-// maximum keeps about 40 - k bits (fp16's exponent range ends there), so the relative error of an output channel grows with the
-// PRODUCT of the per-channel spreads of the two tensors multiplied.  These kernels measure spreads: per-channel max|.| of a
-// strided view t[b * sB + c * sC + i] (b < B, i < HW) into chmax[c] (atomicMax of bit patterns; chmax must be zero), then one
-// verdict block enters log2(max_c / smallest non-zero chmax) (+1) into the two largest spreads seen so far, *top2 = first |
-// second << 16, and zeroes chmax again.  launch_pair_spread does the same for the per-channel vector max(|a_c|, |b_c|)
-// (BatchNorm gamma / beta: they set the channel ranges of every tensor behind a BatchNorm).  The caller compares first + second
-// with its budget (net.hip: 20 bits).
+// maximum keeps about 40 - k bits (fp16's exponent range ends there).  Where a kernel's reduction runs over a channel index (the
+// forward and the data gradient: activation x weight), the worst-case relative error of an output channel grows with the PRODUCT
+// of the two tensors' per-channel spreads; where it runs over pixels (the weight gradient: activation x gradient, one channel
+// pair per sum) with the larger one.  These kernels measure spreads: per-channel max|.| of a strided view t[b * sB + c * sC + i]
+// (b < B, i < HW) into chmax[c] (atomicMax of bit patterns; chmax must be zero), then one verdict block enters
+// log2(max_c / smallest non-zero chmax) (+1) into the largest spread seen so far on its SIDE - *word = activation side (0) |
+// weight side (1) << 16 - and zeroes chmax again.  launch_pair_spread does the same, activation side, for the per-channel vector
+// max(|a_c|, |b_c|) (BatchNorm gamma / beta: they set the channel ranges of every tensor behind a BatchNorm).  The caller compares
+// the sum of the two sides with its budget (net.hip: 20 bits).
 void launch_channel_absmax(const float* t, int B, int C, long HW, long sB, long sC, unsigned* chmax, hipStream_t s);
-void launch_spread_verdict(unsigned* chmax, int C, unsigned* top2, hipStream_t s);
-void launch_pair_spread(const float* a, const float* b, int C, unsigned* top2, hipStream_t s);
+void launch_spread_verdict(unsigned* chmax, int C, unsigned* word, int side, hipStream_t s);
+void launch_pair_spread(const float* a, const float* b, int C, unsigned* word, hipStream_t s);
 void launch_l2_distance_rows(const float* a, const float* b, long n, long d, double* out, hipStream_t s);
 void launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s);
 void launch_upsample2(const float* x, float* up, int B, int C, int Ho, int Wo, hipStream_t s);       // nearest x2, [B,C,Ho/2,Wo/2] -> [B,C,Ho,Wo]

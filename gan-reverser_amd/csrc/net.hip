@@ -388,7 +388,7 @@ struct gr_net {
   bool dy_slots_zeroed = false, w_slots_zeroed = false;   // set by forward_impl's single fill, consumed by backward / weight prep
   bool keep_fp32 = false;            // range-guarded host calls: no lean (operand-ready only) tensors, so a backward can still fall back to bf16x6
   bool last_fwd_fell_back = false;   // the last guarded forward ran on bf16x6: its backward does too
-  unsigned guard_top2 = 0;           // the two largest spreads (bits) the last guarded forward measured
+  unsigned guard_top2 = 0;           // the largest spreads (bits: activation side | weight side << 16) the last guarded forward measured
 };
 
 enum { AG_X = 0, AG_Y = 1, AG_KB = 2, AG_DY = 3, AG_DZ = 4, AG_W = 5, AMAX_GROUPS = 6 };
@@ -783,26 +783,31 @@ static PostArgs post_args(gr_net* n, Stage& s, int B) {
 
 // ------------------------------------------------------------------ f16x3 range guard
 // f16x3 scales each tensor by ONE power of two: an entry 2^k below the tensor's maximum keeps about 40 - k bits (fp16's exponent
-// range ends 2^-40 below the scaled maximum), and the relative error of an output channel grows with the product of the
-// per-channel spreads of the two tensors a kernel multiplies (x and the weights' output-channel view in the forward, dy and
-// their input-channel view in the data gradient, x and dy in the weight gradient).  bf16x6 has fp32's exponent range and no
-// such limit.  The guard measures, before a pass computes anything, the per-channel spread (log2 of largest / smallest
-// non-zero channel maximum) of what enters it: the net input (forward) or gradOutput (backward), every weight tensor an
-// f16x3 kernel will read (per input channel and per output channel), and the BatchNorm (gamma, beta) pairs that set the
-// channel ranges of every tensor behind a BatchNorm.  When the two largest spreads add up to more than GUARD_BUDGET_BITS the
-// whole pass runs on bf16x6 (counted: gr_kernel_times "range_guard_fallback", gr_range_guard_stats).  Budget: 40 bits of
-// range - 20 bits of spread leaves 20 bits per entry of the smallest channel, ~1e-6 of that channel's maximum.
+// range ends 2^-40 below the scaled maximum).  bf16x6 has fp32's exponent range and no such limit.  What a lost bit costs depends
+// on what the kernel sums over.  The forward (x, weights) and the data gradient (dy, weights) sum over a CHANNEL index: an output
+// channel whose weights sit on the small channels of x can be as small as the product of both spreads while the rounding of the
+// large channels' (tiny) weights is not - worst case, the relative error grows with the PRODUCT of the activation-side and the
+// weight-side spread.  The weight gradient (x, dy) sums over pixels, one channel pair per sum: each term carries the relative
+// error of its own two channels, the LARGER spread counts.  The guard measures, before a pass computes anything, the per-channel
+// spread (log2 of largest / smallest non-zero channel maximum) of what enters it, kept per side: ACTIVATION side - the net input
+// (forward) or gradOutput (backward) and the BatchNorm (gamma, beta) pairs that set the channel ranges of every tensor behind a
+// BatchNorm; WEIGHT side - every weight tensor an f16x3 kernel will read, per input channel and per output channel.  When the
+// largest activation-side spread plus the largest weight-side spread exceed GUARD_BUDGET_BITS the whole pass runs on bf16x6
+// (counted: gr_kernel_times "range_guard_fallback", gr_range_guard_stats).  Budget: 40 bits of range - 20 bits of spread leave
+// 20 bits per entry of the smallest channel, ~1e-6 of that channel's maximum.
+// (Until round 3 the two largest spreads of EITHER side were added.  Two BatchNorm layers never multiply each other, and Torch's
+// default gamma ~ U(0, 1) spreads 8-14 bits over 64-512 channels: two of five default-initialised R nets tripped that rule at
+// their first step and trained on bf16x6 for nothing - tools/debug_guard_trip.py.)
 enum { GUARD_BUDGET_BITS = 20 };
-static bool guard_over_budget(unsigned top2) { return (top2 & 0xffffu) + (top2 >> 16) > (unsigned)GUARD_BUDGET_BITS; }
-static unsigned guard_merge(unsigned t, unsigned u) {        // the two largest of both words' entries
-  unsigned v[4] = {t & 0xffffu, t >> 16, u & 0xffffu, u >> 16};
-  for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) if (v[j] > v[i]) { unsigned x = v[i]; v[i] = v[j]; v[j] = x; }
-  return v[0] | v[1] << 16;
+static bool guard_over_budget(unsigned word) { return (word & 0xffffu) + (word >> 16) > (unsigned)GUARD_BUDGET_BITS; }
+static unsigned guard_merge(unsigned t, unsigned u) {        // per side, the larger of both words' entries
+  const unsigned a = (t & 0xffffu) > (u & 0xffffu) ? (t & 0xffffu) : (u & 0xffffu), b = (t >> 16) > (u >> 16) ? (t >> 16) : (u >> 16);
+  return a | b << 16;
 }
 static unsigned* guard_alarm_dev(gr_ctx* c) { return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->d_loss) + 16); }
 static volatile unsigned* guard_alarm_host(gr_ctx* c) { return reinterpret_cast<volatile unsigned*>(reinterpret_cast<char*>(c->h_loss) + 16); }
 static bool f16_consumer(gr_net* n, const Stage& s) { return use_bf16x6(n, s) || use_f16_gemm(n, s); }     // (context in f16x3 mode)
-static int guard_scan(gr_ctx* c, const float* t, int B, int C, long HW, long sB, long sC) {
+static int guard_scan(gr_ctx* c, const float* t, int B, int C, long HW, long sB, long sC, int side) {
   if (C < 2) return GR_OK;
   if ((size_t)C > c->guard_chmax_cap) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -813,7 +818,7 @@ static int guard_scan(gr_ctx* c, const float* t, int B, int C, long HW, long sB,
     c->guard_chmax_cap = (size_t)C;
   }
   launch_channel_absmax(t, B, C, HW, sB, sC, c->guard_chmax, c->stream);
-  launch_spread_verdict(c->guard_chmax, C, guard_alarm_dev(c), c->stream);
+  launch_spread_verdict(c->guard_chmax, C, guard_alarm_dev(c), side, c->stream);
   c->guard_scans++;
   LAUNCHCHK(c);
   return GR_OK;
@@ -826,14 +831,14 @@ static int guard_scan_params(gr_net* n) {
     const float* w = n->params + s.w_off;
     int r = 0;
     if (s.kind == ST_LINEAR) {             // W[out][in]
-      r = guard_scan(c, w, s.Cout, s.Cin, 1, s.Cin, 1); if (r) return r;
-      r = guard_scan(c, w, 1, s.Cout, s.Cin, 0, s.Cin); if (r) return r;
+      r = guard_scan(c, w, s.Cout, s.Cin, 1, s.Cin, 1, 1); if (r) return r;
+      r = guard_scan(c, w, 1, s.Cout, s.Cin, 0, s.Cin, 1); if (r) return r;
     } else if (s.fullconv) {               // W[in][out][3][3]
-      r = guard_scan(c, w, 1, s.Cin, (long)s.Cout * 9, 0, (long)s.Cout * 9); if (r) return r;
-      r = guard_scan(c, w, s.Cin, s.Cout, 9, (long)s.Cout * 9, 9); if (r) return r;
+      r = guard_scan(c, w, 1, s.Cin, (long)s.Cout * 9, 0, (long)s.Cout * 9, 1); if (r) return r;
+      r = guard_scan(c, w, s.Cin, s.Cout, 9, (long)s.Cout * 9, 9, 1); if (r) return r;
     } else {                               // W[out][in][3][3]
-      r = guard_scan(c, w, s.Cout, s.Cin, 9, (long)s.Cin * 9, 9); if (r) return r;
-      r = guard_scan(c, w, 1, s.Cout, (long)s.Cin * 9, 0, (long)s.Cin * 9); if (r) return r;
+      r = guard_scan(c, w, s.Cout, s.Cin, 9, (long)s.Cin * 9, 9, 1); if (r) return r;
+      r = guard_scan(c, w, 1, s.Cout, (long)s.Cin * 9, 0, (long)s.Cin * 9, 1); if (r) return r;
     }
   }
   for (size_t si = 0; si < n->st.size(); ++si) {
@@ -880,7 +885,7 @@ extern "C" int gr_range_guard_scan_params(gr_net* n, int* tripped) {
 // view of a per-sample [C][H][W] tensor as channels: a flat feature vector (H = W = 1 behind a Linear) has C "channels" of one element
 static int guard_scan_activation(gr_ctx* c, const float* t, int B, int C, int H, int W) {
   const long hw = (long)H * W;
-  return guard_scan(c, t, B, C, hw, (long)C * hw, hw);
+  return guard_scan(c, t, B, C, hw, (long)C * hw, hw, 0);
 }
 
 static int forward_impl(gr_net* n, const float* in_dev, int B) {

@@ -310,7 +310,7 @@ def test_f16x3_hostile_channel_ranges(ctx, oracle, kind, e):
     W[o][c] *= t_o / s_c, bias_o *= t_o, gradOutput[:, o] /= t_o with s, t spanning 2^-e .. 2^e - every channel still
     contributes equally to every output, so a channel that lost its digits shows.  Forward, gradInput and the weight
     gradient are held to 1e-4 of the largest reference entry OF THEIR OWN CHANNEL (weight gradient: of the natural size of
-    their own (out, in) pair).  e = 4: the two largest spreads add up to 16 bits, inside the range guard's 20-bit budget - the f16x3
+    their own (out, in) pair).  e = 4: the activation-side and the weight-side spread add up to 18 bits, inside the range guard's 20-bit budget - the f16x3
     kernels run and must meet the bar.  e = 20 (channels spanning 2^-20 .. 2^20): the guard must send both passes to
     bf16x6 (gr_range_guard_stats counts them) and the same bar holds."""
     from ganrev import nn, synth
@@ -401,6 +401,23 @@ def test_range_guard_trips_in_the_device_resident_loop(ctx):
     finally:
         ctx.set_tuning("range_guard", 0); ctx.set_tuning("range_guard", 1)     # clears the tripped state
         ctx.set_conv_mode(prev)
+
+
+def test_default_initialised_nets_stay_on_f16x3(ctx, tmp_path):
+    """Torch's BatchNorm reset draws gamma ~ U(0, 1): over 64-512 channels that is 8-14 bits of spread per layer, and until round 3
+    the guard added the two largest spreads of ANY two tensors - two of five default-initialised R nets (seeds 1 and 3 here) went
+    to bf16x6 at their first step for nothing.  The guard adds what a kernel multiplies (largest activation-side + largest
+    weight-side spread): train_r's loop on default-initialised nets must stay on f16x3, no pass sent to bf16x6."""
+    from ganrev import models, train_r
+    for seed in (1, 3):
+        gam = [m.weight for m in models.create_R((1, 32, 32), 32, "normal", False, seed=seed).leaves() if "BatchNorm" in m.typename]   # what train_r.main builds
+        spread = sorted(float(np.log2(np.abs(g).max() / np.abs(g)[g != 0].min())) for g in gam)
+        assert spread[-1] + spread[-2] > 20, "this seed no longer has the spreads the old rule tripped on"
+        _, falls0 = ctx.range_guard_stats()
+        _, R, losses = train_r.main(["--nbBatches", "3", "--batchSize", "8", "--quiet", "--height", "32", "--width", "32", "--channels", "1",
+                                     "--seed", str(seed), "--save", str(tmp_path / f"r{seed}.net")])
+        assert ctx.conv_mode() == "f16x3" and ctx.range_guard_stats()[1] == falls0, (seed, ctx.conv_mode(), ctx.range_guard_stats())
+        assert len(losses) == 3 and np.all(np.isfinite(losses))
 
 
 def test_dead_channels_between_two_guard_scans_in_the_device_loop(ctx, oracle, conv_mode):
