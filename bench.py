@@ -457,8 +457,13 @@ def run_workload(args, wl_key, modes, ctx, rank, world, shared_gpu, traffic, tra
     from ganrev.parallel import DeviceTrainer, host_allreduce_grads
     wl = WORKLOADS[wl_key]
     dims, nd, B = wl["dims"], wl["nd"], wl["batch"]
-    G = models.create_G(dims, nd); synth.init_params(G, 1)               # random-init weights of the named architecture
-    R = models.create_R(dims, nd); synth.init_params(R, 2)
+    # random-init weights of the named architectures: G is a TRAINED net in the reference (train_r.lua:68 loads it) - synthetic
+    # trained-looking weights and non-trivial running statistics; R is what train_r.lua:106 creates - models.create_R's own initialisation
+    # (weight-init.lua heuristic, biases 0, BatchNorm gamma ~ U(0, 1), beta 0), unless --init synth asks for the parity tests' weights
+    G = models.create_G(dims, nd); synth.init_params(G, 1)
+    R = models.create_R(dims, nd, seed=args.seed)
+    if args.init == "synth":
+        synth.init_params(R, 2)
     G._ctx = R._ctx = ctx
     # compile the nets with one small forward each (allocation happens at the first full-size step, in warm-up)
     G.evaluate(); G.forward(synth.normal((2, nd), 1))
@@ -494,7 +499,9 @@ def run_workload(args, wl_key, modes, ctx, rank, world, shared_gpu, traffic, tra
         """W untimed steps, then EXACTLY K steps between barrier + device sync on both sides (max over ranks); one HIP event per
         step on the library's stream for the percentiles; then 3 instrumented steps for the per-kernel table."""
         nonlocal t_adam
+        ctx.set_tuning("range_guard", 0); ctx.set_tuning("range_guard", 1)    # every mode starts with an untripped f16x3 range guard
         ctx.set_conv_mode(mode)
+        falls0 = ctx.range_guard_stats()[1]
         rnet.set_params(theta0); rnet.adam_reset(); t_adam = 0            # every mode starts from the same state
         trainer.t = 0
         for _ in range(args.warmup):
@@ -513,6 +520,10 @@ def run_workload(args, wl_key, modes, ctx, rank, world, shared_gpu, traffic, tra
             dt = float(t.item())
         per_step = [ctx.event_elapsed_ms(i, i + 1) for i in range(args.steps)]
         loss = step(want_loss=True)
+        # the timed steps must have run the arithmetic the line names: a tripped range guard moves the context to bf16x6 (csrc/net.hip)
+        if ctx.conv_mode() != mode or ctx.range_guard_stats()[1] != falls0:
+            raise SystemExit(f"bench.py: the f16x3 range guard moved the context from {mode} to {ctx.conv_mode()} during the timed steps "
+                             f"({ctx.range_guard_stats()[1] - falls0} fallbacks): the line would be mislabelled - rerun with --conv-mode bf16x6 or another --seed")
         # roofline leg: per-kernel HIP events (on the launch stream) over extra steps of the same workload.  Every rank runs
         # these steps (they contain the collective); only rank 0 instruments and reports.
         nprof = 3
@@ -573,6 +584,8 @@ def main():
     ap.add_argument("--workload", default="both", choices=sorted(WORKLOADS) + ["both"],
                     help="both (default): cfg2 is the headline (BASELINE configs[1], the size north_star's bs256 target is quoted on) and "
                          "cfg3 (configs[2] = the per-GPU shard of configs[3]) rides in the same line as the `cfg3` object")
+    ap.add_argument("--init", default="reference", choices=["reference", "synth"], help="R's initial weights: models.create_R's (the reference's initialisation) or synth.init_params")
+    ap.add_argument("--seed", type=int, default=1, help="seed of R's initialisation (train_r.lua:18 default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the cfg5 (1M x 100, top-50) search leg")
     ap.add_argument("--no-sustained", action="store_true", help="skip the bare f16x3 MFMA loop (roofline.sustained): profiling runs, whose kernel statistics it would dominate")
@@ -672,7 +685,10 @@ def main():
             "config": {"workload": h.pop("workload"), "global_batch": h.pop("global_batch"), "per_gpu_batch": h.pop("per_gpu_batch"),
                        "parallelism": f"dp{world}" + ("" if world == 1 else (" (RCCL all-reduce of R's flat gradient)" if not host_reduce else
                                                       " (TEST HOOK: ranks share one GPU, gradients reduced through gloo on the host)")),
-                       "bn": "per-rank batch statistics"},
+                       "bn": "per-rank batch statistics",
+                       "init": ("G: synthetic trained-looking weights and running statistics (the reference loads a trained G); R: " +
+                                (f"models.create_R's own initialisation, seed {args.seed} (weight-init.lua heuristic, BatchNorm gamma ~ U(0, 1))" if args.init == "reference"
+                                 else "synth.init_params (the parity tests' weights)"))},
             "rccl_ranks": rccl_ranks,
             **h,
         }

@@ -1851,6 +1851,222 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
+// ---------------------------------------------------------------- the same on v_mfma_f32_16x16x32_f16
+// A bare LDS + MFMA loop holds 12-15 % more on this instruction shape (the chip keeps a higher clock under it: roofline.sustained in
+// the bench line).  This layer's K fits it exactly - two column slots x 16 channels per (row phase, dy, column phase) - so the operand
+// images in LDS and in HBM stay as they are; only which lane reads what, the accumulator layout (lane = pixel of a 16-pixel block,
+// register = channel) and the epilogue's index maps change.
+// one source row r3_ of a chunk: per column phase b the B operands of the wave's NB pixel blocks (both terms), per valid row phase a the
+// A operands of its MB channel blocks, three products per accumulator block (small terms first, as split_mma orders them).
+// Uses the enclosing kernel's acc[2][2][MB][NB], pix[NB], wq, PS, PC.
+#define GR_UP16_ROW(pc_, wc_, r3_)                                                                              \
+  _Pragma("unroll") for (int pb = 0; pb < 2; ++pb) {                                                           \
+    uint4 bv[NB][2];                                                                                           \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                          \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) bv[nb][t] = (pc_)[t * 2 * PS + pix[nb] + (r3_) * PC + pb]; \
+    _Pragma("unroll") for (int pa = 0; pa < 2; ++pa) {                                                         \
+      const int dy = (r3_) - pa;                    /* row phase a reads source rows y-1+a (dy 0) and y+a (dy 1) */ \
+      if (dy < 0 || dy > 1) continue;                                                                          \
+      uint4 av[MB][2];                                                                                         \
+      _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                        \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) av[mb][t] = (wc_)[((t * 2 + pa) * 8 + (dy * 2 + pb) * 2) * 64 + wq + mb * 16]; \
+      _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                        \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                    \
+          f32x4 c_ = acc[pa][pb][mb][nb];                                                                      \
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][1]), __builtin_bit_cast(f16x8, bv[nb][0]), c_, 0, 0, 0); \
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][0]), __builtin_bit_cast(f16x8, bv[nb][1]), c_, 0, 0, 0); \
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][0]), __builtin_bit_cast(f16x8, bv[nb][0]), c_, 0, 0, 0); \
+          acc[pa][pb][mb][nb] = c_;                                                                            \
+        }                                                                                                      \
+    }                                                                                                          \
+  }
+template <int TW, int NI, bool DB>
+__global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_s16_kernel(ConvArgs a, const uint4* __restrict__ wup) {
+  constexpr int NT = 512, NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
+  // NI > 1: the tile is NI whole images, so every halo slot of the patch is zero padding for every chunk.  Those slots are
+  // zeroed once and the per-chunk staging walks only the 512 real pixels x 2 channel halves (2 per thread instead of
+  // 3 (16-wide) or 4 (8-wide) slots: a third / half of the loads, conversions and LDS stores).
+  constexpr bool COMPACT = NI > 1;
+  constexpr int NEH = 2 * PS, NSL = COMPACT ? 2 : (NEH + NT - 1) / NT;
+  constexpr int WV = 2 * 2 * 8 * 2 * 32, NWV = WV / NT;           // 2048 weight vectors per chunk: 4 per thread
+  static_assert(NI == 1 || IH * NI * TW == PT, "tile must hold whole images");
+  static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2) || (TW == 8 && NI == 8), "tile_pixel assumes these tilings");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [2][2][PS]
+  uint4* wts = patch + 2 * 2 * PS;                                // [2 terms][2 a][8 slots][2 halves][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4, hh = q & 1, dxq = q >> 1;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = (bid / a.tiles_y) * NI;
+  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * 32;
+  const int Hs = a.H >> 1, Ws = a.W >> 1;                        // source plane
+  const size_t HWs = (size_t)Hs * Ws;
+  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
+  const size_t in_left = (size_t)(a.B - b) * a.Cin * HWs * sizeof(float);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
+      (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
+  const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
+  // weight image [chunk][term][a][slot][half][cout_pad]: 64 rows per chunk, this workgroup takes its 32 channels of each
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wup), 0,
+      (int)((size_t)nchunks * 64 * a.cout_pad * 16), 0x00020000);
+  const int kin = f16_scale_exp(absmax_read(a.amax_in));
+  const int ktot = kin + f16_scale_exp(absmax_read(a.amax_w)) - 2;   // summed weights: up to 4 max|w|
+  const float sc_in = pow2f(kin);
+  int voff[NSL], clim[NSL], eoff[NSL];                             // eoff: slot index in the term-0 patch image ((half) * PS + position)
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) {
+    if (COMPACT) {
+      const int q = tid + NT * s, hh = q >> 9, p = q & 511, prr = p / TW, pc = p - prr * TW, img = prr / IH, r = prr - img * IH;
+      const int yy = y0 + r, xx = x0 + pc;
+      const bool inb = yy < Hs && xx < Ws && b + img < a.B;
+      const int so = yy * Ws + xx + (img * a.Cin + 8 * hh) * (int)HWs;
+      voff[s] = inb ? so * 4 : (int)0x7FFFF000;
+      clim[s] = a.Cin - 8 * hh;
+      eoff[s] = hh * PS + (img * (IH + 2) + r + 1) * PC + pc + 1;
+    } else {
+      const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
+      const int yy = y0 + rr - 1, xx = x0 + c - 1;
+      const bool inb = eh < NEH && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws && b < a.B;
+      const int so = yy * Ws + xx + (8 * hh) * (int)HWs;
+      voff[s] = inb ? so * 4 : (int)0x7FFFF000;
+      clim[s] = a.Cin - 8 * hh;
+      eoff[s] = eh < NEH ? eh : -1;
+    }
+  }
+  const int wvoff = ((tid >> 5) * a.cout_pad + o0 + (tid & 31)) * 16;   // weight vector f = tid + NT*i: row (tid>>5) + 16i
+  float pv[NSL][8];
+  uint4 wv[NWV];
+#define GR_UP_LOAD(ch_)                                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
+      const int soff_ = (int)(((ch_) * BF_CK + j) * HWs * 4);                                             \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
+        pv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
+    }                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NWV; ++i)                                                       \
+      wv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rwt, wvoff, ((ch_) * 64 + 16 * i) * a.cout_pad * 16, 0)); \
+  }
+#define GR_UP_STORE(patch, wts, ch_)                                                                      \
+  {                                                                                                       \
+    if (((ch_) + 1) * BF_CK > a.Cin) {                                                                    \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) if ((ch_) * BF_CK + j >= clim[s]) pv[s][j] = 0.f;   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
+      if (COMPACT || eoff[s] >= 0) {                                                                      \
+        uint4 t0, t1;                                                                                     \
+        split8_f16(pv[s], sc_in, t0, t1);                                                                 \
+        patch[eoff[s]] = t0; patch[2 * PS + eoff[s]] = t1;                                                \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < NWV; ++i) wts[tid + NT * i] = wv[i];                            \
+  }
+  // v_mfma_f32_16x16x32_f16: K = 32 = the two column slots dx = 0, 1 of a (row phase, dy, column phase) x 16 input channels.  Lane
+  // quarter q = lane / 16 feeds K rows 8q .. 8q+7: channel half q & 1 of slot dx = q >> 1 - the weight image and the patch are read
+  // as they are, at per-lane bases (weights: + dx * 64 vectors; patch: one source column to the right for dx = 1).
+  constexpr int MB = 2, NB = 2 * NG;                               // 16-channel / 16-pixel blocks per wave
+  f32x4 acc[2][2][MB][NB];                                         // [row phase a][column phase b][channel block][pixel block]
+#pragma unroll
+  for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[pa][pb][mb][nb][r] = 0.f;
+  int pix[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int p = (wave * NB + nb) * 16 + l15; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;
+    pix[nb] = hh * PS + pr * PC + pc + dxq;                        // patch row pr = source row y - 1; column slot dx reads x - 1 + b + dx
+  }
+  const int wq = dxq * 64 + hh * 32 + l15;
+  constexpr int LBUF = 2 * 2 * PS + WV;                           // uint4s of one (patch, weights) image
+  GR_UP_LOAD(0)
+  if (COMPACT) {                                                   // the padding slots, once (both images when double-buffered)
+    for (int i = tid; i < (DB ? 2 : 1) * LBUF; i += NT) if (i % LBUF < 2 * 2 * PS) patch[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+  }
+  if (DB) {
+    // two LDS images (TW >= 16: 144-148 KB): chunk ch+1 is converted and stored after the first source row of chunk ch, one
+    // barrier per chunk - as in conv3x3_split_wide_kernel
+    GR_UP_STORE(patch, wts, 0)
+    if (nchunks > 1) GR_UP_LOAD(1)
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const uint4* pc_ = patch + (ch & 1) * LBUF; const uint4* wc_ = wts + (ch & 1) * LBUF;
+      uint4* pn_ = patch + ((ch + 1) & 1) * LBUF; uint4* wn_ = wts + ((ch + 1) & 1) * LBUF;
+      GR_UP16_ROW(pc_, wc_, 0)
+      if (ch + 1 < nchunks) GR_UP_STORE(pn_, wn_, ch + 1)
+      if (ch + 2 < nchunks) GR_UP_LOAD(ch + 2)
+      GR_UP16_ROW(pc_, wc_, 1)
+      GR_UP16_ROW(pc_, wc_, 2)
+      __syncthreads();
+    }
+  } else {
+  for (int ch = 0; ch < nchunks; ++ch) {
+    GR_UP_STORE(patch, wts, ch)
+    __syncthreads();
+    if (ch + 1 < nchunks) GR_UP_LOAD(ch + 1)
+    GR_UP16_ROW(patch, wts, 0)
+    GR_UP16_ROW(patch, wts, 1)
+    GR_UP16_ROW(patch, wts, 2)
+    __syncthreads();
+  }
+  }
+#undef GR_UP_LOAD
+#undef GR_UP_STORE
+  // epilogue: scale back + bias (+ evaluate()-mode BatchNorm) per channel, one activation switch per block, then two output
+  // rows x float2 per lane
+  float omax = 0.f;
+  const bool has_bn = a.ep.mean != nullptr;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int p = (wave * NB + nb) * 16 + l15; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
+    const int y = y0 + pr, x = x0 + pc;
+    const bool pin = y < Hs && x < Ws && b + img < a.B;
+    float v[32];                                                   // [mb][r][pa][pb]: accumulator register r of block mb = channel mb * 16 + q * 4 + r
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = min(o0 + mb * 16 + q * 4 + r, a.Cout - 1);
+        const float bvv = a.bias ? a.bias[o] : 0.f;
+        float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
+        if (has_bn) { mean = a.ep.mean[o]; invstd = a.ep.invstd[o]; gam = a.ep.gamma[o]; bet = a.ep.beta[o]; }
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+          float t = ldexpf(acc[ph >> 1][ph & 1][mb][nb][r], -ktot) + bvv;
+          if (has_bn) t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t, mean), invstd), gam), bet);   // same order as conv_epilogue
+          v[(mb * 4 + r) * 4 + ph] = t;
+        }
+      }
+    conv_act_block<32>(a.ep, v);
+    {
+      // (both lanes of a pair share the row and the image: `pin` is the same for them, Ws is even)
+      const bool odd = (pc & 1) != 0;
+      float* orow = a.out + ((size_t)(b + img) * a.Cout * a.H + 2 * y + (odd ? 1 : 0)) * a.W + 2 * (x - (odd ? 1 : 0));
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + mb * 16 + q * 4 + r;
+          const float4 res = up2_pair_rows(v + (mb * 4 + r) * 4, odd);   // every lane takes part in the exchange
+          if (pin && o < a.Cout) {
+            store4(orow + (size_t)o * a.H * a.W, res, a.nt_out != 0);
+            omax = absmax4(omax, res);
+          }
+        }
+    }
+  }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+
 // ---------------------------------------------------------------- the same layer as TWO independent four-wave workgroups per CU
 // conv3x3_up2_f16x3_kernel keeps two operand images (144-148 KB): one eight-wave workgroup per CU whose waves move through
 // staging, multiply and epilogue in lock-step - the structure conv3x3_p16_quad_kernel left behind for R's layers (+35 % there).
@@ -2042,6 +2258,171 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, 
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
 
+// ---------------------------------------------------------------- the four-wave kernel on v_mfma_f32_16x16x32_f16 (see conv3x3_up2_f16x3_s16_kernel)
+template <int TW, int NI>
+__global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_s16_kernel(ConvArgs a, const uint4* __restrict__ wup) {
+  constexpr int NW = 4, NT = 64 * NW, NG = 2, PT = 64 * NW, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
+  static_assert(NI == 1 && (TW == 16 || TW == 32), "one image (16x16) or 8 rows of a 32-wide plane per tile");
+  constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;            // (position, half) pairs staged per thread
+  constexpr int PV = 2 * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;
+  constexpr int WV = 2 * 2 * 8 * 2 * 32, NWI = WV / 64, NWS = NWI / NW;   // weight vectors per chunk; DMA instructions; per wave
+  static_assert(2 * (PVP + WV) * 16 <= 160 * 1024, "two workgroups per CU");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [2 terms][2 halves][PS]
+  uint4* wts = patch + PVP;                                       // [2 terms][2 a][8 slots][2 halves][32 o]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4, hh = q & 1, dxq = q >> 1;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * 32;
+  const int Hs = a.H >> 1, Ws = a.W >> 1;                        // source plane
+  const size_t HWs = (size_t)Hs * Ws;
+  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
+  const size_t in_left = (size_t)(a.B - b) * a.Cin * HWs * sizeof(float);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
+      (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
+  const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wup), 0,
+      (int)((size_t)nchunks * 64 * a.cout_pad * 16), 0x00020000);
+  const int kin = f16_scale_exp(absmax_read(a.amax_in));
+  const int ktot = kin + f16_scale_exp(absmax_read(a.amax_w)) - 2;   // summed weights: up to 4 max|w|
+  const float sc_in = pow2f(kin);
+  const int dbg = a.up >> 1;            // diagnostic ablations (gr_set_tuning "up2_debug"; outputs are then wrong by design): 1 no stores, 2 no MFMA, 4 no activation staging, 8 no weight DMA
+  int voff[NSL], eoff[NSL];
+#pragma unroll
+  for (int s = 0; s < NSL; ++s) {
+    const int eh = tid + NT * s, eh_h = eh >= PS ? 1 : 0, e = eh - eh_h * PS, rr = e / PC, c = e - rr * PC;
+    const int yy = y0 + rr - 1, xx = x0 + c - 1;
+    const bool inb = eh < NEH && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws && b < a.B;
+    const int so = yy * Ws + xx + (8 * eh_h) * (int)HWs;
+    voff[s] = inb ? so * 4 : (int)0x7FFFF000;
+    eoff[s] = eh < NEH ? eh : -1;
+  }
+  // weight DMA: instruction i = wave + NW * j covers LDS vectors 64 i .. 64 i + 63 = rows 2 i, 2 i + 1 of the chunk's 64 rows
+  const int woff0 = ((2 * wave + (lane >> 5)) * a.cout_pad + o0 + (lane & 31)) * 16, wstep = 2 * NW * a.cout_pad * 16;
+  float pv[NSL][8];
+#define GR_UQ_LOAD(ch_)                                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
+      const int soff_ = (int)(((ch_) * BF_CK + j) * HWs * 4);                                             \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
+        pv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
+    }                                                                                                     \
+  }
+#define GR_UQ_DMAW(ch_)                                                                                   \
+  {                                                                                                       \
+    const int wsoff_ = (ch_) * 64 * a.cout_pad * 16;                                                      \
+    _Pragma("unroll") for (int j = 0; j < NWS; ++j) lds_dma16(rwt, wts + 64 * (wave + NW * j), woff0 + j * wstep, wsoff_); \
+  }
+#define GR_UQ_STORE(ch_)                                                                                  \
+  {                                                                                                       \
+    if (((ch_) + 1) * BF_CK > a.Cin) {                                                                    \
+      _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                   \
+        const int clim_ = a.Cin - ((tid + NT * s) >= PS ? 8 : 0);                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) if ((ch_) * BF_CK + j >= clim_) pv[s][j] = 0.f;     \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
+      if (eoff[s] >= 0) {                                                                                 \
+        uint4 t0, t1;                                                                                     \
+        split8_f16(pv[s], sc_in, t0, t1);                                                                 \
+        patch[eoff[s]] = t0; patch[2 * PS + eoff[s]] = t1;                                                \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+  constexpr int MB = 2, NB = 2 * NG;                               // 16-channel / 16-pixel blocks per wave (conv3x3_up2_f16x3_s16_kernel)
+  f32x4 acc[2][2][MB][NB];
+#pragma unroll
+  for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[pa][pb][mb][nb][r] = 0.f;
+  int pix[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int p = (wave * NB + nb) * 16 + l15; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    pix[nb] = hh * PS + prr * PC + pc + dxq;                       // patch row prr = source row y - 1; column slot dx reads x - 1 + b + dx
+  }
+  const int wq = dxq * 64 + hh * 32 + l15;
+  // The two workgroups of a CU run the same program from (almost) the same start: left alone they stay IN phase - both convert,
+  // both multiply (sharing the matrix pipe), both store - and the phases add up instead of overlapping (ablation, round 3:
+  // skeleton 38 + MFMA 122 + staging 62 + stores 34 = 256 us against 246 measured on G.convB at cfg2).  The workgroup whose waves
+  // sit in the odd wave slots of their SIMDs (HW_ID.wave_id: the one that arrived second, whatever its block index) starts late
+  // by a.nchunks x 512 clocks (gr_set_tuning "up2_stagger"), about half a chunk iteration.
+  if (a.nchunks > 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));     // HW_REG_HW_ID bits [3:0] = wave slot on its SIMD
+    if (hwid & 1) {
+#pragma unroll 1
+      for (int i = 0; i < a.nchunks; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  if (!(dbg & 4)) GR_UQ_LOAD(0)
+  if (!(dbg & 8)) GR_UQ_DMAW(0)
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (!(dbg & 4)) GR_UQ_STORE(ch)                                // the image is free: every wave passed the barrier below
+    dma_publish_barrier();                                         // this chunk's weights have landed, every wave's patch stores are visible
+    if (ch + 1 < nchunks && !(dbg & 4)) GR_UQ_LOAD(ch + 1)         // lands behind the MFMAs
+    if (!(dbg & 2))
+    { GR_UP16_ROW(patch, wts, 0) GR_UP16_ROW(patch, wts, 1) GR_UP16_ROW(patch, wts, 2) }
+    __syncthreads();                                               // every wave is past the image
+    if (ch + 1 < nchunks && !(dbg & 8)) GR_UQ_DMAW(ch + 1)
+  }
+#undef GR_UQ_LOAD
+#undef GR_UQ_DMAW
+#undef GR_UQ_STORE
+  // epilogue: scale back + bias (+ evaluate()-mode BatchNorm) per channel, one activation switch per block, then two output
+  // rows x float2 per lane
+  float omax = 0.f;
+  const bool has_bn = a.ep.mean != nullptr;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int p = (wave * NB + nb) * 16 + l15; int prr, pc; tile_pixel<TW>(p, prr, pc);
+    const int y = y0 + prr, x = x0 + pc;
+    const bool pin = y < Hs && x < Ws && b < a.B && !(dbg & 1);
+    float v[32];                                                   // [mb][r][pa][pb]
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = min(o0 + mb * 16 + q * 4 + r, a.Cout - 1);
+        const float bvv = a.bias ? a.bias[o] : 0.f;
+        float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
+        if (has_bn) { mean = a.ep.mean[o]; invstd = a.ep.invstd[o]; gam = a.ep.gamma[o]; bet = a.ep.beta[o]; }
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+          float t = ldexpf(acc[ph >> 1][ph & 1][mb][nb][r], -ktot) + bvv;
+          if (has_bn) t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t, mean), invstd), gam), bet);   // same order as conv_epilogue
+          v[(mb * 4 + r) * 4 + ph] = t;
+        }
+      }
+    conv_act_block<32>(a.ep, v);
+    {
+      const bool odd = (pc & 1) != 0;
+      float* orow = a.out + ((size_t)b * a.Cout * a.H + 2 * y + (odd ? 1 : 0)) * a.W + 2 * (x - (odd ? 1 : 0));
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + mb * 16 + q * 4 + r;
+          const float4 res = up2_pair_rows(v + (mb * 4 + r) * 4, odd);
+          if (pin && o < a.Cout) {
+            store4(orow + (size_t)o * a.H * a.W, res, a.nt_out != 0);
+            omax = absmax4(omax, res);
+          }
+        }
+    }
+  }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+
+#undef GR_UP16_ROW
+
 // weight image of the up-sampling kernel: [cin_pad16/16][2 terms][2 a][8 slots (dy, b, dx)][2 halves][cout_pad32][8 ch] f16,
 // slot weight = sum of the taps (ky, kx) that read source pixel (y - 1 + a + dy, x - 1 + b + dx): ky in {0} / {1,2} (a = 0) or
 // {0,1} / {2} (a = 1) for dy = 0 / 1, the same for kx with (b, dx); summed in double, scaled by 2^(k_w - 2), split in two terms.
@@ -2105,6 +2486,14 @@ static void launch_conv_up2_db(ConvArgs a, const void* wup, hipStream_t s) {
   static const std::string name = "conv3x3_up2_f16x3_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + (DB ? ", true>" : ", false>");   // as rocprofv3 prints it
   const double px = (double)a.B * a.H * a.W;
   // FLOPs reported = those of the layer as the reference defines it (9 taps per output); the kernel issues 4/9 of them
+  if (g_up2_shape == 1) {
+    static bool attr16_set = false;
+    if (!attr16_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_f16x3_s16_kernel<TW, NI, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr16_set = true; }
+    static const std::string name16 = "conv3x3_up2_f16x3_s16_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + (DB ? ", true>" : ", false>");
+    KtScope kt16(name16.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+    hipLaunchKernelGGL((conv3x3_up2_f16x3_s16_kernel<TW, NI, DB>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wup));
+    return;
+  }
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_up2_f16x3_kernel<TW, NI, DB>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wup));
 }
@@ -2130,6 +2519,14 @@ static void launch_conv_up2q(ConvArgs a, const void* wup, hipStream_t s) {
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2q_f16x3_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   static const std::string name = "conv3x3_up2q_f16x3_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";   // as rocprofv3 prints it
   const double px = (double)a.B * a.H * a.W;
+  if (g_up2_shape == 1) {
+    static bool attr16_set = false;
+    if (!attr16_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2q_f16x3_s16_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr16_set = true; }
+    static const std::string name16 = "conv3x3_up2q_f16x3_s16_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";
+    KtScope kt16(name16.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+    hipLaunchKernelGGL((conv3x3_up2q_f16x3_s16_kernel<TW, NI>), dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wup));
+    return;
+  }
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_up2q_f16x3_kernel<TW, NI>), dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wup));
 }
@@ -2317,6 +2714,7 @@ bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {
   return W >= 32 && W % 32 == 0 && H % 16 == 0 && (long)B * (H / 16) * (W / 32) * otiles >= g_p16_min_tiles;
 }
 int g_p16_stagger = 0;           // start delay (x 512 clocks) of the second-dispatched workgroups: measured useless (tools/stagger_p16.py), kept as a knob
+int g_up2_shape = getenv("GR_UP2_SHAPE") ? atoi(getenv("GR_UP2_SHAPE")) : 1;      // MFMA shape of the eight-wave up-sampling kernel: 0 = 32x32x16, 1 = 16x16x32 (default: -5 to -12 % per launch)
 int g_p16_variant = 1;          // 1: four-wave workgroups, two per CU (conv3x3_p16_quad_kernel); 0: eight-wave persistent (conv3x3_p16_wide_kernel)
 template <int TW, int NI, int NG = 4, int MT = 2>
 static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {

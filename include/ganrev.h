@@ -159,11 +159,11 @@ int gr_get_conv_mode(gr_ctx* ctx);
 int gr_set_tuning(gr_ctx* ctx, const char* key, int value);
 /* f16x3 range guard ("range_guard" 1/0 in gr_set_tuning, default on; GR_RANGE_GUARD=0 before gr_init turns it off).  f16x3 scales a
  * tensor by one power of two: an entry 2^k below the tensor maximum keeps about 40 - k bits, and an output channel's relative
- * error grows with the product of the per-channel spreads of the two tensors multiplied.  The host-memory calls
+ * error grows with the product of the per-channel spreads of the activation and the weight tensor multiplied.  The host-memory calls
  * (gr_net_forward_host / gr_net_backward_host) measure, before computing, the per-channel spread (log2 largest / smallest
  * non-zero channel maximum) of the input / gradOutput, of every weight tensor an f16x3 kernel reads (per input and per output
- * channel) and of the BatchNorm (gamma, beta) pairs, and run the pass on bf16x6 (fp32 exponent range) when the two largest
- * spreads add up to more than 20 bits.  gr_train_r_step scans the parameters every 64th step without synchronising and
+ * channel) and of the BatchNorm (gamma, beta) pairs, and run the pass on bf16x6 (fp32 exponent range) when the largest
+ * activation-side spread (input, gradOutput, BatchNorm pairs) plus the largest weight-side spread exceed 20 bits.  gr_train_r_step scans the parameters every 64th step without synchronising and
  * switches the context to bf16x6 when a scan trips.  Counters: scan launches and passes sent to bf16x6 since gr_init (the
  * latter also in gr_kernel_times as "range_guard_fallback"). */
 int gr_range_guard_stats(gr_ctx* ctx, int64_t* scans, int64_t* fallbacks);

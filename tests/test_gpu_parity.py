@@ -1533,28 +1533,38 @@ def test_adversarial_step_vs_oracle(oracle, conv_mode):
 @pytest.mark.parametrize("method", ["sgd", "adagrad", "adadelta", "adamax", "rmsprop"])
 def test_adversarial_game_with_the_other_optimisers(method):
     """adversarial.lua:156-171 / 183-198 with --D_optmethod / --G_optmethod other than adam: the closures run on the GPU, the update is the
-    host mirror of the optim rock on PARAMETERS_D / PARAMETERS_G.  One batch: the step each network took equals the method's rule
-    applied to the gradient its closure left in GRAD_PARAMETERS_* (first step from an empty state), and the next forward sees it."""
+    host mirror of the optim rock on PARAMETERS_D / PARAMETERS_G.  The dispatch itself on fevalD (first step from an empty state: the step
+    equals the method's rule applied to the gradient the closure returned), then one whole batch of adversarial.train: both networks move,
+    the state lands in OPTSTATE[method], and the next forward runs with the stepped parameters."""
     from ganrev import adversarial, models, synth
     dims, nd, B = (1, 16, 16), 8, 8
     G, D = models.create_G(dims, nd, True, 3), models.create_D2(dims, True, 4)
     env = adversarial.make_env(G, D, dims, batchSize=B, noiseDim=nd, N_epoch=1, D_optmethod=method, G_optmethod=method, D_sgd_momentum=0.5)
-    pd, pg = env.PARAMETERS_D.copy(), env.PARAMETERS_G.copy()
-    adversarial.train(env, synth.uniform((B // 2,) + dims, 40, 0, 1))
     first = {"sgd": lambda g: 0.02 * g, "adagrad": lambda g: 1e-3 * g / (np.abs(g) + 1e-10),
              "adadelta": lambda g: np.sqrt(1e-6) / np.sqrt(0.1 * g * g + 1e-6) * g, "adamax": lambda g: 2e-3 * g / (np.abs(g) + 1e-38),
              "rmsprop": lambda g: 1e-2 * g / (np.sqrt(0.01 * g * g) + 1e-8)}[method]
-    for name, before, after, grad in (("D", pd, env.PARAMETERS_D, env.GRAD_PARAMETERS_D), ("G", pg, env.PARAMETERS_G, env.GRAD_PARAMETERS_G)):
-        g = grad.astype(np.float64)
-        nz = g != 0
-        assert nz.any() and np.all(np.isfinite(after))
-        assert np.allclose((before.astype(np.float64) - after)[nz], first(g[nz]), rtol=1e-3, atol=2e-7), (method, name)
-        assert np.array_equal(before[~nz], after[~nz])
+    G.evaluate()
+    inputs = np.concatenate([synth.uniform((B // 2,) + dims, 7, 0, 1), G.forward(synth.normal((B // 2, nd), 8))]).astype(np.float32)
+    G.training()
+    targets = np.concatenate([np.ones(B // 2, np.float32), np.zeros(B // 2, np.float32)])
+    before = env.PARAMETERS_D.copy()
+    x, fs = adversarial._optimize(env, "D", adversarial.make_fevalD(env, inputs, targets), env.PARAMETERS_D, D)
+    g = env.GRAD_PARAMETERS_D.astype(np.float64)                      # what the closure returned (penalty and clamp applied)
+    nz = g != 0
+    assert x is env.PARAMETERS_D and len(fs) == 1 and np.isfinite(fs[0]) and nz.any() and np.all(np.isfinite(x))
+    assert np.allclose((before.astype(np.float64) - x)[nz], first(g[nz]), rtol=1e-3, atol=2e-7), method
+    assert np.array_equal(before[~nz], x[~nz])
     assert env.OPTSTATE["adam"]["D"] == {} and len(env.OPTSTATE[method]["D"]) > 0
-    D.evaluate(); x = synth.uniform((2,) + dims, 41, 0, 1)
-    y1 = D.forward(x).copy()
-    env.PARAMETERS_D[:] = pd
-    assert not np.array_equal(D.forward(x), y1)                        # the device ran with the stepped parameters
+    pd, pg = env.PARAMETERS_D.copy(), env.PARAMETERS_G.copy()
+    adversarial.train(env, synth.uniform((B // 2,) + dims, 40, 0, 1))
+    assert np.all(np.isfinite(env.PARAMETERS_D)) and np.all(np.isfinite(env.PARAMETERS_G))
+    assert not np.array_equal(env.PARAMETERS_D, pd) and len(env.OPTSTATE[method]["G"]) > 0
+    # (rmsprop's first step moves every weight of D by 0.1: D saturates and hands G a gradient of exact zeros - then G rightly stays)
+    assert not np.array_equal(env.PARAMETERS_G, pg) or not env.GRAD_PARAMETERS_G.any()
+    D.evaluate(); D.forward(synth.uniform((2,) + dims, 41, 0, 1))
+    for ch, lo, hi in D._param_chunks():                               # the next forward runs with the stepped parameters
+        if hi > lo:
+            assert np.array_equal(ch._net.get_params(), env.PARAMETERS_D[lo:hi])
 
 
 from golden_cases import DCASES as _DCASES, build_dcase as _build_dcase  # noqa: E402
