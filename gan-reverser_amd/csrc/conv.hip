@@ -1584,278 +1584,10 @@ __device__ __forceinline__ float4 up2_pair_rows(const float* v, bool odd) {
 // (a, dy, b, dx) - one patch conversion serves 96 MFMAs per wave.  f16x3 arithmetic only.
 //   LDS patch   [2 terms][2 halves][PS] (zero-padded source patch, 1-pixel halo; NI whole images stacked)
 //   LDS weights [2 terms][2 a][8 slots = (dy, b, dx)][2 halves][32 o]
-template <int TW, int NI, bool DB>
-__global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, const uint4* __restrict__ wup) {
-  constexpr int NT = 512, NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
-  // NI > 1: the tile is NI whole images, so every halo slot of the patch is zero padding for every chunk.  Those slots are
-  // zeroed once and the per-chunk staging walks only the 512 real pixels x 2 channel halves (2 per thread instead of
-  // 3 (16-wide) or 4 (8-wide) slots: a third / half of the loads, conversions and LDS stores).
-  constexpr bool COMPACT = NI > 1;
-  constexpr int NEH = 2 * PS, NSL = COMPACT ? 2 : (NEH + NT - 1) / NT;
-  constexpr int WV = 2 * 2 * 8 * 2 * 32, NWV = WV / NT;           // 2048 weight vectors per chunk: 4 per thread
-  static_assert(NI == 1 || IH * NI * TW == PT, "tile must hold whole images");
-  static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2) || (TW == 8 && NI == 8), "tile_pixel assumes these tilings");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [2][2][PS]
-  uint4* wts = patch + 2 * 2 * PS;                                // [2 terms][2 a][8 slots][2 halves][32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y; const int b = (bid / a.tiles_y) * NI;
-  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * 32;
-  const int Hs = a.H >> 1, Ws = a.W >> 1;                        // source plane
-  const size_t HWs = (size_t)Hs * Ws;
-  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
-  const size_t in_left = (size_t)(a.B - b) * a.Cin * HWs * sizeof(float);
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
-      (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
-  const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
-  // weight image [chunk][term][a][slot][half][cout_pad]: 64 rows per chunk, this workgroup takes its 32 channels of each
-  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wup), 0,
-      (int)((size_t)nchunks * 64 * a.cout_pad * 16), 0x00020000);
-  const int kin = f16_scale_exp(absmax_read(a.amax_in));
-  const int ktot = kin + f16_scale_exp(absmax_read(a.amax_w)) - 2;   // summed weights: up to 4 max|w|
-  const float sc_in = pow2f(kin);
-  int voff[NSL], clim[NSL], eoff[NSL];                             // eoff: slot index in the term-0 patch image ((half) * PS + position)
-#pragma unroll
-  for (int s = 0; s < NSL; ++s) {
-    if (COMPACT) {
-      const int q = tid + NT * s, hh = q >> 9, p = q & 511, prr = p / TW, pc = p - prr * TW, img = prr / IH, r = prr - img * IH;
-      const int yy = y0 + r, xx = x0 + pc;
-      const bool inb = yy < Hs && xx < Ws && b + img < a.B;
-      const int so = yy * Ws + xx + (img * a.Cin + 8 * hh) * (int)HWs;
-      voff[s] = inb ? so * 4 : (int)0x7FFFF000;
-      clim[s] = a.Cin - 8 * hh;
-      eoff[s] = hh * PS + (img * (IH + 2) + r + 1) * PC + pc + 1;
-    } else {
-      const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
-      const int yy = y0 + rr - 1, xx = x0 + c - 1;
-      const bool inb = eh < NEH && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws && b < a.B;
-      const int so = yy * Ws + xx + (8 * hh) * (int)HWs;
-      voff[s] = inb ? so * 4 : (int)0x7FFFF000;
-      clim[s] = a.Cin - 8 * hh;
-      eoff[s] = eh < NEH ? eh : -1;
-    }
-  }
-  const int wvoff = ((tid >> 5) * a.cout_pad + o0 + (tid & 31)) * 16;   // weight vector f = tid + NT*i: row (tid>>5) + 16i
-  float pv[NSL][8];
-  uint4 wv[NWV];
-#define GR_UP_LOAD(ch_)                                                                                   \
-  {                                                                                                       \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
-      const int soff_ = (int)(((ch_) * BF_CK + j) * HWs * 4);                                             \
-      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
-        pv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
-    }                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < NWV; ++i)                                                       \
-      wv[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rwt, wvoff, ((ch_) * 64 + 16 * i) * a.cout_pad * 16, 0)); \
-  }
-#define GR_UP_STORE(patch, wts, ch_)                                                                      \
-  {                                                                                                       \
-    if (((ch_) + 1) * BF_CK > a.Cin) {                                                                    \
-      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) if ((ch_) * BF_CK + j >= clim[s]) pv[s][j] = 0.f;   \
-    }                                                                                                     \
-    _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
-      if (COMPACT || eoff[s] >= 0) {                                                                      \
-        uint4 t0, t1;                                                                                     \
-        split8_f16(pv[s], sc_in, t0, t1);                                                                 \
-        patch[eoff[s]] = t0; patch[2 * PS + eoff[s]] = t1;                                                \
-      }                                                                                                   \
-    }                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < NWV; ++i) wts[tid + NT * i] = wv[i];                            \
-  }
-  f32x16 acc[2][2][NG];                                            // [row phase a][column phase b][pixel group]
-#pragma unroll
-  for (int pa = 0; pa < 2; ++pa)
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-      for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pa][pb][ng][r] = 0.f;
-  int pix[NG];
-#pragma unroll
-  for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
-    const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;
-    pix[ng] = h * PS + pr * PC + pc;                               // patch row pr = source row y - 1
-  }
-  constexpr int LBUF = 2 * 2 * PS + WV;                           // uint4s of one (patch, weights) image
-  GR_UP_LOAD(0)
-  if (COMPACT) {                                                   // the padding slots, once (both images when double-buffered)
-    for (int i = tid; i < (DB ? 2 : 1) * LBUF; i += NT) if (i % LBUF < 2 * 2 * PS) patch[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-  }
-  if (DB) {
-    // two LDS images (TW >= 16: 144-148 KB): chunk ch+1 is converted and stored after the first source row of chunk ch, one
-    // barrier per chunk - as in conv3x3_split_wide_kernel
-    GR_UP_STORE(patch, wts, 0)
-    if (nchunks > 1) GR_UP_LOAD(1)
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const uint4* pc_ = patch + (ch & 1) * LBUF; const uint4* wc_ = wts + (ch & 1) * LBUF;
-      uint4* pn_ = patch + ((ch + 1) & 1) * LBUF; uint4* wn_ = wts + ((ch + 1) & 1) * LBUF;
-    {
-      uint4 bv[3][NG][2];                                          // source columns x-1, x, x+1
-#pragma unroll
-      for (int c3 = 0; c3 < 3; ++c3)
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) bv[c3][ng][t] = pc_[t * 2 * PS + pix[ng] + 0 * PC + c3];
-#pragma unroll
-      for (int pa = 0; pa < 2; ++pa) {
-        const int dy = 0 - pa;                                    // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
-        if (dy < 0 || dy > 1) continue;
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            uint4 av[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) av[t] = wc_[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[pb + dx][ng], acc[pa][pb][ng]);
-          }
-      }
-    }
-      if (ch + 1 < nchunks) GR_UP_STORE(pn_, wn_, ch + 1)
-      if (ch + 2 < nchunks) GR_UP_LOAD(ch + 2)
-    {
-      uint4 bv[3][NG][2];                                          // source columns x-1, x, x+1
-#pragma unroll
-      for (int c3 = 0; c3 < 3; ++c3)
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) bv[c3][ng][t] = pc_[t * 2 * PS + pix[ng] + 1 * PC + c3];
-#pragma unroll
-      for (int pa = 0; pa < 2; ++pa) {
-        const int dy = 1 - pa;                                    // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
-        if (dy < 0 || dy > 1) continue;
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            uint4 av[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) av[t] = wc_[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[pb + dx][ng], acc[pa][pb][ng]);
-          }
-      }
-    }
-    {
-      uint4 bv[3][NG][2];                                          // source columns x-1, x, x+1
-#pragma unroll
-      for (int c3 = 0; c3 < 3; ++c3)
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) bv[c3][ng][t] = pc_[t * 2 * PS + pix[ng] + 2 * PC + c3];
-#pragma unroll
-      for (int pa = 0; pa < 2; ++pa) {
-        const int dy = 2 - pa;                                    // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
-        if (dy < 0 || dy > 1) continue;
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            uint4 av[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) av[t] = wc_[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[pb + dx][ng], acc[pa][pb][ng]);
-          }
-      }
-    }
-      __syncthreads();
-    }
-  } else {
-  for (int ch = 0; ch < nchunks; ++ch) {
-    GR_UP_STORE(patch, wts, ch)
-    __syncthreads();
-    if (ch + 1 < nchunks) GR_UP_LOAD(ch + 1)
-#pragma unroll
-    for (int r3 = 0; r3 < 3; ++r3) {                               // source rows y-1, y, y+1
-      uint4 bv[3][NG][2];                                          // source columns x-1, x, x+1
-#pragma unroll
-      for (int c3 = 0; c3 < 3; ++c3)
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) bv[c3][ng][t] = patch[t * 2 * PS + pix[ng] + r3 * PC + c3];
-#pragma unroll
-      for (int pa = 0; pa < 2; ++pa) {
-        const int dy = r3 - pa;                                    // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
-        if (dy < 0 || dy > 1) continue;
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            uint4 av[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) av[t] = wts[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[pb + dx][ng], acc[pa][pb][ng]);
-          }
-      }
-    }
-    __syncthreads();
-  }
-  }
-#undef GR_UP_LOAD
-#undef GR_UP_STORE
-  // epilogue: scale back + bias (+ evaluate()-mode BatchNorm) per channel, one activation switch per block, then two output
-  // rows x float2 per lane
-  float omax = 0.f;
-  const bool has_bn = a.ep.mean != nullptr;
-#pragma unroll
-  for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
-    const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
-    const int y = y0 + pr, x = x0 + pc;
-    const bool pin = y < Hs && x < Ws && b + img < a.B;
-    float v[64];                                                   // [r][pa][pb]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = min(o0 + (r & 3) + 8 * (r >> 2) + 4 * h, a.Cout - 1);
-      const float bvv = a.bias ? a.bias[o] : 0.f;
-      float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
-      if (has_bn) { mean = a.ep.mean[o]; invstd = a.ep.invstd[o]; gam = a.ep.gamma[o]; bet = a.ep.beta[o]; }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t = ldexpf(acc[q >> 1][q & 1][ng][r], -ktot) + bvv;
-        if (has_bn) t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t, mean), invstd), gam), bet);   // same order as conv_epilogue
-        v[r * 4 + q] = t;
-      }
-    }
-    conv_act_block<64>(a.ep, v);
-    {
-      // (both lanes of a pair share the row and the image: `pin` is the same for them, Ws is even)
-      const bool odd = (pc & 1) != 0;
-      float* orow = a.out + ((size_t)(b + img) * a.Cout * a.H + 2 * y + (odd ? 1 : 0)) * a.W + 2 * (x - (odd ? 1 : 0));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float4 res = up2_pair_rows(v + r * 4, odd);            // every lane takes part in the exchange
-        if (pin && o < a.Cout) {
-          store4(orow + (size_t)o * a.H * a.W, res, a.nt_out != 0);
-          omax = absmax4(omax, res);
-        }
-      }
-    }
-  }
-  if (a.amax_out) absmax_commit(omax, a.amax_out);
-}
-
-// ---------------------------------------------------------------- the same on v_mfma_f32_16x16x32_f16
-// A bare LDS + MFMA loop holds 12-15 % more on this instruction shape (the chip keeps a higher clock under it: roofline.sustained in
-// the bench line).  This layer's K fits it exactly - two column slots x 16 channels per (row phase, dy, column phase) - so the operand
-// images in LDS and in HBM stay as they are; only which lane reads what, the accumulator layout (lane = pixel of a 16-pixel block,
-// register = channel) and the epilogue's index maps change.
+// MFMA shape: v_mfma_f32_16x16x32_f16.  A bare LDS + MFMA loop holds 12-15 % more on it than on 32x32x16 (the chip keeps a higher clock
+// under it: roofline.sustained in the bench line), and this layer's K fits it exactly - two column slots x 16 channels per (row phase, dy,
+// column phase).  Round 3, same box, against the 32x32x16 version of this kernel (same LDS and HBM images; git history): 202 -> 177 and
+// 184 -> 168 us at cfg2, 1687 -> 1498 and 1385 -> 1310 us at cfg3.  Accumulator block: lane = pixel of a 16-pixel block, register = channel.
 // one source row r3_ of a chunk: per column phase b the B operands of the wave's NB pixel blocks (both terms), per valid row phase a the
 // A operands of its MB channel blocks, three products per accumulator block (small terms first, as split_mma orders them).
 // Uses the enclosing kernel's acc[2][2][MB][NB], pix[NB], wq, PS, PC.
@@ -1881,7 +1613,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
     }                                                                                                          \
   }
 template <int TW, int NI, bool DB>
-__global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_s16_kernel(ConvArgs a, const uint4* __restrict__ wup) {
+__global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, const uint4* __restrict__ wup) {
   constexpr int NT = 512, NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
   // NI > 1: the tile is NI whole images, so every halo slot of the patch is zero padding for every chunk.  Those slots are
   // zeroed once and the per-chunk staging walks only the 512 real pixels x 2 channel halves (2 per thread instead of
@@ -2079,188 +1811,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_s16_kernel(ConvArgs 
 // operand-ready image to read) and are split on the VALU: they are prefetched into registers behind the MFMAs of the chunk
 // before.  The weights are pre-split by the prep kernel, so they go HBM/L2 -> LDS by DMA (no registers, no ds_write).
 // Per chunk and wave: 96 MFMAs, 62 ds_read_b128, ~60 VALU, 6 ds_write_b128, 8 DMA instructions.
+// ---------------------------------------------------------------- the four-wave kernel on v_mfma_f32_16x16x32_f16 (see conv3x3_up2_f16x3_kernel)
 template <int TW, int NI>
 __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, const uint4* __restrict__ wup) {
-  constexpr int NW = 4, NT = 64 * NW, NG = 2, PT = 64 * NW, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
-  static_assert(NI == 1 && (TW == 16 || TW == 32), "one image (16x16) or 8 rows of a 32-wide plane per tile");
-  constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;            // (position, half) pairs staged per thread
-  constexpr int PV = 2 * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;
-  constexpr int WV = 2 * 2 * 8 * 2 * 32, NWI = WV / 64, NWS = NWI / NW;   // weight vectors per chunk; DMA instructions; per wave
-  static_assert(2 * (PVP + WV) * 16 <= 160 * 1024, "two workgroups per CU");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [2 terms][2 halves][PS]
-  uint4* wts = patch + PVP;                                       // [2 terms][2 a][8 slots][2 halves][32 o]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
-  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * 32;
-  const int Hs = a.H >> 1, Ws = a.W >> 1;                        // source plane
-  const size_t HWs = (size_t)Hs * Ws;
-  const float* in_base = a.in + (size_t)b * a.Cin * HWs;
-  const size_t in_left = (size_t)(a.B - b) * a.Cin * HWs * sizeof(float);
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_base), 0,
-      (int)(in_left < 0x7FFFF000ul ? in_left : 0x7FFFF000ul), 0x00020000);
-  const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
-  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wup), 0,
-      (int)((size_t)nchunks * 64 * a.cout_pad * 16), 0x00020000);
-  const int kin = f16_scale_exp(absmax_read(a.amax_in));
-  const int ktot = kin + f16_scale_exp(absmax_read(a.amax_w)) - 2;   // summed weights: up to 4 max|w|
-  const float sc_in = pow2f(kin);
-  const int dbg = a.up >> 1;            // diagnostic ablations (gr_set_tuning "up2_debug"; outputs are then wrong by design): 1 no stores, 2 no MFMA, 4 no activation staging, 8 no weight DMA
-  int voff[NSL], eoff[NSL];
-#pragma unroll
-  for (int s = 0; s < NSL; ++s) {
-    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
-    const int yy = y0 + rr - 1, xx = x0 + c - 1;
-    const bool inb = eh < NEH && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws && b < a.B;
-    const int so = yy * Ws + xx + (8 * hh) * (int)HWs;
-    voff[s] = inb ? so * 4 : (int)0x7FFFF000;
-    eoff[s] = eh < NEH ? eh : -1;
-  }
-  // weight DMA: instruction i = wave + NW * j covers LDS vectors 64 i .. 64 i + 63 = rows 2 i, 2 i + 1 of the chunk's 64 rows
-  const int woff0 = ((2 * wave + (lane >> 5)) * a.cout_pad + o0 + (lane & 31)) * 16, wstep = 2 * NW * a.cout_pad * 16;
-  float pv[NSL][8];
-#define GR_UQ_LOAD(ch_)                                                                                   \
-  {                                                                                                       \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
-      const int soff_ = (int)(((ch_) * BF_CK + j) * HWs * 4);                                             \
-      _Pragma("unroll") for (int s = 0; s < NSL; ++s)                                                     \
-        pv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[s], soff_, 0)); \
-    }                                                                                                     \
-  }
-#define GR_UQ_DMAW(ch_)                                                                                   \
-  {                                                                                                       \
-    const int wsoff_ = (ch_) * 64 * a.cout_pad * 16;                                                      \
-    _Pragma("unroll") for (int j = 0; j < NWS; ++j) lds_dma16(rwt, wts + 64 * (wave + NW * j), woff0 + j * wstep, wsoff_); \
-  }
-#define GR_UQ_STORE(ch_)                                                                                  \
-  {                                                                                                       \
-    if (((ch_) + 1) * BF_CK > a.Cin) {                                                                    \
-      _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                   \
-        const int clim_ = a.Cin - ((tid + NT * s) >= PS ? 8 : 0);                                         \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) if ((ch_) * BF_CK + j >= clim_) pv[s][j] = 0.f;     \
-      }                                                                                                   \
-    }                                                                                                     \
-    _Pragma("unroll") for (int s = 0; s < NSL; ++s) {                                                     \
-      if (eoff[s] >= 0) {                                                                                 \
-        uint4 t0, t1;                                                                                     \
-        split8_f16(pv[s], sc_in, t0, t1);                                                                 \
-        patch[eoff[s]] = t0; patch[2 * PS + eoff[s]] = t1;                                                \
-      }                                                                                                   \
-    }                                                                                                     \
-  }
-  f32x16 acc[2][2][NG];                                            // [row phase a][column phase b][pixel group]
-#pragma unroll
-  for (int pa = 0; pa < 2; ++pa)
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-      for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pa][pb][ng][r] = 0.f;
-  int pix[NG];
-#pragma unroll
-  for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
-    pix[ng] = h * PS + prr * PC + pc;                              // patch row prr = source row y - 1
-  }
-  // The two workgroups of a CU run the same program from (almost) the same start: left alone they stay IN phase - both convert,
-  // both multiply (sharing the matrix pipe), both store - and the phases add up instead of overlapping (ablation, round 3:
-  // skeleton 38 + MFMA 122 + staging 62 + stores 34 = 256 us against 246 measured on G.convB at cfg2).  The workgroup whose waves
-  // sit in the odd wave slots of their SIMDs (HW_ID.wave_id: the one that arrived second, whatever its block index) starts late
-  // by a.nchunks x 512 clocks (gr_set_tuning "up2_stagger"), about half a chunk iteration.
-  if (a.nchunks > 0) {
-    const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (0 << 6) | ((4 - 1) << 11));     // HW_REG_HW_ID bits [3:0] = wave slot on its SIMD
-    if (hwid & 1) {
-#pragma unroll 1
-      for (int i = 0; i < a.nchunks; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  if (!(dbg & 4)) GR_UQ_LOAD(0)
-  if (!(dbg & 8)) GR_UQ_DMAW(0)
-  for (int ch = 0; ch < nchunks; ++ch) {
-    if (!(dbg & 4)) GR_UQ_STORE(ch)                                // the image is free: every wave passed the barrier below
-    dma_publish_barrier();                                         // this chunk's weights have landed, every wave's patch stores are visible
-    if (ch + 1 < nchunks && !(dbg & 4)) GR_UQ_LOAD(ch + 1)         // lands behind the MFMAs
-    if (!(dbg & 2))
-#pragma unroll
-    for (int r3 = 0; r3 < 3; ++r3) {                               // source rows y-1, y, y+1
-#pragma unroll
-      for (int c3 = 0; c3 < 3; ++c3) {                             // source columns x-1, x, x+1: one column's operands at a time
-        uint4 bv[NG][2];
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) bv[ng][t] = patch[t * 2 * PS + pix[ng] + r3 * PC + c3];
-#pragma unroll
-        for (int pa = 0; pa < 2; ++pa) {
-          const int dy = r3 - pa;                                  // row phase a reads source rows y-1+a (dy 0) and y+a (dy 1)
-          if (dy < 0 || dy > 1) continue;
-#pragma unroll
-          for (int pb = 0; pb < 2; ++pb) {
-            const int dx = c3 - pb;                                // column phase b reads source columns x-1+b (dx 0) and x+b (dx 1)
-            if (dx < 0 || dx > 1) continue;
-            uint4 av[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) av[t] = wts[(((t * 2 + pa) * 8 + (dy * 2 + pb) * 2 + dx) * 2 + h) * 32 + l31];
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng) acc[pa][pb][ng] = split_mma<2>(av, bv[ng], acc[pa][pb][ng]);
-          }
-        }
-      }
-    }
-    __syncthreads();                                               // every wave is past the image
-    if (ch + 1 < nchunks && !(dbg & 8)) GR_UQ_DMAW(ch + 1)
-  }
-#undef GR_UQ_LOAD
-#undef GR_UQ_DMAW
-#undef GR_UQ_STORE
-  // epilogue: scale back + bias (+ evaluate()-mode BatchNorm) per channel, one activation switch per block, then two output
-  // rows x float2 per lane
-  float omax = 0.f;
-  const bool has_bn = a.ep.mean != nullptr;
-#pragma unroll
-  for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
-    const int y = y0 + prr, x = x0 + pc;
-    const bool pin = y < Hs && x < Ws && b < a.B && !(dbg & 1);
-    float v[64];                                                   // [r][pa][pb]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = min(o0 + (r & 3) + 8 * (r >> 2) + 4 * h, a.Cout - 1);
-      const float bvv = a.bias ? a.bias[o] : 0.f;
-      float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
-      if (has_bn) { mean = a.ep.mean[o]; invstd = a.ep.invstd[o]; gam = a.ep.gamma[o]; bet = a.ep.beta[o]; }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t = ldexpf(acc[q >> 1][q & 1][ng][r], -ktot) + bvv;
-        if (has_bn) t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(t, mean), invstd), gam), bet);   // same order as conv_epilogue
-        v[r * 4 + q] = t;
-      }
-    }
-    conv_act_block<64>(a.ep, v);
-    {
-      const bool odd = (pc & 1) != 0;
-      float* orow = a.out + ((size_t)b * a.Cout * a.H + 2 * y + (odd ? 1 : 0)) * a.W + 2 * (x - (odd ? 1 : 0));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float4 res = up2_pair_rows(v + r * 4, odd);
-        if (pin && o < a.Cout) {
-          store4(orow + (size_t)o * a.H * a.W, res, a.nt_out != 0);
-          omax = absmax4(omax, res);
-        }
-      }
-    }
-  }
-  if (a.amax_out) absmax_commit(omax, a.amax_out);
-}
-
-// ---------------------------------------------------------------- the four-wave kernel on v_mfma_f32_16x16x32_f16 (see conv3x3_up2_f16x3_s16_kernel)
-template <int TW, int NI>
-__global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_s16_kernel(ConvArgs a, const uint4* __restrict__ wup) {
   constexpr int NW = 4, NT = 64 * NW, NG = 2, PT = 64 * NW, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
   static_assert(NI == 1 && (TW == 16 || TW == 32), "one image (16x16) or 8 rows of a 32-wide plane per tile");
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;            // (position, half) pairs staged per thread
@@ -2331,7 +1884,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_s16_kernel(ConvArgs
       }                                                                                                   \
     }                                                                                                     \
   }
-  constexpr int MB = 2, NB = 2 * NG;                               // 16-channel / 16-pixel blocks per wave (conv3x3_up2_f16x3_s16_kernel)
+  constexpr int MB = 2, NB = 2 * NG;                               // 16-channel / 16-pixel blocks per wave (conv3x3_up2_f16x3_kernel)
   f32x4 acc[2][2][MB][NB];
 #pragma unroll
   for (int pa = 0; pa < 2; ++pa)
@@ -2486,14 +2039,6 @@ static void launch_conv_up2_db(ConvArgs a, const void* wup, hipStream_t s) {
   static const std::string name = "conv3x3_up2_f16x3_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + (DB ? ", true>" : ", false>");   // as rocprofv3 prints it
   const double px = (double)a.B * a.H * a.W;
   // FLOPs reported = those of the layer as the reference defines it (9 taps per output); the kernel issues 4/9 of them
-  if (g_up2_shape == 1) {
-    static bool attr16_set = false;
-    if (!attr16_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_f16x3_s16_kernel<TW, NI, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr16_set = true; }
-    static const std::string name16 = "conv3x3_up2_f16x3_s16_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + (DB ? ", true>" : ", false>");
-    KtScope kt16(name16.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-    hipLaunchKernelGGL((conv3x3_up2_f16x3_s16_kernel<TW, NI, DB>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wup));
-    return;
-  }
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_up2_f16x3_kernel<TW, NI, DB>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wup));
 }
@@ -2519,14 +2064,6 @@ static void launch_conv_up2q(ConvArgs a, const void* wup, hipStream_t s) {
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2q_f16x3_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   static const std::string name = "conv3x3_up2q_f16x3_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";   // as rocprofv3 prints it
   const double px = (double)a.B * a.H * a.W;
-  if (g_up2_shape == 1) {
-    static bool attr16_set = false;
-    if (!attr16_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2q_f16x3_s16_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr16_set = true; }
-    static const std::string name16 = "conv3x3_up2q_f16x3_s16_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ">";
-    KtScope kt16(name16.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-    hipLaunchKernelGGL((conv3x3_up2q_f16x3_s16_kernel<TW, NI>), dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wup));
-    return;
-  }
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / 4 + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_up2q_f16x3_kernel<TW, NI>), dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wup));
 }
@@ -2714,7 +2251,6 @@ bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {
   return W >= 32 && W % 32 == 0 && H % 16 == 0 && (long)B * (H / 16) * (W / 32) * otiles >= g_p16_min_tiles;
 }
 int g_p16_stagger = 0;           // start delay (x 512 clocks) of the second-dispatched workgroups: measured useless (tools/stagger_p16.py), kept as a knob
-int g_up2_shape = getenv("GR_UP2_SHAPE") ? atoi(getenv("GR_UP2_SHAPE")) : 1;      // MFMA shape of the eight-wave up-sampling kernel: 0 = 32x32x16, 1 = 16x16x32 (default: -5 to -12 % per launch)
 int g_p16_variant = 1;          // 1: four-wave workgroups, two per CU (conv3x3_p16_quad_kernel); 0: eight-wave persistent (conv3x3_p16_wide_kernel)
 template <int TW, int NI, int NG = 4, int MT = 2>
 static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {
@@ -3640,6 +3176,9 @@ struct WgradP16Args {
   int B, Cin, Cout, H, W, n_ob, n_cb, nsplit, cinp, coutp, units;     // units = B * H * W / 64 chunks of 64 pixels
   const unsigned *amax_x, *amax_dy;
 };
+// MFMA shape: v_mfma_f32_16x16x32_f16, K = 32 pixels per step, the wave's 32 x 32 block per tap as 2 x 2 accumulator blocks of 16 x 16 (a
+// 16-lane group of a transposing read covers 8 pixels of ONE 16-channel block).  Round 3, same box, against the 32x32x16 version (16 pixels
+// per step, one f32x16 accumulator per tap; git history): 1018 -> 878 us (32-wide) and 794 -> 736 (64-wide) at cfg3, 137 -> 124 at cfg2.
 template <int W_>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args a) {
   constexpr int R = 64 / W_ > 0 ? 64 / W_ : 1;                 // image rows per 64-pixel chunk (W_ = 16, 32 or 64)
@@ -3666,19 +3205,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.x), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.dy), 0, (int)(dbytes < 0x7FFFF000ul ? dbytes : 0x7FFFF000ul), 0x00020000);
   const int ktot = f16_scale_exp(absmax_read(a.amax_x)) + f16_scale_exp(absmax_read(a.amax_dy));
-  f32x16 acc[9];
+  f32x4 acc[9][2][2];                                           // [tap][16-o block][16-ci block]: lane = ci, register = o 4 G + r
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  // transposing-read addresses: 16-lane group G = lane >> 4 covers channels 16 (G & 1) .. +15 and pixels 8 (G >> 1) .. +3
-  // (+4 for the second read); lane 4q + p of the group points at pixel row q, channels 4p .. 4p+3 of that 16-channel block
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][m >> 1][m & 1][r] = 0.f;
+  // transposing-read addresses for v_mfma_f32_16x16x32_f16 (K = 32 pixels per step): 16-lane group G = lane >> 4 covers pixels 8 G .. +3
+  // (+4 for the second read) of ONE 16-channel block; lane 4q + p of the group points at pixel row q, channels 4p .. 4p+3 of that block
   const int li = lane & 15, q = li >> 2, pp = li & 3, G = lane >> 4;
-  const int chg = 2 * (G & 1) + (pp >> 1), boff = 8 * (pp & 1);  // 8-channel group within the wave's 32 channels, byte offset in the vector
-  const int pxl = 8 * (G >> 1) + q;                              // pixel within a 16-pixel step (first read; second: + 4)
-  // per-lane vector addresses of step 0 (the lane's pixel row pxl of the step, its 8-channel group); a step adds a uniform offset
+  const int chg = pp >> 1, boff = 8 * (pp & 1);                  // 8-channel group within the 16-channel block, byte offset in the vector
+  const int pxl = 8 * G + q;                                     // pixel within a 32-pixel step (first read; second: + 4)
+  // per-lane vector addresses of step 0, block 0; a step or a block adds a uniform offset.  x patch: 32 pixels are two rows of a 16-wide plane
   const uint4* abase = ds + (wo * 4 + chg) * 2 * DSP + pxl;
-  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + pxl;
+  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + (W_ == 16 ? (pxl >> 4) * PC + (pxl & 15) : pxl);
   // DMA addresses: the flat index -> (plane, row, column) decomposition of a patch vector does not depend on the chunk, only the
   // image (scalar offset of the instruction) and the chunk's first row do.  Per lane and instruction: static byte offset with the
   // patch row in its low 4 bits (15 = never valid).  (Recomputing it per chunk cost ~30 VALU instructions per DMA instruction:
@@ -3713,29 +3254,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
     for (int j = 0; j < NDS; ++j) lds_dma16(rd, ds + DSP * (wave + 4 * j), dst_[j] + p0b, dsoff);      // plane = (o group, term): 64 pixels = one instruction
     dma_publish_barrier();                                       // the image has landed
 #pragma unroll 1
-    for (int ks = 0; ks < 4; ++ks) {
-      const int srow = (16 * ks) / W_, scol = 16 * ks - srow * W_;     // the step's 16 pixels: row srow of the chunk, columns scol .. scol + 15
-      // A = dy: [o][k]; two transposing reads (4 pixels each) per term
-      uint4 av[2];
+    for (int ks = 0; ks < 2; ++ks) {
+      const int srow = (32 * ks) / W_, scol = 32 * ks - srow * W_;     // the step's 32 pixels start at row srow of the chunk, column scol
+      // A = dy: [o][k]; two transposing reads (4 pixels each) per term and 16-channel block
+      uint4 av[2][2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const uint4* base = abase + t * DSP + 16 * ks;
-        const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
-        av[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      }
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint4* base = abase + (mo * 4 + t) * DSP + 32 * ks;
+          const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+          av[mo][t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
       const uint4* bstep = bbase + srow * PC + scol;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - 3 * ky;
-        uint4 bv[2];
+        uint4 bv[2][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          // (the second read is 4 pixels further along x: same row - 16-pixel steps never straddle a row, W_ % 16 == 0)
-          const uint4* base = bstep + t * PSP + ky * PC + kx;
-          const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
-          bv[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-        acc[tap] = split_mma<2>(av, bv, acc[tap]);
+        for (int mc = 0; mc < 2; ++mc)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            // (the second read is 4 pixels further along x: same row - 8-pixel runs never straddle a row, W_ % 16 == 0)
+            const uint4* base = bstep + (mc * 4 + t) * PSP + ky * PC + kx;
+            const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+            bv[mc][t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+          for (int mc = 0; mc < 2; ++mc) {
+            f32x4 c_ = acc[tap][mo][mc];
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][1]), __builtin_bit_cast(f16x8, bv[mc][0]), c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[mc][1]), c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[mc][0]), c_, 0, 0, 0);
+            acc[tap][mo][mc] = c_;
+          }
       }
     }
   }
@@ -3745,15 +3299,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
   // store tails run at a few bytes per clock per CU) that was most of the kernel's fixed ~23 us.  conv3x3_wgrad_reduce_tiled_kernel
   // reads the same order back with 16-byte loads and scatters only the final 9 * Cout * Cin values.
   float4* slp = reinterpret_cast<float4*>(a.slab) + (size_t)split * 9 * a.coutp * a.cinp / 4;
+  // (accumulator block (mo, mc), lane group G: output channels 16 mo + 4 G .. + 3 of input channel 16 mc + li - entered at the slab position the
+  // 32x32 accumulator layout gives that (o, ci) quad, so conv3x3_wgrad_reduce_tiled_kernel reads both kernels' slabs alike)
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + q) * 64 + lane;
-      slp[f] = make_float4(ldexpf(acc[tap][4 * q], -ktot), ldexpf(acc[tap][4 * q + 1], -ktot), ldexpf(acc[tap][4 * q + 2], -ktot), ldexpf(acc[tap][4 * q + 3], -ktot));
-    }
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int mc = 0; mc < 2; ++mc) {
+        const int qs = 2 * mo + (G >> 1), ls = 32 * (G & 1) + 16 * mc + li;
+        const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + qs) * 64 + ls;
+        const f32x4 c_ = acc[tap][mo][mc];
+        slp[f] = make_float4(ldexpf(c_[0], -ktot), ldexpf(c_[1], -ktot), ldexpf(c_[2], -ktot), ldexpf(c_[3], -ktot));
+      }
 }
-
+// The same with the two workgroups of a CU fused into ONE of eight waves whose halves PING-PONG: while half A multiplies its
+// chunk, half B requests its next chunk by DMA and waits for it; a workgroup barrier swaps the roles.  Four-wave workgroups
+// left this to chance (both resident workgroups often loaded, or multiplied, at the same time); here a multiplying half always
+// has the matrix pipe to itself and a loading half always has a full multiply phase to hide its DMA behind.  Each half
+// accumulates its own part of the workgroup's pixel range; at the end half B's accumulators go through LDS into half A's, so
+// the kernel leaves HALF as many slabs (one per CU instead of two): half the slab write and half the reduction.
 // The same with the two workgroups of a CU fused into ONE of eight waves whose halves PING-PONG: while half A multiplies its
 // chunk, half B requests its next chunk by DMA and waits for it; a workgroup barrier swaps the roles.  Four-wave workgroups
 // left this to chance (both resident workgroups often loaded, or multiplied, at the same time); here a multiplying half always
@@ -3788,19 +3353,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.x), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.dy), 0, (int)(dbytes < 0x7FFFF000ul ? dbytes : 0x7FFFF000ul), 0x00020000);
   const int ktot = f16_scale_exp(absmax_read(a.amax_x)) + f16_scale_exp(absmax_read(a.amax_dy));
-  f32x16 acc[9];
+  f32x4 acc[9][2][2];                                           // [tap][16-o block][16-ci block]: lane = ci, register = o 4 G + r
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  // transposing-read addresses: 16-lane group G = lane >> 4 covers channels 16 (G & 1) .. +15 and pixels 8 (G >> 1) .. +3
-  // (+4 for the second read); lane 4q + p of the group points at pixel row q, channels 4p .. 4p+3 of that 16-channel block
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][m >> 1][m & 1][r] = 0.f;
+  // transposing-read addresses for v_mfma_f32_16x16x32_f16 (K = 32 pixels per step): 16-lane group G = lane >> 4 covers pixels 8 G .. +3
+  // (+4 for the second read) of ONE 16-channel block; lane 4q + p of the group points at pixel row q, channels 4p .. 4p+3 of that block
   const int li = lane & 15, q = li >> 2, pp = li & 3, G = lane >> 4;
-  const int chg = 2 * (G & 1) + (pp >> 1), boff = 8 * (pp & 1);  // 8-channel group within the wave's 32 channels, byte offset in the vector
-  const int pxl = 8 * (G >> 1) + q;                              // pixel within a 16-pixel step (first read; second: + 4)
-  // per-lane vector addresses of step 0 (the lane's pixel row pxl of the step, its 8-channel group); a step adds a uniform offset
+  const int chg = pp >> 1, boff = 8 * (pp & 1);                  // 8-channel group within the 16-channel block, byte offset in the vector
+  const int pxl = 8 * G + q;                                     // pixel within a 32-pixel step (first read; second: + 4)
+  // per-lane vector addresses of step 0, block 0; a step or a block adds a uniform offset.  x patch: 32 pixels are two rows of a 16-wide plane
   const uint4* abase = ds + (wo * 4 + chg) * 2 * DSP + pxl;
-  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + pxl;
+  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + (W_ == 16 ? (pxl >> 4) * PC + (pxl & 15) : pxl);
   // DMA addresses: the flat index -> (plane, row, column) decomposition of a patch vector does not depend on the chunk, only the
   // image (scalar offset of the instruction) and the chunk's first row do.  Per lane and instruction: static byte offset with the
   // patch row in its low 4 bits (15 = never valid).  (Recomputing it per chunk cost ~30 VALU instructions per DMA instruction:
@@ -3836,29 +3403,42 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   };
   auto multiply = [&]() {
 #pragma unroll 1
-    for (int ks = 0; ks < 4; ++ks) {
-      const int srow = (16 * ks) / W_, scol = 16 * ks - srow * W_;     // the step's 16 pixels: row srow of the chunk, columns scol .. scol + 15
-      // A = dy: [o][k]; two transposing reads (4 pixels each) per term
-      uint4 av[2];
+    for (int ks = 0; ks < 2; ++ks) {
+      const int srow = (32 * ks) / W_, scol = 32 * ks - srow * W_;     // the step's 32 pixels start at row srow of the chunk, column scol
+      // A = dy: [o][k]; two transposing reads (4 pixels each) per term and 16-channel block
+      uint4 av[2][2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const uint4* base = abase + t * DSP + 16 * ks;
-        const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
-        av[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      }
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint4* base = abase + (mo * 4 + t) * DSP + 32 * ks;
+          const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+          av[mo][t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
       const uint4* bstep = bbase + srow * PC + scol;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - 3 * ky;
-        uint4 bv[2];
+        uint4 bv[2][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          // (the second read is 4 pixels further along x: same row - 16-pixel steps never straddle a row, W_ % 16 == 0)
-          const uint4* base = bstep + t * PSP + ky * PC + kx;
-          const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
-          bv[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-        acc[tap] = split_mma<2>(av, bv, acc[tap]);
+        for (int mc = 0; mc < 2; ++mc)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            // (the second read is 4 pixels further along x: same row - 8-pixel runs never straddle a row, W_ % 16 == 0)
+            const uint4* base = bstep + (mc * 4 + t) * PSP + ky * PC + kx;
+            const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+            bv[mc][t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+          for (int mc = 0; mc < 2; ++mc) {
+            f32x4 c_ = acc[tap][mo][mc];
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][1]), __builtin_bit_cast(f16x8, bv[mc][0]), c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[mc][1]), c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[mc][0]), c_, 0, 0, 0);
+            acc[tap][mo][mc] = c_;
+          }
       }
     }
   };
@@ -3882,14 +3462,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t0 + t][r];
+        for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t0 + t][r >> 3][(r >> 2) & 1][r & 3];
     }
     __syncthreads();
     if (half == 0) {
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t0 + t][r] += red[((t * 4 + wave) * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[t0 + t][r >> 3][(r >> 2) & 1][r & 3] += red[((t * 4 + wave) * 16 + r) * 64 + lane];
     }
     __syncthreads();
   }
@@ -3900,13 +3480,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   // store tails run at a few bytes per clock per CU) that was most of the kernel's fixed ~23 us.  conv3x3_wgrad_reduce_tiled_kernel
   // reads the same order back with 16-byte loads and scatters only the final 9 * Cout * Cin values.
   float4* slp = reinterpret_cast<float4*>(a.slab) + (size_t)split * 9 * a.coutp * a.cinp / 4;
+  // (accumulator block (mo, mc), lane group G: output channels 16 mo + 4 G .. + 3 of input channel 16 mc + li - entered at the slab position the
+  // 32x32 accumulator layout gives that (o, ci) quad, so conv3x3_wgrad_reduce_tiled_kernel reads both kernels' slabs alike)
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + q) * 64 + lane;
-      slp[f] = make_float4(ldexpf(acc[tap][4 * q], -ktot), ldexpf(acc[tap][4 * q + 1], -ktot), ldexpf(acc[tap][4 * q + 2], -ktot), ldexpf(acc[tap][4 * q + 3], -ktot));
-    }
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int mc = 0; mc < 2; ++mc) {
+        const int qs = 2 * mo + (G >> 1), ls = 32 * (G & 1) + 16 * mc + li;
+        const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + qs) * 64 + ls;
+        const f32x4 c_ = acc[tap][mo][mc];
+        slp[f] = make_float4(ldexpf(c_[0], -ktot), ldexpf(c_[1], -ktot), ldexpf(c_[2], -ktot), ldexpf(c_[3], -ktot));
+      }
 }
 // GR_WGRAD_PP: 1 (default) = the ping-pong kernel on 16-wide planes only, 2 = everywhere, 0 = never.  Measured at cfg2 per launch:
 // 16-wide 52 -> 50 us, and the slab reduction 16.5 -> 10.8 us; 32-wide 70 -> 98 us (its 34 KB x patch per 64 pixels makes the

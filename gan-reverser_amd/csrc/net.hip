@@ -234,7 +234,6 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!strcmp(key, "p16_min_tiles")) { gr::g_p16_min_tiles = value; return GR_OK; }
   if (!strcmp(key, "p16_stagger")) { gr::g_p16_stagger = value; return GR_OK; }
   if (!strcmp(key, "p16_variant")) { gr::g_p16_variant = value; return GR_OK; }
-  if (!strcmp(key, "up2_shape")) { gr::g_up2_shape = value; return GR_OK; }
   if (!strcmp(key, "p16_debug")) { gr::g_p16_debug = value; return GR_OK; }
   if (!strcmp(key, "up2_debug")) { gr::g_up2_debug = value; return GR_OK; }     // diagnostic ablations of the four-wave up-sampling kernel
   if (!strcmp(key, "nt_stores")) { gr::g_nt_stores = value; return GR_OK; }        // bit mask: which kernels store their outputs non-temporally (kernels.h)
