@@ -1595,7 +1595,7 @@ __device__ __forceinline__ float4 up2_pair_rows(const float* v, bool odd) {
   _Pragma("unroll") for (int pb = 0; pb < 2; ++pb) {                                                           \
     uint4 bv[NB][2];                                                                                           \
     _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                          \
-      _Pragma("unroll") for (int t = 0; t < 2; ++t) bv[nb][t] = (pc_)[t * 2 * PS + pix[nb] + (r3_) * PC + pb]; \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) bv[nb][t] = (pc_)[t * 2 * PSL + pix[nb] + (r3_) * PC + pb]; \
     _Pragma("unroll") for (int pa = 0; pa < 2; ++pa) {                                                         \
       const int dy = (r3_) - pa;                    /* row phase a reads source rows y-1+a (dy 0) and y+a (dy 1) */ \
       if (dy < 0 || dy > 1) continue;                                                                          \
@@ -1615,6 +1615,10 @@ __device__ __forceinline__ float4 up2_pair_rows(const float* v, bool odd) {
 template <int TW, int NI, bool DB>
 __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, const uint4* __restrict__ wup) {
   constexpr int NT = 512, NG = 2, PT = 512, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
+  // plane stride in LDS: a multiple of 16 vectors.  A ds_read_b128 whose four 16-lane groups start at different 16-byte slots of the 256-byte
+  // bank row runs at half rate (tools/probe/lds_conflict_probe: +648 vectors = 8 slots: 127 B/clk/CU, +656: 239) - on the counters a third
+  // of this kernel's LDS cycles were bank conflicts with the unpadded planes (round 3, 16x16x32 lane mapping: lane quarter = channel half)
+  constexpr int PSL = (PS + 15) / 16 * 16;
   // NI > 1: the tile is NI whole images, so every halo slot of the patch is zero padding for every chunk.  Those slots are
   // zeroed once and the per-chunk staging walks only the 512 real pixels x 2 channel halves (2 per thread instead of
   // 3 (16-wide) or 4 (8-wide) slots: a third / half of the loads, conversions and LDS stores).
@@ -1624,8 +1628,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
   static_assert(NI == 1 || IH * NI * TW == PT, "tile must hold whole images");
   static_assert((TW == 32 && NI == 1) || (TW == 16 && NI == 2) || (TW == 8 && NI == 8), "tile_pixel assumes these tilings");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [2][2][PS]
-  uint4* wts = patch + 2 * 2 * PS;                                // [2 terms][2 a][8 slots][2 halves][32]
+  uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [2][2][PSL]
+  uint4* wts = patch + 2 * 2 * PSL;                                // [2 terms][2 a][8 slots][2 halves][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4, hh = q & 1, dxq = q >> 1;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ot = bid % a.n_otiles; bid /= a.n_otiles;
@@ -1655,7 +1659,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
       const int so = yy * Ws + xx + (img * a.Cin + 8 * hh) * (int)HWs;
       voff[s] = inb ? so * 4 : (int)0x7FFFF000;
       clim[s] = a.Cin - 8 * hh;
-      eoff[s] = hh * PS + (img * (IH + 2) + r + 1) * PC + pc + 1;
+      eoff[s] = hh * PSL + (img * (IH + 2) + r + 1) * PC + pc + 1;
     } else {
       const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, rr = e / PC, c = e - rr * PC;
       const int yy = y0 + rr - 1, xx = x0 + c - 1;
@@ -1663,7 +1667,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
       const int so = yy * Ws + xx + (8 * hh) * (int)HWs;
       voff[s] = inb ? so * 4 : (int)0x7FFFF000;
       clim[s] = a.Cin - 8 * hh;
-      eoff[s] = eh < NEH ? eh : -1;
+      eoff[s] = eh < NEH ? hh * PSL + e : -1;
     }
   }
   const int wvoff = ((tid >> 5) * a.cout_pad + o0 + (tid & 31)) * 16;   // weight vector f = tid + NT*i: row (tid>>5) + 16i
@@ -1689,7 +1693,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
       if (COMPACT || eoff[s] >= 0) {                                                                      \
         uint4 t0, t1;                                                                                     \
         split8_f16(pv[s], sc_in, t0, t1);                                                                 \
-        patch[eoff[s]] = t0; patch[2 * PS + eoff[s]] = t1;                                                \
+        patch[eoff[s]] = t0; patch[2 * PSL + eoff[s]] = t1;                                                \
       }                                                                                                   \
     }                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < NWV; ++i) wts[tid + NT * i] = wv[i];                            \
@@ -1714,13 +1718,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
   for (int nb = 0; nb < NB; ++nb) {
     const int p = (wave * NB + nb) * 16 + l15; int prr, pc; tile_pixel<TW>(p, prr, pc);
     const int pr = NI > 1 ? prr + 2 * (prr / IH) : prr;
-    pix[nb] = hh * PS + pr * PC + pc + dxq;                        // patch row pr = source row y - 1; column slot dx reads x - 1 + b + dx
+    pix[nb] = hh * PSL + pr * PC + pc + dxq;                        // patch row pr = source row y - 1; column slot dx reads x - 1 + b + dx
   }
   const int wq = dxq * 64 + hh * 32 + l15;
-  constexpr int LBUF = 2 * 2 * PS + WV;                           // uint4s of one (patch, weights) image
+  constexpr int LBUF = 2 * 2 * PSL + WV;                           // uint4s of one (patch, weights) image
   GR_UP_LOAD(0)
   if (COMPACT) {                                                   // the padding slots, once (both images when double-buffered)
-    for (int i = tid; i < (DB ? 2 : 1) * LBUF; i += NT) if (i % LBUF < 2 * 2 * PS) patch[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < (DB ? 2 : 1) * LBUF; i += NT) if (i % LBUF < 2 * 2 * PSL) patch[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
   }
   if (DB) {
@@ -1817,7 +1821,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, 
   constexpr int NW = 4, NT = 64 * NW, NG = 2, PT = 64 * NW, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC;
   static_assert(NI == 1 && (TW == 16 || TW == 32), "one image (16x16) or 8 rows of a 32-wide plane per tile");
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;            // (position, half) pairs staged per thread
-  constexpr int PV = 2 * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;
+  constexpr int PSL = (PS + 15) / 16 * 16;                          // plane stride in LDS (conv3x3_up2_f16x3_kernel: the four lane quarters of a read start at the same 16-byte slot)
+  constexpr int PV = 2 * 2 * PSL, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;
   constexpr int WV = 2 * 2 * 8 * 2 * 32, NWI = WV / 64, NWS = NWI / NW;   // weight vectors per chunk; DMA instructions; per wave
   static_assert(2 * (PVP + WV) * 16 <= 160 * 1024, "two workgroups per CU");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1850,7 +1855,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, 
     const bool inb = eh < NEH && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws && b < a.B;
     const int so = yy * Ws + xx + (8 * eh_h) * (int)HWs;
     voff[s] = inb ? so * 4 : (int)0x7FFFF000;
-    eoff[s] = eh < NEH ? eh : -1;
+    eoff[s] = eh < NEH ? eh_h * PSL + e : -1;
   }
   // weight DMA: instruction i = wave + NW * j covers LDS vectors 64 i .. 64 i + 63 = rows 2 i, 2 i + 1 of the chunk's 64 rows
   const int woff0 = ((2 * wave + (lane >> 5)) * a.cout_pad + o0 + (lane & 31)) * 16, wstep = 2 * NW * a.cout_pad * 16;
@@ -1880,7 +1885,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, 
       if (eoff[s] >= 0) {                                                                                 \
         uint4 t0, t1;                                                                                     \
         split8_f16(pv[s], sc_in, t0, t1);                                                                 \
-        patch[eoff[s]] = t0; patch[2 * PS + eoff[s]] = t1;                                                \
+        patch[eoff[s]] = t0; patch[2 * PSL + eoff[s]] = t1;                                                \
       }                                                                                                   \
     }                                                                                                     \
   }
@@ -1900,7 +1905,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, 
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int p = (wave * NB + nb) * 16 + l15; int prr, pc; tile_pixel<TW>(p, prr, pc);
-    pix[nb] = hh * PS + prr * PC + pc + dxq;                       // patch row prr = source row y - 1; column slot dx reads x - 1 + b + dx
+    pix[nb] = hh * PSL + prr * PC + pc + dxq;                       // patch row prr = source row y - 1; column slot dx reads x - 1 + b + dx
   }
   const int wq = dxq * 64 + hh * 32 + l15;
   // The two workgroups of a CU run the same program from (almost) the same start: left alone they stay IN phase - both convert,
@@ -2028,11 +2033,11 @@ void launch_conv_weight_up2_split(const float* w_native, void* dst, int cin, int
 }
 template <int TW, int NI, bool DB>
 static void launch_conv_up2_db(ConvArgs a, const void* wup, hipStream_t s) {
-  constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2);
+  constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), PSL = (PS + 15) / 16 * 16;
   const int Hs = a.H / 2, Ws = a.W / 2;
   a.tiles_x = (Ws + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (Hs + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / 32;
-  const size_t lds = (DB ? 2 : 1) * 16 * (size_t)(2 * 2 * PS + 2 * 2 * 8 * 2 * 32);
+  const size_t lds = (DB ? 2 : 1) * 16 * (size_t)(2 * 2 * PSL + 2 * 2 * 8 * 2 * 32);
   const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_f16x3_kernel<TW, NI, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
@@ -2044,8 +2049,8 @@ static void launch_conv_up2_db(ConvArgs a, const void* wup, hipStream_t s) {
 }
 template <int TW, int NI>
 static void launch_conv_up2_t(const ConvArgs& a, const void* wup, hipStream_t s) {
-  constexpr int IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2);
-  constexpr bool FITS = 2 * 16 * (2 * 2 * PS + 2 * 2 * 8 * 2 * 32) <= 160 * 1024;    // two LDS images where they fit (not the 8-wide tile)
+  constexpr int IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), PSL = (PS + 15) / 16 * 16;
+  constexpr bool FITS = 2 * 16 * (2 * 2 * PSL + 2 * 2 * 8 * 2 * 32) <= 160 * 1024;    // two LDS images where they fit (not the 8-wide tile)
   static int db = -1;
   if (db < 0) { const char* e = getenv("GR_UP2_DB"); db = e ? atoi(e) : 1; }
   if (FITS && db) launch_conv_up2_db<TW, NI, FITS>(a, wup, s);
@@ -2053,7 +2058,7 @@ static void launch_conv_up2_t(const ConvArgs& a, const void* wup, hipStream_t s)
 }
 template <int TW, int NI>
 static void launch_conv_up2q(ConvArgs a, const void* wup, hipStream_t s) {
-  constexpr int PT = 256, TR = PT / TW, IH = PT / (NI * TW), PS = NI * (IH + 2) * (TW + 2), PV = 2 * 2 * PS, PVP = (PV + 63) / 64 * 64;
+  constexpr int PT = 256, TR = PT / TW, IH = PT / (NI * TW), PS = NI * (IH + 2) * (TW + 2), PSL = (PS + 15) / 16 * 16, PV = 2 * 2 * PSL, PVP = (PV + 63) / 64 * 64;
   const int Hs = a.H / 2, Ws = a.W / 2;
   a.tiles_x = (Ws + TW - 1) / TW; a.tiles_y = (Hs + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / 32;
