@@ -3199,7 +3199,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
   uint4* xs = reinterpret_cast<uint4*>(smem_raw);               // [ci group 8][term 2][PS]
   uint4* ds = xs + XVP;                                         // [o group 8][term 2][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int wo = wave >> 1, wc = wave & 1;                      // this wave's 32-o and 32-ci halves of the 64 x 64 block
+  // wave tile: ALL 64 output channels x the wave's 16 input channels x 9 taps.  A tap's x fragment cannot be shared between taps, so what a B read
+  // feeds is the number of output-channel blocks it meets: four here (52 transposing-read pairs per 108 MFMAs) against two with 32 x 32 tiles
+  // (80 per 108) - these kernels sat at 87-92 % LDS-active on the counters (round 3, profiles/r03_pmc_step_conv_cfg3.txt)
   int bid = blockIdx.x;
   const int cb = bid % a.n_cb; bid /= a.n_cb;
   const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
@@ -3210,21 +3212,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.x), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.dy), 0, (int)(dbytes < 0x7FFFF000ul ? dbytes : 0x7FFFF000ul), 0x00020000);
   const int ktot = f16_scale_exp(absmax_read(a.amax_x)) + f16_scale_exp(absmax_read(a.amax_dy));
-  f32x4 acc[9][2][2];                                           // [tap][16-o block][16-ci block]: lane = ci, register = o 4 G + r
+  f32x4 acc[9][4];                                              // [tap][16-o block]: lane = ci (16 wave + li), register = o 16 mo + 4 G + r
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][m >> 1][m & 1][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[t][m][r] = 0.f;
   // transposing-read addresses for v_mfma_f32_16x16x32_f16 (K = 32 pixels per step): 16-lane group G = lane >> 4 covers pixels 8 G .. +3
   // (+4 for the second read) of ONE 16-channel block; lane 4q + p of the group points at pixel row q, channels 4p .. 4p+3 of that block
   const int li = lane & 15, q = li >> 2, pp = li & 3, G = lane >> 4;
   const int chg = pp >> 1, boff = 8 * (pp & 1);                  // 8-channel group within the 16-channel block, byte offset in the vector
   const int pxl = 8 * G + q;                                     // pixel within a 32-pixel step (first read; second: + 4)
   // per-lane vector addresses of step 0, block 0; a step or a block adds a uniform offset.  x patch: 32 pixels are two rows of a 16-wide plane
-  const uint4* abase = ds + (wo * 4 + chg) * 2 * DSP + pxl;
-  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + (W_ == 16 ? (pxl >> 4) * PC + (pxl & 15) : pxl);
+  const uint4* abase = ds + chg * 2 * DSP + pxl;
+  const uint4* bbase = xs + (wave * 2 + chg) * 2 * PSP + (W_ == 16 ? (pxl >> 4) * PC + (pxl & 15) : pxl);
   // DMA addresses: the flat index -> (plane, row, column) decomposition of a patch vector does not depend on the chunk, only the
   // image (scalar offset of the instruction) and the chunk's first row do.  Per lane and instruction: static byte offset with the
   // patch row in its low 4 bits (15 = never valid).  (Recomputing it per chunk cost ~30 VALU instructions per DMA instruction:
@@ -3262,9 +3264,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
     for (int ks = 0; ks < 2; ++ks) {
       const int srow = (32 * ks) / W_, scol = 32 * ks - srow * W_;     // the step's 32 pixels start at row srow of the chunk, column scol
       // A = dy: [o][k]; two transposing reads (4 pixels each) per term and 16-channel block
-      uint4 av[2][2];
+      uint4 av[4][2];
 #pragma unroll
-      for (int mo = 0; mo < 2; ++mo)
+      for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const uint4* base = abase + (mo * 4 + t) * DSP + 32 * ks;
@@ -3275,26 +3277,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - 3 * ky;
-        uint4 bv[2][2];
+        uint4 bv[2];
 #pragma unroll
-        for (int mc = 0; mc < 2; ++mc)
+        for (int t = 0; t < 2; ++t) {
+          // (the second read is 4 pixels further along x: same row - 8-pixel runs never straddle a row, W_ % 16 == 0)
+          const uint4* base = bstep + t * PSP + ky * PC + kx;
+          const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+          bv[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            // (the second read is 4 pixels further along x: same row - 8-pixel runs never straddle a row, W_ % 16 == 0)
-            const uint4* base = bstep + (mc * 4 + t) * PSP + ky * PC + kx;
-            const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
-            bv[mc][t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          }
-#pragma unroll
-        for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-          for (int mc = 0; mc < 2; ++mc) {
-            f32x4 c_ = acc[tap][mo][mc];
-            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][1]), __builtin_bit_cast(f16x8, bv[mc][0]), c_, 0, 0, 0);
-            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[mc][1]), c_, 0, 0, 0);
-            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[mc][0]), c_, 0, 0, 0);
-            acc[tap][mo][mc] = c_;
-          }
+        for (int mo = 0; mo < 4; ++mo) {
+          f32x4 c_ = acc[tap][mo];
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][1]), __builtin_bit_cast(f16x8, bv[0]), c_, 0, 0, 0);
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[1]), c_, 0, 0, 0);
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[0]), c_, 0, 0, 0);
+          acc[tap][mo] = c_;
+        }
       }
     }
   }
@@ -3304,19 +3302,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
   // store tails run at a few bytes per clock per CU) that was most of the kernel's fixed ~23 us.  conv3x3_wgrad_reduce_tiled_kernel
   // reads the same order back with 16-byte loads and scatters only the final 9 * Cout * Cin values.
   float4* slp = reinterpret_cast<float4*>(a.slab) + (size_t)split * 9 * a.coutp * a.cinp / 4;
-  // (accumulator block (mo, mc), lane group G: output channels 16 mo + 4 G .. + 3 of input channel 16 mc + li - entered at the slab position the
-  // 32x32 accumulator layout gives that (o, ci) quad, so conv3x3_wgrad_reduce_tiled_kernel reads both kernels' slabs alike)
+  // (accumulator block mo of wave w, lane group G: output channels 16 mo + 4 G .. + 3 of input channel 16 w + li - entered at the slab position
+  // [wo][wc][q][lane] that a 32 x 32 accumulator layout gives that (o, ci) quad: the format conv3x3_wgrad_reduce_tiled_kernel reads)
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-      for (int mc = 0; mc < 2; ++mc) {
-        const int qs = 2 * mo + (G >> 1), ls = 32 * (G & 1) + 16 * mc + li;
-        const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + qs) * 64 + ls;
-        const f32x4 c_ = acc[tap][mo][mc];
-        slp[f] = make_float4(ldexpf(c_[0], -ktot), ldexpf(c_[1], -ktot), ldexpf(c_[2], -ktot), ldexpf(c_[3], -ktot));
-      }
+    for (int mo = 0; mo < 4; ++mo) {
+      const int wo = mo >> 1, wc = wave >> 1, qs = 2 * (mo & 1) + (G >> 1), ls = 32 * (G & 1) + 16 * (wave & 1) + li;
+      const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + qs) * 64 + ls;
+      const f32x4 c_ = acc[tap][mo];
+      slp[f] = make_float4(ldexpf(c_[0], -ktot), ldexpf(c_[1], -ktot), ldexpf(c_[2], -ktot), ldexpf(c_[3], -ktot));
+    }
 }
 // The same with the two workgroups of a CU fused into ONE of eight waves whose halves PING-PONG: while half A multiplies its
 // chunk, half B requests its next chunk by DMA and waits for it; a workgroup barrier swaps the roles.  Four-wave workgroups
@@ -3345,7 +3341,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   uint4* xs = reinterpret_cast<uint4*>(smem_raw) + half * IMG;  // this half's image: [ci group 8][term 2][PS]
   uint4* ds = xs + XVP;                                         // [o group 8][term 2][64]
-  const int wo = wave >> 1, wc = wave & 1;                      // this wave's 32-o and 32-ci halves of the 64 x 64 block
+  // wave tile: ALL 64 output channels x the wave's 16 input channels x 9 taps.  A tap's x fragment cannot be shared between taps, so what a B read
+  // feeds is the number of output-channel blocks it meets: four here (52 transposing-read pairs per 108 MFMAs) against two with 32 x 32 tiles
+  // (80 per 108) - these kernels sat at 87-92 % LDS-active on the counters (round 3, profiles/r03_pmc_step_conv_cfg3.txt)
   int bid = blockIdx.x;
   const int cb = bid % a.n_cb; bid /= a.n_cb;
   const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
@@ -3358,21 +3356,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.x), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.dy), 0, (int)(dbytes < 0x7FFFF000ul ? dbytes : 0x7FFFF000ul), 0x00020000);
   const int ktot = f16_scale_exp(absmax_read(a.amax_x)) + f16_scale_exp(absmax_read(a.amax_dy));
-  f32x4 acc[9][2][2];                                           // [tap][16-o block][16-ci block]: lane = ci, register = o 4 G + r
+  f32x4 acc[9][4];                                              // [tap][16-o block]: lane = ci (16 wave + li), register = o 16 mo + 4 G + r
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][m >> 1][m & 1][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[t][m][r] = 0.f;
   // transposing-read addresses for v_mfma_f32_16x16x32_f16 (K = 32 pixels per step): 16-lane group G = lane >> 4 covers pixels 8 G .. +3
   // (+4 for the second read) of ONE 16-channel block; lane 4q + p of the group points at pixel row q, channels 4p .. 4p+3 of that block
   const int li = lane & 15, q = li >> 2, pp = li & 3, G = lane >> 4;
   const int chg = pp >> 1, boff = 8 * (pp & 1);                  // 8-channel group within the 16-channel block, byte offset in the vector
   const int pxl = 8 * G + q;                                     // pixel within a 32-pixel step (first read; second: + 4)
   // per-lane vector addresses of step 0, block 0; a step or a block adds a uniform offset.  x patch: 32 pixels are two rows of a 16-wide plane
-  const uint4* abase = ds + (wo * 4 + chg) * 2 * DSP + pxl;
-  const uint4* bbase = xs + (wc * 4 + chg) * 2 * PSP + (W_ == 16 ? (pxl >> 4) * PC + (pxl & 15) : pxl);
+  const uint4* abase = ds + chg * 2 * DSP + pxl;
+  const uint4* bbase = xs + (wave * 2 + chg) * 2 * PSP + (W_ == 16 ? (pxl >> 4) * PC + (pxl & 15) : pxl);
   // DMA addresses: the flat index -> (plane, row, column) decomposition of a patch vector does not depend on the chunk, only the
   // image (scalar offset of the instruction) and the chunk's first row do.  Per lane and instruction: static byte offset with the
   // patch row in its low 4 bits (15 = never valid).  (Recomputing it per chunk cost ~30 VALU instructions per DMA instruction:
@@ -3411,9 +3409,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
     for (int ks = 0; ks < 2; ++ks) {
       const int srow = (32 * ks) / W_, scol = 32 * ks - srow * W_;     // the step's 32 pixels start at row srow of the chunk, column scol
       // A = dy: [o][k]; two transposing reads (4 pixels each) per term and 16-channel block
-      uint4 av[2][2];
+      uint4 av[4][2];
 #pragma unroll
-      for (int mo = 0; mo < 2; ++mo)
+      for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const uint4* base = abase + (mo * 4 + t) * DSP + 32 * ks;
@@ -3424,26 +3422,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - 3 * ky;
-        uint4 bv[2][2];
+        uint4 bv[2];
 #pragma unroll
-        for (int mc = 0; mc < 2; ++mc)
+        for (int t = 0; t < 2; ++t) {
+          // (the second read is 4 pixels further along x: same row - 8-pixel runs never straddle a row, W_ % 16 == 0)
+          const uint4* base = bstep + t * PSP + ky * PC + kx;
+          const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
+          bv[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            // (the second read is 4 pixels further along x: same row - 8-pixel runs never straddle a row, W_ % 16 == 0)
-            const uint4* base = bstep + (mc * 4 + t) * PSP + ky * PC + kx;
-            const uint2 lo = lds_tr16(base, boff), hi = lds_tr16(base + 4, boff);
-            bv[mc][t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          }
-#pragma unroll
-        for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-          for (int mc = 0; mc < 2; ++mc) {
-            f32x4 c_ = acc[tap][mo][mc];
-            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][1]), __builtin_bit_cast(f16x8, bv[mc][0]), c_, 0, 0, 0);
-            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[mc][1]), c_, 0, 0, 0);
-            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[mc][0]), c_, 0, 0, 0);
-            acc[tap][mo][mc] = c_;
-          }
+        for (int mo = 0; mo < 4; ++mo) {
+          f32x4 c_ = acc[tap][mo];
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][1]), __builtin_bit_cast(f16x8, bv[0]), c_, 0, 0, 0);
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[1]), c_, 0, 0, 0);
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mo][0]), __builtin_bit_cast(f16x8, bv[0]), c_, 0, 0, 0);
+          acc[tap][mo] = c_;
+        }
       }
     }
   };
@@ -3467,14 +3461,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t0 + t][r >> 3][(r >> 2) & 1][r & 3];
+        for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t0 + t][r >> 2][r & 3];
     }
     __syncthreads();
     if (half == 0) {
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t0 + t][r >> 3][(r >> 2) & 1][r & 3] += red[((t * 4 + wave) * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[t0 + t][r >> 2][r & 3] += red[((t * 4 + wave) * 16 + r) * 64 + lane];
     }
     __syncthreads();
   }
@@ -3485,19 +3479,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   // store tails run at a few bytes per clock per CU) that was most of the kernel's fixed ~23 us.  conv3x3_wgrad_reduce_tiled_kernel
   // reads the same order back with 16-byte loads and scatters only the final 9 * Cout * Cin values.
   float4* slp = reinterpret_cast<float4*>(a.slab) + (size_t)split * 9 * a.coutp * a.cinp / 4;
-  // (accumulator block (mo, mc), lane group G: output channels 16 mo + 4 G .. + 3 of input channel 16 mc + li - entered at the slab position the
-  // 32x32 accumulator layout gives that (o, ci) quad, so conv3x3_wgrad_reduce_tiled_kernel reads both kernels' slabs alike)
+  // (accumulator block mo of wave w, lane group G: output channels 16 mo + 4 G .. + 3 of input channel 16 w + li - entered at the slab position
+  // [wo][wc][q][lane] that a 32 x 32 accumulator layout gives that (o, ci) quad: the format conv3x3_wgrad_reduce_tiled_kernel reads)
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int mo = 0; mo < 2; ++mo)
-#pragma unroll
-      for (int mc = 0; mc < 2; ++mc) {
-        const int qs = 2 * mo + (G >> 1), ls = 32 * (G & 1) + 16 * mc + li;
-        const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + qs) * 64 + ls;
-        const f32x4 c_ = acc[tap][mo][mc];
-        slp[f] = make_float4(ldexpf(c_[0], -ktot), ldexpf(c_[1], -ktot), ldexpf(c_[2], -ktot), ldexpf(c_[3], -ktot));
-      }
+    for (int mo = 0; mo < 4; ++mo) {
+      const int wo = mo >> 1, wc = wave >> 1, qs = 2 * (mo & 1) + (G >> 1), ls = 32 * (G & 1) + 16 * (wave & 1) + li;
+      const size_t f = ((((((size_t)tap * a.n_ob + ob) * a.n_cb + cb) * 2 + wo) * 2 + wc) * 4 + qs) * 64 + ls;
+      const f32x4 c_ = acc[tap][mo];
+      slp[f] = make_float4(ldexpf(c_[0], -ktot), ldexpf(c_[1], -ktot), ldexpf(c_[2], -ktot), ldexpf(c_[3], -ktot));
+    }
 }
 // GR_WGRAD_PP: 1 (default) = the ping-pong kernel on 16-wide planes only, 2 = everywhere, 0 = never.  Measured at cfg2 per launch:
 // 16-wide 52 -> 50 us, and the slab reduction 16.5 -> 10.8 us; 32-wide 70 -> 98 us (its 34 KB x patch per 64 pixels makes the
