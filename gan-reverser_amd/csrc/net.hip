@@ -714,7 +714,12 @@ static int ensure_batch(gr_net* n, int B) {
 
 // bf16x6 mode: every plain convolution runs on the split kernel except few-output-channel layers the HBM-bound VALU
 // kernel covers (same predicate as launch_conv3x3); only the split images are kept current in that mode.
-static bool fewout_applies(const Stage& s) { return s.ksz == 3 && s.Cout <= 4 && !s.up && s.W % 4 == 0 && s.W >= 16; }
+static bool fewout_applies(const Stage& s) {
+  // GR_FEWOUT_MAX=0 sends the few-output layers to the MFMA split kernels too (A/B, round 3: G's last convolution 0.388 -> 0.53 ms at cfg3,
+  // 39 -> 73 us at cfg2 - a 32-channel output block for 1-3 real channels)
+  static const int maxc = getenv("GR_FEWOUT_MAX") ? atoi(getenv("GR_FEWOUT_MAX")) : 4;
+  return s.ksz == 3 && s.Cout <= maxc && !s.up && s.W % 4 == 0 && s.W >= 16;
+}
 // f16x3 GEMM for the large nn.Linear layers (R.fc1: 90-97 % of R's parameters); small ones stay on the fp32 MFMA kernel
 static bool use_f16_gemm(gr_net* n, const Stage& s) {
   static const bool on = !getenv("GR_NO_F16_GEMM");
