@@ -1108,8 +1108,8 @@ void launch_channel_absmax(const float* t, int B, int C, long HW, long sB, long 
 void launch_spread_verdict(unsigned* chmax, int C, unsigned* word, int side, hipStream_t s) {
   hipLaunchKernelGGL(spread_verdict_kernel, dim3(1), dim3(256), 0, s, chmax, C, word, side);
 }
-void launch_pair_spread(const float* a, const float* b, int C, unsigned* top2, hipStream_t s) {
-  hipLaunchKernelGGL(pair_spread_kernel, dim3(1), dim3(256), 0, s, a, b, C, top2);
+void launch_pair_spread(const float* a, const float* b, int C, unsigned* sides, hipStream_t s) {
+  hipLaunchKernelGGL(pair_spread_kernel, dim3(1), dim3(256), 0, s, a, b, C, sides);
 }
 
 // ------------------------------------------------------------------ nn.MSECriterion

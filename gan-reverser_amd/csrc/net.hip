@@ -280,8 +280,15 @@ extern "C" int gr_kernel_times(gr_ctx* c, char* buf, int buflen) {
   }
   if (g_evtimer->failed > 0) {       // samples the timer could not read: a row of their own, so a table with holes says so
     char line[512];
+    std::string esc;                 // the message comes from hipGetErrorString: keep the table parseable whatever it holds
+    for (unsigned char ch : g_evtimer->first_error) {
+      if (ch == '"' || ch == '\\') { esc += '\\'; esc += (char)ch; }
+      else if (ch < 0x20) esc += ' ';
+      else esc += (char)ch;
+    }
+    if (esc.size() > 300) esc.resize(300);
     snprintf(line, sizeof line, "%s{\"kernel\": \"timer_failed_samples\", \"phase\": \"%s\", \"launches\": %ld, \"total_ms\": 0.0, \"flops\": 0.0, \"bytes\": 0.0}",
-             g_evtimer->agg.empty() ? "" : ", ", g_evtimer->first_error.c_str(), g_evtimer->failed);
+             g_evtimer->agg.empty() ? "" : ", ", esc.c_str(), g_evtimer->failed);
     out += line;
   }
   if (c->guard_fallbacks > 0) {      // passes the f16x3 range guard sent to bf16x6 since gr_init (not a kernel: a count)
@@ -388,7 +395,7 @@ struct gr_net {
   bool dy_slots_zeroed = false, w_slots_zeroed = false;   // set by forward_impl's single fill, consumed by backward / weight prep
   bool keep_fp32 = false;            // range-guarded host calls: no lean (operand-ready only) tensors, so a backward can still fall back to bf16x6
   bool last_fwd_fell_back = false;   // the last guarded forward ran on bf16x6: its backward does too
-  unsigned guard_top2 = 0;           // the largest spreads (bits: activation side | weight side << 16) the last guarded forward measured
+  unsigned guard_sides = 0;           // the largest spreads (bits: activation side | weight side << 16) the last guarded forward measured
 };
 
 enum { AG_X = 0, AG_Y = 1, AG_KB = 2, AG_DY = 3, AG_DZ = 4, AG_W = 5, AMAX_GROUPS = 6 };
@@ -877,12 +884,19 @@ static bool guard_applies(gr_net* n) {
 extern "C" int gr_range_guard_scan_params(gr_net* n, int* tripped) {
   if (!n) return GR_ERR_INVALID;
   gr_ctx* c = n->ctx;
+  // a sampled scan of gr_train_r_step may still be in flight on this context: its verdict lands in the same host word the
+  // synchronous scan below overwrites, so it is consumed first (otherwise a hostile range of the OTHER nets would go unnoticed)
+  if (c->guard_pending) {
+    HIPCHK(c, hipEventSynchronize(c->ev_guard));
+    c->guard_pending = false;
+    if (guard_over_budget(*guard_alarm_host(c)) && !c->guard_tripped) { c->guard_tripped = true; c->guard_fallbacks++; }
+  }
   if (c->guard_tripped && c->conv_mode == 2) c->conv_mode = 1;
   if (guard_applies(n)) {
     int r = guard_scan_params(n); if (r) return r;
-    unsigned top2 = 0;
-    r = guard_verdict(c, &top2); if (r) return r;
-    if (guard_over_budget(top2) && !c->guard_tripped) { c->guard_tripped = true; c->guard_fallbacks++; c->conv_mode = 1; }
+    unsigned sides = 0;
+    r = guard_verdict(c, &sides); if (r) return r;
+    if (guard_over_budget(sides) && !c->guard_tripped) { c->guard_tripped = true; c->guard_fallbacks++; c->conv_mode = 1; }
   }
   if (tripped) *tripped = c->guard_tripped ? 1 : 0;
   return GR_OK;
@@ -1098,10 +1112,10 @@ extern "C" int gr_net_forward_host(gr_net* n, const float* in_host, int B, float
     else r = guard_scan_activation(c, n->in_buf, B, n->inC, n->inH, n->inW);
     if (r) return r;
     r = guard_scan_params(n); if (r) return r;
-    unsigned top2 = 0;
-    r = guard_verdict(c, &top2); if (r) return r;
-    n->guard_top2 = top2;
-    n->last_fwd_fell_back = guard_over_budget(top2);
+    unsigned sides = 0;
+    r = guard_verdict(c, &sides); if (r) return r;
+    n->guard_sides = sides;
+    n->last_fwd_fell_back = guard_over_budget(sides);
   }
   if (n->last_fwd_fell_back) { c->guard_fallbacks++; c->conv_mode = 1; }
   r = forward_impl(n, n->in_buf, B);
@@ -1352,9 +1366,9 @@ extern "C" int gr_net_backward_host(gr_net* n, const float* in_host, const float
       int r = sl.kind == ST_LINEAR ? guard_scan_activation(c, n->gout_buf, B, sl.Cout, 1, 1)
                                    : guard_scan_activation(c, n->gout_buf, B, n->outC, n->outH, n->outW);
       if (r) return r;
-      unsigned top2 = 0;
-      r = guard_verdict(c, &top2); if (r) return r;
-      fall_back = guard_over_budget(guard_merge(top2, n->guard_top2));      // gradOutput's spread joins the forward's
+      unsigned sides = 0;
+      r = guard_verdict(c, &sides); if (r) return r;
+      fall_back = guard_over_budget(guard_merge(sides, n->guard_sides));      // gradOutput's spread joins the forward's
     }
   }
   if (fall_back) { c->guard_fallbacks++; c->conv_mode = 1; }

@@ -353,12 +353,14 @@ class DeviceGame:
         OPT, B = self.env.OPT, self.env.OPT.batchSize
         half = B // 2
         ctx = self.ctx
-        nD, nG = max(1, int(OPT.D_iterations)), max(1, int(OPT.G_iterations))
+        # `for k=1,OPT.D_iterations` (adversarial.lua:127,168): 0 iterations run zero times - that phase's net stays frozen
+        nD, nG = max(0, int(OPT.D_iterations)), max(0, int(OPT.G_iterations))
         real = np.ascontiguousarray(real, np.float32).reshape(-1, self.npix)
         if real.shape[0] < nD * half:
             raise IndexError("trainData exhausted (adversarial.lua:146 indexes past the loaded examples): "
                              f"{real.shape[0]} images for {nD} D iterations of {half}")
-        if self.ctx.conv_mode() == "f16x3" and (self.t["D"] // nD) % self.GUARD_PERIOD == 0:
+        self.batches = getattr(self, "batches", 0) + 1
+        if self.ctx.conv_mode() == "f16x3" and (self.batches - 1) % self.GUARD_PERIOD == 0:
             for n in [self.gnet] + self.dg.nets:      # the *_dev calls below are unguarded: sampled parameter scan, as gr_train_r_step does
                 n.range_guard_scan()
         loss_d = loss_g = None

@@ -104,14 +104,16 @@ def main(argv=None):
     only_adam = OPT.D_optmethod == "adam" and OPT.G_optmethod == "adam"      # the fused device update is Adam's; the rest are host mirrors
     game = None if (OPT.compat or not only_adam) else adversarial.DeviceGame(env)
     N_epoch = OPT.N_epoch if OPT.N_epoch > 0 else 100                 # adversarial.lua:42-45: N_epoch <= 0 means 100 batches
-    D_it, G_it = max(1, OPT.D_iterations), max(1, OPT.G_iterations)
+    D_it, G_it = max(0, OPT.D_iterations), max(0, OPT.G_iterations)   # 0 iterations freeze that net (adversarial.lua:127,168 loop zero times)
     # a continued run must not replay the first epochs' noise: the counters start where epoch0 - 1 finished epochs left them
     # (the reference's Torch RNG is not restored from a checkpoint either; Adam's state restarts empty, as train.lua does)
     done = (epoch0 - 1) * N_epoch * (D_it + G_it)
     env.noise_counter = getattr(env, "noise_counter", 0) + done
     if game is not None:
         game.noise_counter += done
-    nbLoad = (N_epoch * OPT.batchSize // 2) * D_it                    # train.lua:214
+    # train.lua:214 multiplies OPT.N_epoch itself; with N_epoch <= 0 that loads nothing while adversarial.lua:42-45 still runs 100
+    # batches and indexes past the loaded examples - here the 100 batches get their images
+    nbLoad = (N_epoch * OPT.batchSize // 2) * D_it
     cursor, last, t0, images = (epoch0 - 1) * nbLoad, None, time.perf_counter(), 0
     for _ in range(OPT.epochs):
         if data is not None:

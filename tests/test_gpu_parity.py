@@ -731,7 +731,7 @@ def test_full_size_step_vs_oracle(ctx, oracle, conv_mode, dims, nd, B, max_flips
     recovered noise and loss at the north-star tolerance against the oracle's own forward.  The gradient - ALL of R's
     parameter tensors - at 2e-4 of its module's largest entry: the pool argmax the device took is read back
     (gr_net_get_pool_index), the windows where it differs from the oracle's must be a handful of rounding-level near-ties
-    (gap below 8 x the forward error MEASURED in this run at that pool's inputs - helpers.pool_input_error - capped at the 1e-4
+    (gap below 2 x the forward error MEASURED in this run at that pool's inputs - helpers.pool_input_error - capped at the 1e-4
     forward tolerance; 6.5M / 52M windows: measured 1-5 / 100-110 flips, at most 4 x that is accepted and the counts are printed),
     and the oracle's backward is run with the device's argmax (helpers.adopt_device_argmax).
     Why 2e-4 and not 1e-4 at this size (the small cases hold 1e-4): BatchNorm's backward makes sum(dy) vanish per channel in
