@@ -265,6 +265,90 @@ def search_cfg5(ctx):
                 note="ms includes the D2H copy of the 5 x 50 results and one host sync per search (gr_cosine_topk_dev)")
 
 
+def embed_cfg5(ctx, rows, with_oracle=True):
+    """BASELINE.json configs[4] as stated: "1M generated 64x64 faces -> 100-d embeddings, top-50".  apply_r.lua:145-153 resident on the
+    GPU (gr_embed_dev): noise drawn on the device -> G forward (evaluate) -> R forward (evaluate) in chunks of 512, every chunk's
+    recovered noise written straight into the [rows x 100] table, no host copies; then apply_r.lua:265-282's search on the table the
+    pipeline produced, checked element by element against the oracle's search of the same table.  HIP events on the library's stream."""
+    import numpy as np
+    import ganrev._lib as L
+    from ganrev import models, nn_utils, synth
+    dims, nd, batch, k = WORKLOADS["cfg3"]["dims"], WORKLOADS["cfg3"]["nd"], 512, 50
+    needles = np.array([100, 200, 300, 400, 500], dtype=np.int64)
+    # apply_r.lua:62-104 loads TRAINED nets: synthetic trained-looking weights and non-trivial running statistics for both
+    G = models.create_G(dims, nd); synth.init_params(G, 1)
+    R = models.create_R(dims, nd); synth.init_params(R, 2)
+    G._ctx = R._ctx = ctx
+    G.evaluate(); R.evaluate()
+    gnet, rnet = G.device_net((nd,)), R.device_net(dims)
+    noise = nn_utils.createNoiseInputsDev(ctx, rows, nd, "normal", seed=4242)
+    table = nn_utils.DeviceTensor(ctx, (rows, nd))
+    L.embed_dev(gnet, [rnet], noise.ptr, min(rows, 2 * batch), batch, [table.ptr])          # warm-up: allocation, weight images
+    ctx.synchronize()
+    ctx.event_record(62000)
+    L.embed_dev(gnet, [rnet], noise.ptr, rows, batch, [table.ptr])
+    ctx.event_record(62001)
+    ms = ctx.event_elapsed_ms(62000, 62001)
+    fl_g, fl_r = step_flops_per_image(dims, nd)[1:3]
+    # per-kernel table of four instrumented chunks
+    nprof = 4
+    ctx.set_timing(2)
+    L.embed_dev(gnet, [rnet], noise.ptr, min(rows, nprof * batch), batch, [table.ptr])
+    ctx.synchronize()
+    kt, pseudo = split_pseudo_rows(ctx.kernel_times())
+    ctx.set_timing(0)
+    by = {}
+    for kk in kt:
+        a = by.setdefault(kk["kernel"], dict(kernel=kk["kernel"], launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+        for f in ("launches", "total_ms", "flops", "bytes"):
+            a[f] += kk[f]
+    chunks = -(-min(rows, nprof * batch) // batch)
+    mfma = [r for r in by.values() if r["kernel"].startswith("conv3x3_") and r["flops"] > 1e9 and "fewout" not in r["kernel"] and "fewin" not in r["kernel"]]
+    dom = max(mfma, key=lambda r: r["total_ms"])
+    avg_ms = dom["total_ms"] / dom["launches"]
+    ach = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+    peak, passes = kernel_ceiling_tflops(dom["kernel"])
+    kernels = {}
+    for r in sorted(by.values(), key=lambda r: -r["total_ms"])[:12]:
+        tf, why = checked_tflops(r["kernel"], r["flops"], r["total_ms"])
+        kernels[r["kernel"]] = dict(ms_per_chunk=round(r["total_ms"] / chunks, 4), launches_per_chunk=round(r["launches"] / chunks, 2), tflops=tf,
+                                    gbs=round(r["bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1) if r["bytes"] else None, **({"rejected": why} if why else {}))
+    phase_ms = {}
+    for kk in kt:
+        phase_ms[kk.get("phase") or "other"] = phase_ms.get(kk.get("phase") or "other", 0.0) + kk["total_ms"] / chunks
+    embed = dict(rows=rows, chunk=batch, images_per_sec=round(rows / ms * 1e3, 1), ms_total=round(ms, 2), ms_per_chunk=round(ms / (rows / batch), 4),
+                 algorithmic_gflop_per_image=round((fl_g + fl_r) / 1e9, 3), tflops=round((fl_g + fl_r) * rows / ms / 1e9, 2),
+                 frac_of_fp32_mfma_peak=round((fl_g + fl_r) * rows / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                 kernel_ms_per_chunk={p_: round(v, 4) for p_, v in phase_ms.items()},
+                 roofline=dict(bound="mfma", kernel=dom["kernel"], achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
+                               avg_launch_ms=round(avg_ms, 4), launches_per_chunk=dom["launches"] / chunks,
+                               algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3)),
+                 kernels=kernels, timer_failed_samples=pseudo.get("timer_failed_samples", dict(count=0))["count"], dtype=DTYPE[ctx.conv_mode()],
+                 note="evaluate()-mode G + R forward (apply_r.lua:146,152), noise and the embedding table resident in HBM, no host copies inside the timed region")
+    # the search on the table the pipeline wrote
+    ctx.cosine_topk(None, needles, k, emb_dev=table.ptr, n=rows, d=nd)
+    r0 = ctx.search_reruns()
+    reps = 5
+    ctx.event_record(62002)
+    for _ in range(reps):
+        idx, sc = ctx.cosine_topk(None, needles, k, emb_dev=table.ptr, n=rows, d=nd)
+    ctx.event_record(62003)
+    sms = ctx.event_elapsed_ms(62002, 62003) / reps
+    search = dict(n=rows, d=nd, k=k, needles=int(needles.size), ms=round(sms, 4), hbm_gbs=round(rows * nd * 4 / sms / 1e6, 1),
+                  reruns_unfiltered=int(ctx.search_reruns() - r0))
+    if with_oracle:
+        from oracle import oracle
+        emb = table.numpy()
+        oracle.set_threads(min(32, os.cpu_count() or 1))
+        t0 = time.perf_counter(); ridx, rsc = oracle.cosine_topk(emb, needles, k); t_cpu = time.perf_counter() - t0
+        search.update(exact_match=bool(np.array_equal(idx, ridx) and np.array_equal(sc, rsc)), cpu_ms=round(t_cpu * 1e3, 1),
+                      distinct_rows=int(len(np.unique(emb[:: max(1, rows // 4096)].round(6), axis=0))),
+                      top1_is_self=bool((idx[:, 0] == needles).all()))
+    noise.free(); table.free()
+    gnet.close(); rnet.close(); G._net = R._net = None
+    return dict(embed=embed, search_on_pipeline_corpus=search)
+
+
 def gan_step(ctx, with_cpu=True):
     """one batch of the GAN game (adversarial.lua:139-201: D on half real / half generated images, then G
     through D) with models.create_G / create_D2 at 32x32 gray, device-resident (ganrev.adversarial.DeviceGame), timed with HIP
@@ -604,6 +688,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1, help="seed of R's initialisation (train_r.lua:18 default 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the cfg5 (1M x 100, top-50) search leg")
+    ap.add_argument("--embed-rows", type=int, default=1_000_000, help="rows of the cfg5 corpus the device-resident G -> R pipeline produces (BASELINE configs[4]: 1M)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the bare f16x3 MFMA loop (roofline.sustained): profiling runs, whose kernel statistics it would dominate")
     ap.add_argument("--no-gan", action="store_true", help="skip the GAN-game leg (SURVEY.md 8f rank 4: G + D2, one adversarial batch)")
     ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "f16x3"), choices=list(MODES),
@@ -723,6 +808,10 @@ def main():
             out["cfg3"] = c3
         if world == 1 and not args.no_search:
             out["search_cfg5"] = search_cfg5(ctx)
+            try:                      # configs[4] as stated: the corpus produced by the device-resident G -> R pipeline, then searched
+                out["search_cfg5"].update(embed_cfg5(ctx, args.embed_rows, with_oracle=not args.no_cpu_baseline))
+            except Exception as e:  # noqa: BLE001
+                out["search_cfg5"]["embed"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_gan:
             try:                      # a side leg: its failure is reported in the line, it never takes the headline measurement down
                 out["gan_step"] = gan_step(ctx, with_cpu=not args.no_cpu_baseline)

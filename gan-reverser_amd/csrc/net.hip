@@ -382,6 +382,7 @@ struct gr_net {
   uint64_t seed = 1, fwd_counter = 0;   // fwd_counter: Philox counter of the dropout noise (gr_net_set_seed restarts it)
   uint64_t amax_gen = 0;                // generation of the f16x3 scale slots: one per forward, never restarted, so a reseed cannot make a stale slot look fresh
   int capB = 0, lastB = 0;
+  float* last_out = nullptr;         // m.output of the last forward: the last stage's buffer, or the caller's destination it was written to directly
   float *in_buf = nullptr, *gout_buf = nullptr, *dy_buf = nullptr, *g_buf[2] = {nullptr, nullptr};
   void* dy_p16 = nullptr;            // operand-ready copy of dy_buf for the data-gradient convolution
   float* dy_buf_b = nullptr; void* dy_p16_b = nullptr;   // second pair: stages alternate, so stage s - 1 can write its dy while stage s's weight gradient (side stream) still reads
@@ -907,7 +908,7 @@ static int guard_scan_activation(gr_ctx* c, const float* t, int B, int C, int H,
   return guard_scan(c, t, B, C, hw, (long)C * hw, hw, 0);
 }
 
-static int forward_impl(gr_net* n, const float* in_dev, int B) {
+static int forward_stages(gr_net* n, const float* in_dev, int B) {
   gr_ctx* c = n->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   int r = ensure_batch(n, B); if (r) return r;
@@ -1087,14 +1088,81 @@ static int forward_impl(gr_net* n, const float* in_dev, int B) {
   return GR_OK;
 }
 
-extern "C" float* gr_net_output_dev(gr_net* n) { return (n && !n->st.empty()) ? n->st.back().out : nullptr; }
+// One forward.  final_dst (nullable): where the caller wants the result.  In evaluate() mode the LAST stage writes it there itself (its
+// kernel's destination pointer is swapped for the call: no staging copy - utils/nn_utils.lua:25-28's row loop becomes nothing at all);
+// in training mode the stage buffers are state the backward reads, so the result is copied.  m.output (gr_net_output_dev) is
+// wherever the last forward left its result.
+static int forward_impl(gr_net* n, const float* in_dev, int B, float* final_dst = nullptr) {
+  gr_ctx* c = n->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = ensure_batch(n, B); if (r) return r;          // (buffers may move: before the swap)
+  Stage& ls = n->st.back();
+  const bool redirect = final_dst && !n->training && ((uintptr_t)final_dst & 15) == 0;
+  float** slot = ls.has_post ? &ls.out : &ls.y;
+  float* const saved = *slot;
+  if (redirect) *slot = final_dst;
+  r = forward_stages(n, in_dev, B);
+  if (redirect) { *slot = saved; if (!ls.has_post) ls.out = saved; }
+  if (r) return r;
+  n->last_out = ls.out;
+  if (redirect) n->last_out = final_dst;
+  else if (final_dst) {
+    HIPCHK(c, hipMemcpyAsync(final_dst, ls.out, sizeof(float) * (size_t)B * vol3(n->outC, n->outH, n->outW), hipMemcpyDeviceToDevice, c->stream));
+  }
+  return GR_OK;
+}
+
+extern "C" float* gr_net_output_dev(gr_net* n) { return (n && !n->st.empty()) ? (n->last_out ? n->last_out : n->st.back().out) : nullptr; }
 
 extern "C" int gr_net_forward_dev(gr_net* n, const float* in_dev, int B, float* out_dev) {
   if (!n || !in_dev || B <= 0) return GR_ERR_INVALID;
   n->keep_fp32 = false; n->last_fwd_fell_back = false;      // device-resident callers: no stream synchronisation, so no range guard here (gr_train_r_step samples one)
-  int r = forward_impl(n, in_dev, B); if (r) return r;
-  if (out_dev) HIPCHK(n->ctx, hipMemcpyAsync(out_dev, n->st.back().out, sizeof(float) * (size_t)B * vol3(n->outC, n->outH, n->outW), hipMemcpyDeviceToDevice, n->ctx->stream));
+  return forward_impl(n, in_dev, B, out_dev);
+}
+
+// NN_UTILS.forwardBatched(model, input, batchSize) (utils/nn_utils.lua:5-33) on device-resident rows: chunk c of `batch` rows goes
+// through the net and lands at out_dev + c * batch * outdim - the chunk's last kernel writes there itself (forward_impl).
+extern "C" int gr_net_forward_batched_dev(gr_net* n, const float* in_dev, int64_t rows, int batch, float* out_dev) {
+  if (!n || !in_dev || !out_dev || rows <= 0 || batch <= 0) return GR_ERR_INVALID;
+  n->keep_fp32 = false; n->last_fwd_fell_back = false;
+  const int64_t iv = vol3(n->inC, n->inH, n->inW), ov = vol3(n->outC, n->outH, n->outW);
+  for (int64_t off = 0; off < rows; off += batch) {
+    const int b = (int)(rows - off < batch ? rows - off : batch);
+    int r = forward_impl(n, in_dev + off * iv, b, out_dev + off * ov); if (r) return r;
+  }
   return GR_OK;
+}
+
+// apply_r.lua:145-153 as ONE device-resident pipeline: per chunk  images = G:forward(noise)  (:146)  ->  attributes_k = R_k:forward(images)
+// (:152 MODEL_R, :153 MODEL_R_FIXER), the recovered noise written straight into the [rows x nd] tables the search (apply_r.lua:265-282)
+// reads.  The images never leave the GPU; they are kept (images_out_dev) only when the caller wants them (pixel-wise search, fix-faces).
+extern "C" int gr_embed_dev(gr_net* g, gr_net* const* rnets, int n_rnets, const float* noise_dev, int64_t rows, int batch,
+                            float* images_out_dev, float* const* attr_out_dev) {
+  if (!g || !noise_dev || rows <= 0 || batch <= 0 || n_rnets < 0 || (n_rnets > 0 && (!rnets || !attr_out_dev))) return GR_ERR_INVALID;
+  gr_ctx* c = g->ctx;
+  const int64_t nd = vol3(g->inC, g->inH, g->inW), iv = vol3(g->outC, g->outH, g->outW);
+  for (int k = 0; k < n_rnets; ++k) {
+    if (!rnets[k] || !attr_out_dev[k]) return GR_ERR_INVALID;
+    if (rnets[k]->ctx != c) return fail(c, GR_ERR_INVALID, "gr_embed_dev: nets live on different contexts");
+    if (vol3(rnets[k]->inC, rnets[k]->inH, rnets[k]->inW) != iv) return fail(c, GR_ERR_INVALID, "gr_embed_dev: image dim mismatch between G and R net %d", k);
+    rnets[k]->keep_fp32 = false; rnets[k]->last_fwd_fell_back = false;
+  }
+  g->keep_fp32 = false; g->last_fwd_fell_back = false;
+  int r = GR_OK;
+  for (int64_t off = 0; off < rows && !r; off += batch) {
+    const int b = (int)(rows - off < batch ? rows - off : batch);
+    g_kphase = 1;
+    { PhaseRange pr("G forward"); r = forward_impl(g, noise_dev + off * nd, b, images_out_dev ? images_out_dev + off * iv : nullptr); }
+    const float* images = g->last_out;
+    g_kphase = 2;
+    for (int k = 0; k < n_rnets && !r; ++k) {
+      PhaseRange pr("R forward");
+      const int64_t ov = vol3(rnets[k]->outC, rnets[k]->outH, rnets[k]->outW);
+      r = forward_impl(rnets[k], images, b, attr_out_dev[k] + off * ov);
+    }
+  }
+  g_kphase = 0;
+  return r;
 }
 
 extern "C" int gr_net_forward_host(gr_net* n, const float* in_host, int B, float* out_host) {
@@ -1136,6 +1204,7 @@ extern "C" int gr_net_layer_output(gr_net* n, int layer, float* host, int64_t cn
       if (s.out_skipped) return fail(c, GR_ERR_UNSUPPORTED, "layer %d: the last forward left this output operand-ready (fp16 hi/lo image of the next convolution) only", layer);
       p = s.out; e = (int64_t)n->lastB * vol3(s.outC, s.outH, s.outW);
     }
+    if (p && &s == &n->st.back() && n->last_out && p == (s.has_post ? s.out : s.y)) p = n->last_out;   // the last forward wrote its result at the caller's destination
     if (p) {
       if (cnt != e) return fail(c, GR_ERR_INVALID, "layer %d output has %lld elements", layer, (long long)e);
       HIPCHK(c, hipMemcpyAsync(host, p, sizeof(float) * (size_t)e, hipMemcpyDeviceToHost, c->stream));

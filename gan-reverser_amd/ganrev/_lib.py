@@ -81,6 +81,8 @@ _SIGS = {
     "gr_net_forward_host": (C.c_int, [_P, _P, C.c_int, _P]),
     "gr_net_forward_dev": (C.c_int, [_P, _P, C.c_int, _P]),
     "gr_net_output_dev": (_P, [_P]),
+    "gr_net_forward_batched_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "gr_embed_dev": (C.c_int, [_P, C.POINTER(_P), C.c_int, _P, C.c_int64, C.c_int, _P, C.POINTER(_P)]),
     "gr_net_backward_host": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "gr_net_backward_dev": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "gr_net_layer_output": (C.c_int, [_P, C.c_int, _P, C.c_int64]),
@@ -486,6 +488,10 @@ class Net:
         self._c(self.lib.gr_net_forward_dev(self.h, _ptr(x_dev), int(batch), _ptr(out_dev)), "gr_net_forward_dev")
         return self.lib.gr_net_output_dev(self.h)
 
+    def forward_batched_dev(self, x_dev, rows, batch, out_dev):
+        """utils/nn_utils.lua:5-33 on device-resident rows: chunks of `batch` rows, each written straight into out_dev"""
+        self._c(self.lib.gr_net_forward_batched_dev(self.h, _ptr(x_dev), int(rows), int(batch), _ptr(out_dev)), "gr_net_forward_batched_dev")
+
     def backward(self, x, gout, want_gin=True):
         x, gout = f32(x), f32(gout)
         b = x.shape[0]
@@ -539,6 +545,15 @@ class Net:
     def _shape(d):
         c, h, w = d
         return (c,) if (h == 1 and w == 1) else (c, h, w)
+
+
+def embed_dev(gnet, rnets, noise_dev, rows, batch, attr_out_devs, images_out_dev=None):
+    """apply_r.lua:145-153 on the device: noise -> G -> images -> every net of `rnets` -> attr_out_devs[k]; nothing visits the host"""
+    n = len(rnets)
+    nets = (_P * max(n, 1))(*[r.h for r in rnets])
+    outs = (_P * max(n, 1))(*[_ptr(p) for p in attr_out_devs])
+    rc = gnet.lib.gr_embed_dev(gnet.h, nets, n, _ptr(noise_dev), int(rows), int(batch), _ptr(images_out_dev), outs)
+    gnet.ctx.check(rc, "gr_embed_dev")
 
 
 def train_r_step(gnet, rnet, noise_dev, batch, global_batch, hyper, t, want_loss=True):

@@ -15,7 +15,7 @@ import math
 import numpy as np
 
 from . import _lib as L
-from .nn_utils import forwardBatched
+from .nn_utils import DeviceTensor, forwardBatched
 
 
 def embed(model_g, model_r, noise, batchSize=32, model_r_fixer=None):
@@ -28,6 +28,46 @@ def embed(model_g, model_r, noise, batchSize=32, model_r_fixer=None):
         return images, attributes
     model_r_fixer.evaluate()                                                # the fixer's first Dropout stays on (models.lua:402-405)
     return images, attributes, forwardBatched(model_r_fixer, images, batchSize)   # :153
+
+
+def embed_dev(model_g, model_r, noise, batchSize=512, model_r_fixer=None, keep_images=False, dims=None):
+    """apply_r.lua:145-153 resident on the GPU (gr_embed_dev): `noise` is a DeviceTensor [N x noiseDim] (nn_utils.createNoiseInputsDev);
+    per chunk of batchSize rows  G:forward -> R:forward [-> R_fixer:forward], the recovered noise written straight into [N x nd] device
+    tables.  -> (images or None, attributes[, attributesFixer]) as DeviceTensors.  The images are a chunk-sized intermediate unless
+    keep_images (the pixel-wise search and fix-faces want them: N x C x H x W floats).  dims = (C, H, W) of the images; taken from
+    model_g's compiled net when it has run before.  Same kernels, same chunking as forwardBatched with this batchSize: same bits."""
+    ctx = noise.ctx
+    model_g.evaluate(); model_r.evaluate()
+    gnet = model_g.device_net(noise.shape[1:])
+    dims = tuple(dims) if dims is not None else gnet.out_dims
+    rs = [model_r] + ([model_r_fixer] if model_r_fixer is not None else [])
+    if model_r_fixer is not None:
+        model_r_fixer.evaluate()                                            # its first Dropout stays on (models.lua:402-405)
+    rnets = [m.device_net(dims) for m in rs]
+    N = noise.shape[0]
+    if ctx.conv_mode() == "f16x3":
+        for n in [gnet] + rnets:          # the *_dev calls are not range-guarded (include/ganrev.h): one synchronous scan per net
+            n.range_guard_scan()
+    images = DeviceTensor(ctx, (N,) + tuple(dims)) if keep_images else None
+    attrs = [DeviceTensor(ctx, (N,) + L.Net._shape(n.out_dims)) for n in rnets]
+    L.embed_dev(gnet, rnets, noise.ptr, N, batchSize, [a.ptr for a in attrs], images.ptr if images is not None else None)
+    return (images,) + tuple(attrs)
+
+
+def createSimilaritySearchDev(nbSimilarNeedles, nbShowMax, attributes, images=None):
+    """apply_r.lua:265-318 on device-resident tables (DeviceTensors from embed_dev): the needles' rows are searched where the embeddings
+    were written.  -> (idx_by_attributes, idx_by_pixels or None)."""
+    N = attributes.shape[0]
+    needles = np.array([i * 100 - 1 for i in range(1, nbSimilarNeedles + 1)], dtype=np.int64)
+    if needles.max() >= N:
+        raise IndexError(f"needle row {needles.max() + 1} out of range for {N} rows")
+    n = min(nbShowMax, N)
+    ctx = attributes.ctx
+    by_attr, _ = ctx.cosine_topk(None, needles, n, emb_dev=attributes.ptr, n=N, d=attributes.size // N)
+    by_pix = None
+    if images is not None:
+        by_pix, _ = ctx.cosine_topk(None, needles, n, emb_dev=images.ptr, n=N, d=images.size // N)
+    return by_attr, by_pix
 
 
 def cosineSimilarity(v1, v2):

@@ -226,8 +226,8 @@ class Module:
             self._net.set_seed(self._seed)
 
     # ---- the nn.Module protocol
-    def forward(self, input):
-        x = L.f32(input)
+    def _prepare(self, x):
+        """Everything :forward does before the data moves: compile for x's dims, seed, parameters, mode, injected noise."""
         net = self._compile(x)
         if getattr(self, "_seed", None) is not None and not getattr(self, "_seed_applied", False):
             net.set_seed(self._seed)
@@ -240,6 +240,18 @@ class Module:
         for module, keep in self._pending_masks.values():
             net.set_mask(self._leaf_layer(module), keep)
         self._pending_masks = {}
+        return net
+
+    def device_net(self, dims):
+        """The compiled gr_net for per-sample input dims (C, H, W) / (n,), ready for the *_dev calls (no data moved): what the
+        device-resident loops (apply_r.embed_dev, DeviceTrainer) drive instead of :forward."""
+        dims = tuple(int(d) for d in (dims if len(dims) == 3 else (dims[0], 1, 1)))
+        probe = np.empty((0,) + (dims if dims[1:] != (1, 1) else dims[:1]), np.float32)
+        return self._prepare(probe)
+
+    def forward(self, input):
+        x = L.f32(input)
+        net = self._prepare(x)
         b = x.shape[0]
         shape = (b,) + L.Net._shape(net.out_dims)
         if self.output is None or self.output.shape != shape:

@@ -54,6 +54,12 @@ int gr_fill_normal_dev(gr_ctx*, float* dst_dev, int64_t n, uint64_t seed);
 int gr_fill_uniform_dev(gr_ctx*, float* dst_dev, int64_t n, float lo, float hi, uint64_t seed);
 int gr_net_forward_dev(gr_net*, const float* in_dev, int batch, float* out_dev);
 float* gr_net_output_dev(gr_net*);
+int gr_net_forward_batched_dev(gr_net*, const float* in_dev, int64_t rows, int batch, float* out_dev);   /* utils/nn_utils.lua:5-33 */
+int gr_embed_dev(gr_net* gnet, gr_net* const* rnets, int n_rnets, const float* noise_dev, int64_t rows, int batch,
+                 float* images_out_dev, float* const* attr_out_dev);                                       /* apply_r.lua:145-153 */
+int gr_cosine_topk_dev(gr_ctx*, const float* emb_dev, int64_t n, int d, const int64_t* rows, int q, int k,
+                       int64_t* idx, float* score, int accumulate_in_float);
+int gr_synchronize(gr_ctx*);
 int gr_adam_reset(gr_net*);
 int gr_train_r_step(gr_net* gnet, gr_net* rnet, const float* noise_dev, int batch, int global_batch,
                     const gr_hyper* h, int t, double* loss_out);
@@ -248,6 +254,44 @@ function hipnn.cosineTopK(attributes, needles, k)
    check(C.gr_cosine_topk_host(context(), attributes:contiguous():data(), N, d, rows, Q, k,
                                ffi.cast('int64_t*', idx:data()), sc:data(), 0), 'gr_cosine_topk_host')
    return idx:add(1), sc
+end
+
+-- apply_r.lua:145-153 replacement, device-resident: N noise rows are drawn on the GPU (utils/nn_utils.lua:39-51), pushed through G and
+-- through every reverser net in `Rs` (MODEL_R, MODEL_R_FIXER) in chunks of batchSize; images and recovered noise never visit the host.
+--   local emb = hipnn.embed(MODEL_G, {MODEL_R, MODEL_R_FIXER}, 10000, 512, OPT.noiseMethod, OPT.seed)
+--   local idx = emb:cosineTopK(1, {100, 200, 300, 400, 500}, 100)      -- apply_r.lua:266-282 on table 1 (MODEL_R's attributes)
+--   local attributes = emb:attributes(1)                              -- FloatTensor copy, when a script still wants one
+-- All nets must have been compiled by one forward each and be in :evaluate() mode (apply_r.lua:64,94,103).
+function hipnn.embed(G, Rs, N, batchSize, noiseMethod, seed)
+   assert(G.net, 'hipnn.embed: run one forward through G first')
+   local nd = G.inner:get(1).weight and G.inner:get(1).weight:size(2) or Rs[1].output:size(2)
+   local function dev(bytes) local p = ffi.new('void*[1]'); check(C.gr_malloc(context(), bytes, p), 'gr_malloc'); return ffi.cast('float*', p[0]) end
+   local noise = dev(4 * N * nd)
+   if noiseMethod == 'uniform' then check(C.gr_fill_uniform_dev(context(), noise, N * nd, -1, 1, seed or 1), 'fill')
+   else check(C.gr_fill_normal_dev(context(), noise, N * nd, seed or 1), 'fill') end
+   local nets = ffi.new('gr_net*[?]', #Rs); local outs = ffi.new('float*[?]', #Rs); local dims = {}
+   C.gr_net_set_training(G.net, 0)
+   for i, R in ipairs(Rs) do
+      assert(R.net, 'hipnn.embed: run one forward through every R first')
+      C.gr_net_set_training(R.net, 0)
+      local o = ffi.new('int[3]'); C.gr_net_out_dim(R.net, o, o + 1, o + 2)
+      dims[i] = o[0] * o[1] * o[2]; nets[i-1] = R.net; outs[i-1] = dev(4 * N * dims[i])
+   end
+   check(C.gr_embed_dev(G.net, nets, #Rs, noise, N, batchSize, nil, outs), 'gr_embed_dev')
+   local emb = {N = N, noise = noise, tables = outs, dims = dims}
+   function emb:attributes(i)
+      local t = torch.FloatTensor(self.N, self.dims[i])
+      check(C.gr_memcpy_d2h(context(), t:data(), self.tables[i-1], 4 * self.N * self.dims[i]), 'gr_memcpy_d2h'); return t
+   end
+   function emb:cosineTopK(i, needles, k)
+      local Q = #needles
+      local rows = ffi.new('int64_t[?]', Q); for j = 1, Q do rows[j-1] = needles[j] - 1 end
+      local idx = torch.LongTensor(Q, k); local sc = torch.FloatTensor(Q, k)
+      check(C.gr_cosine_topk_dev(context(), self.tables[i-1], self.N, self.dims[i], rows, Q, k, ffi.cast('int64_t*', idx:data()), sc:data(), 0), 'gr_cosine_topk_dev')
+      return idx:add(1), sc
+   end
+   function emb:free() C.gr_free(context(), self.noise); for i = 1, #self.dims do C.gr_free(context(), self.tables[i-1]) end end
+   return emb
 end
 
 -- apply_r.lua:198 replacement: unsup.kmeans(attributes, nbClusters, nbIterations) -> centroids, totalcounts

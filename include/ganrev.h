@@ -99,6 +99,18 @@ int gr_net_get_mask(gr_net* net, int layer_index, uint8_t* keep_host, int64_t n)
 int gr_net_forward_host(gr_net* net, const float* in_host, int batch, float* out_host);
 int gr_net_forward_dev(gr_net* net, const float* in_dev, int batch, float* out_dev /*nullable: result stays in m.output*/);
 float* gr_net_output_dev(gr_net* net);                     /* m.output (device), valid until the next forward */
+/* NN_UTILS.forwardBatched(model, input, batchSize) (utils/nn_utils.lua:5-33; apply_r.lua:146,152,153) on device-resident rows:
+ * in_dev [rows x in] -> out_dev [rows x out] in chunks of `batch` rows (the last one ragged).  In evaluate() mode each chunk's last
+ * kernel writes its rows of out_dev itself: the reference's per-row copy loop (utils/nn_utils.lua:25-28) has no counterpart.
+ * m.output afterwards = the last chunk's rows of out_dev. */
+int gr_net_forward_batched_dev(gr_net* net, const float* in_dev, int64_t rows, int batch, float* out_dev);
+/* apply_r.lua:145-153 as one device-resident pipeline: per chunk of `batch` rows  images = G:forward(noise) (:146), then for each of
+ * the n_rnets reverser nets (MODEL_R :152, MODEL_R_FIXER :153)  attributes_k = R_k:forward(images)  written to attr_out_dev[k]
+ * [rows x nd_k] - the tables gr_cosine_topk_dev searches (apply_r.lua:265-282).  images_out_dev [rows x C x H x W] is nullable: the images
+ * are kept only when the caller needs them (pixel-wise search, fix-faces); otherwise a chunk's images live in G's output buffer
+ * until R has read them.  Every net keeps the mode its m:evaluate() / m:training() call set (apply_r.lua:64,94,103: evaluate). */
+int gr_embed_dev(gr_net* gnet, gr_net* const* rnets, int n_rnets, const float* noise_dev, int64_t rows, int batch,
+                 float* images_out_dev /*nullable*/, float* const* attr_out_dev);
 /* m:backward(input, gradOutput) -> m.gradInput ; accumulates into the flat gradient  (train_r.lua:151) */
 int gr_net_backward_host(gr_net* net, const float* in_host, const float* grad_out_host, int batch, float* grad_in_host /*nullable*/);
 int gr_net_backward_dev(gr_net* net, const float* in_dev, const float* grad_out_dev, int batch, float* grad_in_dev /*nullable*/);

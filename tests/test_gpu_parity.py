@@ -645,6 +645,9 @@ def _make_pair(oracle, dims, nd, seed):
     return G, R, oracle.from_model(G, (nd, 1, 1)), oracle.from_model(R, dims)
 
 
+_STEP_SEEDS = {}
+
+
 @pytest.mark.parametrize("dims,nd,B", [((1, 32, 32), 32, 8), ((3, 16, 16), 12, 8)])
 def test_train_r_steps_vs_oracle(ctx, oracle, conv_mode, dims, nd, B):
     """train_r.lua:138-170, three iterations.  Each iteration starts from the ORACLE's state (theta, m, v): Adam's
@@ -665,13 +668,17 @@ def test_train_r_steps_vs_oracle(ctx, oracle, conv_mode, dims, nd, B):
     seed = 100
     for t in (1, 2, 3):
         theta0, m0, v0 = oR.params.copy(), m.copy(), v.copy()
-        for k in range(40):                          # pick a batch without pooling near-ties (helpers): wide gap first
-            seed += 1
+        # the search below runs on the oracle alone, so the batch it settles on does not depend on the arithmetic mode under test:
+        # the seed found by the first mode is reused by the others (40 oracle steps per search were most of this test's time)
+        found = _STEP_SEEDS.get((dims, nd, B, t))
+        for k in ([39] if found else range(40)):     # pick a batch without pooling near-ties (helpers): wide gap first
+            seed = found if found else seed + 1
             noise = synth.normal((B, nd), seed)
             inject_noise(R, oR, B, seed)
             oR.params[...] = theta0; m[...] = m0; v[...] = v0
             rloss, rimg = oracle.train_r_step(oG, oR, noise, ohyper, m, v, t, want_images=True)
             if pools_well_conditioned(R, oR, B, 1e-5 if k < 30 else 2e-6):
+                _STEP_SEEDS[(dims, nd, B, t)] = seed
                 break
         else:
             raise AssertionError("no batch without a max-pool near-tie among 40 seeds: the conditioning filter is broken")
@@ -704,7 +711,8 @@ def _full_size_case(oracle, dims, nd, B):
     from ganrev import synth
     key = (dims, nd, B)
     if key not in _FULL_CACHE:
-        _FULL_CACHE.clear()                          # one full-size case resident at a time (host memory)
+        # (cfg2 and cfg3 both stay resident: the modes alternate between them, and rebuilding cfg3's G forward on the host cores
+        # for every mode was 30 s of the suite; the lean oracle net of cfg3 holds about 6 GB of host memory)
         oracle.set_threads(max(1, min(32, os.cpu_count() or 1)))
         G, R, oG, oR = _make_pair(oracle, dims, nd, 21)
         G.evaluate(); G.forward(synth.normal((8, nd), 1))
