@@ -689,6 +689,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the cfg5 (1M x 100, top-50) search leg")
     ap.add_argument("--embed-rows", type=int, default=1_000_000, help="rows of the cfg5 corpus the device-resident G -> R pipeline produces (BASELINE configs[4]: 1M)")
+    ap.add_argument("--sync-bn", action="store_true", help="synchronised BatchNorm over the ranks (gr_set_tuning sync_bn: per-channel batch sums all-reduced, "
+                    "forward and backward); default: per-rank batch statistics")
     ap.add_argument("--no-sustained", action="store_true", help="skip the bare f16x3 MFMA loop (roofline.sustained): profiling runs, whose kernel statistics it would dominate")
     ap.add_argument("--no-gan", action="store_true", help="skip the GAN-game leg (SURVEY.md 8f rank 4: G + D2, one adversarial batch)")
     ap.add_argument("--conv-mode", default=os.environ.get("GR_CONV_MODE", "f16x3"), choices=list(MODES),
@@ -766,6 +768,8 @@ def main():
         if rccl_ranks != world or rccl_rank != rank:
             raise SystemExit(f"bench.py: RCCL communicator has {rccl_ranks} ranks (this is {rccl_rank}), expected {world} / {rank}")
 
+    if args.sync_bn:
+        ctx.set_tuning("sync_bn", 1)                                          # takes effect with a communicator (N > 1)
     modes = [args.conv_mode] + [m for m in args.modes.split(",") if m in MODES and m != args.conv_mode]
     res = {}
     for w in workloads:
@@ -786,7 +790,8 @@ def main():
             "config": {"workload": h.pop("workload"), "global_batch": h.pop("global_batch"), "per_gpu_batch": h.pop("per_gpu_batch"),
                        "parallelism": f"dp{world}" + ("" if world == 1 else (" (RCCL all-reduce of R's flat gradient)" if not host_reduce else
                                                       " (TEST HOOK: ranks share one GPU, gradients reduced through gloo on the host)")),
-                       "bn": "per-rank batch statistics",
+                       "bn": ("sync (per-channel batch sums all-reduced over the ranks, forward and backward: the global batch's statistics)"
+                              if (args.sync_bn and world > 1 and not host_reduce) else "per-rank batch statistics"),
                        "init": ("G: synthetic trained-looking weights and running statistics (the reference loads a trained G); R: " +
                                 (f"models.create_R's own initialisation, seed {args.seed} (weight-init.lua heuristic, BatchNorm gamma ~ U(0, 1))" if args.init == "reference"
                                  else "synth.init_params (the parity tests' weights)"))},

@@ -587,9 +587,21 @@ __device__ __forceinline__ f32x16 split_mma(const uint4* av, const uint4* bv, f3
     GR_M_(2, 0) GR_M_(1, 1) GR_M_(0, 2) GR_M_(1, 0) GR_M_(0, 1) GR_M_(0, 0)
 #undef GR_M_
   } else {
+#ifdef GR_PROBE_SHAPE16
+    // TIMING-ONLY probe build (tools/build_probe.sh; results are wrong by design): every v_mfma_f32_32x32x16_f16 replaced by two
+    // v_mfma_f32_16x16x32_f16 on the same operand registers and quarters of the same accumulator - same LDS reads, same multiply-adds,
+    // same register footprint.  What the instruction SHAPE alone would buy these kernels, before any re-tiling is written.
+    f32x4 q0 = {acc[0], acc[1], acc[2], acc[3]}, q1 = {acc[4], acc[5], acc[6], acc[7]}, q2 = {acc[8], acc[9], acc[10], acc[11]}, q3 = {acc[12], acc[13], acc[14], acc[15]};
+#define GR_Q_(i, j, qa, qb) qa = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]), qa, 0, 0, 0); \
+                            qb = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]), qb, 0, 0, 0);
+    GR_Q_(1, 0, q0, q1) GR_Q_(0, 1, q2, q3) GR_Q_(0, 0, q0, q1)
+#undef GR_Q_
+    acc = f32x16{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3], q3[0], q3[1], q3[2], q3[3]};
+#else
 #define GR_M_(i, j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]), acc, 0, 0, 0);
     GR_M_(1, 0) GR_M_(0, 1) GR_M_(0, 0)
 #undef GR_M_
+#endif
   }
   return acc;
 }

@@ -521,8 +521,32 @@ __global__ __launch_bounds__(256) void bn_stats_partial_vec_kernel(const float* 
   if (threadIdx.x == 0) { partials[((long)c * STAT_SPLITS + sp) * 2] = s; partials[((long)c * STAT_SPLITS + sp) * 2 + 1] = q; }
 }
 
+// one wave per channel: lane l adds pairs l, l + 64, ... of its row, the lanes meet in a fixed shuffle tree
+__global__ __launch_bounds__(256) void pair_sums_kernel(const double* __restrict__ part, int stride, int count, int C, double* __restrict__ out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  const double2* row = reinterpret_cast<const double2*>(part) + (size_t)c * stride;
+  double s = 0, q = 0;
+  for (int t = lane; t < count; t += 64) { const double2 v = row[t]; s += v.x; q += v.y; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+  if (lane == 0) { out[2 * c] = s; out[2 * c + 1] = q; }
+}
+__global__ void pair_scatter_kernel(const double* __restrict__ in, int C, int stride, double* __restrict__ part) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  part[(size_t)c * stride * 2] = in[2 * c]; part[(size_t)c * stride * 2 + 1] = in[2 * c + 1];
+}
+void launch_pair_sums(const double* part, int stride, int count, int C, double* out, hipStream_t s) {
+  KtScope kt("pair_sums_kernel", 0.0, 16.0 * count * C, s);
+  hipLaunchKernelGGL(pair_sums_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, stride, count, C, out);
+}
+void launch_pair_scatter(const double* in, int C, int stride, double* part, hipStream_t s) {
+  hipLaunchKernelGGL(pair_scatter_kernel, dim3((C + 255) / 256), dim3(256), 0, s, in, C, stride, part);
+}
+
 void launch_bn_stats(const float* y, int B, int C, int HW, double* partials, float* mean, float* invstd,
-                     float* run_mean, float* run_var, int training, hipStream_t s) {
+                     float* run_mean, float* run_var, int training, hipStream_t s, const StatSync* sync) {
   (void)training;
   const long n = (long)B * HW;
   int splits = stat_splits(n);
@@ -533,6 +557,12 @@ void launch_bn_stats(const float* y, int B, int C, int HW, double* partials, flo
   } else {
     KtScope kt("bn_stats_partial_kernel", 0.0, 4.0 * (double)n * C, s);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, splits), dim3(256), 0, s, y, B, C, HW, splits, partials);
+  }
+  if (sync) {      // synchronised BatchNorm: the ranks' (sum, sum of squares) are added before the statistics are formed from them
+    launch_pair_sums(partials, STAT_SPLITS, splits, C, sync->buf, s);
+    if (sync->sum(sync->user, sync->buf, 2L * C)) return;
+    launch_bn_stats_from_tiles(sync->buf, 1, C, sync->n_global, mean, invstd, run_mean, run_var, s, nullptr);
+    return;
   }
   KtScope kt("bn_stats_finalize_kernel", 0.0, 0.0, s);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partials, C, splits, (double)n,
@@ -790,19 +820,19 @@ __device__ __forceinline__ void post_bwd_coef(const PostBwdArgs& a, int c, int s
     const double invstd = a.f.invstd[c];
     sh_coef[0] = (float)(s / n);
     sh_coef[1] = (float)(q * invstd * invstd / n);
-    if (sp == 0) { a.ggamma[c] += (float)(q * invstd); a.gbeta[c] += (float)s; }
+    if (sp == 0) { const double gs = a.gscale != 0.0 ? a.gscale : 1.0; a.ggamma[c] += (float)(q * invstd * gs); a.gbeta[c] += (float)(s * gs); }
   }
   __syncthreads();
 }
 
 template <int CB>
-__global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a, int splits, double n) {
+__global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a, int splits, double n, int psplits) {
   __shared__ double sh[8];
   __shared__ float sh_coef[2];
   post_specialize<CB>(a.f);
   const PostArgs& f = a.f;
   const int c = blockIdx.x, sp = blockIdx.y;
-  post_bwd_coef(a, c, sp, splits, n, sh_coef);
+  post_bwd_coef(a, c, sp, psplits, n, sh_coef);      // psplits: pass A's pairs per channel (one under synchronised BatchNorm); splits: this grid's batch slices
   const unsigned H = f.H, W = f.W, Wo = f.pool ? W >> 1 : W, HW = H * W, HWo = f.pool ? (H >> 1) * Wo : HW, q4 = HW >> 2, wq = W >> 2;
   const int per = (f.B + splits - 1) / splits, b0 = sp * per, b1 = min(f.B, b0 + per);
   const float mean = f.mean[c], invstd = f.invstd[c], w = f.gamma[c], bt = f.beta[c], gm = sh_coef[0], k = sh_coef[1];
@@ -866,7 +896,7 @@ __global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, 
     par[threadIdx.x][0] = f.mean[c]; par[threadIdx.x][1] = f.invstd[c]; par[threadIdx.x][2] = f.gamma[c]; par[threadIdx.x][3] = f.beta[c];
     par[threadIdx.x][4] = (float)(s / n);
     par[threadIdx.x][5] = (float)(q * invstd * invstd / n);
-    if (sp == 0) { a.ggamma[c] += (float)(q * invstd); a.gbeta[c] += (float)s; }
+    if (sp == 0) { const double gs = a.gscale != 0.0 ? a.gscale : 1.0; a.ggamma[c] += (float)(q * invstd * gs); a.gbeta[c] += (float)(s * gs); }
   }
   if (threadIdx.x == 0) a.amax_dy[((blockIdx.x + blockIdx.y * gridDim.x) % AMAX_ENTRIES) * AMAX_STRIDE] = __float_as_uint(bound);   // the same value from every block
   __syncthreads();
@@ -943,12 +973,12 @@ __global__ void post_backward_finalize_kernel(PostBwdArgs a, int splits, double 
 }
 
 // pass B (BN only): dy = ((dz - gm) - (y-mean)*k) * invstd * gamma ; per-channel sum of dy for the bias gradient
-__global__ __launch_bounds__(256) void post_backward_b_kernel(PostBwdArgs a, int splits, double nn) {
+__global__ __launch_bounds__(256) void post_backward_b_kernel(PostBwdArgs a, int splits, double nn, int psplits) {
   __shared__ double sh[8];
   __shared__ float sh_coef[2];
   const PostArgs& f = a.f;
   const int c = blockIdx.x, sp = blockIdx.y;
-  post_bwd_coef(a, c, sp, splits, nn, sh_coef);
+  post_bwd_coef(a, c, sp, psplits, nn, sh_coef);
   const long HW = (long)f.H * f.W;
   const long n = (long)f.B * HW, chunk = (n + splits - 1) / splits;
   const long j0 = sp * chunk, j1 = min(n, j0 + chunk);
@@ -990,8 +1020,10 @@ void launch_bias_grad_batch(BiasJobs& jobs, hipStream_t s) {
   jobs.n = 0;
 }
 
-void launch_post_backward(const PostBwdArgs& a0, hipStream_t s, BiasJobs* defer) {
+void launch_post_backward(const PostBwdArgs& a0, hipStream_t s, BiasJobs* defer, const StatSync* sync) {
   PostBwdArgs a = a0, aB = a0;
+  if (!a0.f.has_bn) sync = nullptr;          // nothing is reduced over the batch without a BatchNorm
+  if (sync) aB.gscale = a.gscale = sync->grad_scale;
   // pass A and the operand-ready pass B: tensors the Infinity Cache cannot hold (at cfg2's 34 / 67 MB a non-temporal pass A takes from
   // pass B what it would have found in the cache: A 0.169 -> 0.161 ms but B 0.163 -> 0.181); the float4 pass B measured no gain
   a.nt = post_nt_mode() >= 0 ? post_nt_mode() & 1 : (post_big(a0.f) ? 1 : 0);
@@ -1015,16 +1047,27 @@ void launch_post_backward(const PostBwdArgs& a0, hipStream_t s, BiasJobs* defer)
     hipLaunchKernelGGL(post_backward_finalize_kernel, dim3((f.C + 255) / 256), dim3(256), 0, s, a, splits, (double)n);
     return;
   }
+  double nb = (double)n;        // elements per channel the BatchNorm-backward means are taken over
+  int psplits = splits;         // pass A's (sum, dot) pairs per channel that pass B adds
+  if (sync) {
+    // synchronised BatchNorm: pass A's (sum dz, sum dz (y - mean)) added over the ranks; pass B then finds ONE pair per channel.  The
+    // operand-ready dy is scaled by a bound built from max|dz|: the means pass B subtracts are global, so the maximum must be too.
+    launch_pair_sums(a.partials, STAT_SPLITS, splits, f.C, sync->buf, s);
+    if (sync->sum(sync->user, sync->buf, 2L * f.C)) return;
+    launch_pair_scatter(sync->buf, f.C, STAT_SPLITS, a.partials, s);
+    if (a.amax_dz && sync->max_u32(sync->user, a.amax_dz, AMAX_WORDS)) return;
+    psplits = 1; nb = sync->n_global;
+  }
   if (vec && a.dy_p16) {      // caller checked post_g8_supported
     KtScope kt("post_backward_b_g8_kernel", 0.0, 4.0 * ((a.dy ? 3.0 : 2.0) * pre + post), s);        // reads g and y, writes dy operand-ready (and as fp32 when a consumer needs that)
     // 8 channels per block: a (C / 8, splits) grid would leave 2 blocks per CU on a 64-channel layer (measured 72 us against
     // 35 for the per-channel kernel): the batch is sliced down to single images instead, up to PB_SPLITS slices
     int slices = f.B < PB_SPLITS ? f.B : PB_SPLITS;
     { const int per = (f.B + slices - 1) / slices; slices = (f.B + per - 1) / per; }
-    if (f.H * f.W <= 256) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, splits, slices, (double)n, g_p16_debug); });
-    else if (g8_half_tiles() == 2) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, splits, slices, (double)n, g_p16_debug); });
-    else if (g8_half_tiles() && (f.H * f.W) % 512 == 0) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<512, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, splits, slices, (double)n, g_p16_debug); });
-    else with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<1024, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, splits, slices, (double)n, g_p16_debug); });
+    if (f.H * f.W <= 256) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, psplits, slices, nb, g_p16_debug); });
+    else if (g8_half_tiles() == 2) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, psplits, slices, nb, g_p16_debug); });
+    else if (g8_half_tiles() && (f.H * f.W) % 512 == 0) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<512, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, psplits, slices, nb, g_p16_debug); });
+    else with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<1024, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, psplits, slices, nb, g_p16_debug); });
     if (a.gbias) {
       BiasJobs one{}; one.n = 0;
       BiasJobs* q = defer ? defer : &one;
@@ -1035,10 +1078,10 @@ void launch_post_backward(const PostBwdArgs& a0, hipStream_t s, BiasJobs* defer)
     return;
   } else if (vec) {
     KtScope kt("post_backward_b_vec_kernel", 0.0, 4.0 * (2.0 * pre + post), s);                      // reads g and y, writes dy
-    with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL(post_backward_b_vec_kernel<decltype(cb)::value>, dim3(f.C, splits), dim3(256), 0, s, aB, splits, (double)n); });
+    with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL(post_backward_b_vec_kernel<decltype(cb)::value>, dim3(f.C, splits), dim3(256), 0, s, aB, splits, nb, psplits); });
   } else {
     KtScope kt("post_backward_b_kernel", 0.0, 4.0 * 3.0 * pre, s);
-    hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits, (double)n);
+    hipLaunchKernelGGL(post_backward_b_kernel, dim3(f.C, splits), dim3(256), 0, s, a, splits, nb, psplits);
   }
   if (a.gbias) {
     BiasJobs one{}; one.n = 0;

@@ -256,8 +256,27 @@ void launch_post_forward(const PostArgs& a, hipStream_t s);
 constexpr int PB_SPLITS = 256;   // row length of partials_b: pass B of the operand-ready pipeline slices the batch finer than pass A (blocks of 8 channels)
 constexpr int STAT_SPLITS = 64;  // partial sums per channel (16 -> 64: 4 -> 16 waves per SIMD in flight on the 64-channel layers; pass A 1.41 -> 1.12 ms at cfg3)
 // per-channel (sum, sumsq) partials in double -> mean / invstd (+ running stats update when run_mean != null)
+// Synchronised BatchNorm under data parallelism (optional): the per-channel sums a BatchNorm layer reduces over its batch -
+// (sum y, sum y^2) in the forward, (sum dz, sum dz (y - mean)) in the backward - are added over the ranks before they are used, so
+// that P ranks of B images compute exactly what one device computes on P x B images (models.lua:410-448 on the global batch).
+// `sum` is called in stream order with a compact device buffer [count] of doubles and must leave the SUM over the ranks in it;
+// `max_u32` likewise with the element-wise maximum (the f16x3 scale bound of dy needs the GLOBAL max|dz|).  n_global = elements per
+// channel over all ranks; grad_scale = 1 / ranks for the gamma / beta gradients, which come out of the GLOBAL sums on every rank and
+// meet the gradient all-reduce (a SUM) afterwards.
+struct StatSync {
+  int (*sum)(void* user, double* buf, long count);
+  int (*max_u32)(void* user, unsigned* buf, long count);
+  void* user;
+  double* buf;             // device scratch, >= 2 * C doubles
+  double n_global;
+  float grad_scale;
+};
+// per-channel sums of `count` (a, b) pairs at row stride `stride` pairs -> compact out[C][2]  (fixed order: deterministic)
+void launch_pair_sums(const double* part, int stride, int count, int C, double* out, hipStream_t s);
+// out[C][2] -> pair 0 of every row of a [C][stride][2] array
+void launch_pair_scatter(const double* in, int C, int stride, double* part, hipStream_t s);
 void launch_bn_stats(const float* y, int B, int C, int HW, double* partials /*[C][STAT_SPLITS][2]*/,
-                     float* mean, float* invstd, float* run_mean, float* run_var, int training, hipStream_t s);
+                     float* mean, float* invstd, float* run_mean, float* run_var, int training, hipStream_t s, const StatSync* sync = nullptr);
 void launch_bn_eval_prepare(const float* run_mean, const float* run_var, float* mean, float* invstd, int C, hipStream_t s);
 
 struct PostBwdArgs {
@@ -276,13 +295,14 @@ struct PostBwdArgs {
   // (which then must not be accumulated into) and scales by it.
   void* dy_p16; unsigned* amax_dz; const unsigned* kb;
   int nt;                  // non-temporal loads of gradOutput and y (set by the launcher, per pass)
+  double gscale;           // factor on the gamma / beta gradients: 1, or 1 / ranks under synchronised BatchNorm (StatSync); 0 reads as 1
 };
 bool post_g8_supported(int C, int H, int W, bool pool, bool backward = false);
 // Bias gradients are summed from partials_b by one batched launch for several stages (launch_bias_grad_batch) when
 // `defer` is given; otherwise inside the call.
 struct BiasJob { const double* partials; float* gbias; int C, splits; };     // partials: rows of PB_SPLITS
 struct BiasJobs { BiasJob job[16]; int n; };
-void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer = nullptr);
+void launch_post_backward(const PostBwdArgs& a, hipStream_t s, BiasJobs* defer = nullptr, const StatSync* sync = nullptr);
 void launch_bias_grad_batch(BiasJobs& jobs, hipStream_t s);    // runs and empties the list
 
 // ---------------------------------------------------------------- K x K convolution (odd K other than 3) and nn.PReLU: convk.hip

@@ -53,6 +53,11 @@ struct gr_ctx {
   void* pin = nullptr; size_t pin_bytes = 0;   // pinned staging for small results (search)
   hipEvent_t ev_guard = nullptr; bool guard_pending = false;   // device-resident trainer: sampled scans, verdict read one call later
   bool guard_tripped = false;          // ... which found a hostile range: the context stays on bf16x6
+  // synchronised BatchNorm (gr_set_tuning "sync_bn", SURVEY.md 8e optional) and the host-exchange hook that can stand in for RCCL
+  int sync_bn = 0;
+  double* sync_buf = nullptr; size_t sync_cap = 0;     // compact per-channel pairs that travel through the collective
+  gr_exchange_fn xchg = nullptr; void* xchg_user = nullptr;
+  int coll_rc = 0;                     // first failure of a collective issued from inside a kernel launcher (StatSync callbacks)
 };
 
 // ---- per-kernel event timer (gr_set_timing(ctx, 2)) -------------------------------------------------------------
@@ -131,6 +136,34 @@ static int comm_check(gr_ctx* c) {
   if (st != ncclSuccess && st != ncclInProgress) return fail(c, GR_ERR_COMM, "RCCL asynchronous error: %s", ncclGetErrorString(st));
   return GR_OK;
 }
+// A small collective in stream order on the COMPUTE stream (BatchNorm statistics sit on the critical path): kind 0 = fp32 SUM,
+// 1 = fp64 SUM, 2 = uint32 MAX.  RCCL, or the host-exchange hook (gr_comm_set_host_exchange) when one is installed.
+static bool have_peers(gr_ctx* c) { return c->xchg != nullptr || c->comm != nullptr; }
+static int small_allreduce(gr_ctx* c, void* buf, long count, int kind) {
+  if (c->xchg) {
+    const int rc = c->xchg(c->xchg_user, buf, (int64_t)count, kind);
+    return rc ? fail(c, GR_ERR_COMM, "host exchange hook failed (%d)", rc) : GR_OK;
+  }
+  if (!c->comm) return GR_OK;
+  NCCLCHK(c, ncclAllReduce(buf, buf, (size_t)count, kind == 0 ? ncclFloat : (kind == 1 ? ncclDouble : ncclUint32), kind == 2 ? ncclMax : ncclSum, c->comm, c->stream));
+  return GR_OK;
+}
+static int statsync_sum(void* user, double* buf, long count) { gr_ctx* c = static_cast<gr_ctx*>(user); const int r = small_allreduce(c, buf, count, 1); if (r && !c->coll_rc) c->coll_rc = r; return r; }
+static int statsync_max(void* user, unsigned* buf, long count) { gr_ctx* c = static_cast<gr_ctx*>(user); const int r = small_allreduce(c, buf, count, 2); if (r && !c->coll_rc) c->coll_rc = r; return r; }
+// the StatSync of a stage with C channels and n_local elements per channel on this rank, or null when BatchNorm is per rank
+static const StatSync* stat_sync(gr_ctx* c, StatSync& ss, int C, double n_local) {
+  if (!c->sync_bn || !have_peers(c)) return nullptr;
+  if ((size_t)C * 2 > c->sync_cap) {
+    if (c->sync_buf) { if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr; (void)hipFree(c->sync_buf); c->sync_buf = nullptr; c->sync_cap = 0; }
+    const size_t cap = (size_t)(C > 2048 ? C : 2048) * 2;
+    if (hipMalloc((void**)&c->sync_buf, sizeof(double) * cap) != hipSuccess) return nullptr;
+    c->sync_cap = cap;
+  }
+  ss.sum = statsync_sum; ss.max_u32 = statsync_max; ss.user = c; ss.buf = c->sync_buf;
+  ss.n_global = n_local * c->nranks; ss.grad_scale = 1.f / (float)c->nranks;     // equal shards (gr_train_r_step checks global_batch)
+  return &ss;
+}
+
 // roctx range of one phase of gr_train_r_step (shows up in rocprofv3 --marker-trace / the rocprof timeline; a no-op without a tool)
 struct PhaseRange { explicit PhaseRange(const char* name) { roctxRangePushA(name); } ~PhaseRange() { roctxRangePop(); } };
 
@@ -198,6 +231,7 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   if (c->ev_dy_ready) (void)hipEventDestroy(c->ev_dy_ready);
   for (auto& e : c->ev_wgrad_done) if (e) (void)hipEventDestroy(e);
   if (c->guard_chmax) (void)hipFree(c->guard_chmax);
+  if (c->sync_buf) (void)hipFree(c->sync_buf);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->ev_guard) (void)hipEventDestroy(c->ev_guard);
   (void)hipFree(c->d_loss); (void)hipFree(c->amax); (void)hipHostFree(c->h_loss);
@@ -239,7 +273,9 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!strcmp(key, "nt_stores")) { gr::g_nt_stores = value; return GR_OK; }        // bit mask: which kernels store their outputs non-temporally (kernels.h)
   if (!strcmp(key, "up2_stagger")) { gr::g_up2_stagger = value; return GR_OK; }   // start delay of a CU's second workgroup, x 512 clocks
   if (!strcmp(key, "up2_quad")) { gr::g_up2_quad = value; return GR_OK; }       // 1 (default): four-wave up-sampling kernel where it applies; 0: eight-wave     // diagnostic ablations (outputs are then wrong by design)
-  if (!strcmp(key, "side_wgrad")) { c->side_wgrad = value; return GR_OK; }          // weight gradients on the side stream (1) or in line (0, default)
+  if (!strcmp(key, "side_wgrad")) { c->side_wgrad = value; return GR_OK; }
+  // synchronised BatchNorm under data parallelism: per-channel batch sums are all-reduced, fwd and bwd (include/ganrev.h)
+  if (!strcmp(key, "sync_bn")) { c->sync_bn = value != 0; return GR_OK; }          // weight gradients on the side stream (1) or in line (0, default)
   // f16x3 range guard on / off.  Off also clears a tripped trainer guard AND drops a verdict still in flight: that verdict is about the
   // nets scanned by an earlier gr_train_r_step and must not trip the context under whoever trains next on it.
   if (!strcmp(key, "range_guard")) { c->range_guard = value; if (!value) { c->guard_tripped = false; c->guard_pending = false; } return GR_OK; }
@@ -1064,9 +1100,19 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
           bd.bound_out = p16_out ? nx->amax_x : nullptr; bd.kb_out = s.amax_kb;
           bdp = &bd; s.kb_gen = n->amax_gen;
         }
+        StatSync ss; const StatSync* sync = stat_sync(c, ss, s.Cout, (double)B * s.H * s.W);
+        if (sync) {     // synchronised BatchNorm: the ranks' per-channel (sum, sum of squares) are added before the statistics are formed
+          launch_pair_sums(s.stat_part, s.stat_tiles_last, s.stat_tiles_last, s.Cout, sync->buf, c->stream);
+          r = small_allreduce(c, sync->buf, 2L * s.Cout, 1); if (r) return r;
+          launch_bn_stats_from_tiles(sync->buf, 1, s.Cout, sync->n_global, s.mean, s.invstd, s.run_mean, s.run_var, c->stream, bdp);
+        } else
         launch_bn_stats_from_tiles(s.stat_part, s.stat_tiles_last, s.Cout, (double)B * s.H * s.W, s.mean, s.invstd, s.run_mean, s.run_var, c->stream, bdp);
       }
-      else if (n->training) launch_bn_stats(yv, B, s.Cout, s.H * s.W, s.partials, s.mean, s.invstd, s.run_mean, s.run_var, 1, c->stream);
+      else if (n->training) {
+        StatSync ss;
+        launch_bn_stats(yv, B, s.Cout, s.H * s.W, s.partials, s.mean, s.invstd, s.run_mean, s.run_var, 1, c->stream, stat_sync(c, ss, s.Cout, (double)B * s.H * s.W));
+        if (c->coll_rc) { r = c->coll_rc; c->coll_rc = 0; return r; }
+      }
       else if (!s.eval_ready) { launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream); s.eval_ready = true; }
     }
     pa.amax_out = p16_out ? nullptr : amax_next;      // operand-ready: the slot already holds the bound and must not move
@@ -1240,6 +1286,7 @@ extern "C" int gr_net_get_pool_index(gr_net* n, int layer, uint8_t* host, int64_
 static int reduce_bucket(gr_net* n, int64_t lo, int64_t hi) {
   gr_ctx* c = n->ctx;
   if (hi <= lo) return GR_OK;
+  if (c->xchg) return small_allreduce(c, n->grads + lo, (long)(hi - lo), 0);        // host-exchange hook: in stream order on the compute stream
   HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
   NCCLCHK(c, ncclAllReduce(n->grads + lo, n->grads + lo, (size_t)(hi - lo), ncclFloat, ncclSum, c->comm, c->comm_stream));
@@ -1251,7 +1298,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
   gr_ctx* c = n->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   if (B != n->lastB) return fail(c, GR_ERR_STATE, "backward batch %d does not match the last forward (%d)", B, n->lastB);
-  reduce = reduce && c->comm != nullptr;
+  reduce = reduce && have_peers(c);
   int64_t bucket_hi = n->n_params;            // everything in [stage first offset, bucket_hi) is final but not yet reduced
   BiasJobs bias_jobs{}; bias_jobs.n = 0;
   { int r = prep_weights(n); if (r) return r; }   // no-op unless the arithmetic mode changed since the forward
@@ -1299,7 +1346,11 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       int r = ensure_ws(c, prelu_grad_workspace_bytes()); if (r) return r;
       launch_prelu_grad(g, s.kind == ST_ELEM ? x : s.y, (long)B * vol3(s.Cout, s.H, s.W), static_cast<double*>(c->ws), n->grads + s.slope_off, c->stream);
     }
-    launch_post_backward(pb, c->stream, &bias_jobs);       // bias gradients of several stages are summed by one launch
+    {
+      StatSync ss;
+      launch_post_backward(pb, c->stream, &bias_jobs, s.has_bn ? stat_sync(c, ss, s.Cout, (double)B * s.H * s.W) : nullptr);       // bias gradients of several stages are summed by one launch
+      if (c->coll_rc) { const int rc = c->coll_rc; c->coll_rc = 0; return rc; }
+    }
     LAUNCHCHK(c);
     if (s.kind == ST_CONV && s.ksz != 3) {
       int r = ensure_ws(c, convk_workspace_bytes(B, s.Cin, s.Cout, s.ksz)); if (r) return r;
@@ -1404,10 +1455,12 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
   LAUNCHCHK(c);
   if (reduce) {
     int r = reduce_bucket(n, 0, bucket_hi); if (r) return r;
-    // Adam (compute stream) must see every reduced bucket
-    HIPCHK(c, hipEventRecord(c->ev_done, c->comm_stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
-    r = comm_check(c); if (r) return r;
+    if (!c->xchg) {
+      // Adam (compute stream) must see every reduced bucket
+      HIPCHK(c, hipEventRecord(c->ev_done, c->comm_stream));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_done, 0));
+      r = comm_check(c); if (r) return r;
+    }
   }
   return GR_OK;
 }
@@ -1539,6 +1592,7 @@ extern "C" int gr_comm_unique_id(gr_ctx* c, void* id_out) {
 extern "C" int gr_comm_init(gr_ctx* c, const void* idb, int nranks, int rank) {
   if (!c || !idb || nranks < 1 || rank < 0 || rank >= nranks) return GR_ERR_INVALID;
   if (c->comm) return fail(c, GR_ERR_STATE, "communicator already initialised");
+  if (c->xchg) return fail(c, GR_ERR_STATE, "a host-exchange hook is installed on this context");
   HIPCHK(c, hipSetDevice(c->device));
   ncclUniqueId id; memcpy(&id, idb, sizeof id);
   NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
@@ -1551,9 +1605,20 @@ extern "C" int gr_comm_destroy(gr_ctx* c) {
   c->nranks = 1; c->rank = 0;
   return GR_OK;
 }
+// Host-exchange hook: stands in for the RCCL collectives of this context (gradient / loss / BatchNorm-statistics all-reduce).  What
+// SURVEY.md section 4 asks for on a box whose ranks cannot each own a GPU: "a fake comm that sums host buffers in-process so the
+// sharding / reduction logic is testable" - here with the HIP path as the compute (tests/test_gpu_syncbn.py: two contexts on one GPU).
+extern "C" int gr_comm_set_host_exchange(gr_ctx* c, int nranks, int rank, gr_exchange_fn fn, void* user) {
+  if (!c || nranks < 1 || rank < 0 || rank >= nranks) return GR_ERR_INVALID;
+  if (c->comm) return fail(c, GR_ERR_STATE, "an RCCL communicator is active on this context");
+  c->xchg = fn; c->xchg_user = user;
+  c->nranks = fn ? nranks : 1; c->rank = fn ? rank : 0;
+  return GR_OK;
+}
 extern "C" int gr_comm_ranks(gr_ctx* c, int* nr, int* r) { if (!c) return GR_ERR_INVALID; if (nr) *nr = c->nranks; if (r) *r = c->rank; return GR_OK; }
 extern "C" int gr_allreduce_dev(gr_ctx* c, float* buf, int64_t n) {
   if (!c || !buf || n <= 0) return GR_ERR_INVALID;
+  if (c->xchg) return small_allreduce(c, buf, (long)n, 0);
   if (!c->comm) return GR_OK;          // (a one-rank communicator still goes through RCCL: the path a 1-GPU box can exercise)
   NCCLCHK(c, ncclAllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
   return comm_check(c);
@@ -1592,6 +1657,8 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   const int64_t nd = vol3(rn->outC, rn->outH, rn->outW);
   if (vol3(g->inC, g->inH, g->inW) != nd) return fail(c, GR_ERR_INVALID, "noise dim mismatch: G takes %lld, R emits %lld", (long long)vol3(g->inC, g->inH, g->inW), (long long)nd);
   if (vol3(g->outC, g->outH, g->outW) != vol3(rn->inC, rn->inH, rn->inW)) return fail(c, GR_ERR_INVALID, "image dim mismatch between G and R");
+  if (c->sync_bn && have_peers(c) && (int64_t)B * c->nranks != GB)
+    return fail(c, GR_ERR_INVALID, "synchronised BatchNorm needs equal shards: batch %d x %d ranks != global batch %d", B, c->nranks, GB);
   const bool tm = c->timing;
   int r;
   // Range guard of the device-resident loop: no synchronisation is allowed here, so the parameter scans (weights, BatchNorm
@@ -1628,7 +1695,8 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   PhaseRange pr("loss");
   launch_mse(rn->st.back().out, noise_dev, (long)B * nd, (long)GB * nd, c->d_loss, rn->gout_buf, c->stream);  // :147,150
   LAUNCHCHK(c);
-  if (c->comm) {   // global MSE = sum of the ranks' partial means (same communicator, same stream as the gradient buckets)
+  if (c->xchg) { r = small_allreduce(c, c->d_loss, 1, 1); if (r) return r; }
+  else if (c->comm) {   // global MSE = sum of the ranks' partial means (same communicator, same stream as the gradient buckets)
     HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_ready, 0));
     NCCLCHK(c, ncclAllReduce(c->d_loss, c->d_loss, 1, ncclDouble, ncclSum, c->comm, c->comm_stream));

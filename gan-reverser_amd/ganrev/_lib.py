@@ -99,6 +99,7 @@ _SIGS = {
     "gr_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "gr_comm_destroy": (C.c_int, [_P]),
     "gr_comm_ranks": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gr_comm_set_host_exchange": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "gr_allreduce_grads": (C.c_int, [_P]),
     "gr_allreduce_dev": (C.c_int, [_P, _P, C.c_int64]),
     "gr_allgather_dev": (C.c_int, [_P, _P, _P, C.c_int64]),
@@ -318,6 +319,27 @@ class Context:
 
     def comm_destroy(self):
         self.check(self.lib.gr_comm_destroy(self.h), "gr_comm_destroy")
+
+    EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+    def set_host_exchange(self, nranks, rank, fn):
+        """Install fn(dev_ptr, count, kind) -> 0 as this context's collectives (gr_comm_set_host_exchange: kind 0 fp32 SUM, 1 fp64 SUM,
+        2 uint32 MAX over the ranks, result left in the device buffer); fn = None removes it.  The "fake comm" of SURVEY.md section 4."""
+        if fn is None:
+            self._xchg_cb = None
+            self.check(self.lib.gr_comm_set_host_exchange(self.h, 1, 0, None, None), "gr_comm_set_host_exchange")
+            return
+
+        def tramp(user, buf, count, kind):
+            try:
+                return int(fn(buf, int(count), int(kind)) or 0)
+            except Exception:  # noqa: BLE001 - an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._xchg_cb = self.EXCHANGE_FN(tramp)           # keep the trampoline alive as long as the library may call it
+        self.check(self.lib.gr_comm_set_host_exchange(self.h, int(nranks), int(rank), C.cast(self._xchg_cb, C.c_void_p), None),
+                   "gr_comm_set_host_exchange")
 
     def allreduce(self, dptr, n):
         self.check(self.lib.gr_allreduce_dev(self.h, _ptr(dptr), int(n)), "gr_allreduce_dev")

@@ -145,6 +145,14 @@ int gr_comm_unique_id(gr_ctx* ctx, void* id_out /*GR_COMM_ID_BYTES, generated on
 int gr_comm_init(gr_ctx* ctx, const void* id, int nranks, int rank);    /* RCCL communicator over xGMI */
 int gr_comm_destroy(gr_ctx* ctx);
 int gr_comm_ranks(gr_ctx* ctx, int* nranks, int* rank);
+/* Host-exchange hook (tests / bring-up on boxes whose ranks cannot each own a GPU; SURVEY.md section 4: "a fake comm that sums host
+ * buffers in-process"): stands in for EVERY collective this context would issue through RCCL - the gradient and loss all-reduce of
+ * gr_train_r_step, gr_allreduce_dev, the BatchNorm-statistics exchange of "sync_bn".  fn is called in stream order from inside the
+ * library call with a device buffer of `count` elements and must return 0 with the reduction over all ranks in it:
+ * kind 0 = fp32 SUM, 1 = fp64 SUM, 2 = uint32 MAX.  It may synchronise (gr_memcpy_d2h / gr_memcpy_h2d on this context are allowed
+ * from inside it).  fn = NULL removes the hook.  Mutually exclusive with gr_comm_init. */
+typedef int (*gr_exchange_fn)(void* user, void* buf_dev, int64_t count, int kind);
+int gr_comm_set_host_exchange(gr_ctx* ctx, int nranks, int rank, gr_exchange_fn fn, void* user);
 int gr_allreduce_grads(gr_net* net);                        /* SUM over ranks of the flat gradient; no-op when nranks == 1 */
 int gr_allreduce_dev(gr_ctx* ctx, float* buf_dev, int64_t n);
 /* all-gather of bytes_per_rank bytes from every rank into recv_dev [nranks x bytes_per_rank], rank order (the sharded search's
@@ -169,6 +177,11 @@ int gr_get_conv_mode(gr_ctx* ctx);
 /* kernel-selection thresholds (process-wide).  "p16_min_tiles" (default 256): smallest tile count at which a convolution takes the
  * operand-ready (P16) kernel; tests set 1 to exercise that path on small shapes. */
 int gr_set_tuning(gr_ctx* ctx, const char* key, int value);
+/* "sync_bn" (default 0): synchronised BatchNorm under data parallelism (optional).  With a communicator (or the host-exchange
+ * hook) on the context, every training-mode BatchNorm adds its per-channel batch sums over the ranks - (sum y, sum y^2) in the forward,
+ * (sum dz, sum dz (y - mean)) in the backward, 2 x C doubles each - before it uses them, so that P ranks of B images compute what ONE
+ * device computes on P x B images (models.lua:410-448 on the global batch; running statistics identical on every rank).  Default = per-rank
+ * statistics (the oracle's "BatchNorm in P groups").  Needs equal shards: gr_train_r_step checks batch x ranks == global_batch. */
 /* f16x3 range guard ("range_guard" 1/0 in gr_set_tuning, default on; GR_RANGE_GUARD=0 before gr_init turns it off).  f16x3 scales a
  * tensor by one power of two: an entry 2^k below the tensor maximum keeps about 40 - k bits, and an output channel's relative
  * error grows with the product of the per-channel spreads of the activation and the weight tensor multiplied.  The host-memory calls

@@ -40,7 +40,7 @@ def shard(arr, rank, world=WORLD):
     return arr[rank * per:(rank + 1) * per]
 
 
-def oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, hyper, dev_index=None, dev_y=None, R=None, max_flips=64, report=None, mode=None):
+def oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, hyper, dev_index=None, dev_y=None, R=None, max_flips=64, report=None, mode=None, groups=WORLD):
     """The reference side: one train_r.lua:138-170 iteration on the global batch with BatchNorm in WORLD groups.
     Returns dict(images, preds, loss, raw = the un-penalised flat gradient (the SUM the ranks must reproduce),
     grads = penalised + clamped, theta, m, v).  dev_index / dev_y: the device's pool argmax and raw conv outputs of the pooled
@@ -49,7 +49,7 @@ def oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, hyper, dev_index=N
     GB = noise.shape[0]
     oG.set_training(False)
     images = oG.forward(noise)                                    # train_r.lua:139
-    oR.set_bn_groups(WORLD)
+    oR.set_bn_groups(groups)          # WORLD: per-rank batch statistics (the default DP semantics); 1: synchronised BatchNorm
     oR.set_training(True)
     oR.params[...] = theta0
     release_argmax(R, oR)
@@ -58,7 +58,7 @@ def oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, hyper, dev_index=N
     oR.zero_grads()
     preds = np.array(oR.forward(images), copy=True)               # :146
     if dev_index is not None:
-        adopt_device_argmax(R, oR, GB, max_flips, dev_index=dev_index, dev_y=dev_y, groups=WORLD, report=report, mode=mode)
+        adopt_device_argmax(R, oR, GB, max_flips, dev_index=dev_index, dev_y=dev_y, groups=groups, report=report, mode=mode)
         for li, k in masks.items():
             oR.set_mask(li, k)
         oR.zero_grads()

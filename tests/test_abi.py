@@ -59,7 +59,7 @@ def _strip_comments(txt):
 
 
 _C_TYPE_WORDS = {"const", "unsigned", "signed", "struct", "int", "float", "double", "char", "void", "long", "short",
-                 "int32_t", "int64_t", "uint8_t", "uint64_t", "uint32_t", "size_t", "gr_ctx", "gr_net", "gr_layer_desc", "gr_hyper"}
+                 "int32_t", "int64_t", "uint8_t", "uint64_t", "uint32_t", "size_t", "gr_ctx", "gr_net", "gr_layer_desc", "gr_hyper", "gr_exchange_fn"}
 
 
 def _param_type(p):

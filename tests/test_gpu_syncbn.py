@@ -1,0 +1,149 @@
+"""-m gpu: synchronised BatchNorm under data parallelism (optional; gr_set_tuning "sync_bn") on ONE GPU.
+
+The only way a data-parallel run of P ranks x B images equals a single-device run of models.lua:410-448's BatchNorms on P x B images:
+every BatchNorm adds its per-channel batch sums over the ranks, forward ((sum y, sum y^2)) and backward ((sum dz, sum dz (y - mean))).
+Here the two ranks are two THREADS of this process, each with its own gr_ctx on GPU 0 and its own nets, and the collectives go through
+the host-exchange hook (gr_comm_set_host_exchange - SURVEY.md section 4's "fake comm that sums host buffers in-process"): every
+exchange downloads the rank's buffer, meets the other rank at a barrier, adds in rank order and uploads the sum.  Each rank runs the
+real gr_train_r_step (G forward, R forward with the statistics exchange in every BatchNorm, MSE with the global normaliser, R backward
+with the exchange in every BatchNorm backward, gradient all-reduce, penalty + clamp + Adam).  Reference: the oracle run ONCE on the 2B
+batch with ONE statistics group (go_net_set_bn_groups(1)) - the control that tests/test_gpu_dp.py asserts per-rank BatchNorm DIFFERS from."""
+import threading
+
+import numpy as np
+import pytest
+
+import dp_common as D
+from helpers import TOL, assert_close, assert_grads_close, maxdiff, pool_layers
+from test_gpu_dp import _check_against_oracle, _compile, _layer_of, _pooled_convs
+
+pytestmark = pytest.mark.gpu
+
+
+class HostExchange:
+    """In-process stand-in for the all-reduce between `world` ranks (threads)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.slots = [None] * world
+        self.barrier = threading.Barrier(world, timeout=120)
+        self.calls = [0] * world
+        self.bytes = 0
+
+    def fn(self, rank, ctx):
+        dt = {0: np.float32, 1: np.float64, 2: np.uint32}
+
+        def exchange(buf, count, kind):
+            mine = ctx.download(buf, (count,), dt[kind])         # waits for the rank's stream: the buffer is final
+            self.slots[rank] = mine
+            self.barrier.wait()
+            parts = list(self.slots)                             # rank order: the same sum on every rank
+            tot = parts[0].copy()
+            for p in parts[1:]:
+                tot = np.maximum(tot, p) if kind == 2 else tot + p
+            self.barrier.wait()                                  # everyone has read the slots before the next exchange overwrites them
+            ctx.upload(tot, buf)
+            self.calls[rank] += 1
+            if rank == 0:
+                self.bytes += mine.nbytes
+            return 0
+        return exchange
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+@pytest.mark.parametrize("name,dims,nd,B", [pytest.param(*c, id=c[0]) for c in D.CASES])
+def test_sync_bn_two_ranks_equal_one_device_on_the_global_batch(oracle, mode, name, dims, nd, B):
+    import ganrev._lib as L
+    GB = B * D.WORLD
+    G0, R0 = D.make_models(dims, nd)
+    oG, oR = oracle.from_model(G0, (nd, 1, 1)), oracle.from_model(R0, dims)
+    theta0 = oR.params.copy()
+    noise, masks = D.global_inputs(R0, _layer_of(R0, oR), oR.mask_size, dims, nd, B)
+    pooled = _pooled_convs(R0, oR)
+    zeros = np.zeros_like(theta0)
+    xch = HostExchange(D.WORLD)
+    out, errors = [None] * D.WORLD, []
+
+    def rank_main(r):
+        try:
+            ctx = L.Context(0)
+            ctx.set_conv_mode(mode)
+            G, R = D.make_models(dims, nd)
+            G._ctx = R._ctx = ctx
+            _compile(G, R, dims, nd)                              # (before the hook: a lone forward must not wait for a peer)
+            gnet, rnet = G._net, R._net
+            ctx.set_tuning("sync_bn", 1)
+            ctx.set_host_exchange(D.WORLD, r, xch.fn(r, ctx))
+            assert ctx.comm_ranks() == (D.WORLD, r)
+            dn = ctx.upload(D.shard(noise, r))
+            res = {}
+            for tag, hyper in (("raw", L.Hyper(l1=0.0, l2=0.0, clamp=0.0)), ("step", L.Hyper())):
+                rnet.set_params(theta0); rnet.set_adam_state(zeros, zeros)
+                for i in range(rnet.n_bn()):
+                    f = rnet.lib.gr_net_bn_features(rnet.h, i)
+                    rnet.set_bn_running(i, np.zeros(f, np.float32), np.ones(f, np.float32))
+                for li, k in masks.items():
+                    rnet.set_mask(li, D.shard(k.reshape(GB, -1), r).ravel())
+                res[tag + "_loss"] = L.train_r_step(gnet, rnet, dn, B, GB, hyper, D.T_STEP)
+                res[tag + "_grads"] = rnet.get_grads()
+            res["theta"] = rnet.get_params()
+            res["m"], res["v"] = rnet.adam_state()
+            res["preds"] = ctx.download(rnet.lib.gr_net_output_dev(rnet.h), (B, nd))
+            res["images"] = ctx.download(gnet.lib.gr_net_output_dev(gnet.h), (B,) + dims)
+            res["running"] = [rnet.get_bn_running(i) for i in range(rnet.n_bn())]
+            for m, li, (c, h, w) in pool_layers(R0, oR):   # (layer numbers: the same module list on every rank)
+                res[f"pool{li}"] = rnet.pool_index(li, B * c * (h // 2) * (w // 2))
+                res[f"y{pooled[li]}"] = rnet.layer_output(pooled[li], (B * c * h * w,))
+            # a step with unequal shards is refused, not silently mis-normalised
+            with pytest.raises(L.GanrevError):
+                L.train_r_step(gnet, rnet, dn, B, GB + 1, L.Hyper(), D.T_STEP)
+            ctx.set_host_exchange(1, 0, None)
+            ctx.free(dn)
+            gnet.close(); rnet.close(); ctx.close()
+            out[r] = res
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((r, e))
+            xch.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(D.WORLD)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, f"rank failures: {errors}"
+    a, b = out
+    # both replicas end identical: reduced gradient, parameters, Adam state, running statistics
+    for k in ("raw_grads", "step_grads", "theta", "m", "v"):
+        assert np.array_equal(a[k], b[k]), f"replicas differ in {k}"
+    assert a["raw_loss"] == b["raw_loss"] == a["step_loss"]
+    for (ma, va), (mb, vb) in zip(a["running"], b["running"]):
+        assert np.array_equal(ma, mb) and np.array_equal(va, vb), "running statistics differ between the ranks"
+    # exchanges per train step and rank: 1 loss + 7 BatchNorm forwards + 7 BatchNorm backwards (+ their max|dz| where dy goes out operand-ready) + gradient buckets
+    assert xch.calls[0] == xch.calls[1] and xch.calls[0] >= 2 * (1 + 7 + 7 + 1), xch.calls
+
+    dev_index = {li: np.concatenate([rk[f"pool{li}"] for rk in out]) for li in pooled}
+    dev_y = {cl: np.concatenate([rk[f"y{cl}"] for rk in out]) for cl in pooled.values()}
+    for i in range(oR.n_bn()):                                   # the oracle's running statistics start where the ranks' did: (0, 1)
+        om, ov = oR.bn_running(i)
+        om[...] = 0.0; ov[...] = 1.0
+    rep = {}
+    ref = D.oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, oracle.GoHyper(), dev_index, dev_y, R0, max_flips=16, report=rep, mode=mode, groups=1)
+    assert_close(np.concatenate([rk["images"] for rk in out]), ref["images"], TOL, "G images of both shards")
+    preds = np.concatenate([rk["preds"] for rk in out])
+    assert_close(preds, ref["preds"], TOL, "recovered noise: two ranks with synchronised BatchNorm vs ONE statistics group over 2B")
+    _check_against_oracle(oracle, R0, ref, a["step_loss"], a["raw_grads"], a["step_grads"], a["theta"], a["m"], a["v"], f"[sync-BN {mode}, argmax flips {rep.get('flips')}]")
+    # running statistics = the global batch's (unbiased variance over 2B x H x W elements), momentum 0.1 from (0, 1)
+    # (the oracle ran its forward twice - natural and argmax-forced - from (0, 1): r2 = 0.19 s + 0.81 r0; the ranks once: 0.1 s + 0.9 r0)
+    for i, (rm, rv) in enumerate(a["running"]):
+        om, ov = oR.bn_running(i)
+        want_m, want_v = 0.1 * (om / 0.19), 0.1 * ((ov - 0.81) / 0.19) + 0.9
+        assert_close(rm, want_m, 1e-5 * max(1.0, float(np.abs(want_m).max())), f"running_mean of BatchNorm {i}")
+        assert_close(rv, want_v, 1e-5 * max(1.0, float(np.abs(want_v).max())), f"running_var of BatchNorm {i}")
+    # control: per-rank statistics (the default) are a different computation on this case
+    oR.set_bn_groups(D.WORLD)
+    oR.params[...] = theta0
+    for li, k in masks.items():
+        oR.set_mask(li, k)
+    grouped = oR.forward(ref["images"])
+    oR.set_bn_groups(1)
+    assert maxdiff(grouped, preds) > 10 * TOL, "per-rank and synchronised BatchNorm agree: the case does not separate them"
