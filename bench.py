@@ -265,7 +265,7 @@ def search_cfg5(ctx):
                 note="ms includes the D2H copy of the 5 x 50 results and one host sync per search (gr_cosine_topk_dev)")
 
 
-def embed_cfg5(ctx, rows, with_oracle=True):
+def embed_cfg5(ctx, rows, with_oracle=True, train_steps=300):
     """BASELINE.json configs[4] as stated: "1M generated 64x64 faces -> 100-d embeddings, top-50".  apply_r.lua:145-153 resident on the
     GPU (gr_embed_dev): noise drawn on the device -> G forward (evaluate) -> R forward (evaluate) in chunks of 512, every chunk's
     recovered noise written straight into the [rows x 100] table, no host copies; then apply_r.lua:265-282's search on the table the
@@ -275,10 +275,28 @@ def embed_cfg5(ctx, rows, with_oracle=True):
     from ganrev import models, nn_utils, synth
     dims, nd, batch, k = WORKLOADS["cfg3"]["dims"], WORKLOADS["cfg3"]["nd"], 512, 50
     needles = np.array([100, 200, 300, 400, 500], dtype=np.int64)
-    # apply_r.lua:62-104 loads TRAINED nets: synthetic trained-looking weights and non-trivial running statistics for both
+    # apply_r.lua:62-104 loads a TRAINED G and the R that train_r.lua trained against it.  G: synthetic trained-looking weights and running
+    # statistics.  R: models.create_R's initialisation, then `train_steps` iterations of train_r.lua:138-170 at batch 512 on the device
+    # (the reference's own workflow, shortened: README "2000 batches") - an untrained R maps every face to nearly the same direction
+    # (all cosines 0.9999.., ties broken by row index), which is no search corpus
+    from ganrev.parallel import DeviceTrainer
     G = models.create_G(dims, nd); synth.init_params(G, 1)
-    R = models.create_R(dims, nd); synth.init_params(R, 2)
+    R = models.create_R(dims, nd, seed=1)
     G._ctx = R._ctx = ctx
+    G.evaluate(); R.training()
+    gnet, rnet = G.device_net((nd,)), R.device_net(dims)
+    rnet.set_seed(99); rnet.adam_reset()
+    trainer = DeviceTrainer(ctx, gnet, rnet, L.Hyper(), batch)
+    loss0 = loss1 = None
+    ctx.event_record(61990)
+    for i in range(train_steps):
+        trainer.new_noise(7_000_000 + i)
+        l_ = trainer.step(want_loss=(i == 0 or i == train_steps - 1))
+        loss0 = l_ if i == 0 else loss0
+        loss1 = l_ if i == train_steps - 1 else loss1
+    ctx.event_record(61991)
+    train_ms = ctx.event_elapsed_ms(61990, 61991) if train_steps else 0.0
+    trainer.close()
     G.evaluate(); R.evaluate()
     gnet, rnet = G.device_net((nd,)), R.device_net(dims)
     noise = nn_utils.createNoiseInputsDev(ctx, rows, nd, "normal", seed=4242)
@@ -324,6 +342,8 @@ def embed_cfg5(ctx, rows, with_oracle=True):
                                avg_launch_ms=round(avg_ms, 4), launches_per_chunk=dom["launches"] / chunks,
                                algorithmic_gflop_per_launch=round(dom["flops"] / dom["launches"] / 1e9, 3)),
                  kernels=kernels, timer_failed_samples=pseudo.get("timer_failed_samples", dict(count=0))["count"], dtype=DTYPE[ctx.conv_mode()],
+                 r_trained=dict(steps=train_steps, batch=batch, mse_first=loss0, mse_last=loss1, ms=round(train_ms, 1),
+                                note="R trained here against the fixed G with gr_train_r_step before it is applied (train_r.lua -> apply_r.lua)"),
                  note="evaluate()-mode G + R forward (apply_r.lua:146,152), noise and the embedding table resident in HBM, no host copies inside the timed region")
     # the search on the table the pipeline wrote
     ctx.cosine_topk(None, needles, k, emb_dev=table.ptr, n=rows, d=nd)
@@ -689,6 +709,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true", help="skip the cfg5 (1M x 100, top-50) search leg")
     ap.add_argument("--embed-rows", type=int, default=1_000_000, help="rows of the cfg5 corpus the device-resident G -> R pipeline produces (BASELINE configs[4]: 1M)")
+    ap.add_argument("--embed-train-steps", type=int, default=300, help="train_r.lua iterations (batch 512) R gets before the cfg5 pipeline applies it")
     ap.add_argument("--sync-bn", action="store_true", help="synchronised BatchNorm over the ranks (gr_set_tuning sync_bn: per-channel batch sums all-reduced, "
                     "forward and backward); default: per-rank batch statistics")
     ap.add_argument("--no-sustained", action="store_true", help="skip the bare f16x3 MFMA loop (roofline.sustained): profiling runs, whose kernel statistics it would dominate")
@@ -814,7 +835,7 @@ def main():
         if world == 1 and not args.no_search:
             out["search_cfg5"] = search_cfg5(ctx)
             try:                      # configs[4] as stated: the corpus produced by the device-resident G -> R pipeline, then searched
-                out["search_cfg5"].update(embed_cfg5(ctx, args.embed_rows, with_oracle=not args.no_cpu_baseline))
+                out["search_cfg5"].update(embed_cfg5(ctx, args.embed_rows, with_oracle=not args.no_cpu_baseline, train_steps=args.embed_train_steps))
             except Exception as e:  # noqa: BLE001
                 out["search_cfg5"]["embed"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_gan:

@@ -230,10 +230,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 // same pixels, added through LDS (in group order) at the end - KS times the workgroups (a batch-256 layer on 32x32 planes
 // has one 32-row tile per CU: 4 waves per CU, every chunk's load latency exposed; cfg2: 57 -> 47.5 us with two groups, 38.8
 // with four, 3.5 TB/s).
-template <int CO, int KS = 1>
+template <int CO, int KS = 1, int TW = 32>
 __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, const float* __restrict__ w_native) {
-  constexpr int TW = 32, TRr = 32 / KS, CK = 8, PR = TRr + 2, PCS = 40, PS = PR * PCS;   // interior columns at [4, 36), halo at 3 and 36
-  constexpr int NV = (CK * PR * (TW / 4) + 255) / 256;     // float4 loads per thread per chunk (interior)
+  // TW = 64 (round 4): a 64-wide plane as ONE tile column.  With 32-wide tiles every workgroup's two halo columns (4-byte loads at x0 - 1
+  // and x0 + 32) pull the NEIGHBOUR tile's whole 128-byte line of every patch row out of the fabric - horizontally adjacent tiles run on
+  // different XCDs (round-robin dispatch), so the neighbour's L2 copy does not help: G's last convolution at cfg3 fetched 1981 MB per launch
+  // for 1074 MB of input (request-size counters, profiles/r04_traffic_two_ways_cfg3.txt) at 5.1 TB/s - it was traffic-bound, not LDS-bound.
+  constexpr int SPR = TW / 4;                              // 4-pixel strips per tile row
+  constexpr int TRr = 1024 / TW / KS, CK = 8, PR = TRr + 2, PCS = TW + 8, PS = PR * PCS;   // interior columns at [4, TW + 4), halo at 3 and TW + 4
+  constexpr int NV = (CK * PR * SPR + 255) / 256;          // float4 loads per thread per chunk (interior)
   constexpr int NHL = (CK * PR * 2 + 255) / 256;           // scalar loads per thread per chunk (halo columns)
   // the chunk's weights sit in LDS next to the patch ([ci][o][tap], rows padded to float4s) and are read back as broadcast
   // vectors: scalar-cache loads share the LDS counter and return out of order, so every use of one drained the whole
@@ -248,9 +253,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
   const int y0 = ty * TRr, x0 = tx * TW, H = a.H, W = a.W;
   const size_t HW = (size_t)H * W;
   const float* in_base = a.in + (size_t)b * a.Cin * HW;
-  constexpr int TPG = 256 / KS;                            // threads per channel group: TRr rows x 8 strips
+  constexpr int TPG = 256 / KS;                            // threads per channel group: TRr rows x SPR strips
   const int kg = tid / TPG;                                // channel group of this thread (KS groups share the chunk's 8 channels)
-  const int row = (tid % TPG) >> 3, strip = tid & 7;       // this thread's 4 output pixels: (y0+row, x0+4*strip ..+3)
+  const int row = (tid % TPG) / SPR, strip = tid % SPR;    // this thread's 4 output pixels: (y0+row, x0+4*strip ..+3)
   static_assert(CK * WS <= 512, "two weight words per thread");
   const int wl_c = tid / WS, wl_e = tid % WS, wl_c2 = (tid + 256) / WS, wl_e2 = (tid + 256) % WS;
   float wreg[2];
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
 #define GR_FO_LOAD(ch_)                                                                          \
   {                                                                                              \
     _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                             \
-      const int f = tid + 256 * i, q = f & 7, rr = (f >> 3) % PR, cil = (f >> 3) / PR;           \
+      const int f = tid + 256 * i, q = f % SPR, rr = (f / SPR) % PR, cil = (f / SPR) / PR;       \
       const int ci = (ch_) * CK + cil, yy = y0 + rr - 1, xx = x0 + 4 * q;                        \
       xv[i] = (cil < CK && ci < a.Cin && yy >= 0 && yy < H && xx < W)                            \
                   ? *reinterpret_cast<const float4*>(in_base + (size_t)ci * HW + (size_t)yy * W + xx) \
@@ -287,13 +292,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
   for (int ch = 0; ch < a.nchunks; ++ch) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + 256 * i, q = f & 7, rr = (f >> 3) % PR, cil = (f >> 3) / PR;
+      const int f = tid + 256 * i, q = f % SPR, rr = (f / SPR) % PR, cil = (f / SPR) / PR;
       if (cil < CK) *reinterpret_cast<float4*>(patch + cil * PS + rr * PCS + 4 + 4 * q) = xv[i];
     }
 #pragma unroll
     for (int i = 0; i < NHL; ++i) {
       const int e = tid + 256 * i, side = e & 1, rr = (e >> 1) % PR, cil = (e >> 1) / PR;
-      if (cil < CK) patch[cil * PS + rr * PCS + (side ? 36 : 3)] = hv[i];
+      if (cil < CK) patch[cil * PS + rr * PCS + (side ? TW + 4 : 3)] = hv[i];
     }
     if (wl_c < CK) wsh[wl_c * WS + wl_e] = wreg[0];
     if (wl_c2 < CK) wsh[wl_c2 * WS + wl_e2] = wreg[1];
@@ -313,12 +318,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
         for (int ky = 0; ky < 3; ++ky) {
           const float* pr = patch + cil * PS + (row + ky) * PCS + 4 * strip;
           const float4 m = *reinterpret_cast<const float4*>(pr + 4);
-          // the pixels left and right of this thread's four come from the neighbouring lanes' vectors (DPP row shifts: the 8
-          // strips of a patch row are 8 consecutive lanes of a 16-lane DPP row); only the two edge strips read the halo columns
+          // the pixels left and right of this thread's four come from the neighbouring lanes' vectors (DPP row shifts: the 8 or 16
+          // strips of a patch row are consecutive lanes of ONE 16-lane DPP row); only the two edge strips read the halo columns
           // from LDS, in one instruction.  (Both neighbours as single-dword LDS reads: 64 lanes on 16 banks, 59 % of this kernel's
           // LDS cycles were bank conflicts on the counters.)
           float lf = dpp_take<0x111, 0xF>(m.w), rt = dpp_take<0x101, 0xF>(m.x);      // row_shr:1 / row_shl:1
-          if (strip == 0 || strip == 7) { const float hv = pr[strip == 0 ? 3 : 8]; if (strip == 0) lf = hv; else rt = hv; }
+          if (strip == 0 || strip == SPR - 1) { const float hv = pr[strip == 0 ? 3 : 8]; if (strip == 0) lf = hv; else rt = hv; }
           const fo_f2 p01 = {lf, m.x}, p12 = {m.x, m.y}, p23 = {m.y, m.z}, p34 = {m.z, m.w}, p45 = {m.w, rt};
 #pragma unroll
           for (int o = 0; o < CO; ++o) {
@@ -504,7 +509,10 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
     // (decided by the plane alone, not by the batch: a row must get the same bits whatever batch it travels in)
     const bool ks2 = fo_split && H % 16 == 0 && ((W + 31) / 32) * ((H + 31) / 32) < 4;      // small planes: too few 32-row tiles per image to fill the chip
     const bool ks4 = fo_split == 4 && ks2 && H % 8 == 0;
-    a.tiles_x = (W + 31) / 32; a.tiles_y = ks4 ? H / 8 : (ks2 ? H / 16 : (H + 31) / 32); a.n_otiles = 1;
+    // planes whose width is a multiple of 64: one 64-wide x 16-row tile per workgroup (no halo columns fetched from a neighbour's lines)
+    static const bool fo_wide = !getenv("GR_FEWOUT_NO_WIDE");
+    const bool wide64 = fo_wide && !ks2 && W % 64 == 0;
+    a.tiles_x = wide64 ? W / 64 : (W + 31) / 32; a.tiles_y = wide64 ? (H + 15) / 16 : (ks4 ? H / 8 : (ks2 ? H / 16 : (H + 31) / 32)); a.n_otiles = 1;
     const int grid = B * a.tiles_x * a.tiles_y;
     const double px = (double)B * H * W;
     const std::string fo_name = "conv3x3_fewout_kernel<" + std::to_string(Cout <= 3 ? Cout : 4) + ">";
@@ -519,6 +527,11 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
       case 2: hipLaunchKernelGGL((conv3x3_fewout_kernel<2, 2>), dim3(grid), dim3(256), 0, s, a, w_native); break;
       case 3: hipLaunchKernelGGL((conv3x3_fewout_kernel<3, 2>), dim3(grid), dim3(256), 0, s, a, w_native); break;
       default: hipLaunchKernelGGL((conv3x3_fewout_kernel<4, 2>), dim3(grid), dim3(256), 0, s, a, w_native); break;
+    } else if (wide64) switch (Cout) {
+      case 1: hipLaunchKernelGGL((conv3x3_fewout_kernel<1, 1, 64>), dim3(grid), dim3(256), 0, s, a, w_native); break;
+      case 2: hipLaunchKernelGGL((conv3x3_fewout_kernel<2, 1, 64>), dim3(grid), dim3(256), 0, s, a, w_native); break;
+      case 3: hipLaunchKernelGGL((conv3x3_fewout_kernel<3, 1, 64>), dim3(grid), dim3(256), 0, s, a, w_native); break;
+      default: hipLaunchKernelGGL((conv3x3_fewout_kernel<4, 1, 64>), dim3(grid), dim3(256), 0, s, a, w_native); break;
     } else
     switch (Cout) {
       case 1: hipLaunchKernelGGL(conv3x3_fewout_kernel<1>, dim3(grid), dim3(256), 0, s, a, w_native); break;
@@ -3192,10 +3205,29 @@ struct WgradP16Args {
   const uint4* x; const uint4* dy; float* slab;
   int B, Cin, Cout, H, W, n_ob, n_cb, nsplit, cinp, coutp, units;     // units = B * H * W / 64 chunks of 64 pixels
   const unsigned *amax_x, *amax_dy;
+  int dy_nt;               // non-temporal LDS-DMA of the dy stream (four-wave kernel)
+  int plain_order;         // GR_WGRAD_PLAIN_ORDER=1: consecutive block ids = the combinations of one split (A/B of the XCD-aware numbering)
 };
 // MFMA shape: v_mfma_f32_16x16x32_f16, K = 32 pixels per step, the wave's 32 x 32 block per tap as 2 x 2 accumulator blocks of 16 x 16 (a
 // 16-lane group of a transposing read covers 8 pixels of ONE 16-channel block).  Round 3, same box, against the 32x32x16 version (16 pixels
 // per step, one f32x16 accumulator per tap; git history): 1018 -> 878 us (32-wide) and 794 -> 736 (64-wide) at cfg3, 137 -> 124 at cfg2.
+// Workgroup -> (input-channel block, output-channel block, batch split).  The n_cb x n_ob workgroups of one split stream the SAME chunks:
+// each x block is read by n_ob of them, each dy block by n_cb.  Numbered consecutively they land on n_cb x n_ob DIFFERENT XCDs (blocks are
+// dealt round-robin over the 8 XCDs: b and b + 8 share one, MI355X_MICROARCH.md) and nobody finds the other's lines in its L2: the
+// 128-channel layers fetched 2.07x their operands (1111 MB per launch for 537 MB at cfg3: profiles/r04_traffic_two_ways_cfg3.txt).  Here the
+// combinations of a split are 8 block ids apart - the same XCD, dispatched within the same fraction of a microsecond - while consecutive ids
+// walk the splits.  Speed only: any placement computes the same slabs.
+__device__ __forceinline__ void wgrad_p16_block(const WgradP16Args& a, int bid, int& cb, int& ob, int& split) {
+  const int C = a.n_cb * a.n_ob;
+  if (C > 1 && a.nsplit % 8 == 0 && !a.plain_order) {
+    const int grp = bid / (8 * C), rem = bid - grp * 8 * C, combo = rem >> 3;
+    split = grp * 8 + (rem & 7);
+    cb = combo % a.n_cb; ob = combo / a.n_cb;
+  } else {
+    cb = bid % a.n_cb; bid /= a.n_cb;
+    ob = bid % a.n_ob; split = bid / a.n_ob;
+  }
+}
 template <int W_>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args a) {
   constexpr int R = 64 / W_ > 0 ? 64 / W_ : 1;                 // image rows per 64-pixel chunk (W_ = 16, 32 or 64)
@@ -3214,9 +3246,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
   // wave tile: ALL 64 output channels x the wave's 16 input channels x 9 taps.  A tap's x fragment cannot be shared between taps, so what a B read
   // feeds is the number of output-channel blocks it meets: four here (52 transposing-read pairs per 108 MFMAs) against two with 32 x 32 tiles
   // (80 per 108) - these kernels sat at 87-92 % LDS-active on the counters (round 3, profiles/r03_pmc_step_conv_cfg3.txt)
-  int bid = blockIdx.x;
-  const int cb = bid % a.n_cb; bid /= a.n_cb;
-  const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
+  int cb, ob, split;
+  wgrad_p16_block(a, blockIdx.x, cb, ob, split);
   const int H = a.H, HW = H * W_, Gin = a.Cin >> 3, Gout = a.Cout >> 3;
   const int cpi = HW / 64;                                      // chunks per image
   const int u0 = (int)((long)split * a.units / a.nsplit), u1 = (int)((long)(split + 1) * a.units / a.nsplit);
@@ -3269,8 +3300,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
       const int voff = inb ? (xst[j] & ~15) + yrow : (int)0x7FFFF000;
       if (i < NXI) lds_dma16(rx, xs + 64 * i, voff, xsoff);
     }
+    // dy is streamed once per (input-channel block): with the non-temporal policy its lines do not push the x rows - re-read by the next
+    // chunk - out of the XCD's L2 (a.dy_nt: GR_WGRAD_DY_NT)
+    if (a.dy_nt) {
 #pragma unroll
-    for (int j = 0; j < NDS; ++j) lds_dma16(rd, ds + DSP * (wave + 4 * j), dst_[j] + p0b, dsoff);      // plane = (o group, term): 64 pixels = one instruction
+      for (int j = 0; j < NDS; ++j) lds_dma16_nt(rd, ds + DSP * (wave + 4 * j), dst_[j] + p0b, dsoff);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NDS; ++j) lds_dma16(rd, ds + DSP * (wave + 4 * j), dst_[j] + p0b, dsoff);      // plane = (o group, term): 64 pixels = one instruction
+    }
     dma_publish_barrier();                                       // the image has landed
 #pragma unroll 1
     for (int ks = 0; ks < 2; ++ks) {
@@ -3356,9 +3394,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   // wave tile: ALL 64 output channels x the wave's 16 input channels x 9 taps.  A tap's x fragment cannot be shared between taps, so what a B read
   // feeds is the number of output-channel blocks it meets: four here (52 transposing-read pairs per 108 MFMAs) against two with 32 x 32 tiles
   // (80 per 108) - these kernels sat at 87-92 % LDS-active on the counters (round 3, profiles/r03_pmc_step_conv_cfg3.txt)
-  int bid = blockIdx.x;
-  const int cb = bid % a.n_cb; bid /= a.n_cb;
-  const int ob = bid % a.n_ob; const int split = bid / a.n_ob;
+  int cb, ob, split;
+  wgrad_p16_block(a, blockIdx.x, cb, ob, split);
   const int H = a.H, HW = H * W_, Gin = a.Cin >> 3, Gout = a.Cout >> 3;
   const int cpi = HW / 64;                                      // chunks per image
   const int w0 = (int)((long)split * a.units / a.nsplit), w1 = (int)((long)(split + 1) * a.units / a.nsplit), wm = w0 + (w1 - w0 + 1) / 2;
@@ -3591,6 +3628,8 @@ void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, 
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.n_ob = Cout / 64; a.n_cb = Cin / 64; a.cinp = Cin; a.coutp = Cout;
   a.nsplit = wgrad_p16_splits(B, Cin, Cout, H, W); a.units = (int)((long)B * H * W / 64);
   a.amax_x = amax_x; a.amax_dy = amax_dy;
+  { static const int plain = getenv("GR_WGRAD_PLAIN_ORDER") ? atoi(getenv("GR_WGRAD_PLAIN_ORDER")) : 0; a.plain_order = plain; }
+  { static const int dynt = getenv("GR_WGRAD_DY_NT") ? atoi(getenv("GR_WGRAD_DY_NT")) : 0; a.dy_nt = dynt; }
   const int grid = a.nsplit * a.n_ob * a.n_cb;
   const double px = (double)B * H * W;
   {

@@ -632,7 +632,8 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
   if (accf) hipLaunchKernelGGL(needle_prep_kernel<true>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
   else hipLaunchKernelGGL(needle_prep_kernel<false>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
   static const bool batched_on = !getenv("GR_SEARCH_NO_BATCHED");
-  if (filter && batched_on && Q >= BATCH_MIN_Q && Q <= BQ_MAX && d <= BD_MAX) {
+  static const int batch_min_q = getenv("GR_BATCH_MIN_Q") ? atoi(getenv("GR_BATCH_MIN_Q")) : BATCH_MIN_Q;
+  if (filter && batched_on && Q >= batch_min_q && Q <= BQ_MAX && d <= BD_MAX) {
     // keys A = sample scores [Q][S] | tau [Qpad] | sqrt(w22) [Qpad] | bf16 needles [Qpad][KS] | candidate rows [Q][nwg][BSLOT] | scores | counts [Q][nwg]
     const long S = SAMPLE_ROWS, nwg = (N + 255) / 256, stride = N / S;
     const int NK = d <= 32 ? 2 : (d <= 64 ? 4 : (d <= 112 ? 7 : 8)), KS = NK * 16 + 8, Qpad = (Q + 63) / 64 * 64;
