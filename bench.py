@@ -262,7 +262,9 @@ def search_cfg5(ctx):
                 hbm_frac=round(N * d * 4 / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
                 exact_match=bool(np.array_equal(idx, ridx) and np.array_equal(sc, rsc)), cpu_ms=round(t_cpu * 1e3, 1),
                 batched_1024=batched,
-                note="ms includes the D2H copy of the 5 x 50 results and one host sync per search (gr_cosine_topk_dev)")
+                note="ms = one gr_cosine_topk_dev call: three launches (fp32 filter over a strided sample with the bound folded in, fp32 filter over "
+                     "the table by LDS-DMA tiles, exact re-score + sort of the survivors), the 5 x 50 results written by the last kernel into pinned "
+                     "host memory, one host wait")
 
 
 def embed_cfg5(ctx, rows, with_oracle=True, train_steps=300):

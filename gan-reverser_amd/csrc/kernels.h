@@ -353,8 +353,11 @@ void launch_downsum2(const float* gup, float* gin, int B, int C, int Hs, int Ws,
 size_t cosine_topk_workspace_bytes(long N, int d, int Q, int k);
 // idx_out/score_out are DEVICE buffers [Q][k].  status_dev (device word, nullable): large tables take the sample-bound filter
 // (search.hip) when it is given; it receives 1 when a candidate list overflowed - call again with unfiltered = 1 - else 0.
+// query_rows_host (nullable): the same rows in host memory - a handful of needles (cosine_topk_small_path) travel in the kernel arguments
 int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_dev, int Q, int k,
-                       long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s, unsigned* status_dev = nullptr, int unfiltered = 0);
+                       long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s, unsigned* status_dev = nullptr, int unfiltered = 0,
+                       const long* query_rows_host = nullptr);
+bool cosine_topk_small_path(long N, int d, int Q, int k);     // the filtered search takes the fp32-filter path (query rows by value, no device copy of them needed)
 
 // ---------------------------------------------------------------- k-means + nearest-centroid pass (apply_r.lua:197-217)
 size_t kmeans_workspace_bytes(long N, int d, int k);

@@ -1744,10 +1744,31 @@ extern "C" int gr_cosine_topk_dev(gr_ctx* c, const float* emb, int64_t N, int d,
     HIPCHK(c, hipHostMalloc(&c->pin, res_bytes * 2));
     c->pin_bytes = res_bytes * 2;
   }
-  HIPCHK(c, hipMemcpyAsync(d_q, qrows, sizeof(long) * Q, hipMemcpyHostToDevice, c->stream));
   static const bool filter_on = !getenv("GR_SEARCH_UNFILTERED");
-  for (int unfiltered = filter_on ? 0 : 1; unfiltered < 2; ++unfiltered) {
-    if (launch_cosine_topk(emb, N, d, d_q, Q, k, d_idx, d_sc, accf, c->ws, c->stream, d_status, unfiltered)) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
+  // A handful of needles (the reference's five): their rows travel in the kernel arguments and the kernels write idx | scores | status
+  // straight into the pinned result block (host memory the device can address): no upload, no copy-out - launches, one wait.
+  if (filter_on && cosine_topk_small_path(N, d, Q, k)) {
+    void* pin_dev = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(&pin_dev, c->pin, 0));
+    char* pd = static_cast<char*>(pin_dev);
+    long* p_idx = reinterpret_cast<long*>(pd); float* p_sc = reinterpret_cast<float*>(pd + sizeof(long) * (size_t)Q * k);
+    unsigned* p_status = reinterpret_cast<unsigned*>(pd + res_bytes - sizeof(unsigned));
+    if (launch_cosine_topk(emb, N, d, d_q, Q, k, p_idx, p_sc, accf, c->ws, c->stream, p_status, 0, qrows)) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
+    LAUNCHCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const char* hres = (const char*)c->pin;
+    unsigned status; memcpy(&status, hres + res_bytes - sizeof(unsigned), sizeof status);
+    if (status == 0) {
+      memcpy(idx_out, hres, sizeof(long) * (size_t)Q * k);
+      if (score_out) memcpy(score_out, hres + sizeof(long) * (size_t)Q * k, sizeof(float) * (size_t)Q * k);
+      return GR_OK;
+    }
+    c->search_reruns++;       // a candidate list overflowed (adversarial row order): the unfiltered search below decides
+  }
+  HIPCHK(c, hipMemcpyAsync(d_q, qrows, sizeof(long) * Q, hipMemcpyHostToDevice, c->stream));
+  const bool small_failed = filter_on && cosine_topk_small_path(N, d, Q, k);
+  for (int unfiltered = (filter_on && !small_failed) ? 0 : 1; unfiltered < 2; ++unfiltered) {
+    if (launch_cosine_topk(emb, N, d, d_q, Q, k, d_idx, d_sc, accf, c->ws, c->stream, d_status, unfiltered, qrows)) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
     LAUNCHCHK(c);
     HIPCHK(c, hipMemcpyAsync(c->pin, d_idx, res_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -18,6 +18,16 @@
 
 namespace gr {
 
+// one LDS-DMA wave-instruction (as in conv.hip): 64 lanes x 16 bytes land at lds_dst + 16 * lane, lane l fetching rsrc[voff_l + soff]; lanes
+// whose offset lies past the descriptor's range write zeros
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, uint4* lds_dst, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+#else
+  (void)rsrc; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
+
 constexpr int QG = 8;        // needles scored per pass of cos_keys (register accumulators)
 constexpr int ROWS = 256;    // rows per workgroup
 constexpr int CHUNK = 2048;  // keys per top-k workgroup
@@ -305,6 +315,8 @@ __global__ void topk_decode_kernel(const unsigned long long* __restrict__ keys, 
 // Every row whose exact score is among the k best passes both cuts, so indices and scores are bit-identical to the unbatched
 // search; an overflowing entry list raises the status word and the caller reruns the unbatched path.
 constexpr int BATCH_MIN_Q = 32;
+constexpr int AQ_MAX = 8;             // needles of the small path (cos_approx_kernel below): their rows travel by value
+struct SmallQ { long rows[AQ_MAX]; };
 constexpr int BQ_MAX = 2048;          // needles per call of the batched path (LDS counters)
 constexpr int BSLOT = 16;             // (row, score) entries per workgroup (256 rows) and needle: expected 1.2 at cfg5, P(> 16) ~ 1e-14
 constexpr int BD_MAX = 128;           // widest row the batched kernel stages whole
@@ -515,47 +527,97 @@ template <bool ACCF>
 __global__ __launch_bounds__(1024) void batched_select_kernel(const float* __restrict__ emb, int d, const float* __restrict__ needles,
                                                               const float* __restrict__ w22, const unsigned* __restrict__ cand_idx,
                                                               const float* __restrict__ cand_sc, const unsigned* __restrict__ counts, long nwg, int k,
-                                                              long* __restrict__ idx, float* __restrict__ score, unsigned* __restrict__ status) {
+                                                              long* __restrict__ idx, float* __restrict__ score, unsigned* __restrict__ status,
+                                                              int slot, float margin2, SmallQ qr, int from_rows) {
   typedef typename std::conditional<ACCF, float, double>::type acc_t;
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CHUNK];
   __shared__ unsigned rows[CHUNK];
   __shared__ unsigned list_n, over;
+  __shared__ float sh_w22;
   unsigned* list = reinterpret_cast<unsigned*>(keys);            // the 1024 maxima live in the key array before it is needed
   const int q = blockIdx.x, tid = threadIdx.x;
   const unsigned* cnt = counts + (long)q * nwg;
-  const unsigned* ci = cand_idx + (long)q * nwg * BSLOT;
-  const float* cs = cand_sc + (long)q * nwg * BSLOT;
+  const unsigned* ci = cand_idx + (long)q * nwg * slot;
+  const float* cs = cand_sc + (long)q * nwg * slot;
   if (tid == 0) { list_n = 0u; over = 0u; }
   __syncthreads();
+  // The needle itself: from the workspace (batched path: needle_prep_kernel's copy and w22), or - a handful of needles, rows by value - straight
+  // from the table, its 1 / (|a|^2 + 1e-12) formed here in needle_prep_kernel's arithmetic by one thread while the others scan the lists
+  const float* nd = from_rows ? emb + qr.rows[q] * (long)d : needles + (long)q * d;
+  if (from_rows && tid == 1023) {
+    acc_t t = 0;
+    for (int i0 = 0; i0 < d; i0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = nd[i0 + u < d ? i0 + u : d - 1];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) if (i0 + u < d) t += v[u] * v[u];
+    }
+    float w = (float)t;
+    w = w + 1e-12f;
+    sh_w22 = 1.f / w;
+  }
+  // a list's entries are contiguous: eight scores per round as two 16-byte loads (one dependent load per entry, ~8 per list, was most of this kernel)
   unsigned mine = 0u, o = 0u;
   for (long g = tid; g < nwg; g += 1024) {
-    const unsigned c = cnt[g];
-    if (c > (unsigned)BSLOT) o = 1u;
-    for (unsigned e = 0; e < min(c, (unsigned)BSLOT); ++e) { const unsigned v = orderable(cs[g * BSLOT + e]); mine = v > mine ? v : mine; }
+    const unsigned c0 = cnt[g];
+    if (c0 > (unsigned)slot) o = 1u;
+    const unsigned c = min(c0, (unsigned)slot);
+    for (unsigned e0 = 0; e0 < c; e0 += 8) {
+      const float4 va = *reinterpret_cast<const float4*>(cs + g * slot + e0), vb = *reinterpret_cast<const float4*>(cs + g * slot + e0 + 4);
+      const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (e0 + u < c) { const unsigned ov = orderable(v[u]); mine = ov > mine ? ov : mine; }
+    }
   }
   if (o) over = 1u;
   const unsigned kth = kth_of_maxima(mine, list, k);
   if (over) { if (tid == 0 && status) *status = 1u; return; }
-  const float tau2 = kth ? unorderable(kth) - 2.f * GR_BERR : -INFINITY;
+  const float tau2 = kth ? unorderable(kth) - margin2 : -INFINITY;
   for (long g = tid; g < nwg; g += 1024) {
-    const unsigned c = min(cnt[g], (unsigned)BSLOT);
-    for (unsigned e = 0; e < c; ++e)
-      if (cs[g * BSLOT + e] >= tau2) { const unsigned pos = atomicAdd(&list_n, 1u); if (pos < (unsigned)CHUNK) rows[pos] = ci[g * BSLOT + e]; }
+    const unsigned c = min(cnt[g], (unsigned)slot);
+    for (unsigned e0 = 0; e0 < c; e0 += 8) {
+      const float4 va = *reinterpret_cast<const float4*>(cs + g * slot + e0), vb = *reinterpret_cast<const float4*>(cs + g * slot + e0 + 4);
+      const float v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + u < c && v[u] >= tau2) { const unsigned pos = atomicAdd(&list_n, 1u); if (pos < (unsigned)CHUNK) rows[pos] = ci[g * slot + e0 + u]; }
+    }
   }
   __syncthreads();
   const unsigned m = list_n;
   if (m > (unsigned)CHUNK) { if (tid == 0 && status) *status = 1u; return; }
   // exact scores, cos_keys_kernel's arithmetic: fp32 products, sequential sums over the columns, the same w22 / w32 steps
-  const float* nd = needles + (long)q * d;
+  const float w22q = from_rows ? sh_w22 : w22[q];
   for (unsigned i = tid; i < m; i += 1024) {
     const long row = rows[i];
     const float* b = emb + row * (long)d;
     acc_t s1 = 0, s3 = 0;
+    if ((d & 3) == 0) {
+      // eight float4s of the row (and of the needle) are requested together, THEN summed in column order: a loop of d dependent scalar loads was
+      // most of this kernel (and the whole row at once - 64 vectors - did not fit the 128 registers of a 1024-thread workgroup)
+      const int n4 = d >> 2;
+#pragma unroll 1
+      for (int c0 = 0; c0 < n4; c0 += 8) {
+        float4 bv4[8], nv4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c4 = c0 + u < n4 ? c0 + u : n4 - 1;
+          bv4[u] = reinterpret_cast<const float4*>(b)[c4]; nv4[u] = reinterpret_cast<const float4*>(nd)[c4];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (c0 + u < n4) {
+          const float bb[4] = {bv4[u].x, bv4[u].y, bv4[u].z, bv4[u].w}, nn[4] = {nv4[u].x, nv4[u].y, nv4[u].z, nv4[u].w};
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) { s3 += (acc_t)(bb[jj] * bb[jj]); s1 += (acc_t)(nn[jj] * bb[jj]); }
+        }
+      }
+    } else
     for (int c = 0; c < d; ++c) { const float bv = b[c]; s3 += (acc_t)(bv * bv); s1 += (acc_t)(nd[c] * bv); }
     float w32 = (float)s3;
     w32 = w32 + 1e-12f;
     w32 = 1.f / w32;
-    float w = w22[q] * w32;
+    float w = w22q * w32;
     w = sqrtf(w);
     const float sc = (float)s1 * w;
     keys[i] = ((unsigned long long)orderable(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)row);
@@ -577,6 +639,208 @@ __global__ __launch_bounds__(1024) void batched_select_kernel(const float* __res
     const unsigned long long key = keys[r];
     idx[(long)q * k + r] = (long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
     if (score) score[(long)q * k + r] = unorderable((uint32_t)(key >> 32));
+  }
+}
+
+// ------------------------------------------------------------------ a handful of needles (the reference's five, apply_r.lua:267): fp32 filter + exact re-score
+// The exact pass (cos_keys_kernel) streams emb in column chunks of 80-128 bytes per row - every 128-byte line is touched by several chunks, two
+// barriers per chunk - and reached 3.1-3.5 TB/s whatever its arithmetic (round 4 ablation: 114 us with the multiply-adds switched off, 127 with
+// them).  The exact op order (fp32 products summed sequentially in fp64) is only needed for rows that can make the top k, so this path, like the
+// batched one above, lets a cheap APPROXIMATE score decide which rows those are and scores only them exactly (batched_select_kernel):
+//   cos_approx_kernel: one wave per workgroup, thread = row, tiles of 64 whole rows - 64 * d * 4 contiguous bytes - brought HBM -> LDS by LDS-DMA
+//   (two tiles per workgroup: the next one is requested as soon as the current one has landed), the needles' values next to them; fp32 FMA sums in
+//   any order.  |approximate - exact as computed| <= (2 d + 16) 2^-24 =: eps  (both are within (d + 8) 2^-24 of the real cosine: each product and
+//   each of the few fp32 steps behind the sums rounds by 2^-24 relative, and sum |a_i b_i| <= |a| |b|), so with margins of 2 eps at the two cuts
+//   no row of the exact top k is lost: indices and scores stay bit-identical to the exact search.
+//   MODE 0: the strided sample; every workgroup leaves the maximum of its 64 rows per needle, and the LAST workgroup to finish (arrival counter,
+//   agent-scope release / acquire around it) takes the k-th largest of those S / 64 maxima (k of them are k distinct rows at or above it) minus
+//   2 eps as the needle's threshold tau: one launch instead of needle_prep + sample + bound.  MODE 1: every row, (row, score) pairs >= tau into
+//   the workgroup's own entries.
+constexpr int ASLOT = 96;             // entries per (persistent workgroup, needle): expected ~7 at cfg5 (5200 candidates over 768 workgroups)
+constexpr int APPROX_WGS_MAX = 768;   // at most 3 one-wave workgroups per CU (two 25.6 KB tiles each at d = 100); wider rows: what fits 160 KB of LDS
+static int approx_wgs(int d, int Q) {        // ONE resident round: a grid of 768 where only two workgroups fit a CU ran its last third alone (d = 128: 335 us)
+  const int d4 = d / 4, v = (d4 & 1) ? d4 : d4 + 1;
+  const int nq = Q <= 2 ? 2 : (Q <= 5 ? 5 : 8);      // the instantiation launch_approx_nq picks
+  const size_t lds = (size_t)2 * 64 * v * 16 + (size_t)nq * d * 4 + 256 + 64;
+  int per_cu = (int)((size_t)160 * 1024 / lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
+  return 256 * per_cu;
+}
+struct ApproxArgs {
+  float* needles; float* w22;                    // [Q][d], [Q]: written by workgroup 0 of the sample launch for the selection kernel (exact: needle_prep's arithmetic)
+  float* wgmax; unsigned* counter; float* tau;   // sample: [Q][nwg] maxima, arrival counter, [Q] thresholds
+  unsigned* cand_idx; float* cand_sc; unsigned* counts;   // main pass: [Q][nwg][ASLOT], [Q][nwg]
+  unsigned* status;
+  int Q, k, accf; float eps2;
+};
+template <int D4, int NQ, int MODE>
+__global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict__ emb, long N, long stride, SmallQ qr, ApproxArgs a) {
+  constexpr int V = (D4 & 1) ? D4 : D4 + 1, d = D4 * 4;      // vectors per LDS row: odd, so that the 16 lanes of a ds_read_b128 group hit 64 distinct banks
+  __shared__ __attribute__((aligned(16))) uint4 tile[2][64 * V];
+  __shared__ __attribute__((aligned(16))) float4 nd[NQ * D4];
+  __shared__ float srt[MODE == 0 ? 64 : 1];
+  const int lane = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x, Q = a.Q;
+  const size_t bytes = (size_t)N * (MODE == 0 ? stride : 1) * d * 4;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(emb), 0, (int)(bytes < 0x7FFFF000ul ? bytes : 0x7FFFF000ul), 0x00020000);
+  // DMA instruction j of a tile covers LDS vectors 64 j + lane = (row, column vector) of the padded row-major tile; the pad column is parked out of range
+  int voff[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int e = 64 * j + lane, r = e / V, c4 = e - r * V;
+    voff[j] = c4 < D4 ? (int)(((long)r * (MODE == 0 ? stride : 1) * d + 4 * c4) * 4) : (int)0x7FFFF000;
+  }
+  const long ntiles = (N + 63) / 64;
+  auto request = [&](long t, int buf) {
+    const int soff = (int)(t * 64 * (MODE == 0 ? stride : 1) * d * 4);      // (rows past N lie past the descriptor's range: zeros)
+#pragma unroll
+    for (int j = 0; j < V; ++j) lds_dma16(rs, &tile[buf][64 * j], voff[j], soff);
+  };
+  if (wg < ntiles) request(wg, 0);
+  // the needles: every workgroup gathers them itself (Q rows of d floats; rows come in the kernel arguments - no upload, no launch of their own)
+  for (int e = lane; e < NQ * D4; e += 64) {
+    const int q = e / D4, c4 = e - q * D4;
+    nd[e] = *reinterpret_cast<const float4*>(emb + qr.rows[q < Q ? q : 0] * (long)d + 4 * c4);
+  }
+  __syncthreads();
+  float w22a[NQ];                      // approximate 1 / (|needle|^2 + 1e-12): same arithmetic in every workgroup
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {       // lanes across the row's vectors, then a shuffle tree (a serial walk - 25 dependent LDS reads per needle - was 5 us per workgroup)
+    float t = 0.f;
+    for (int c4 = lane; c4 < D4; c4 += 64) { const float4 n = nd[q * D4 + c4]; t = fmaf(n.x, n.x, t); t = fmaf(n.y, n.y, t); t = fmaf(n.z, n.z, t); t = fmaf(n.w, n.w, t); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    w22a[q] = 1.f / (t + 1e-12f);
+  }
+  if (MODE == 0 && wg == 0 && lane == 0 && a.status) *a.status = 0u;
+  float tauq[NQ]; unsigned cnt[NQ]; float wmax[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { tauq[q] = (MODE == 1 && q < Q) ? a.tau[q] : INFINITY; cnt[q] = 0u; wmax[q] = -INFINITY; }
+  int buf = 0;
+  for (long t = wg; t < ntiles; t += nwg, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // tile t has landed (only its requests were outstanding)
+    __builtin_amdgcn_s_barrier();                                 // (one wave: orders the LDS-DMA writes before the reads below for the compiler too)
+    if (t + nwg < ntiles) request(t + nwg, buf ^ 1);             // the next tile streams in behind this tile's arithmetic
+    const uint4* row = &tile[buf][lane * V];
+    float s3 = 0.f, s1[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s1[q] = 0.f;
+    // UB column vectors per round: their (NQ + 1) x UB LDS reads are in flight together, then the FMAs (a fully unrolled row - 150 reads at
+    // d = 100, five needles - took all 512 registers and spilled)
+    constexpr int UB = (D4 % 5 == 0) ? 5 : 4;
+    static_assert(D4 % UB == 0, "row width");
+#pragma unroll 1
+    for (int c0 = 0; c0 < D4; c0 += UB) {
+      float4 b[UB], n[NQ][UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        b[u] = __builtin_bit_cast(float4, row[c0 + u]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) n[q][u] = nd[q * D4 + c0 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        s3 = fmaf(b[u].x, b[u].x, s3); s3 = fmaf(b[u].y, b[u].y, s3); s3 = fmaf(b[u].z, b[u].z, s3); s3 = fmaf(b[u].w, b[u].w, s3);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          s1[q] = fmaf(n[q][u].x, b[u].x, s1[q]); s1[q] = fmaf(n[q][u].y, b[u].y, s1[q]); s1[q] = fmaf(n[q][u].z, b[u].z, s1[q]); s1[q] = fmaf(n[q][u].w, b[u].w, s1[q]);
+        }
+      }
+    }
+    const long i = t * 64 + lane;
+    const float w32 = 1.f / (s3 + 1e-12f);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float v = s1[q] * sqrtf(w22a[q] * w32);
+      if (MODE == 0) { if (i < N) wmax[q] = fmaxf(wmax[q], v); }
+      else {
+        const bool hit = i < N && q < Q && v >= tauq[q];
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+          const unsigned pos = cnt[q] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+          if (hit && pos < (unsigned)ASLOT) { const long at = ((long)q * nwg + wg) * ASLOT + pos; a.cand_idx[at] = (unsigned)i; a.cand_sc[at] = v; }
+          cnt[q] += (unsigned)__popcll(m);
+        }
+      }
+    }
+  }
+  if (MODE == 1) {
+    if (lane < Q) {
+      unsigned c = 0u;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) if (q == lane) c = cnt[q];
+      a.counts[(long)lane * nwg + wg] = c;
+    }
+    return;
+  }
+  // MODE 0: this workgroup's maxima, then the arrival; the last workgroup turns the nwg maxima per needle into tau
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    float m = wmax[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0 && q < Q) a.wgmax[(long)q * nwg + wg] = m;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned arrived = 0u;
+  if (lane == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  arrived = (unsigned)__shfl((int)arrived, 0, 64);
+  if (arrived != (unsigned)nwg - 1u) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next search
+  // A lower bound of the k-th largest of the nwg maxima per needle, by one wave: 64 value buckets between the smallest and the largest maximum,
+  // a suffix count over the buckets, the lower edge of the last bucket that still has k maxima at or above it - minus one bucket width, so that
+  // the float rounding of the bucket index cannot put a counted value below the edge.  (An exact k-th by a bitonic sort of 256 x Q values on one
+  // wave took longer than the sample itself; the price of the bucket form is a threshold up to (hi - lo) / 32 lower, ~20 % more candidates.)
+  unsigned* hist = reinterpret_cast<unsigned*>(srt);
+  for (int q = 0; q < Q; ++q) {
+    float v[4], lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = lane + 64 * u;
+      v[u] = e < nwg ? __hip_atomic_load(a.wgmax + (long)q * nwg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NAN;
+      if (e < nwg) { lo = fminf(lo, v[u]); hi = fmaxf(hi, v[u]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+    const float width = (hi - lo) * (1.f / 64.f), inv = width > 0.f ? 1.f / width : 0.f;
+    hist[lane] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (lane + 64 * u < nwg) { int bkt = (int)((v[u] - lo) * inv); bkt = bkt < 0 ? 0 : (bkt > 63 ? 63 : bkt); atomicAdd(&hist[bkt], 1u); }
+    __syncthreads();
+    unsigned suf = hist[lane];                                   // maxima in buckets >= lane: suffix sum over the lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned t = (unsigned)__shfl_down((int)suf, off, 64); if (lane + off < 64) suf += t; }
+    const unsigned long long ok = __ballot(suf >= (unsigned)a.k);      // lane 0 always qualifies (nwg >= k)
+    const int top = 63 - __builtin_clzll(ok | 1ull);
+    if (lane == 0) a.tau[q] = lo + (float)(top - 1) * width - a.eps2;
+    __syncthreads();
+  }
+}
+bool cosine_topk_small_path(long N, int d, int Q, int k) {
+  static const bool on = !getenv("GR_SEARCH_NO_APPROX");
+  const int d4 = d / 4;
+  return on && Q >= 1 && Q <= AQ_MAX && (d & 3) == 0 && (d4 == 8 || d4 == 16 || d4 == 25 || d4 == 32) && N >= FILTER_MIN_ROWS && k <= 128 &&
+         (size_t)N * d * 4 < 0x7FFFF000ul;
+}
+template <int D4, int MODE>
+static void launch_approx_nq(int Q, unsigned grid, hipStream_t s, const float* emb, long N, long stride, const SmallQ& qr, const ApproxArgs& a) {
+  if (Q <= 2) hipLaunchKernelGGL((cos_approx_kernel<D4, 2, MODE>), dim3(grid), dim3(64), 0, s, emb, N, stride, qr, a);
+  else if (Q <= 5) hipLaunchKernelGGL((cos_approx_kernel<D4, 5, MODE>), dim3(grid), dim3(64), 0, s, emb, N, stride, qr, a);
+  else hipLaunchKernelGGL((cos_approx_kernel<D4, 8, MODE>), dim3(grid), dim3(64), 0, s, emb, N, stride, qr, a);
+}
+template <int MODE>
+static void launch_approx(int d4, int Q, unsigned grid, hipStream_t s, const float* emb, long N, long stride, const SmallQ& qr, const ApproxArgs& a) {
+  switch (d4) {
+    case 8: launch_approx_nq<8, MODE>(Q, grid, s, emb, N, stride, qr, a); break;
+    case 16: launch_approx_nq<16, MODE>(Q, grid, s, emb, N, stride, qr, a); break;
+    case 25: launch_approx_nq<25, MODE>(Q, grid, s, emb, N, stride, qr, a); break;
+    default: launch_approx_nq<32, MODE>(Q, grid, s, emb, N, stride, qr, a); break;
   }
 }
 
@@ -615,7 +879,8 @@ static void launch_keys(bool accf, int mode, int nq, unsigned nb, hipStream_t s,
 
 // status_dev (nullable): receives 0, or 1 when the filtered path dropped candidates (rerun with unfiltered = 1)
 int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_dev, int Q, int k,
-                       long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s, unsigned* status_dev, int unfiltered) {
+                       long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s, unsigned* status_dev, int unfiltered,
+                       const long* query_rows_host) {
   if (k > 1024 || k < 1 || k > N || N >= 0xFFFFFFFFl || d < 1 || d > 4096 * 4) return -1;
   { static const char* e = getenv("GR_SEARCH_DEBUG"); if (e) g_search_debug = atoi(e); }
   // workspace carve: needles [Q][d] | w22 [Q] | counts [Q] | keys A | keys B | keys C
@@ -629,6 +894,33 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
   unsigned long long* keysB = keysA + (size_t)Q * N;
   unsigned long long* keysC = keysB + (size_t)Q * n1;
   const bool filter = !unfiltered && status_dev && N >= FILTER_MIN_ROWS && k * 8 <= SAMPLE_ROWS && k <= CHUNK / 2;      // (entries + sample + bounds + counts fit the N keys of region A: SLOT * 8 / ROWS + ... < 8 bytes per row)
+  if (filter && query_rows_host && cosine_topk_small_path(N, d, Q, k)) {
+    // keys A = maxima [Q][256] | tau [8] | arrival counter | candidate rows [Q][wgs][ASLOT] | scores | counts [Q][wgs]
+    const long S = SAMPLE_ROWS, stride = N / S;
+    const unsigned swg = (unsigned)(S / 64);
+    float* wgmax = reinterpret_cast<float*>(keysA); float* tau = wgmax + (size_t)AQ_MAX * 256; unsigned* counter = reinterpret_cast<unsigned*>(tau + AQ_MAX);
+    const int awgs = approx_wgs(d, Q);
+    unsigned* cidx = counter + 8; float* csc = reinterpret_cast<float*>(cidx + (size_t)Q * awgs * ASLOT);
+    unsigned* wcnt = reinterpret_cast<unsigned*>(csc + (size_t)Q * awgs * ASLOT);
+    static bool counter_zeroed = false; static const void* zeroed_for = nullptr;
+    if (!counter_zeroed || zeroed_for != (const void*)counter) { (void)hipMemsetAsync(counter, 0, 32, s); counter_zeroed = true; zeroed_for = counter; }   // the kernel leaves it at 0 again
+    SmallQ qr{}; for (int q = 0; q < AQ_MAX; ++q) qr.rows[q] = query_rows_host[q < Q ? q : 0];
+    ApproxArgs a{};
+    a.needles = needles; a.w22 = w22; a.wgmax = wgmax; a.counter = counter; a.tau = tau; a.cand_idx = cidx; a.cand_sc = csc; a.counts = wcnt;
+    a.status = status_dev; a.Q = Q; a.k = k; a.accf = accf; a.eps2 = 2.f * (float)(2 * d + 16) * 5.9604645e-8f;
+    {
+      KtScope kt("cos_approx_kernel (sample + bound)", 0.0, 4.0 * S * d, s);
+      launch_approx<0>(d / 4, Q, swg, s, emb, S, stride, qr, a);
+    }
+    {
+      KtScope kt("cos_approx_kernel", 2.0 * N * d * Q, 4.0 * N * d, s);
+      launch_approx<1>(d / 4, Q, (unsigned)awgs, s, emb, N, 1L, qr, a);
+    }
+    KtScope kt("batched_select_kernel", 0.0, 0.0, s);
+    if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, (long)awgs, k, idx_out, score_out, status_dev, ASLOT, a.eps2, qr, 1);
+    else hipLaunchKernelGGL(batched_select_kernel<false>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, (long)awgs, k, idx_out, score_out, status_dev, ASLOT, a.eps2, qr, 1);
+    return 0;
+  }
   if (accf) hipLaunchKernelGGL(needle_prep_kernel<true>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
   else hipLaunchKernelGGL(needle_prep_kernel<false>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
   static const bool batched_on = !getenv("GR_SEARCH_NO_BATCHED");
@@ -666,8 +958,8 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
     }
 #undef GR_MFMA
     KtScope kt("batched_select_kernel", 0.0, 0.0, s);
-    if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev);
-    else hipLaunchKernelGGL(batched_select_kernel<false>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev);
+    if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev, BSLOT, 2.f * GR_BERR, SmallQ{}, 0);
+    else hipLaunchKernelGGL(batched_select_kernel<false>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev, BSLOT, 2.f * GR_BERR, SmallQ{}, 0);
     return 0;
   }
   if (filter) {
