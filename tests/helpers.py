@@ -241,6 +241,7 @@ def assert_grads_close(model, got, ref, rtol=1e-4, floor=1e-3, what=""):
     mod_max = {}
     for mod, nm, lo, hi in segs:
         mod_max[id(mod)] = max(mod_max.get(id(mod), 0.0), float(np.abs(ref[lo:hi]).max()))
+    worst = 0.0
     for mod, nm, lo, hi in segs:
         r, g = ref[lo:hi], got[lo:hi]
         gmax = max(mod_max[id(mod)], floor)
@@ -252,6 +253,13 @@ def assert_grads_close(model, got, ref, rtol=1e-4, floor=1e-3, what=""):
             continue
         d = maxdiff(g, r)
         assert d <= rtol * gmax, f"{what} {mod.typename}.{nm} [{lo}:{hi}]: max |diff| {d:.3e} vs module max |g| {gmax:.3e}"
+        # and per tensor in relative L2 (the max-norm bar alone is set by the module's largest entry)
+        nr = float(np.linalg.norm(r.astype(np.float64)))
+        if nr > floor * np.sqrt(r.size) * 1e-3:
+            rel = float(np.linalg.norm(g.astype(np.float64) - r.astype(np.float64))) / nr
+            worst = max(worst, rel)
+            assert rel <= 3.0 * rtol, f"{what} {mod.typename}.{nm} [{lo}:{hi}]: relative L2 error {rel:.3e} > {3.0 * rtol:g}"
+    print(f"[grads] {what} worst per-tensor relative L2 error {worst:.2e} (bar {3.0 * rtol:g})")
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -147,3 +147,42 @@ def test_sync_bn_two_ranks_equal_one_device_on_the_global_batch(oracle, mode, na
     grouped = oR.forward(ref["images"])
     oR.set_bn_groups(1)
     assert maxdiff(grouped, preds) > 10 * TOL, "per-rank and synchronised BatchNorm agree: the case does not separate them"
+
+
+def test_sync_bn_through_a_one_rank_rccl_communicator_changes_no_bit(ctx, oracle):
+    """The RCCL side of the same code (ncclAllReduce of doubles on the compute stream, and of the uint32 max|dz| words): with a ONE-rank
+    communicator on the context the synchronised path - compacted per-channel sums -> all-reduce -> statistics - must reproduce the plain
+    step bit for bit (the compaction adds the same values in the same order as the fused finalisation)."""
+    import ganrev._lib as L
+    name, dims, nd, B = D.CASES[0]
+    G, R = D.make_models(dims, nd)
+    oR = oracle.from_model(R, dims)
+    _compile(G, R, dims, nd)
+    gnet, rnet = G._net, R._net
+    theta0 = rnet.get_params()
+    zeros = np.zeros_like(theta0)
+    noise, masks = D.global_inputs(R, _layer_of(R, oR), oR.mask_size, dims, nd, B)
+    dn = ctx.upload(D.shard(noise, 0))
+
+    def one_step():
+        rnet.set_params(theta0); rnet.set_adam_state(zeros, zeros)
+        for i in range(rnet.n_bn()):
+            f = rnet.lib.gr_net_bn_features(rnet.h, i)
+            rnet.set_bn_running(i, np.zeros(f, np.float32), np.ones(f, np.float32))
+        for li, k in masks.items():
+            rnet.set_mask(li, D.shard(k.reshape(B * D.WORLD, -1), 0).ravel())
+        loss = L.train_r_step(gnet, rnet, dn, B, B, L.Hyper(), 1)
+        return loss, rnet.get_grads(), rnet.get_params(), [rnet.get_bn_running(i) for i in range(rnet.n_bn())]
+    plain = one_step()
+    ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+    try:
+        ctx.set_tuning("sync_bn", 1)
+        synced = one_step()
+    finally:
+        ctx.set_tuning("sync_bn", 0)
+        ctx.comm_destroy()
+    ctx.free(dn)
+    assert plain[0] == synced[0]
+    assert np.array_equal(plain[1], synced[1]) and np.array_equal(plain[2], synced[2])
+    for (ma, va), (mb, vb) in zip(plain[3], synced[3]):
+        assert np.array_equal(ma, mb) and np.array_equal(va, vb)
