@@ -185,7 +185,7 @@ static int ensure_ws2(gr_ctx* c, size_t bytes) {
   return GR_OK;
 }
 
-extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.3 (round 3)"; }
+extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.4 (round 4)"; }
 
 extern "C" int gr_init(int device, gr_ctx** out) {
   if (!out) return GR_ERR_INVALID;
