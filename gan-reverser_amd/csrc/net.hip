@@ -36,7 +36,7 @@ struct gr_ctx {
                                        // MFMA kernels take the whole register file of a CU (2 waves x 256 VGPRs per SIMD), so the pipeline kernels of the main
                                        // stream cannot become resident beside a weight gradient and only kernel tails overlap - not worth per-kernel
                                        // timings that no longer add up to the step
-  double* d_loss = nullptr;     // device scalar
+  double* d_loss = nullptr;     // device scalar (64-byte block: +0 the loss, +16 the range guard's alarm word, +32 the search's arrival counter)
   double* h_loss = nullptr;     // pinned host scalar
   bool timing = false;
   int conv_mode = 2;            // 2 = f16x3 split (fp32-accurate, f16 MFMA; default), 1 = bf16x6 split (fp32-accurate, bf16 MFMA), 0 = exact fp32 MFMA
@@ -1753,7 +1753,7 @@ extern "C" int gr_cosine_topk_dev(gr_ctx* c, const float* emb, int64_t N, int d,
     char* pd = static_cast<char*>(pin_dev);
     long* p_idx = reinterpret_cast<long*>(pd); float* p_sc = reinterpret_cast<float*>(pd + sizeof(long) * (size_t)Q * k);
     unsigned* p_status = reinterpret_cast<unsigned*>(pd + res_bytes - sizeof(unsigned));
-    if (launch_cosine_topk(emb, N, d, d_q, Q, k, p_idx, p_sc, accf, c->ws, c->stream, p_status, 0, qrows)) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
+    if (launch_cosine_topk(emb, N, d, d_q, Q, k, p_idx, p_sc, accf, c->ws, c->stream, p_status, 0, qrows, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->d_loss) + 32))) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
     LAUNCHCHK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const char* hres = (const char*)c->pin;

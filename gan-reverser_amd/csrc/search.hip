@@ -880,7 +880,7 @@ static void launch_keys(bool accf, int mode, int nq, unsigned nb, hipStream_t s,
 // status_dev (nullable): receives 0, or 1 when the filtered path dropped candidates (rerun with unfiltered = 1)
 int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_dev, int Q, int k,
                        long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s, unsigned* status_dev, int unfiltered,
-                       const long* query_rows_host) {
+                       const long* query_rows_host, unsigned* arrival_counter) {
   if (k > 1024 || k < 1 || k > N || N >= 0xFFFFFFFFl || d < 1 || d > 4096 * 4) return -1;
   { static const char* e = getenv("GR_SEARCH_DEBUG"); if (e) g_search_debug = atoi(e); }
   // workspace carve: needles [Q][d] | w22 [Q] | counts [Q] | keys A | keys B | keys C
@@ -894,16 +894,15 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
   unsigned long long* keysB = keysA + (size_t)Q * N;
   unsigned long long* keysC = keysB + (size_t)Q * n1;
   const bool filter = !unfiltered && status_dev && N >= FILTER_MIN_ROWS && k * 8 <= SAMPLE_ROWS && k <= CHUNK / 2;      // (entries + sample + bounds + counts fit the N keys of region A: SLOT * 8 / ROWS + ... < 8 bytes per row)
-  if (filter && query_rows_host && cosine_topk_small_path(N, d, Q, k)) {
+  if (filter && query_rows_host && arrival_counter && cosine_topk_small_path(N, d, Q, k)) {
     // keys A = maxima [Q][256] | tau [8] | arrival counter | candidate rows [Q][wgs][ASLOT] | scores | counts [Q][wgs]
     const long S = SAMPLE_ROWS, stride = N / S;
     const unsigned swg = (unsigned)(S / 64);
-    float* wgmax = reinterpret_cast<float*>(keysA); float* tau = wgmax + (size_t)AQ_MAX * 256; unsigned* counter = reinterpret_cast<unsigned*>(tau + AQ_MAX);
+    float* wgmax = reinterpret_cast<float*>(keysA); float* tau = wgmax + (size_t)AQ_MAX * 256; unsigned* counter = arrival_counter;     // (the context's: zero between searches)
+    unsigned* pad_ = reinterpret_cast<unsigned*>(tau + AQ_MAX);
     const int awgs = approx_wgs(d, Q);
-    unsigned* cidx = counter + 8; float* csc = reinterpret_cast<float*>(cidx + (size_t)Q * awgs * ASLOT);
+    unsigned* cidx = pad_ + 8; float* csc = reinterpret_cast<float*>(cidx + (size_t)Q * awgs * ASLOT);
     unsigned* wcnt = reinterpret_cast<unsigned*>(csc + (size_t)Q * awgs * ASLOT);
-    static bool counter_zeroed = false; static const void* zeroed_for = nullptr;
-    if (!counter_zeroed || zeroed_for != (const void*)counter) { (void)hipMemsetAsync(counter, 0, 32, s); counter_zeroed = true; zeroed_for = counter; }   // the kernel leaves it at 0 again
     SmallQ qr{}; for (int q = 0; q < AQ_MAX; ++q) qr.rows[q] = query_rows_host[q < Q ? q : 0];
     ApproxArgs a{};
     a.needles = needles; a.w22 = w22; a.wgmax = wgmax; a.counter = counter; a.tau = tau; a.cand_idx = cidx; a.cand_sc = csc; a.counts = wcnt;
