@@ -318,6 +318,7 @@ constexpr int BATCH_MIN_Q = 32;
 constexpr int AQ_MAX = 8;             // needles of the small path (cos_approx_kernel below): their rows travel by value
 struct SmallQ { long rows[AQ_MAX]; };
 constexpr int BQ_MAX = 2048;          // needles per call of the batched path (LDS counters)
+constexpr long BSAMPLE_ROWS = 65536;  // the batched path's sample: 256 workgroups of 256 rows, ONE value per (workgroup, needle) - their maximum - leaves the kernel
 constexpr int BSLOT = 16;             // (row, score) entries per workgroup (256 rows) and needle: expected 1.2 at cfg5, P(> 16) ~ 1e-14
 constexpr int BD_MAX = 128;           // widest row the batched kernel stages whole
 #define GR_BERR 0.0087890625f      /* 2^-7 + 2^-10: see the bound above */
@@ -326,6 +327,11 @@ typedef float f32x16s __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ unsigned short to_bf16(float x) { const __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
 __device__ __forceinline__ float from_bf16(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
+// lane i of a 16-lane DPP row receives lane i - n's value (row_shr:n = 0x110 + n); lanes without a source keep their own
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shr(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
 // needles as the MFMA kernel stages them: bf16 rows [Qpad64][KS] (zero columns past d, zero rows past Q), sqrt(w22), tau = +inf past Q
 __global__ void needles_bf16_kernel(const float* __restrict__ needles, const float* __restrict__ w22, int Q, int Qpad, int d, int KS,
                                     unsigned short* __restrict__ nb16, float* __restrict__ sw22s, float* __restrict__ tau) {
@@ -358,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const long r0 = (long)blockIdx.x * 256;
   if (MODE == 1) for (int q = tid; q < Q; q += 256) lds_cnt[q] = 0u;
+  if (MODE == 0 && tid < 128) lds_cnt[tid] = 0u;               // two slots of 64 per-needle maxima (orderable bits; 0 = below everything)
   // stage the row tile as bf16 (zero columns past d, zero rows past N): float4 loads when the rows are 16-byte aligned
   if ((d & 3) == 0) {
     constexpr int C4 = KP / 4, TOT = 256 * C4, PER = (TOT + 255) / 256, HALF = (PER + 1) / 2;
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
   __syncthreads();                                              // rows are in registers: the tile region now holds needle tiles
   float s32[2];
 #pragma unroll
-  for (int rb = 0; rb < 2; ++rb) s32[rb] = sw32s[64 * wave + 32 * rb + l31];
+  for (int rb = 0; rb < 2; ++rb) s32[rb] = (MODE == 1 && r0 + 64 * wave + 32 * rb + l31 >= N) ? NAN : sw32s[64 * wave + 32 * rb + l31];   // (a NaN score passes no threshold)
   uint4* ndA = reinterpret_cast<uint4*>(rowsB);                 // [2][TV]
   const uint4* nsrc = reinterpret_cast<const uint4*>(nb16);
   const int ntiles = (Q + 63) / 64;
@@ -468,6 +475,12 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) pv[nb][rq] = *reinterpret_cast<const float4*>((MODE == 1 ? taut : sw22t) + cur * 64 + 32 * nb + 8 * rq + 4 * h);
+    float vmax0[2][16];                                         // MODE 0: this lane's maximum per needle over its two row blocks
+    if (MODE == 0 && tid < 64 && nt > 0) {                      // the previous tile's maxima are complete (the barrier above): out they go, slot cleared
+      const int qp = (nt - 1) * 64 + tid;
+      if (qp < Q) out[(long)qp * gridDim.x + blockIdx.x] = unorderable(lds_cnt[(cur ^ 1) * 64 + tid]) * sw22t[(cur ^ 1) * 64 + tid];
+      lds_cnt[(cur ^ 1) * 64 + tid] = 0u;
+    }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       const long i = r0 + 64 * wave + 32 * rb + l31;
@@ -479,14 +492,34 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
           const float4 p4 = pv[nb][r >> 2];
           const float pq = (r & 3) == 0 ? p4.x : ((r & 3) == 1 ? p4.y : ((r & 3) == 2 ? p4.z : p4.w));
           const float v = acc[nb][rb][r] * s32[rb];
-          if (MODE == 0) { if (q < Q && i < N) out[(long)q * N + i] = v * pq; }
-          else if (v >= pq && i < N) {                          // (the threshold is +inf past Q)
+          if (MODE == 0) { if (i < N) vmax0[nb][r] = rb == 0 ? v : fmaxf(vmax0[nb][r], v); else if (rb == 0) vmax0[nb][r] = -INFINITY; }
+          else if (v >= pq) {                                   // (the threshold is +inf past Q; rows past N carry a NaN scale: never true)
             const unsigned pos = atomicAdd(&lds_cnt[q], 1u);
             if (pos < (unsigned)BSLOT) { const long at2 = ((long)q * gridDim.x + blockIdx.x) * BSLOT + pos; cand_idx[at2] = (unsigned)i; cand_sc[at2] = v * sw22t[cur * 64 + ql]; }
           }
         }
     }
+    if (MODE == 0) {
+      // the sample leaves ONE value per (workgroup, needle): the maximum over the workgroup's 256 rows (their k-th largest over the
+      // workgroups bounds the k-th largest sample score from below - k distinct rows at or above it - without writing S x Q scores).
+      // Lanes with the same h hold the same needles for 32 different rows: shuffle tree over them, then one LDS max per (wave, needle).
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float m = vmax0[nb][r];
+          // maximum over each 16-lane DPP row (row_shr 1, 2, 4, 8: lane 15 of the row ends with it - VALU moves, no LDS crossbar), then the
+          // four row leaders add their value to the needle's LDS word (lanes 15, 31: h = 0; 47, 63: h = 1)
+          m = fmaxf(m, dpp_row_shr<0x111>(m)); m = fmaxf(m, dpp_row_shr<0x112>(m)); m = fmaxf(m, dpp_row_shr<0x114>(m)); m = fmaxf(m, dpp_row_shr<0x118>(m));
+          if ((lane & 15) == 15) atomicMax(&lds_cnt[cur * 64 + 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * h], orderable(m));
+        }
+    }
     if (nt + 1 < ntiles) commit(cur ^ 1);
+  }
+  if (MODE == 0) {
+    __syncthreads();
+    const int lastb = (ntiles - 1) & 1, qp = (ntiles - 1) * 64 + tid;
+    if (tid < 64 && qp < Q) out[(long)qp * gridDim.x + blockIdx.x] = unorderable(lds_cnt[lastb * 64 + tid]) * sw22t[lastb * 64 + tid];
   }
   if (MODE == 1) {
     __syncthreads();
@@ -924,15 +957,16 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
   else hipLaunchKernelGGL(needle_prep_kernel<false>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
   static const bool batched_on = !getenv("GR_SEARCH_NO_BATCHED");
   static const int batch_min_q = getenv("GR_BATCH_MIN_Q") ? atoi(getenv("GR_BATCH_MIN_Q")) : BATCH_MIN_Q;
-  if (filter && batched_on && Q >= batch_min_q && Q <= BQ_MAX && d <= BD_MAX) {
+  if (filter && batched_on && Q >= batch_min_q && Q <= BQ_MAX && d <= BD_MAX && k <= 128 && N >= 2 * BSAMPLE_ROWS) {      // (k distinct workgroup maxima must exist: 256 workgroups)
     // keys A = sample scores [Q][S] | tau [Qpad] | sqrt(w22) [Qpad] | bf16 needles [Qpad][KS] | candidate rows [Q][nwg][BSLOT] | scores | counts [Q][nwg]
-    const long S = SAMPLE_ROWS, nwg = (N + 255) / 256, stride = N / S;
+    // sample: BSAMPLE_ROWS strided rows in workgroups of 256; each leaves its maximum per needle, tau from the k-th largest of those
+    const long S = BSAMPLE_ROWS, nwg = (N + 255) / 256, stride = N / S, swg = S / 256;
     const int NK = d <= 32 ? 2 : (d <= 64 ? 4 : (d <= 112 ? 7 : 8)), KS = NK * 16 + 8, Qpad = (Q + 63) / 64 * 64;
-    float* samp = reinterpret_cast<float*>(keysA); float* tau = samp + (size_t)Q * S; float* sw22s = tau + Qpad;
+    float* samp = reinterpret_cast<float*>(keysA); float* tau = samp + (size_t)Q * swg; float* sw22s = tau + Qpad;
     unsigned short* nb16 = reinterpret_cast<unsigned short*>(sw22s + Qpad);
     unsigned* cidx = reinterpret_cast<unsigned*>(nb16 + (size_t)Qpad * KS); float* csc = reinterpret_cast<float*>(cidx + (size_t)Q * nwg * BSLOT);
     unsigned* wcnt = reinterpret_cast<unsigned*>(csc + (size_t)Q * nwg * BSLOT);
-    const size_t lds = (size_t)256 * KS * 2 + sizeof(float) * (256 + 128 + 128) + sizeof(unsigned) * (size_t)Q;
+    const size_t lds = (size_t)256 * KS * 2 + sizeof(float) * (256 + 128 + 128) + sizeof(unsigned) * (size_t)(Q > 128 ? Q : 128);
     hipLaunchKernelGGL(needles_bf16_kernel, dim3((unsigned)(((long)Qpad * KS + 255) / 256)), dim3(256), 0, s, needles, w22, Q, Qpad, d, KS, nb16, sw22s, tau);
 #define GR_MFMA(MODE_, grid_, N_, stride_, tau_, out_, ci_, cs_, wc_)                                                                  \
     do {                                                                                                                              \
@@ -948,8 +982,8 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
       GR_MFMA(0, (unsigned)((S + 255) / 256), S, stride, (const float*)nullptr, samp, (unsigned*)nullptr, (float*)nullptr, (unsigned*)nullptr);
     }
     {
-      KtScope kt("batched_tau_kernel", 0.0, 4.0 * S * Q, s);
-      hipLaunchKernelGGL(batched_tau_kernel, dim3(Q), dim3(1024), 0, s, samp, S, k, sw22s, tau);
+      KtScope kt("batched_tau_kernel", 0.0, 4.0 * swg * Q, s);
+      hipLaunchKernelGGL(batched_tau_kernel, dim3(Q), dim3(1024), 0, s, samp, swg, k, sw22s, tau);
     }
     {
       KtScope kt("cos_mfma_kernel", 2.0 * N * d * Q, 4.0 * N * d, s);
