@@ -6,8 +6,9 @@
                                                                                        -> profiles/<tag>_hbm_traffic.json
                                                                                        -> profiles/traffic.json (read by bench.py)
 HBM bytes per launch follow MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-reports half the bytes of a wide coalesced streaming read, so the corrected figure doubles it (calibrated for 16 B/lane
-streams; this repo's conv staging loads are 4 B/lane, where the factor is uncalibrated — both raw and corrected are kept).
+reports half the bytes of a wide coalesced streaming read, so the corrected figure doubles it.  Round 4 calibrated the factor per load
+shape (tools/probe/fetch_probe.hip: exactly 2.0 for every vector-load and LDS-DMA shape that reads whole 128-byte lines, 1.0 for
+scalar-cache loads) and cross-checked it per kernel against the request-size counters (tools/pmc_traffic.sh): both raw and corrected are kept.
 """
 import collections
 import csv
