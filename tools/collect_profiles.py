@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 outputs a gpurun call left under gpurun_out/ into the committed summaries under profiles/.
 
-  gpurun_out/prof_stats/**/_kernel_stats.csv       (rocprofv3 --kernel-trace --stats)   -> profiles/<tag>_kernel_stats.csv
-  gpurun_out/prof_fetch|prof_write/**/_counter_collection.csv (--pmc FETCH_SIZE / WRITE_SIZE, separate passes)
+  gpurun_out/prof_stats_<workload>/**/_kernel_stats.csv       (rocprofv3 --kernel-trace --stats)   -> profiles/<tag>_<workload>_kernel_stats.csv
+  gpurun_out/prof_fetch_<workload>|prof_write_<workload>/**/_counter_collection.csv (--pmc FETCH_SIZE / WRITE_SIZE, separate passes)
                                                                                        -> profiles/<tag>_hbm_traffic.json
                                                                                        -> profiles/traffic.json (read by bench.py)
 HBM bytes per launch follow MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
@@ -27,7 +27,7 @@ def short(name):
 
 
 def pmc_avg(d, counter):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*_counter_collection.csv"), recursive=True)
+    files = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]
     if not files:
         return {}
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -45,10 +45,10 @@ def main():
     workload = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "**", "*_kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_stats_{workload}", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], os.path.join(out, f"{tag}_{workload}_kernel_stats.csv"))
-    fetch, write = pmc_avg("prof_fetch", "FETCH_SIZE"), pmc_avg("prof_write", "WRITE_SIZE")
+        shutil.copy(stats[-1], os.path.join(out, f"{tag}_{workload}_kernel_stats.csv"))
+    fetch, write = pmc_avg(f"prof_fetch_{workload}", "FETCH_SIZE"), pmc_avg(f"prof_write_{workload}", "WRITE_SIZE")
     summary = {}
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, (0, 0.0))[1] * 1024
@@ -62,7 +62,7 @@ def main():
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     traffic[workload] = {k: v["hbm_bytes_corrected"] for k, v in summary.items()}
     json.dump(traffic, open(tpath, "w"), indent=1)
-    for f in ("bench_prof.log",):
+    for f in (f"bench_prof_{workload}.log",):
         p = os.path.join(ROOT, "gpurun_out", f)
         if os.path.exists(p):
             lines = [l for l in open(p, errors="replace") if l.startswith("{")]
