@@ -141,3 +141,109 @@ def createClusterImages(nbClusters, nbIterations, nbMaxPerCluster, images, attri
         faces.append(images[keep].mean(axis=0, dtype=np.float64).astype(np.float32) if len(keep)
                      else np.zeros(images.shape[1:], np.float32))                                   # :233-243
     return centroids, counts, clusters, faces
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# apply_r.lua:25-193 main(): the whole analysis as one run.  Image writing (image.toDisplayTensor / image.save, apply_r.lua:136,
+# 233-262, 283-300, 336-352, 374-390) is out of scope: what the reference would have rendered is written as arrays (.npy) and one
+# summary.json under --writeTo.  G / R / R_fixer come from Torch7 checkpoints (ganrev.t7: train.lua:256, train_r.lua:234) or, with
+# --synthetic, from random-initialised nets of the requested shape (a smoke run: no trained checkpoint exists in this repository).
+def parse(argv=None):
+    import argparse
+    p = argparse.ArgumentParser(description="apply_r.lua options (apply_r.lua:13-23)")
+    p.add_argument("--batchSize", type=int, default=32)                       # apply_r.lua:14 (the device-resident pipeline likes 512)
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--gpu", type=int, default=0)
+    p.add_argument("--G", default="logs/adversarial.net")
+    p.add_argument("--R", default="logs/r_3x32x32_nd32_normal.net")
+    p.add_argument("--R_fixer", default="logs/r_3x32x32_nd32_normal_fixer.net")
+    p.add_argument("--writeTo", default="r_results")
+    p.add_argument("--nbImages", type=int, default=10000)                     # apply_r.lua:145
+    p.add_argument("--synthetic", default="", help="CxHxWxND, e.g. 1x32x32x32: random-initialised G / R / R_fixer instead of checkpoints")
+    p.add_argument("--host", action="store_true", help="the host-tensor loop (forwardBatched per chunk, as apply_r.lua spells it) instead of the device-resident pipeline")
+    p.add_argument("--conv-mode", default="f16x3", choices=["f32", "bf16x6", "f16x3"])
+    p.add_argument("--quiet", action="store_true")
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    import json
+    import os
+    import time
+    from . import models, nn_utils, synth
+    OPT = parse(argv)
+    ctx = L.Context(OPT.gpu) if OPT.gpu != int(os.environ.get("LOCAL_RANK", "0")) else L.default_context()
+    ctx.set_conv_mode(OPT.conv_mode)
+    say = (lambda *a: None) if OPT.quiet else print
+    if OPT.synthetic:
+        c, h, w, nd = (int(v) for v in OPT.synthetic.split("x"))
+        dims, method = (c, h, w), "normal"
+        MODEL_G = models.create_G(dims, nd, seed=OPT.seed); synth.init_params(MODEL_G, OPT.seed)
+        MODEL_R = models.create_R(dims, nd, method, False, seed=OPT.seed + 1); synth.init_params(MODEL_R, OPT.seed + 1)
+        MODEL_R_FIXER = models.create_R(dims, nd, method, True, seed=OPT.seed + 2); synth.init_params(MODEL_R_FIXER, OPT.seed + 2)
+    else:
+        from . import t7
+        ck = t7.load_checkpoint(OPT.G)                                        # apply_r.lua:62-69
+        MODEL_G, o = ck["G"], ck.get("opt", {})
+        nd, method = int(o.get("noiseDim", 32)), o.get("noiseMethod", "normal")
+        dims = (1 if o.get("colorSpace", "rgb") == "y" else 3, int(o.get("height", 32)), int(o.get("width", 32)))
+        MODEL_R = t7.load_checkpoint(OPT.R)["R"]                              # :92-94
+        MODEL_R_FIXER = t7.load_checkpoint(OPT.R_fixer)["R"]                  # :101-103
+    for m in (MODEL_G, MODEL_R, MODEL_R_FIXER):
+        m._ctx = ctx
+        m.evaluate()
+    MODEL_R_FIXER.manualSeed(OPT.seed)
+    os.makedirs(OPT.writeTo, exist_ok=True)
+    out = lambda name: os.path.join(OPT.writeTo, name)
+    summary = dict(dims=list(dims), noiseDim=nd, noiseMethod=method, nbImages=OPT.nbImages, batchSize=OPT.batchSize, path="host" if OPT.host else "device")
+
+    say("Varying components...")                                              # apply_r.lua:110-136
+    nbSteps = 16
+    steps = np.linspace(-1, 1, nbSteps) if method == "uniform" else np.linspace(-3, 3, nbSteps)
+    noise1 = nn_utils.createNoiseInputs(1, nd, method, seed=OPT.seed)
+    var_noise = np.repeat(noise1, nd * nbSteps, axis=0)
+    for i in range(nd):
+        var_noise[i * nbSteps:(i + 1) * nbSteps, i] = steps
+    np.save(out("variations.npy"), forwardBatched(MODEL_G, var_noise, OPT.batchSize).reshape((nd, nbSteps) + tuple(dims)))
+
+    say("Generating images, converting images to attributes...")             # :141-153
+    N = OPT.nbImages
+    t0 = time.perf_counter()
+    dn = nn_utils.createNoiseInputsDev(ctx, N, nd, method, seed=OPT.seed + 1)      # utils/nn_utils.lua:39-51, drawn on the device (both paths: same noise)
+    if OPT.host:
+        noise = dn.numpy(); dn.free()
+        images, attributes, attributesFixer = embed(MODEL_G, MODEL_R, noise, OPT.batchSize, MODEL_R_FIXER)
+        by_attr, by_pix = createSimilaritySearch(5, 100, images, attributes) if N >= 500 else (None, None)
+    else:
+        di, da, df = embed_dev(MODEL_G, MODEL_R, dn, OPT.batchSize, MODEL_R_FIXER, keep_images=True, dims=dims)
+        by_attr, by_pix = createSimilaritySearchDev(5, 100, da, di) if N >= 500 else (None, None)     # :170-172 on the tables where they were written
+        noise, images, attributes, attributesFixer = dn.numpy(), di.numpy(), da.numpy(), df.numpy()
+        for t in (dn, di, da, df):
+            t.free()
+    ctx.synchronize()
+    summary["embed_and_search_seconds"] = round(time.perf_counter() - t0, 4)
+    np.save(out("attributes.npy"), attributes); np.save(out("attributes_fixer.npy"), attributesFixer)
+    if by_attr is not None:
+        np.save(out("similar_by_attributes.npy"), by_attr); np.save(out("similar_by_pixels.npy"), by_pix)
+
+    say("Clustering...")                                                      # :158-162
+    centroids, counts, clusters, faces = createClusterImages(20, 15, 64 + 7, images, attributes, seed=OPT.seed)
+    np.save(out("cluster_centroids.npy"), centroids); np.save(out("cluster_average_faces.npy"), np.stack(faces))
+    summary["cluster_sizes"] = [len(c) for c in clusters]; summary["cluster_total_counts"] = [float(v) for v in counts]
+
+    say("Fixing faces...")                                                    # :178-181
+    nbFixed = min(512 + 16, N)
+    np.save(out("fixed_faces.npy"), fixFaces(nbFixed, MODEL_G, attributesFixer, OPT.batchSize))
+
+    say("Detecting anomalies...")                                             # :186-191
+    nbCalc = min(1024, N)
+    dist, below, is_anom = detectAnomalies(nbCalc, 0.15, images, MODEL_G, attributesFixer, OPT.batchSize)
+    np.save(out("anomaly_distances.npy"), dist)
+    summary.update(anomaly_below=float(below), anomalies=int(is_anom.sum()))
+    json.dump(summary, open(out("summary.json"), "w"), indent=1)
+    say("<apply_r> results in", OPT.writeTo, summary)
+    return summary
+
+
+if __name__ == "__main__":
+    main()

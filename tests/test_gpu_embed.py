@@ -117,3 +117,22 @@ def test_forward_dev_destination_in_training_mode_is_a_copy(ctx):
     assert np.array_equal(ctx.download(odd.ptr + 4, (B, nd)), ref)
     for t in (x, out, odd):
         t.free()
+
+
+def test_apply_r_main_device_resident_and_host_loops_agree(tmp_path):
+    """python -m ganrev.apply_r (apply_r.lua:25-193 without the image writing): the device-resident run - embed_dev, the search on the device
+    tables - and the --host run - forwardBatched per chunk as apply_r.lua spells it - leave the same arrays, bit for bit."""
+    import json
+    from ganrev import apply_r
+    outs = {}
+    for mode in ("device", "host"):
+        d = tmp_path / mode
+        args = ["--synthetic", "1x16x16x8", "--nbImages", "700", "--batchSize", "64", "--writeTo", str(d), "--quiet"] + (["--host"] if mode == "host" else [])
+        summary = apply_r.main(args)
+        assert summary["path"] == mode and summary["anomalies"] == int(np.floor(700 * 0.15)) and sum(summary["cluster_sizes"]) > 0
+        outs[mode] = {f: np.load(d / f) for f in ("attributes.npy", "attributes_fixer.npy", "similar_by_attributes.npy", "similar_by_pixels.npy",
+                                                  "fixed_faces.npy", "anomaly_distances.npy", "cluster_centroids.npy", "variations.npy")}
+        assert json.load(open(d / "summary.json"))["nbImages"] == 700
+    for f, a in outs["device"].items():
+        assert np.array_equal(a, outs["host"][f]), f"{f}: device-resident and host loops differ"
+    assert outs["device"]["similar_by_attributes.npy"].shape == (5, 100) and outs["device"]["variations.npy"].shape == (8, 16, 1, 16, 16)
