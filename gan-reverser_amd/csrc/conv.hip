@@ -619,10 +619,13 @@ __device__ __forceinline__ f32x16 split_mma(const uint4* av, const uint4* bv, f3
   return acc;
 }
 
-template <int TW, int MT, int NTERM>
+// NI (round 4) = whole images stacked in one tile (planes exactly TW wide and TR / NI high: the D network's 8x8 planes, NI = 4): a 256-pixel
+// tile of ONE 8x8 image was three quarters padding (conv3x3_split_kernel<8, 1, 2> ran the deep tower of create_D2 at 83 TFLOP/s).  Each image
+// keeps its own zero halo rows in the patch, as in the wide kernels.
+template <int TW, int MT, int NTERM, int NI = 1>
 __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
   constexpr int NT = 256 * MT;                                    // MT = 2: 8 waves = 2 channel blocks x 4 pixel quarters
-  constexpr int NG = 2, PT = 256, TR = PT / TW, PR = TR + 2, PC = TW + 2, PS = PR * PC, CT = 32 * MT;
+  constexpr int NG = 2, PT = 256, TR = PT / TW, IH = TR / NI, PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
   constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int ot = bid % a.n_otiles; bid /= a.n_otiles;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int ty = bid % a.tiles_y; const int b = (bid / a.tiles_y) * NI;      // (first image of the tile)
   const int y0 = ty * TR, x0 = tx * TW, o0 = ot * CT;
   const int H = a.H, W = a.W;
   const int Hs = a.up ? H >> 1 : H, Ws = a.up ? W >> 1 : W;
@@ -643,10 +646,11 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
   int src_off[NSL]; bool inb[NSL]; int sh[NSL];
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
-    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, r = e / PC, c = e - r * PC;
+    const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, r0_ = e / PC, c = e - r0_ * PC;
+    const int img = NI > 1 ? r0_ / (IH + 2) : 0, r = NI > 1 ? r0_ - img * (IH + 2) : r0_;
     const int yy = y0 + r - 1, xx = x0 + c - 1;
-    inb[s] = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    src_off[s] = a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx;
+    inb[s] = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W && b + img < a.B;
+    src_off[s] = (a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx) + img * a.Cin * (int)HWs;
     sh[s] = hh;
   }
   const float* in_base = a.in + (size_t)b * a.Cin * HWs;
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
     const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
-    pix[ng] = h * PS + pr * PC + pc;
+    pix[ng] = h * PS + (NI > 1 ? pr + 2 * (pr / IH) : pr) * PC + pc;
   }
   const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
   GR_BF_LOAD(0)
@@ -733,9 +737,10 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
   float omax = 0.f;
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
-    const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
+    const int p = (wave * NG + ng) * 32 + l31, pr0 = p / TW, pc = p - pr0 * TW;
+    const int img = NI > 1 ? pr0 / IH : 0, pr = NI > 1 ? pr0 - img * IH : pr0;
     const int y = y0 + pr, x = x0 + pc;
-    if (y < H && x < W) {
+    if (y < H && x < W && b + img < a.B) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + wmt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
           const float bvv = a.bias ? a.bias[o] : 0.f;
           const float v = NTERM == 2 ? ldexpf(acc[ng][r], -ktot) : acc[ng][r];
           const float res = conv_epilogue(a.ep, v + bvv, o);
-          a.out[(((size_t)b * a.Cout + o) * H + y) * W + x] = res;
+          a.out[(((size_t)(b + img) * a.Cout + o) * H + y) * W + x] = res;
           omax = fmaxf(omax, fabsf(res));
         }
       }
@@ -2181,19 +2186,19 @@ void launch_conv_weight_split(const float* w_native, void* dst, int cin, int cou
                      cin, cout, CI, CO, cin_pad, cout_pad, bwd ? 1 : 0, nterm, amax);
 }
 
-template <int TW, int MT, int NTERM>
+template <int TW, int MT, int NTERM, int NI = 1>
 static void launch_conv_split_t(ConvArgs a, const void* wsplit, hipStream_t s) {
-  constexpr int TR = 256 / TW, PS = (TR + 2) * (TW + 2), CT = 32 * MT;
-  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TR - 1) / TR;
+  constexpr int TR = 256 / TW, IH = TR / NI, PS = NI * (IH + 2) * (TW + 2), CT = 32 * MT;
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (a.H + TR - 1) / TR;        // (NI > 1: planes are exactly TW x IH, the caller checked)
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / CT;
   const size_t lds = 16 * (size_t)(NTERM * 2 * PS + NTERM * 9 * 2 * CT);
-  const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
+  const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<TW, MT, NTERM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-  static const std::string name = "conv3x3_split_kernel<" + std::to_string(TW) + ", " + std::to_string(MT) + ", " + std::to_string(NTERM) + ">";   // as rocprofv3 prints it (NTERM 3 = bf16x6, 2 = f16x3)
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<TW, MT, NTERM, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = "conv3x3_split_kernel<" + std::to_string(TW) + ", " + std::to_string(MT) + ", " + std::to_string(NTERM) + (NI > 1 ? ", " + std::to_string(NI) : std::string()) + ">";   // as rocprofv3 prints it (NTERM 3 = bf16x6, 2 = f16x3)
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin / (a.up ? 4 : 1) + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL((conv3x3_split_kernel<TW, MT, NTERM>), dim3(grid), dim3(256 * MT), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
+  hipLaunchKernelGGL((conv3x3_split_kernel<TW, MT, NTERM, NI>), dim3(grid), dim3(256 * MT), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
 }
 
 template <int TW, int NI, int NTERM, bool DB>
@@ -2238,7 +2243,13 @@ static int launch_conv3x3_split_n(ConvArgs a, const void* wsplit, hipStream_t s)
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("GR_BF16X6_VARIANT"); variant = e ? atoi(e) : 0; }
   const bool wide = round_up(Cout, 32) % 64 == 0 && variant != 1;      // 64 output channels per workgroup (8 waves share one patch)
-  if (W <= 8) launch_conv_split_t<8, 1, NTERM>(a, wsplit, s);
+  static const bool stack8 = !getenv("GR_NO_STACK8");
+  // four 8x8 images per tile - while that still leaves half a workgroup per CU (batch 32 of the GAN game: 32 workgroups stacked, 0.38 -> 0.45 ms;
+  // batch 256: 1.37 -> 0.5 ms)
+  const long st_tiles = (B + 3) / 4, cp32 = round_up(Cout, 32) / 32;
+  if (stack8 && W == 8 && H == 8 && !a.up && wide && st_tiles * (cp32 / 2) >= g_stack8_min_wgs) launch_conv_split_t<8, 2, NTERM, 4>(a, wsplit, s);
+  else if (stack8 && W == 8 && H == 8 && !a.up && st_tiles * cp32 >= g_stack8_min_wgs) launch_conv_split_t<8, 1, NTERM, 4>(a, wsplit, s);
+  else if (W <= 8) launch_conv_split_t<8, 1, NTERM>(a, wsplit, s);
   else if (W <= 16) {
     // two stacked 16x16 images per 512-pixel tile (G.convA 799 -> 716 us) when that still leaves a workgroup for every CU
     if (wide && variant != 4 && H == 16 && W == 16 && (long)((B + 1) / 2) * (round_up(Cout, 32) / 64) >= 256) { launch_conv_split_wide<16, 2, NTERM>(aw, wsplit, s); return want_stats ? ((B + 1) / 2) : 0; }
@@ -2271,6 +2282,7 @@ int g_up2_stagger = getenv("GR_UP2_STAGGER") ? atoi(getenv("GR_UP2_STAGGER")) : 
 int g_nt_stores = getenv("GR_NT_STORES") ? atoi(getenv("GR_NT_STORES")) : 0;      // kernels.h store4: which kernels store non-temporally (measured: no effect; off)
 int g_up2_debug = 0;       // diagnostic ablations of conv3x3_up2q_f16x3_kernel (gr_set_tuning "up2_debug")
 void* g_p16_stamps = nullptr;     // diagnostic: device buffer of 32 x 8 bytes per workgroup (gr_debug_stamps)
+int g_stack8_min_wgs = 128;     // smallest grid at which 8x8 planes are stacked four to a tile (gr_set_tuning("stack8_min_wgs"): tests force the path)
 int g_p16_min_tiles = 128;      // below half a workgroup per CU the 256-pixel-tile kernels fill the chip better (gr_set_tuning("p16_min_tiles"): tests force the path)
 bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {
   static int on = -1;

@@ -164,6 +164,7 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
 // consecutive lanes hold consecutive pixels and a wave's store is 1 KB contiguous.  (A "quad-major" order - pixel 4q + k at
 // 64k + q, for producers whose threads own 4 pixels x 8 channels - was measured first: those threads were too heavy.)
 extern int g_p16_min_tiles, g_p16_variant, g_p16_stagger, g_up2_debug, g_up2_quad, g_up2_stagger, g_nt_stores;
+extern int g_stack8_min_wgs;
 extern void* g_p16_stamps;
 extern int g_p16_debug;       // diagnostic builds only (GR_P16_DEBUG bit mask: 1 no output stores, 2 no statistics, 4 no DMA, 8 no MFMA)
 void launch_to_p16(const float* x, void* p16, int B, int C, int HW, const unsigned* slot, hipStream_t s);   // C % 8 == 0, HW % 4 == 0

@@ -266,6 +266,7 @@ extern "C" int gr_debug_stamps(gr_ctx* c, void* dev_buf) { if (!c) return GR_ERR
 extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!c || !key) return GR_ERR_INVALID;
   if (!strcmp(key, "p16_min_tiles")) { gr::g_p16_min_tiles = value; return GR_OK; }
+  if (!strcmp(key, "stack8_min_wgs")) { gr::g_stack8_min_wgs = value; return GR_OK; }      // four 8x8 images per convolution tile from this many workgroups on (default 128)
   if (!strcmp(key, "p16_stagger")) { gr::g_p16_stagger = value; return GR_OK; }
   if (!strcmp(key, "p16_variant")) { gr::g_p16_variant = value; return GR_OK; }
   if (!strcmp(key, "p16_debug")) { gr::g_p16_debug = value; return GR_OK; }

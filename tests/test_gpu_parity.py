@@ -26,6 +26,8 @@ CONV_SHAPES = [
     (3, 128, 3, 32, 32),     # G.convC RGB
     (2, 128, 1, 32, 32),     # G.convC gray
     (2, 16, 40, 8, 8),       # ragged: Cout not a multiple of 32
+    (9, 32, 40, 8, 8),       # 8x8 planes, four images stacked per tile (conv3x3_split_kernel<8, 1, *, 4>), ragged last tile, ragged Cout
+    (8, 48, 128, 8, 8),      # ... and the 64-channel workgroups (<8, 2, *, 4>): the D network's deep tower (models.lua:304-317)
     (2, 20, 64, 4, 4),       # tiny spatial (tile mostly masked)
     (1, 8, 32, 64, 64),      # W = 64 (two column tiles)
     (2, 12, 32, 24, 20),     # non power-of-two H, W
@@ -47,12 +49,17 @@ def test_conv3_kernels_vs_oracle(ctx, oracle, conv_mode, B, Cin, Cout, H, W):
     dx, dw, db, dgy = _dev(ctx, x), _dev(ctx, w), _dev(ctx, b), _dev(ctx, gy)
     dout = ctx.malloc(4 * B * Cout * H * W)
     lib = ctx.lib
-    ctx.check(lib.gr_conv3_forward_dev(ctx.h, dx, dw, db, dout, B, Cin, Cout, H, W, 0), "fwd")
-    y = ctx.download(dout, (B, Cout, H, W))
-    assert_close(y, oracle.conv3_forward(x, w, b), TOL, "conv forward")
-    # backward-data
-    dgin = ctx.malloc(4 * B * Cin * H * W)
-    ctx.check(lib.gr_conv3_backward_data_dev(ctx.h, dgy, dw, dgin, B, Cin, Cout, H, W), "bwd-data")
+    if H == 8 and W == 8 and B >= 4:
+        ctx.set_tuning("stack8_min_wgs", 1)          # four 8x8 images per tile on these small grids too (the library stacks from 128 workgroups on)
+    try:
+        ctx.check(lib.gr_conv3_forward_dev(ctx.h, dx, dw, db, dout, B, Cin, Cout, H, W, 0), "fwd")
+        y = ctx.download(dout, (B, Cout, H, W))
+        assert_close(y, oracle.conv3_forward(x, w, b), TOL, "conv forward")
+        # backward-data
+        dgin = ctx.malloc(4 * B * Cin * H * W)
+        ctx.check(lib.gr_conv3_backward_data_dev(ctx.h, dgy, dw, dgin, B, Cin, Cout, H, W), "bwd-data")
+    finally:
+        ctx.set_tuning("stack8_min_wgs", 128)
     gin = ctx.download(dgin, (B, Cin, H, W))
     assert_close(gin, oracle.conv3_backward_data(gy, w), TOL * 3, "conv backward-data")
     # backward-weight (accumulating)
