@@ -622,12 +622,16 @@ __device__ __forceinline__ f32x16 split_mma(const uint4* av, const uint4* bv, f3
 // NI (round 4) = whole images stacked in one tile (planes exactly TW wide and TR / NI high: the D network's 8x8 planes, NI = 4): a 256-pixel
 // tile of ONE 8x8 image was three quarters padding (conv3x3_split_kernel<8, 1, 2> ran the deep tower of create_D2 at 83 TFLOP/s).  Each image
 // keeps its own zero halo rows in the patch, as in the wide kernels.
-template <int TW, int MT, int NTERM, int NI = 1>
-__global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, const uint4* __restrict__ wsplit) {
+// KS (round 4) = taps per side: 3, or 5 for the D network's nn.SpatialConvolution(128, 64, 5, 5, 1, 1, 2, 2) (models.lua:297) - the same
+// kernel with a 2-pixel halo and 25 taps (conv5x5_split_kernel below; f16x3 only), in place of the fp32 VALU kernel of convk.hip
+// (74 TFLOP/s at batch 256: 15 % of the GAN batch).
+template <int TW, int MT, int NTERM, int NI, int KS>
+__device__ __forceinline__ void conv_split_body(const ConvArgs& a, const uint4* __restrict__ wsplit) {
   constexpr int NT = 256 * MT;                                    // MT = 2: 8 waves = 2 channel blocks x 4 pixel quarters
-  constexpr int NG = 2, PT = 256, TR = PT / TW, IH = TR / NI, PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
+  constexpr int HALO = KS / 2, KK = KS * KS;
+  constexpr int NG = 2, PT = 256, TR = PT / TW, IH = TR / NI, PR = NI * (IH + 2 * HALO), PC = TW + 2 * HALO, PS = PR * PC, CT = 32 * MT;
   constexpr int NEH = 2 * PS, NSL = (NEH + NT - 1) / NT;         // (pixel, half) pairs staged per thread
-  constexpr int WROWS = NTERM * 9 * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
+  constexpr int WROWS = NTERM * KK * 2, WV = WROWS * CT, NWV = (WV + NT - 1) / NT;   // 16-byte weight vectors per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint4* patch = reinterpret_cast<uint4*>(smem_raw);              // [NTERM][2][PS]   (one uint4 = 8 bf16 / f16)
   uint4* wts = patch + NTERM * 2 * PS;                            // [NTERM][9][2][CT]
@@ -647,8 +651,8 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
     const int eh = tid + NT * s, hh = eh >= PS ? 1 : 0, e = eh - hh * PS, r0_ = e / PC, c = e - r0_ * PC;
-    const int img = NI > 1 ? r0_ / (IH + 2) : 0, r = NI > 1 ? r0_ - img * (IH + 2) : r0_;
-    const int yy = y0 + r - 1, xx = x0 + c - 1;
+    const int img = NI > 1 ? r0_ / (IH + 2 * HALO) : 0, r = NI > 1 ? r0_ - img * (IH + 2 * HALO) : r0_;
+    const int yy = y0 + r - HALO, xx = x0 + c - HALO;
     inb[s] = eh < NEH && yy >= 0 && yy < H && xx >= 0 && xx < W && b + img < a.B;
     src_off[s] = (a.up ? (yy >> 1) * Ws + (xx >> 1) : yy * Ws + xx) + img * a.Cin * (int)HWs;
     sh[s] = hh;
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
 #pragma unroll
   for (int ng = 0; ng < NG; ++ng) {
     const int p = (wave * NG + ng) * 32 + l31, pr = p / TW, pc = p - pr * TW;
-    pix[ng] = h * PS + (NI > 1 ? pr + 2 * (pr / IH) : pr) * PC + pc;
+    pix[ng] = h * PS + (NI > 1 ? pr + 2 * HALO * (pr / IH) : pr) * PC + pc;
   }
   const int nchunks = (a.Cin + BF_CK - 1) / BF_CK;
   GR_BF_LOAD(0)
@@ -708,15 +712,16 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
     uint4 avA[NTERM], bvA[NG][NTERM], avB[NTERM], bvB[NG][NTERM];
 #define GR_BF_OPS(tap_, av_, bv_)                                                                        \
     {                                                                                                     \
-      const int toff_ = ((tap_) / 3) * PC + ((tap_) % 3);                                                 \
+      const int toff_ = ((tap_) / KS) * PC + ((tap_) % KS);                                               \
       _Pragma("unroll") for (int s = 0; s < NTERM; ++s) {                                                 \
-        av_[s] = wts[((s * 9 + (tap_)) * 2 + h) * CT + wmt * 32 + l31];                                   \
+        av_[s] = wts[((s * KK + (tap_)) * 2 + h) * CT + wmt * 32 + l31];                                  \
         _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) bv_[ng][s] = patch[s * 2 * PS + pix[ng] + toff_]; \
       }                                                                                                   \
     }
 #define GR_BF_MMA(av_, bv_)                                                                               \
     _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) acc[ng] = split_mma<NTERM>(av_, bv_[ng], acc[ng]);
 #define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, 3 * NTERM, 0); __builtin_amdgcn_sched_group_barrier(0x008, NTERM == 3 ? 12 : 6, 0);
+    if (KS == 3) {
     GR_BF_OPS(0, avA, bvA)
     GR_BF_OPS(1, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
     GR_BF_OPS(2, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
@@ -727,6 +732,16 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
     GR_BF_OPS(7, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
     GR_BF_OPS(8, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
     GR_BF_MMA(avA, bvA)
+    } else {
+      // the same two-register-set pipeline, tap pairs walked by an unrolled loop (KK is odd: the last tap is in set A)
+      GR_BF_OPS(0, avA, bvA)
+#pragma unroll
+      for (int t2 = 0; t2 < KK / 2; ++t2) {
+        GR_BF_OPS(2 * t2 + 1, avB, bvB) GR_BF_MMA(avA, bvA) GR_BF_PIN()
+        GR_BF_OPS(2 * t2 + 2, avA, bvA) GR_BF_MMA(avB, bvB) GR_BF_PIN()
+      }
+      GR_BF_MMA(avA, bvA)
+    }
 #undef GR_BF_OPS
 #undef GR_BF_MMA
 #undef GR_BF_PIN
@@ -756,6 +771,10 @@ __global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, 
   }
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
+template <int TW, int MT, int NTERM, int NI = 1>
+__global__ __launch_bounds__(256 * MT, 2) void conv3x3_split_kernel(ConvArgs a, const uint4* __restrict__ wsplit) { conv_split_body<TW, MT, NTERM, NI, 3>(a, wsplit); }
+template <int TW, int MT, int NTERM>
+__global__ __launch_bounds__(256 * MT, 2) void conv5x5_split_kernel(ConvArgs a, const uint4* __restrict__ wsplit) { conv_split_body<TW, MT, NTERM, 1, 5>(a, wsplit); }
 
 // Which pixel of the 512-pixel tile lane l of 32-lane group g = p / 32 owns (p = 32 g + l).  ds_read_b128 serves a wave in four
 // fixed 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...): it is conflict-free when lane l reads 16-byte slot
@@ -2155,35 +2174,35 @@ __device__ __forceinline__ void weight_split_store(unsigned short* dst, long bas
 }
 __global__ void conv_weight_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst,
                                          int cin, int cout, int CI, int CO, int cin_pad, int cout_pad, int bwd,
-                                         int nterm, const unsigned* __restrict__ amax) {
-  const long n = (long)(cin_pad / BF_CK) * 9 * 2 * cout_pad * 8;     // one thread per (chunk, tap, half, o, j): writes all terms
+                                         int nterm, const unsigned* __restrict__ amax, int kk) {      // kk = taps: 9 (3x3) or 25 (5x5)
+  const long n = (long)(cin_pad / BF_CK) * kk * 2 * cout_pad * 8;     // one thread per (chunk, tap, half, o, j): writes all terms
   const float sc = nterm == 2 ? pow2f(f16_scale_exp(absmax_read(amax))) : 1.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int j = (int)(i & 7); long r = i >> 3;
     const int oo = (int)(r % cout_pad); r /= cout_pad;
     const int hh = (int)(r & 1); r >>= 1;
-    const int tap = (int)(r % 9); const int ch = (int)(r / 9);
+    const int tap = (int)(r % kk); const int ch = (int)(r / kk);
     const int ci = ch * BF_CK + 8 * hh + j;
     float v = 0.f;
-    if (ci < CI && oo < CO) v = bwd ? w[((long)ci * cin + oo) * 9 + (8 - tap)] : w[((long)oo * cin + ci) * 9 + tap];
-    const long term = (long)9 * 2 * cout_pad * 8;
+    if (ci < CI && oo < CO) v = bwd ? w[((long)ci * cin + oo) * kk + (kk - 1 - tap)] : w[((long)oo * cin + ci) * kk + tap];
+    const long term = (long)kk * 2 * cout_pad * 8;
     weight_split_store(dst, (long)ch * nterm * term, (((long)tap * 2 + hh) * cout_pad + oo) * 8 + j, term, v, nterm, sc);
   }
 }
 
-size_t conv_weight_split_bytes(int cin, int cout, bool bwd) {
+size_t conv_weight_split_bytes(int cin, int cout, bool bwd, int ksz) {
   const int CI = bwd ? cout : cin, CO = bwd ? cin : cout;
-  return (size_t)round_up(CI, BF_CK) * 9 * round_up(CO, 32) * 3 * sizeof(unsigned short);   // sized for 3 terms; f16x3 uses 2/3 of it
+  return (size_t)round_up(CI, BF_CK) * ksz * ksz * round_up(CO, 32) * 3 * sizeof(unsigned short);   // sized for 3 terms; f16x3 uses 2/3 of it
 }
-void launch_conv_weight_split(const float* w_native, void* dst, int cin, int cout, bool bwd, hipStream_t s, int nterm, unsigned* amax) {
-  const int CI = bwd ? cout : cin, CO = bwd ? cin : cout;
+void launch_conv_weight_split(const float* w_native, void* dst, int cin, int cout, bool bwd, hipStream_t s, int nterm, unsigned* amax, int ksz, bool take_absmax) {
+  const int CI = bwd ? cout : cin, CO = bwd ? cin : cout, kk = ksz * ksz;
   const int cin_pad = round_up(CI, BF_CK), cout_pad = round_up(CO, 32);
-  const long n = (long)(cin_pad / BF_CK) * 9 * 2 * cout_pad * 8;
+  const long n = (long)(cin_pad / BF_CK) * kk * 2 * cout_pad * 8;
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-  if (nterm == 2) launch_absmax(w_native, (long)cin * cout * 9, amax, s);
-  KtScope kt("conv_weight_split_kernel", 0.0, 4.0 * 9.0 * cin * cout + 2.0 * nterm * (double)n, s);
+  if (nterm == 2 && take_absmax) launch_absmax(w_native, (long)cin * cout * kk, amax, s);
+  KtScope kt("conv_weight_split_kernel", 0.0, 4.0 * kk * cin * cout + 2.0 * nterm * (double)n, s);
   hipLaunchKernelGGL(conv_weight_split_kernel, dim3(grid), dim3(256), 0, s, w_native, reinterpret_cast<unsigned short*>(dst),
-                     cin, cout, CI, CO, cin_pad, cout_pad, bwd ? 1 : 0, nterm, amax);
+                     cin, cout, CI, CO, cin_pad, cout_pad, bwd ? 1 : 0, nterm, amax, kk);
 }
 
 template <int TW, int MT, int NTERM, int NI = 1>
@@ -2261,6 +2280,31 @@ static int launch_conv3x3_split_n(ConvArgs a, const void* wsplit, hipStream_t s)
 }
 
 // nterm 3: bf16x6 (amax_* unused); nterm 2: f16x3, amax_in / amax_w = device slots holding the bit patterns of max|in|, max|w|
+// 5x5 stride 1 pad 2 on the f16x3 split kernel: 256-pixel tiles (16 rows x 16 columns, or 8 rows x 32), 32 output channels per workgroup (the
+// weight image of a 16-channel chunk is 25 taps x 2 terms x 2 halves x 32 x 16 B = 51 KB: two workgroups per CU)
+bool conv5x5_split_supported(int Cin, int Cout, int H, int W) { return Cin >= 16 && Cin % 8 == 0 && W >= 8 && H >= 4; }
+void launch_conv5x5_split(const float* in, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                          hipStream_t s, const unsigned* amax_in, const unsigned* amax_w) {
+  ConvArgs a{};
+  a.in = in; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = 0;
+  a.amax_in = amax_in; a.amax_w = amax_w;
+  a.cout_pad = round_up(Cout, 32); a.n_otiles = a.cout_pad / 32;
+  const double px = (double)B * H * W;
+  auto go = [&](auto tw) {
+    constexpr int TW = decltype(tw)::value, TR = 256 / TW, PS = (TR + 4) * (TW + 4);
+    a.tiles_x = (W + TW - 1) / TW; a.tiles_y = (H + TR - 1) / TR;
+    const size_t lds = 16 * (size_t)(2 * 2 * PS + 2 * 25 * 2 * 32);
+    const int grid = B * a.tiles_x * a.tiles_y * a.n_otiles;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5x5_split_kernel<TW, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    static const std::string name = "conv5x5_split_kernel<" + std::to_string(TW) + ", 1, 2>";
+    KtScope kt(name.c_str(), 2.0 * px * Cout * Cin * 25.0, 4.0 * (px * Cin + px * Cout + 25.0 * Cin * Cout), s);
+    hipLaunchKernelGGL((conv5x5_split_kernel<TW, 1, 2>), dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit));
+  };
+  if (W <= 8) go(std::integral_constant<int, 8>{});
+  else if (W <= 16) go(std::integral_constant<int, 16>{});
+  else go(std::integral_constant<int, 32>{});
+}
 void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias, float* out,
                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep,
                           int nterm, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out,

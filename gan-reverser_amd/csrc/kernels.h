@@ -143,12 +143,16 @@ void launch_conv3x3_fewin(const float* in, const float* w_native, const float* b
 
 // fp32-accurate convolution on the bf16 MFMA: operands split into 3 bf16 terms, 6 products, fp32 accumulation ("bf16x6").
 // wsplit = image made by launch_conv_weight_split (forward or backward-data flavour, like launch_conv_weight_prep).
-size_t conv_weight_split_bytes(int cin, int cout, bool for_backward_data);
+size_t conv_weight_split_bytes(int cin, int cout, bool bwd, int ksz = 3);
 // nterm 3 = bf16x6; nterm 2 = "f16x3": two fp16 terms of the power-of-two-scaled operands, 3 products.  The scales come from
 // device slots holding the bit pattern of max|tensor| (amax_*), filled by launch_absmax or by the producing kernel.
 void launch_absmax(const float* x, long n, unsigned* slot, hipStream_t s, bool slot_is_zero = false);   // slot_is_zero: the caller has just filled the slot with 0       // zeroes the slot, then max|x| -> slot
-void launch_conv_weight_split(const float* w_native, void* wsplit, int cin, int cout, bool for_backward_data, hipStream_t s,
-                              int nterm = 3, unsigned* amax_w = nullptr);        // nterm 2: also computes amax_w
+void launch_conv_weight_split(const float* w_native, void* dst, int cin, int cout, bool bwd, hipStream_t s, int nterm = 3, unsigned* amax = nullptr,
+                              int ksz = 3, bool take_absmax = true);   // ksz 5: the 25-tap image of conv5x5_split_kernel; take_absmax false: amax already holds max|w|
+// nn.SpatialConvolution(Cin, Cout, 5, 5, 1, 1, 2, 2) (models.lua:297) on the f16x3 split kernel: forward, and the data gradient with the bwd image (Cout -> Cin)
+bool conv5x5_split_supported(int Cin, int Cout, int H, int W);
+void launch_conv5x5_split(const float* in, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
+                          hipStream_t s, const unsigned* amax_in, const unsigned* amax_w);        // nterm 2: also computes amax_w
 void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias, float* out,
                           int B, int Cin, int Cout, int H, int W, bool up, hipStream_t s, const ConvEpilogue* ep = nullptr,
                           int nterm = 3, const unsigned* amax_in = nullptr, const unsigned* amax_w = nullptr,

@@ -585,6 +585,8 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
       if (s.fullconv && (hipMalloc(&s.ws_fwd, conv_weight_split_bytes(s.Cout, s.Cin, true)) || hipMalloc(&s.ws_bwd, conv_weight_split_bytes(s.Cout, s.Cin, false)))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
       if (!s.fullconv && s.up && conv_up2_supported(s.Cin, s.Cout, s.H, s.W) && hipMalloc(&s.ws_up, conv_weight_up2_bytes(s.Cin, s.Cout))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
     }
+    if (s.kind == ST_CONV && s.ksz == 5 && !s.up && conv5x5_split_supported(s.Cin, s.Cout, s.H, s.W) &&
+        (hipMalloc(&s.ws_fwd, conv_weight_split_bytes(s.Cin, s.Cout, false, 5)) || hipMalloc(&s.ws_bwd, conv_weight_split_bytes(s.Cin, s.Cout, true, 5)))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
     const size_t ye = (size_t)vol3(s.Cout, s.H, s.W), ie = (size_t)vol3(s.inC, s.inH, s.inW);
     if (ye > n->max_y) n->max_y = ye;
     if (ie > n->max_in) n->max_in = ie;
@@ -770,7 +772,12 @@ static bool use_f16_gemm(gr_net* n, const Stage& s) {
   static const bool on = !getenv("GR_NO_F16_GEMM");
   return on && n->ctx->conv_mode == 2 && s.kind == ST_LINEAR && (int64_t)s.Cin * s.Cout >= (1 << 20);
 }
-static bool use_bf16x6(gr_net* n, const Stage& s) { return n->ctx->conv_mode >= 1 && s.kind == ST_CONV && s.ksz == 3 && !fewout_applies(s); }   // either split flavour
+// the 5x5 layer of the D network (models.lua:297) on the f16x3 split kernel (round 4; bf16x6 / f32 modes keep convk.hip's fp32 VALU kernels)
+static bool convk_split(gr_net* n, const Stage& s) {
+  static const bool on = !getenv("GR_NO_CONV5_SPLIT");
+  return on && n->ctx->conv_mode == 2 && s.kind == ST_CONV && s.ksz == 5 && !s.up && !s.fullconv && s.ws_fwd && conv5x5_split_supported(s.Cin, s.Cout, s.H, s.W);
+}
+static bool use_bf16x6(gr_net* n, const Stage& s) { return (n->ctx->conv_mode >= 1 && s.kind == ST_CONV && s.ksz == 3 && !fewout_applies(s)) || convk_split(n, s); }   // either split flavour
 // Re-lay every convolution's weights (one launch) when the parameters changed since the last time.  bf16x6 mode needs the
 // split images; the fp32 k-major images are still needed there by SpatialFullConvolution stages (no split kernel).
 static int prep_weights(gr_net* n) {
@@ -789,6 +796,14 @@ static int prep_weights(gr_net* n) {
     n->prepped_version[m] = n->params_version;
     if (m >= 1) n->prepped_version[3 - m] = 0;
   }
+  if (mode == 2)            // 5x5 stages: their own 25-tap images (one max pass, two re-layouts)
+    for (auto& s : n->st)
+      if (convk_split(n, s) && s.ws_version != n->params_version) {
+        launch_conv_weight_split(n->params + s.w_off, s.ws_fwd, s.Cin, s.Cout, false, c->stream, 2, s.amax_w, 5, true);
+        launch_conv_weight_split(n->params + s.w_off, s.ws_bwd, s.Cin, s.Cout, true, c->stream, 2, s.amax_w, 5, false);
+        LAUNCHCHK(c);
+        s.ws_version = n->params_version;
+      }
   if (mode == 2)            // up-sampling stages: the pre-summed four-phase image (its max|w| slot was just refreshed by the batch)
     for (auto& s : n->st)
       if (s.ws_up && s.ws_up_version != n->params_version) {
@@ -886,9 +901,10 @@ static int guard_scan_params(gr_net* n) {
     } else if (s.fullconv) {               // W[in][out][3][3]
       r = guard_scan(c, w, 1, s.Cin, (long)s.Cout * 9, 0, (long)s.Cout * 9, 1); if (r) return r;
       r = guard_scan(c, w, s.Cin, s.Cout, 9, (long)s.Cout * 9, 9, 1); if (r) return r;
-    } else {                               // W[out][in][3][3]
-      r = guard_scan(c, w, s.Cout, s.Cin, 9, (long)s.Cin * 9, 9, 1); if (r) return r;
-      r = guard_scan(c, w, 1, s.Cout, (long)s.Cin * 9, 0, (long)s.Cin * 9, 1); if (r) return r;
+    } else {                               // W[out][in][K][K]
+      const long kk = (long)s.ksz * s.ksz;
+      r = guard_scan(c, w, s.Cout, s.Cin, kk, (long)s.Cin * kk, kk, 1); if (r) return r;
+      r = guard_scan(c, w, 1, s.Cout, (long)s.Cin * kk, 0, (long)s.Cin * kk, 1); if (r) return r;
     }
   }
   for (size_t si = 0; si < n->st.size(); ++si) {
@@ -998,8 +1014,13 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
     s.fused_epilogue = false; s.out_skipped = false;
     if (s.kind == ST_CONV && s.ksz != 3) {
       // K x K convolution (the D network's 5x5 layer): fp32 direct kernel, raw output always written, statistics by the pipeline
+      if (convk_split(n, s)) {
+        if (s.amax_x_fwd != n->amax_gen) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream, true); s.amax_x_fwd = n->amax_gen; }
+        launch_conv5x5_split(x, s.ws_fwd, n->params + s.b_off, s.y, B, s.Cin, s.Cout, s.H, s.W, c->stream, s.amax_x, s.amax_w);
+      } else {
       r = ensure_ws(c, convk_workspace_bytes(B, s.Cin, s.Cout, s.ksz)); if (r) return r;
       launch_convk_forward(x, n->params + s.w_off, n->params + s.b_off, s.y, c->ws, B, s.Cin, s.Cout, s.H, s.W, s.ksz, c->stream);
+      }
       s.stat_tiles_last = 0;
     } else if (s.kind == ST_CONV) {
       // evaluate() mode: BatchNorm is a per-channel affine map of running statistics, so BN + activation ride in the conv
@@ -1356,7 +1377,11 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     if (s.kind == ST_CONV && s.ksz != 3) {
       int r = ensure_ws(c, convk_workspace_bytes(B, s.Cin, s.Cout, s.ksz)); if (r) return r;
       launch_convk_backward_weight(x, dyb, n->grads + s.w_off, c->ws, B, s.Cin, s.Cout, s.H, s.W, s.ksz, c->stream);
-      if (need_gin) launch_convk_backward_data(dyb, n->params + s.w_off, gin, c->ws, B, s.Cin, s.Cout, s.H, s.W, s.ksz, c->stream);
+      if (need_gin) {
+        // the data gradient = the same convolution on the transposed + flipped weights (Cout -> Cin); max|dy| was folded into amax_dy by the pipeline backward
+        if (convk_split(n, s) && conv5x5_split_supported(s.Cout, s.Cin, s.H, s.W)) launch_conv5x5_split(dyb, s.ws_bwd, nullptr, gin, B, s.Cout, s.Cin, s.H, s.W, c->stream, s.amax_dy, s.amax_w);
+        else launch_convk_backward_data(dyb, n->params + s.w_off, gin, c->ws, B, s.Cin, s.Cout, s.H, s.W, s.ksz, c->stream);
+      }
       LAUNCHCHK(c);
     } else if (s.kind == ST_CONV) {
       if (s.up) {
