@@ -42,6 +42,9 @@ struct ConvArgs {
   // (training-mode BatchNorm statistics without a second pass over y; summed in a fixed order by bn_stats_finalize_tiles)
   double* stat_part = nullptr; int stat_tiles = 0;
   int nt_out = 0;        // non-temporal output stores (kernels.h store4; launchers set it from g_nt_stores)
+  // evaluate() mode, f16x3 (kernels.h P16Out): the epilogue's result as the consuming convolution's operand-ready image, scaled by the
+  // bound in p16_scale; `out` may then be null (no fp32 copy)
+  uint4* p16_out = nullptr; const unsigned* p16_scale = nullptr;
 };
 
 // out = act(((conv + bias - mean) * invstd) * gamma + beta): the per-channel pipeline of an evaluate()-mode stage
@@ -50,9 +53,9 @@ struct ConvArgs {
 template <int N>
 __device__ __forceinline__ void conv_act_block(const ConvEpilogue& ep, float (&v)[N]) {
   switch (ep.act) {
-    case ACT_ELU:
+    case ACT_ELU:        // the hardware exponential, as the pipeline kernels take it (elem.hip act_fwd: |error| < 3e-7 for z <= 0)
 #pragma unroll
-      for (int i = 0; i < N; ++i) v[i] = v[i] <= 0.f ? (expf(v[i]) - 1.f) : v[i];
+      for (int i = 0; i < N; ++i) v[i] = v[i] <= 0.f ? (__expf(v[i]) - 1.f) : v[i];
       break;
     case ACT_RELU:
 #pragma unroll
@@ -76,7 +79,7 @@ __device__ __forceinline__ void conv_act_block(const ConvEpilogue& ep, float (&v
 __device__ __forceinline__ float conv_epilogue(const ConvEpilogue& ep, float v, int o) {
   if (ep.mean) v = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v, ep.mean[o]), ep.invstd[o]), ep.gamma[o]), ep.beta[o]);
   switch (ep.act) {
-    case ACT_ELU: return v <= 0.f ? (expf(v) - 1.f) : v;
+    case ACT_ELU: return v <= 0.f ? (__expf(v) - 1.f) : v;
     case ACT_RELU: return v > 0.f ? v : 0.f;
     case ACT_LEAKYRELU: return v > 0.f ? v : __fmul_rn(v, ep.slope);
     case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
@@ -380,8 +383,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
 // output planes.  VALU kernel: a workgroup owns a 32x32 output tile of one image, a thread 4 consecutive pixels of a row;
 // its 3 x 6 x Cin input window lives in registers, weights arrive through the scalar cache (uniform per workgroup), every
 // output channel costs 36*Cin FMAs and one float4 store.  Accumulation order: (ci, ky, kx) ascending, fp32 FMA.
-template <int CI>
-__global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const float* __restrict__ w_native) {
+template <int CI, bool PO>
+__device__ __forceinline__ void conv_fewin_body(const ConvArgs& a, const float* __restrict__ w_native) {
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
@@ -409,6 +412,51 @@ __global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const fl
   // blockIdx.y: slice of the output channels (small grids only: B * tiles workgroups of four waves leave the CUs at one wave
   // per SIMD, nothing to hide the scalar weight loads behind - cfg2: 256 workgroups, 50 us for a 20 us store stream)
   const int o_per = (a.Cout + (int)gridDim.y - 1) / (int)gridDim.y, o_beg = blockIdx.y * o_per, o_end = min(a.Cout, o_beg + o_per);
+  if constexpr (PO) {
+    // operand-ready output (evaluate() mode): eight channels at a time, a pixel's 8 results split into the two fp16 term vectors -
+    // 4 consecutive pixels per thread = 64 contiguous bytes per term, the 8 threads of a row 512 (o_per is a multiple of 8: launcher)
+    const float sc = pow2f(f16_scale_exp(absmax_read(a.p16_scale)));
+    const int G = a.Cout >> 3;
+    for (int o8 = o_beg; o8 < o_end; o8 += 8) {
+      float r8[8][4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int o = o8 + j;
+        const float* wp = w_native + (size_t)o * CI * 9;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const float wv = wp[(ci * 3 + ky) * 3 + kx];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[q] = fmaf(wv, v[ci][ky][q + kx], acc[q]);
+            }
+        const float bv = a.bias ? a.bias[o] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r8[j][q] = conv_epilogue(a.ep, acc[q] + bv, o);
+        if (pin) {
+          const float4 r = make_float4(r8[j][0], r8[j][1], r8[j][2], r8[j][3]);
+          if (a.out) *reinterpret_cast<float4*>(a.out + (((size_t)b * a.Cout + o) * H + y) * W + x) = r;
+          omax = absmax4(omax, r);
+        }
+      }
+      if (pin) {
+        uint4* dst = a.p16_out + ((size_t)b * G + (o8 >> 3)) * 2 * HW + (size_t)y * W + x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float x8[8] = {r8[0][q], r8[1][q], r8[2][q], r8[3][q], r8[4][q], r8[5][q], r8[6][q], r8[7][q]};
+          uint4 t0, t1;
+          split8_f16(x8, sc, t0, t1);
+          dst[q] = t0; dst[HW + q] = t1;
+        }
+      }
+    }
+    if (a.amax_out) absmax_commit(omax, a.amax_out);
+    return;
+  }
   for (int o = o_beg; o < o_end; ++o) {
     const float* wp = w_native + (size_t)o * CI * 9;          // uniform address: scalar loads
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -445,20 +493,34 @@ __global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const fl
   }
   if (a.amax_out) absmax_commit(omax, a.amax_out);
 }
+template <int CI>
+__global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const float* __restrict__ w_native) { conv_fewin_body<CI, false>(a, w_native); }
+template <int CI>
+__global__ __launch_bounds__(256) void conv3x3_fewin_p16o_kernel(ConvArgs a, const float* __restrict__ w_native) { conv_fewin_body<CI, true>(a, w_native); }
 bool conv_fewin_applies(int Cin, int W, bool up) { return Cin <= 3 && !up && W % 4 == 0 && W >= 4; }
+bool conv_fewin_p16_out_supported(int Cout, int H, int W) { return Cout % 8 == 0 && Cout <= 256 && W % 4 == 0; }
 void launch_conv3x3_fewin(const float* in, const float* w_native, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
-                          hipStream_t s, const ConvEpilogue* ep, unsigned* amax_out, double* stat_part, int* stat_tiles) {
+                          hipStream_t s, const ConvEpilogue* ep, unsigned* amax_out, double* stat_part, int* stat_tiles, const P16Out* p16o) {
   ConvArgs a{};
   if (ep) a.ep = *ep;
+  if (p16o && p16o->p16) { a.p16_out = reinterpret_cast<uint4*>(p16o->p16); a.p16_scale = p16o->scale; }
   a.in = in; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.amax_out = amax_out;
   a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 31) / 32;
   const int grid = B * a.tiles_x * a.tiles_y;
   if (stat_tiles) { const bool ok = stat_part && Cout <= 256; a.stat_part = ok ? stat_part : nullptr; a.stat_tiles = grid; *stat_tiles = ok ? grid : 0; }
   const double px = (double)B * H * W;
-  const std::string name = "conv3x3_fewin_kernel<" + std::to_string(Cin) + ">";
+  const std::string name = std::string(a.p16_out ? "conv3x3_fewin_p16o_kernel<" : "conv3x3_fewin_kernel<") + std::to_string(Cin) + ">";
   KtScope kt(name.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
   int og = 1;                                                  // output-channel slices: aim at >= 1024 workgroups, >= 8 channels each
-  while (grid * og < 1024 && Cout / (2 * og) >= 8) og *= 2;
+  while (grid * og < 1024 && Cout / (2 * og) >= 8 && (!a.p16_out || Cout % (16 * og) == 0)) og *= 2;      // operand-ready output: whole 8-channel groups per slice
+  if (a.p16_out) {
+    switch (Cin) {
+      case 1: hipLaunchKernelGGL(conv3x3_fewin_p16o_kernel<1>, dim3(grid, og), dim3(256), 0, s, a, w_native); break;
+      case 2: hipLaunchKernelGGL(conv3x3_fewin_p16o_kernel<2>, dim3(grid, og), dim3(256), 0, s, a, w_native); break;
+      default: hipLaunchKernelGGL(conv3x3_fewin_p16o_kernel<3>, dim3(grid, og), dim3(256), 0, s, a, w_native); break;
+    }
+    return;
+  }
   switch (Cin) {
     case 1: hipLaunchKernelGGL(conv3x3_fewin_kernel<1>, dim3(grid, og), dim3(256), 0, s, a, w_native); break;
     case 2: hipLaunchKernelGGL(conv3x3_fewin_kernel<2>, dim3(grid, og), dim3(256), 0, s, a, w_native); break;
@@ -1370,8 +1432,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
 // waits and epilogue; single-image tiles double the grid).
 // MT = 32-channel output blocks per workgroup: 2, or 1 (with NG = 2: 256 pixels x 32 channels, a 40 KB image and ~110 registers -
 // four workgroups per CU where the batch-256 16x16 layers would otherwise run two).
-template <int TW, int NI, int NG = 4, int MT = 2>
-__global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
+// PO: the result leaves as the NEXT convolution's operand-ready image (evaluate() mode; ConvArgs::p16_out) - its own kernel symbol
+// (conv3x3_p16_quad_po_kernel) so that the training-path instantiations stay exactly what they were
+template <int TW, int NI, int NG, int MT, bool PO>
+__device__ __forceinline__ void conv_p16_quad_body(const ConvArgs& a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
   constexpr int NTERM = 2, NW = 4;
   constexpr int PT = 128 * NG, TR = PT / TW, IH = PT / (NI * TW), PR = NI * (IH + 2), PC = TW + 2, PS = PR * PC, CT = 32 * MT;
   constexpr int PV = NTERM * 2 * PS, PVP = (PV + P16_PAD - 1) / P16_PAD * P16_PAD;
@@ -1569,6 +1633,8 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_kernel(
     // (training-mode stages store the raw output: the per-element epilogue switch is taken once per workgroup, not 128 times)
     const bool plain = a.ep.mean == nullptr && a.ep.act == ACT_NONE;
     const bool want_max = a.amax_out != nullptr;
+    float sc16 = 1.f;
+    if constexpr (PO) sc16 = pow2f(f16_scale_exp(absmax_read(a.p16_scale)));
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (plain) {
@@ -1588,6 +1654,34 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_kernel(
           for (int ng = 0; ng < NG; ++ng) stg[chl * RS + ng * 32 + l31] = v4[ng];
         }
       }
+      if constexpr (PO) {
+        // Operand-ready output: item = (8-channel group g of this 32-channel block, pixel pxl of the wave's 32 * NG): the 8 channel rows of
+        // the staging image at one pixel column (consecutive lanes = consecutive pixels: conflict-free reads), split into the two fp16 term
+        // vectors, two 16-byte stores; a wave-instruction covers 64 consecutive pixels of one (group, term) plane on a 32-wide plane.
+        constexpr int NPX = 32 * NG, ITEMS = 4 * NPX / 64;
+        const int Gout = a.Cout >> 3;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+          const int it = i * 64 + lane, g = it / NPX, pxl = it - g * NPX;
+          float x8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x8[j] = stg[(8 * g + j) * RS + pxl];
+          int prr, pc; tile_pixel<TW>(wave * NPX + pxl, prr, pc);
+          const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
+          const int y = y0 + pr, x = x0 + pc, o8 = o0 + mt * 32 + 8 * g;
+          if (y < H && x < W && b + img < a.B && o8 < a.Cout) {
+            uint4 t0, t1;
+            split8_f16(x8, sc16, t0, t1);
+            uint4* dst = a.p16_out + ((size_t)(b + img) * Gout + (o8 >> 3)) * 2 * HW + (size_t)y * W + x;
+            store4(dst, t0, false); store4(dst + HW, t1, false);
+            if (want_max && !a.out) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) omax = fmaxf(omax, fabsf(x8[j]));
+            }
+          }
+        }
+      }
+      if (!PO || a.out) {
 #pragma unroll
       for (int i = 0; i < 32 / CPI; ++i) {
         const int chl = CPI * i + hq, o = o0 + mt * 32 + chl;
@@ -1597,11 +1691,20 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_kernel(
           if (want_max) omax = absmax4(omax, v);
         }
       }
+      }
     }
   }
   if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GR_STAMP() if (tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[nstamp++] = t_; stamps[31] = nstamp; } }
 #undef GR_STAMP
   if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+template <int TW, int NI, int NG = 4, int MT = 2>
+__global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
+  conv_p16_quad_body<TW, NI, NG, MT, false>(a, wsplit, xin);
+}
+template <int TW, int NI, int NG = 4, int MT = 2>
+__global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_po_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
+  conv_p16_quad_body<TW, NI, NG, MT, true>(a, wsplit, xin);
 }
 
 // Epilogue stores of the up-sampling kernels.  A lane ends with the 2x2 outputs of its source pixel (x, y): two float2 per channel,
@@ -2357,6 +2460,14 @@ static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin,
   }
   static const std::string name = "conv3x3_p16_quad_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ", " + std::to_string(NG) + ", " + std::to_string(MT) + ">";   // as rocprofv3 prints it (default template arguments included)
   const double px = (double)a.B * a.H * a.W;
+  if (a.p16_out) {      // evaluate() mode: the result leaves operand-ready (same kernel body, its own symbol)
+    static bool attr_po = false;
+    if (!attr_po) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_quad_po_kernel<TW, NI, NG, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_po = true; }
+    static const std::string name_po = "conv3x3_p16_quad_po_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ", " + std::to_string(NG) + ", " + std::to_string(MT) + ">";
+    KtScope kt(name_po.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+    hipLaunchKernelGGL((conv3x3_p16_quad_po_kernel<TW, NI, NG, MT>), dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
+    return a.stat_tiles;
+  }
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_p16_quad_kernel<TW, NI, NG, MT>), dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
   return a.stat_tiles;
@@ -2380,11 +2491,13 @@ static int launch_conv_p16_t(ConvArgs a, const void* wsplit, const void* xin, hi
   hipLaunchKernelGGL((conv3x3_p16_wide_kernel<TW, NI>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
   return a.stat_tiles;
 }
+bool conv_p16_out_supported(int Cout) { return g_p16_variant == 1 && Cout % 8 == 0; }
 void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                         hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out,
-                        double* stat_part, int* stat_tiles) {
+                        double* stat_part, int* stat_tiles, const P16Out* p16o) {
   ConvArgs a{};
   if (ep) a.ep = *ep;
+  if (p16o && p16o->p16 && g_p16_variant == 1) { a.p16_out = reinterpret_cast<uint4*>(p16o->p16); a.p16_scale = p16o->scale; }
   a.in = nullptr; a.wt = (g_p16_debug & 32) ? reinterpret_cast<const float*>(g_p16_stamps) : nullptr; a.bias = bias; a.out = out;
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = g_p16_debug; a.nchunks = g_p16_stagger; a.nt_out = g_nt_stores & 1;
   a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
@@ -2402,6 +2515,44 @@ void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias
     nt = (half32 && g_p16_variant == 1 && H % 8 == 0 && tiles512 < half32) ? launch_conv_p16_quad<32, 1, 2>(a, wsplit, x_p16, s) : launch_conv_p16_t<32, 1>(a, wsplit, x_p16, s);
   }
   if (stat_tiles) *stat_tiles = stat_part ? nt : 0;
+}
+
+// ---------------------------------------------------------------- a-priori bound of an evaluate()-mode stage's output (kernels.h)
+__global__ __launch_bounds__(64) void conv_weight_l1_kernel(const float* __restrict__ w, int fan_in, float* __restrict__ wl1) {
+  const float* row = w + (size_t)blockIdx.x * fan_in;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < fan_in; i += 64) t += (double)fabsf(row[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+  if (threadIdx.x == 0) wl1[blockIdx.x] = (float)t * 1.000001f;        // rounded up: an upper bound of the exact sum
+}
+void launch_conv_weight_l1(const float* w_native, int cout, int fan_in, float* wl1, hipStream_t s) {
+  hipLaunchKernelGGL(conv_weight_l1_kernel, dim3(cout), dim3(64), 0, s, w_native, fan_in, wl1);
+}
+__global__ __launch_bounds__(256) void eval_bound_kernel(const float* __restrict__ wl1, const float* __restrict__ bias, ConvEpilogue ep, int Cout, float post_scale,
+                                                         const unsigned* __restrict__ in_max, unsigned* __restrict__ bound_out) {
+  __shared__ float red[4];
+  const float M = __uint_as_float(absmax_read(in_max));
+  float best = 0.f;
+  for (int o = threadIdx.x; o < Cout; o += 256) {
+    float v = wl1 ? wl1[o] * M + (bias ? fabsf(bias[o]) : 0.f) : M;
+    if (ep.mean) v = (v + fabsf(ep.mean[o])) * fabsf(ep.invstd[o]) * fabsf(ep.gamma[o]) + fabsf(ep.beta[o]);
+    if (ep.act == ACT_SIGMOID || ep.act == ACT_TANH) v = fminf(v, 1.f);
+    else if (ep.act == ACT_LEAKYRELU) v *= fmaxf(1.f, fabsf(ep.slope));
+    best = fmaxf(best, v);                                   // ELU, ReLU: |act(z)| <= |z|
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float b = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * post_scale * 1.001f;   // the margin covers the rounding of the sums it bounds
+    bound_out[0] = __float_as_uint(fminf(b, 3.0e38f));       // entry 0 of a zeroed slot: consumers take the maximum over the entries
+  }
+}
+void launch_eval_bound(const float* wl1, const float* bias, const ConvEpilogue* ep, int Cout, float post_scale, const unsigned* in_max, unsigned* bound_out, hipStream_t s) {
+  ConvEpilogue e; if (ep) e = *ep;
+  hipLaunchKernelGGL(eval_bound_kernel, dim3(1), dim3(256), 0, s, wl1, bias, e, Cout, post_scale, in_max, bound_out);
 }
 
 // ---------------------------------------------------------------- weight layout preparation

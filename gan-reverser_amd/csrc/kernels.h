@@ -137,9 +137,15 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
 
 // Cin <= 3 forward (R's first layer): HBM-bound VALU kernel on the native weights, any arithmetic mode
 bool conv_fewin_applies(int Cin, int W, bool up);
+// Operand-ready OUTPUT of a convolution epilogue (evaluate() mode, f16x3; round 4).  The epilogue's result act(BN(conv)) is written
+// as the consuming convolution's P16 image instead of (out == nullptr) or beside the fp32 tensor.  The image's power-of-two scale has
+// to be fixed before the tensor exists: `scale` is the consumer's scale slot and already holds an UPPER BOUND of max|result|
+// (launch_eval_bound: a weight-norm bound, see there); the TRUE maximum still goes to amax_out, for the bound of the stage after.
+struct P16Out { void* p16 = nullptr; const unsigned* scale = nullptr; };
 void launch_conv3x3_fewin(const float* in, const float* w_native, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                           hipStream_t s, const ConvEpilogue* ep = nullptr, unsigned* amax_out = nullptr,
-                          double* stat_part = nullptr, int* stat_tiles = nullptr);
+                          double* stat_part = nullptr, int* stat_tiles = nullptr, const P16Out* p16o = nullptr);
+bool conv_fewin_p16_out_supported(int Cout, int H, int W);
 
 // fp32-accurate convolution on the bf16 MFMA: operands split into 3 bf16 terms, 6 products, fp32 accumulation ("bf16x6").
 // wsplit = image made by launch_conv_weight_split (forward or backward-data flavour, like launch_conv_weight_prep).
@@ -178,7 +184,17 @@ __host__ __device__ __forceinline__ unsigned p16_pos(unsigned p) { return p; }  
 bool conv_p16_supported(int B, int Cin, int Cout, int H, int W);
 void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                         hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out,
-                        double* stat_part, int* stat_tiles);
+                        double* stat_part, int* stat_tiles, const P16Out* p16o = nullptr);
+bool conv_p16_out_supported(int Cout);       // the P16 kernels can write their result operand-ready (whole 8-channel groups; the default four-wave kernels)
+// Upper bound of max|act(BN(conv(x) + bias))| over a whole tensor BEFORE it is computed, from max|x| and the weights alone:
+//   |conv_o| <= (sum_k |w_ok|) * max|x| + |bias_o|,  BatchNorm with running statistics is a per-channel affine map, and every activation
+// here satisfies |act(z)| <= |z| (ELU, ReLU, LeakyReLU with |slope| <= 1) or <= 1 (Sigmoid, Tanh).  wl1 = per-output-channel L1 norms
+// (launch_conv_weight_l1).  wl1 == nullptr: in_max is max|y| of the RAW main-op output (bias included) and only the pipeline is bounded.
+// The bound overshoots the true maximum by a few bits (sqrt(9 Cin) x the crest factor of x); an f16x3 image scaled by a bound 2^m too large
+// keeps 22 bits for elements down to 2^(m-17) of the true maximum and an absolute error of 2^(m-40) of it below - the true maximum of the
+// tensor is tracked beside the bound (P16Out) so the overshoot does not compound from layer to layer.
+void launch_conv_weight_l1(const float* w_native, int cout, int fan_in, float* wl1, hipStream_t s);
+void launch_eval_bound(const float* wl1, const float* bias, const ConvEpilogue* ep, int Cout, float post_scale, const unsigned* in_max, unsigned* bound_out, hipStream_t s);
 inline size_t conv_stat_tiles_max(int B, int H, int W) { return (size_t)B * ((H + 7) / 8) * ((W + 31) / 32) + 1; }     // smallest tile: 8 rows x 32 (or one 16x16 image)
 // mean / invstd (+ running statistics) from the per-tile (sum, sum of squares) the conv epilogue wrote
 // bounds (nullable): from max|y| (slot amax_y) and the fresh statistics, an upper bound of max|pipeline output| is folded into

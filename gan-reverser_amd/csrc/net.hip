@@ -62,6 +62,7 @@ struct gr_ctx {
 
 // ---- per-kernel event timer (gr_set_timing(ctx, 2)) -------------------------------------------------------------
 namespace gr { KernelTimer* g_ktimer = nullptr; }
+static int g_eval_p16 = getenv("GR_NO_EVAL_P16") ? 0 : 1;      // gr_set_tuning "eval_p16"
 static int g_kphase = 0;      // which part of gr_train_r_step is launching: 0 outside, 1 G forward, 2 R forward, 3 loss, 4 R backward, 5 Adam
 struct EventTimer : gr::KernelTimer {
   struct Rec { std::string name; int phase; double flops, bytes; hipEvent_t e0, e1; bool ok; };
@@ -274,6 +275,7 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!strcmp(key, "nt_stores")) { gr::g_nt_stores = value; return GR_OK; }        // bit mask: which kernels store their outputs non-temporally (kernels.h)
   if (!strcmp(key, "up2_stagger")) { gr::g_up2_stagger = value; return GR_OK; }   // start delay of a CU's second workgroup, x 512 clocks
   if (!strcmp(key, "up2_quad")) { gr::g_up2_quad = value; return GR_OK; }       // 1 (default): four-wave up-sampling kernel where it applies; 0: eight-wave     // diagnostic ablations (outputs are then wrong by design)
+  if (!strcmp(key, "eval_p16")) { g_eval_p16 = value; return GR_OK; }           // evaluate()-mode stages hand their output over operand-ready (1, default) or as fp32 (0: the A/B control)
   if (!strcmp(key, "side_wgrad")) { c->side_wgrad = value; return GR_OK; }
   // synchronised BatchNorm under data parallelism: per-channel batch sums are all-reduced, fwd and bwd (include/ganrev.h)
   if (!strcmp(key, "sync_bn")) { c->sync_bn = value != 0; return GR_OK; }          // weight gradients on the side stream (1) or in line (0, default)
@@ -394,6 +396,10 @@ struct Stage {
   unsigned *amax_y = nullptr, *amax_kb = nullptr, *amax_dz = nullptr;  // max|y| (raw main-op output), the backward bound factor K (BnBounds), max|dz|
   void* x_p16 = nullptr; size_t x_p16_cap = 0;   // operand-ready copy of this stage's INPUT, written by the previous stage's pipeline kernel
   uint64_t x_p16_gen = 0;                         // gr_net::amax_gen at which x_p16 (and the bound in amax_x) was written
+  // evaluate() mode (round 4): a convolution EPILOGUE writes the next stage's x_p16, scaled by an a-priori weight-norm bound in amax_x
+  // (launch_eval_bound); the true max|x| it measures while storing goes to amax_xt and feeds the bound of the stage after
+  unsigned* amax_xt = nullptr; const unsigned* x_true = nullptr;   // x_true: the slot that holds (a tight bound of) the TRUE maximum of what x_p16 holds
+  float* wl1 = nullptr; uint64_t wl1_version = 0;                  // per-output-channel L1 norms of the weights (conv3x3 stages)
   uint64_t kb_gen = 0;                            // ... at which amax_kb / amax_y were written (operand-ready dy possible in the backward)
   float *mean = nullptr, *invstd = nullptr, *coef = nullptr; double* partials = nullptr; double* partials_b = nullptr;
   int stat_tiles_last = 0;                  // tiles the last forward's conv epilogue wrote (0: none - run the statistics pass)
@@ -436,7 +442,7 @@ struct gr_net {
   unsigned guard_sides = 0;           // the largest spreads (bits: activation side | weight side << 16) the last guarded forward measured
 };
 
-enum { AG_X = 0, AG_Y = 1, AG_KB = 2, AG_DY = 3, AG_DZ = 4, AG_W = 5, AMAX_GROUPS = 6 };
+enum { AG_X = 0, AG_XT = 1, AG_Y = 2, AG_KB = 3, AG_DY = 4, AG_DZ = 5, AG_W = 6, AMAX_GROUPS = 7 };
 static int64_t vol3(int c, int h, int w) { return (int64_t)c * h * w; }
 static bool is_act(int k) { return k == GR_ELU || k == GR_RELU || k == GR_LEAKYRELU || k == GR_SIGMOID || k == GR_TANH || k == GR_PRELU; }
 
@@ -450,7 +456,7 @@ extern "C" int gr_net_destroy(gr_net* n) {
     if (s.has_post) (void)hipFree(s.out);
     (void)hipFree(s.pool_idx); (void)hipFree(s.wt_fwd); (void)hipFree(s.wt_bwd); (void)hipFree(s.ws_fwd); (void)hipFree(s.ws_up); (void)hipFree(s.ws_bwd);
     (void)hipFree(s.mean); (void)hipFree(s.invstd); (void)hipFree(s.coef); (void)hipFree(s.partials); (void)hipFree(s.partials_b); (void)hipFree(s.stat_part);
-    (void)hipFree(s.run_mean); (void)hipFree(s.run_var); (void)hipFree(s.x_p16);
+    (void)hipFree(s.run_mean); (void)hipFree(s.run_var); (void)hipFree(s.x_p16); (void)hipFree(s.wl1);
   }
   for (auto& m : n->masks) (void)hipFree(m.bits);
   (void)hipFree(n->params); (void)hipFree(n->grads); (void)hipFree(n->adam_m); (void)hipFree(n->adam_v);
@@ -585,6 +591,7 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
       if (s.fullconv && (hipMalloc(&s.ws_fwd, conv_weight_split_bytes(s.Cout, s.Cin, true)) || hipMalloc(&s.ws_bwd, conv_weight_split_bytes(s.Cout, s.Cin, false)))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
       if (!s.fullconv && s.up && conv_up2_supported(s.Cin, s.Cout, s.H, s.W) && hipMalloc(&s.ws_up, conv_weight_up2_bytes(s.Cin, s.Cout))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
     }
+    if (s.kind == ST_CONV && s.ksz == 3 && !s.up && !s.fullconv && hipMalloc((void**)&s.wl1, sizeof(float) * s.Cout)) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
     if (s.kind == ST_CONV && s.ksz == 5 && !s.up && conv5x5_split_supported(s.Cin, s.Cout, s.H, s.W) &&
         (hipMalloc(&s.ws_fwd, conv_weight_split_bytes(s.Cin, s.Cout, false, 5)) || hipMalloc(&s.ws_bwd, conv_weight_split_bytes(s.Cin, s.Cout, true, 5)))) { gr_net_destroy(n); return fail(c, GR_ERR_HIP, "alloc failed"); }
     const size_t ye = (size_t)vol3(s.Cout, s.H, s.W), ie = (size_t)vol3(s.inC, s.inH, s.inW);
@@ -598,7 +605,7 @@ extern "C" int gr_net_create(gr_ctx* c, const gr_layer_desc* L, int nl, int in_c
     for (size_t si = 0, ns = n->st.size(); si < ns; ++si) {
       Stage& s = n->st[si];
       auto slot = [&](int grp) { return n->amax + AMAX_WORDS * (grp * ns + si); };
-      s.amax_x = slot(AG_X); s.amax_y = slot(AG_Y); s.amax_kb = slot(AG_KB); s.amax_dy = slot(AG_DY); s.amax_dz = slot(AG_DZ); s.amax_w = slot(AG_W);
+      s.amax_x = slot(AG_X); s.amax_xt = slot(AG_XT); s.amax_y = slot(AG_Y); s.amax_kb = slot(AG_KB); s.amax_dy = slot(AG_DY); s.amax_dz = slot(AG_DZ); s.amax_w = slot(AG_W);
     }
     for (auto& s : n->st) {
       if (s.kind != ST_CONV || s.ksz != 3) continue;
@@ -976,7 +983,7 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
   n->w_slots_zeroed = false;
   if (f16) {
     const bool w_too = n->training && n->prepped_version[2] != n->params_version;
-    const size_t groups = w_too ? AMAX_GROUPS : (n->training ? AG_W : 1);      // x | y kb dy dz | w
+    const size_t groups = w_too ? AMAX_GROUPS : (n->training ? AG_W : AG_KB);      // x xt y | kb dy dz | w
     HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst * groups, c->stream));
     n->dy_slots_zeroed = groups >= (size_t)AG_W;
     n->w_slots_zeroed = groups == (size_t)AMAX_GROUPS;
@@ -1012,6 +1019,7 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
     unsigned* amax_next = nx ? nx->amax_x : nullptr;
     s.x_in = x;
     s.fused_epilogue = false; s.out_skipped = false;
+    bool post_p16 = false;
     if (s.kind == ST_CONV && s.ksz != 3) {
       // K x K convolution (the D network's 5x5 layer): fp32 direct kernel, raw output always written, statistics by the pipeline
       if (convk_split(n, s)) {
@@ -1039,23 +1047,44 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
       static const bool epi_stats_on = !getenv("GR_NO_EPI_STATS");
       const bool want_stats = epi_stats_on && n->training && s.has_bn && s.stat_part && !s.fused_epilogue;
       int stat_tiles = 0;
+      static const bool fewin_on = !getenv("GR_NO_FEWIN");
+      const bool is_fewin = fewin_on && !s.fullconv && conv_fewin_applies(s.Cin, s.W, s.up);
+      const bool in_p16 = f16 && !s.up && s.x_p16 && s.x_p16_gen == n->amax_gen && use_bf16x6(n, s);      // this stage's input arrived operand-ready
+      // evaluate() mode, f16x3 (round 4: apply_r.lua:145-153's corpus pipeline): the next convolution's input leaves THIS stage operand-ready
+      // too - straight from the conv epilogue (`po`: BatchNorm + activation fused, scale = the weight-norm bound of launch_eval_bound) or, for
+      // a stage with a pipeline kernel (pooling), from that kernel (`post_p16`: scale bounded from max|y|, which the conv epilogue measures).
+      // Pure functions of the stage's input and parameters: the host-tensor mirror (gr_net_forward_host) computes the same bits.
+      const bool nx_p16 = g_eval_p16 && f16 && !n->training && nx && nx->kind == ST_CONV && nx->ksz == 3 && !nx->up && !nx->fullconv && nx->x_p16 &&
+                          use_bf16x6(n, *nx) && conv_p16_supported(B, nx->Cin, nx->Cout, nx->H, nx->W) && !s.up && !s.fullconv && s.wl1;
+      const bool po = nx_p16 && s.fused_epilogue &&
+                      (is_fewin ? conv_fewin_p16_out_supported(s.Cout, s.H, s.W) : (in_p16 && conv_p16_out_supported(s.Cout)));
+      post_p16 = nx_p16 && !s.fused_epilogue && s.has_post && s.act != ACT_PRELU && post_g8_supported(s.Cout, s.H, s.W, s.pool) && (is_fewin || use_bf16x6(n, s));
       // f16x3 training: max|y| of the raw output rides along (slot amax_y): with the batch statistics it bounds max|pipeline
       // output| and max|dy| BEFORE the kernels that write those tensors run, so they can write them operand-ready (P16)
-      const bool track_y = f16 && want_stats;
+      const bool track_y = (f16 && want_stats) || post_p16;
       const bool last_writer = s.fused_epilogue || !s.has_post;
       unsigned* conv_amax_out = last_writer ? amax_next : (track_y ? s.amax_y : nullptr);
-      static const bool fewin_on = !getenv("GR_NO_FEWIN");
-      if (fewin_on && !s.fullconv && conv_fewin_applies(s.Cin, s.W, s.up)) {
+      P16Out p16o;
+      if (po) {
+        if (s.wl1_version != n->params_version) { launch_conv_weight_l1(n->params + s.w_off, s.Cout, s.Cin * 9, s.wl1, c->stream); s.wl1_version = n->params_version; }
+        const unsigned* mslot = s.amax_x;                       // the true max|x| of this stage's input ...
+        if (in_p16 && !is_fewin) mslot = s.x_true ? s.x_true : s.amax_x;                                  // ... tracked beside the bound its image is scaled by
+        else if (s.amax_x_fwd != n->amax_gen) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream, true); s.amax_x_fwd = n->amax_gen; }
+        launch_eval_bound(s.wl1, n->params + s.b_off, &ep, s.Cout, 1.f, mslot, nx->amax_x, c->stream);
+        p16o.p16 = nx->x_p16; p16o.scale = nx->amax_x;
+        conv_amax_out = nx->amax_xt; dst = nullptr;
+      }
+      if (is_fewin) {
         launch_conv3x3_fewin(x, n->params + s.w_off, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, conv_amax_out,
-                             want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
+                             want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr, po ? &p16o : nullptr);
         if (last_writer && nx) nx->amax_x_fwd = n->amax_gen;
       } else if (use_bf16x6(n, s)) {
         const int nterm = c->conv_mode == 2 ? 2 : 3;
         static const bool up2_on = !getenv("GR_NO_UP2");
-        if (nterm == 2 && !s.up && s.x_p16 && s.x_p16_gen == n->amax_gen) {
+        if (nterm == 2 && in_p16) {
           // the previous stage's pipeline kernel left this stage's input operand-ready, scaled by the bound in amax_x
           launch_conv3x3_p16(s.x_p16, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, s.amax_x, s.amax_w, conv_amax_out,
-                             want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr);
+                             want_stats ? s.stat_part : nullptr, want_stats ? &stat_tiles : nullptr, po ? &p16o : nullptr);
         } else {
           // input not produced by a tracking kernel (the net's own input, a GEMM, a VALU conv): take its maximum now
           if (nterm == 2 && s.amax_x_fwd != n->amax_gen) { launch_absmax(x, (long)B * vol3(s.inC, s.inH, s.inW), s.amax_x, c->stream, true); s.amax_x_fwd = n->amax_gen; }
@@ -1070,6 +1099,7 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
         if (last_writer && nx) nx->amax_x_fwd = n->amax_gen;
       }
       else launch_conv3x3(x, s.wt_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, s.up, c->stream, s.fullconv ? nullptr : n->params + s.w_off, epp);
+      if (po) { nx->x_p16_gen = n->amax_gen; nx->x_true = nx->amax_xt; s.out_skipped = true; }      // (no fp32 copy: gr_net_layer_output says so)
       if (s.fused_epilogue) { LAUNCHCHK(c); x = s.out; continue; }
       s.stat_tiles_last = stat_tiles;
     } else if (s.kind == ST_LINEAR) {
@@ -1137,6 +1167,15 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
       }
       else if (!s.eval_ready) { launch_bn_eval_prepare(s.run_mean, s.run_var, s.mean, s.invstd, s.Cout, c->stream); s.eval_ready = true; }
     }
+    if (post_p16) {
+      // evaluate() mode: bound of max|pipeline output| from max|y| (the conv epilogue's) and the running statistics, as the statistics
+      // kernel folds it in training mode
+      ConvEpilogue e2;
+      if (s.has_bn) { e2.mean = s.mean; e2.invstd = s.invstd; e2.gamma = pa.gamma; e2.beta = pa.beta; }
+      e2.act = s.act; e2.slope = s.slope;
+      launch_eval_bound(nullptr, nullptr, &e2, s.Cout, fmaxf(1.f, pa.m1.scale) * fmaxf(1.f, pa.m2.scale), s.amax_y, nx->amax_x, c->stream);
+      p16_out = true; nx->x_true = nx->amax_x;
+    }
     pa.amax_out = p16_out ? nullptr : amax_next;      // operand-ready: the slot already holds the bound and must not move
     pa.p16 = p16_out ? nx->x_p16 : nullptr; pa.p16_scale = p16_out ? nx->amax_x : nullptr;
     // The fp32 copy of the stage output has one more reader than the next convolution's forward: that convolution's weight
@@ -1145,6 +1184,7 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
     static const bool lean_on = !getenv("GR_P16_KEEP_FP32");
     s.out_skipped = lean_on && !n->keep_fp32 && p16_out && nx->has_bn && n->dy_p16 && post_g8_supported(nx->Cout, nx->H, nx->W, nx->pool, true) &&
                     conv_wgrad_p16_supported(B, nx->Cin, nx->Cout, nx->H, nx->W) && nx->stat_part;
+    if (post_p16) s.out_skipped = true;               // evaluate(): nothing else reads the fp32 tensor
     if (s.out_skipped) pa.out = nullptr;
     launch_post_forward(pa, c->stream);
     if (p16_out) nx->x_p16_gen = n->amax_gen;

@@ -136,3 +136,44 @@ def test_apply_r_main_device_resident_and_host_loops_agree(tmp_path):
     for f, a in outs["device"].items():
         assert np.array_equal(a, outs["host"][f]), f"{f}: device-resident and host loops differ"
     assert outs["device"]["similar_by_attributes.npy"].shape == (5, 100) and outs["device"]["variations.npy"].shape == (8, 16, 1, 16, 16)
+
+
+@pytest.mark.parametrize("dims,nd,B", [((1, 32, 32), 32, 12), ((3, 64, 64), 100, 6), ((1, 32, 32), 32, 130)])
+def test_evaluate_mode_operand_ready_chain_vs_oracle(ctx, oracle, dims, nd, B):
+    """evaluate()-mode R (apply_r.lua:120-153) in f16x3: every convolution after the first takes its input operand-ready - written by the
+    epilogue of the convolution before it (scaled by the weight-norm bound of launch_eval_bound, the true maximum tracked beside it) or by the
+    pooling stage's pipeline kernel.  Checked: the kernels that ran; the result against the oracle and against the same forward with the
+    hand-over switched off (fp32 tensors between the stages: round 3's path); a batch whose images carry a few pixels 300 x larger than the
+    rest (the bound then overshoots the next tensors' maxima by many bits: what is left of the 22-bit split must still do)."""
+    from ganrev import models, synth
+    prev = ctx.conv_mode(); ctx.set_conv_mode("f16x3")
+    ctx.set_tuning("p16_min_tiles", 1)
+    try:
+        R = models.create_R(dims, nd); synth.init_params(R, 14)
+        oR = oracle.from_model(R, dims); oR.set_training(False)
+        R.evaluate()
+        x = synth.uniform((B,) + dims, 15, 0, 1)
+        spiky = x.copy()
+        spiky[:, :, 5, 7] *= 300.0; spiky[0, 0, 20, 20] = -900.0
+        for name, inp in (("plain", x), ("spiky", spiky)):
+            ctx.set_tuning("eval_p16", 1)
+            ctx.set_timing(2)
+            got = R.forward(inp).copy()
+            kt = ctx.kernel_times(); ctx.set_timing(0)
+            count = lambda prefix: sum(k["launches"] for k in kt if k["kernel"].startswith(prefix))
+            names = sorted((k["kernel"], k["launches"]) for k in kt if k["kernel"].startswith("conv3x3") or k["kernel"].startswith("post_forward"))
+            assert count("conv3x3_fewin_p16o_kernel") == 1, names
+            assert count("conv3x3_p16_quad_po_kernel") == 3, names        # conv2, conv4, conv5 hand over from their epilogue
+            assert count("conv3x3_p16_quad_kernel") == 2, names           # conv3, conv6: raw output for the pooling stage
+            assert count("post_forward_g8_kernel") == 1 and count("conv3x3_split") == 0, names
+            ctx.set_tuning("eval_p16", 0)
+            ctrl = R.forward(inp).copy()
+            ref = oR.forward(inp)
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert_close(got, ref, TOL * scale, f"{name}: operand-ready chain vs oracle")
+            assert_close(ctrl, ref, TOL * scale, f"{name}: fp32 hand-over vs oracle")
+            assert_close(got, ctrl, 2e-5 * scale, f"{name}: the two hand-overs against each other")
+    finally:
+        ctx.set_tuning("eval_p16", 1)
+        ctx.set_tuning("p16_min_tiles", 128)
+        ctx.set_conv_mode(prev)
