@@ -1533,6 +1533,7 @@ __device__ __forceinline__ void conv_p16_quad_body(const ConvArgs& a, const uint
   for (int ch = 0; ch < nchunks; ++ch) {
     dma_publish_barrier();                                           // the image holds chunk ch
     GR_STAMP()
+    if (dbg & 256) __builtin_amdgcn_s_setprio(1);                     // experiment (GR_P16_DEBUG bit 256): the multiplying workgroup outranks its CU partner's epilogue / DMA issue
     if (!(dbg & 8)) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -1551,6 +1552,7 @@ __device__ __forceinline__ void conv_p16_quad_body(const ConvArgs& a, const uint
           for (int ng = 0; ng < NG; ++ng) acc[mt][ng] = split_mma<NTERM>(av[mt], bv[ng], acc[mt][ng]);
       }
     }
+    if (dbg & 256) __builtin_amdgcn_s_setprio(0);
     __syncthreads();                                                 // every wave is past the image
     GR_STAMP()
     if (ch + 1 < nchunks && !(dbg & 4)) GR_P16_DMA(ch + 1)
