@@ -10,6 +10,8 @@
 #include "kernels.h"
 #include <rccl/rccl.h>
 #include <roctracer/roctx.h>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -51,6 +53,7 @@ struct gr_ctx {
   long guard_scans = 0, guard_fallbacks = 0;
   long search_reruns = 0;              // searches whose sample-bound filter overflowed and ran again unfiltered
   void* pin = nullptr; size_t pin_bytes = 0;   // pinned staging for small results (search)
+  unsigned* pin_done = nullptr; unsigned search_seq = 0;   // per-needle completion words of the small search path (pinned, 64 bytes) and the sequence number they carry
   hipEvent_t ev_guard = nullptr; bool guard_pending = false;   // device-resident trainer: sampled scans, verdict read one call later
   bool guard_tripped = false;          // ... which found a hostile range: the context stays on bf16x6
   // synchronised BatchNorm (gr_set_tuning "sync_bn", SURVEY.md 8e optional) and the host-exchange hook that can stand in for RCCL
@@ -234,6 +237,7 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   if (c->guard_chmax) (void)hipFree(c->guard_chmax);
   if (c->sync_buf) (void)hipFree(c->sync_buf);
   if (c->pin) (void)hipHostFree(c->pin);
+  if (c->pin_done) (void)hipHostFree(c->pin_done);
   if (c->ev_guard) (void)hipEventDestroy(c->ev_guard);
   (void)hipFree(c->d_loss); (void)hipFree(c->amax); (void)hipHostFree(c->h_loss);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1360,6 +1364,9 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
   gr_ctx* c = n->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   if (B != n->lastB) return fail(c, GR_ERR_STATE, "backward batch %d does not match the last forward (%d)", B, n->lastB);
+  if (!n->training)       // an evaluate()-mode forward may have handed stage outputs over operand-ready only (forward_stages: po / post_p16)
+    for (auto& s : n->st)
+      if (s.out_skipped) return fail(c, GR_ERR_STATE, "backward after an evaluate()-mode forward that kept stage outputs operand-ready only (gr_set_tuning \"eval_p16\" 0 keeps the fp32 tensors)");
   reduce = reduce && have_peers(c);
   int64_t bucket_hi = n->n_params;            // everything in [stage first offset, bucket_hi) is final but not yet reduced
   BiasJobs bias_jobs{}; bias_jobs.n = 0;
@@ -1819,9 +1826,33 @@ extern "C" int gr_cosine_topk_dev(gr_ctx* c, const float* emb, int64_t N, int d,
     char* pd = static_cast<char*>(pin_dev);
     long* p_idx = reinterpret_cast<long*>(pd); float* p_sc = reinterpret_cast<float*>(pd + sizeof(long) * (size_t)Q * k);
     unsigned* p_status = reinterpret_cast<unsigned*>(pd + res_bytes - sizeof(unsigned));
-    if (launch_cosine_topk(emb, N, d, d_q, Q, k, p_idx, p_sc, accf, c->ws, c->stream, p_status, 0, qrows, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->d_loss) + 32))) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
+    if (!c->pin_done) { HIPCHK(c, hipHostMalloc((void**)&c->pin_done, 64)); memset(c->pin_done, 0, 64); }
+    void* done_dev = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(&done_dev, c->pin_done, 0));
+    if (++c->search_seq == 0u) c->search_seq = 1u;                                  // never 0: a fresh block reads 0
+    const unsigned seq = c->search_seq;
+    const int lr = launch_cosine_topk(emb, N, d, d_q, Q, k, p_idx, p_sc, accf, c->ws, c->stream, p_status, 0, qrows, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->d_loss) + 32),
+                                      static_cast<unsigned*>(done_dev), seq);
+    if (lr < 0) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
     LAUNCHCHK(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // The selection kernel publishes one completion word per needle behind its results (system-scope release): poll them instead of
+    // synchronising the stream - the wake-up of hipStreamSynchronize costs ~10 us of a 0.13 ms search.  Bounded: after 20 ms the stream is
+    // synchronised after all (a fault shows up there).
+    static const bool poll_on = !getenv("GR_SEARCH_NO_POLL");
+    bool seen = false;
+    if (lr == 2 && poll_on) {
+      volatile unsigned* dw = c->pin_done;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 0;; ++spins) {
+        bool all = true;
+        for (int q = 0; q < Q; ++q) if (dw[q] != seq) { all = false; break; }
+        if (all) { seen = true; break; }
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        __builtin_ia32_pause();
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
     const char* hres = (const char*)c->pin;
     unsigned status; memcpy(&status, hres + res_bytes - sizeof(unsigned), sizeof status);
     if (status == 0) {

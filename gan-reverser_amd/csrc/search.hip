@@ -689,12 +689,15 @@ __global__ __launch_bounds__(1024) void batched_select_kernel(const float* __res
 //   agent-scope release / acquire around it) takes the k-th largest of those S / 64 maxima (k of them are k distinct rows at or above it) minus
 //   2 eps as the needle's threshold tau: one launch instead of needle_prep + sample + bound.  MODE 1: every row, (row, score) pairs >= tau into
 //   the workgroup's own entries.
+constexpr int APPROX_NB = 2;          // LDS tiles per workgroup of the main pass (ring; see cos_approx_kernel).  3 was measured (round 4): two workgroups per CU instead of
+                                      // three, each with two tiles in flight - 101 -> 120 us at d = 100: the pass is bound by what ONE wave gets through (25 DMA instructions
+                                      // + 150 LDS reads + 600 FMAs per tile), so waves per CU count for more than bytes in flight per wave
 constexpr int ASLOT = 96;             // entries per (persistent workgroup, needle): expected ~7 at cfg5 (5200 candidates over 768 workgroups)
 constexpr int APPROX_WGS_MAX = 768;   // at most 3 one-wave workgroups per CU (two 25.6 KB tiles each at d = 100); wider rows: what fits 160 KB of LDS
 static int approx_wgs(int d, int Q) {        // ONE resident round: a grid of 768 where only two workgroups fit a CU ran its last third alone (d = 128: 335 us)
   const int d4 = d / 4, v = (d4 & 1) ? d4 : d4 + 1;
   const int nq = Q <= 2 ? 2 : (Q <= 5 ? 5 : 8);      // the instantiation launch_approx_nq picks
-  const size_t lds = (size_t)2 * 64 * v * 16 + (size_t)nq * d * 4 + 256 + 64;
+  const size_t lds = (size_t)APPROX_NB * 64 * v * 16 + (size_t)nq * d * 4 + 256 + 64;
   int per_cu = (int)((size_t)160 * 1024 / lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
   return 256 * per_cu;
 }
@@ -708,9 +711,10 @@ struct ApproxArgs {
 template <int D4, int NQ, int MODE>
 __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict__ emb, long N, long stride, SmallQ qr, ApproxArgs a) {
   constexpr int V = (D4 & 1) ? D4 : D4 + 1, d = D4 * 4;      // vectors per LDS row: odd, so that the 16 lanes of a ds_read_b128 group hit 64 distinct banks
-  __shared__ __attribute__((aligned(16))) uint4 tile[2][64 * V];
+  // NB tiles per workgroup in a ring: while one is multiplied, NB - 1 are in flight (APPROX_NB: two; three lost)
+  constexpr int NB = MODE == 0 ? 1 : APPROX_NB;
+  __shared__ __attribute__((aligned(16))) uint4 tile[NB][64 * V];
   __shared__ __attribute__((aligned(16))) float4 nd[NQ * D4];
-  __shared__ float srt[MODE == 0 ? 64 : 1];
   const int lane = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x, Q = a.Q;
   const size_t bytes = (size_t)N * (MODE == 0 ? stride : 1) * d * 4;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(emb), 0, (int)(bytes < 0x7FFFF000ul ? bytes : 0x7FFFF000ul), 0x00020000);
@@ -727,7 +731,9 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < V; ++j) lds_dma16(rs, &tile[buf][64 * j], voff[j], soff);
   };
-  if (wg < ntiles) request(wg, 0);
+#pragma unroll
+  for (int j = 0; j < NB - 1; ++j)
+    if (wg + (long)j * nwg < ntiles) request(wg + (long)j * nwg, j);
   // the needles: every workgroup gathers them itself (Q rows of d floats; rows come in the kernel arguments - no upload, no launch of their own)
   for (int e = lane; e < NQ * D4; e += 64) {
     const int q = e / D4, c4 = e - q * D4;
@@ -748,10 +754,16 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
 #pragma unroll
   for (int q = 0; q < NQ; ++q) { tauq[q] = (MODE == 1 && q < Q) ? a.tau[q] : INFINITY; cnt[q] = 0u; wmax[q] = -INFINITY; }
   int buf = 0;
-  for (long t = wg; t < ntiles; t += nwg, buf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // tile t has landed (only its requests were outstanding)
+  for (long t = wg; t < ntiles; t += nwg, buf = buf + 1 == NB ? 0 : buf + 1) {
+    if (NB == 1) request(t, 0);                                   // (the sample: one tile per workgroup)
+    // tile t has landed once at most the requests issued AFTER it are outstanding: V per tile already requested behind it (vmcnt counts in issue order)
+    if (NB >= 3 && t + (long)(NB - 2) * nwg < ntiles) {
+      if (NB == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(V <= 63 ? V : 0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * V <= 63 ? 2 * V : 0) : "memory");
+    } else if (NB >= 4 && t + nwg < ntiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(V <= 63 ? V : 0) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                 // (one wave: orders the LDS-DMA writes before the reads below for the compiler too)
-    if (t + nwg < ntiles) request(t + nwg, buf ^ 1);             // the next tile streams in behind this tile's arithmetic
+    if (NB > 1 && t + (long)(NB - 1) * nwg < ntiles) request(t + (long)(NB - 1) * nwg, buf == 0 ? NB - 1 : buf - 1);   // into the buffer the previous round multiplied
     const uint4* row = &tile[buf][lane * V];
     float s3 = 0.f, s1[NQ];
 #pragma unroll
@@ -824,37 +836,184 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next search
-  // A lower bound of the k-th largest of the nwg maxima per needle, by one wave: 64 value buckets between the smallest and the largest maximum,
-  // a suffix count over the buckets, the lower edge of the last bucket that still has k maxima at or above it - minus one bucket width, so that
-  // the float rounding of the bucket index cannot put a counted value below the edge.  (An exact k-th by a bitonic sort of 256 x Q values on one
-  // wave took longer than the sample itself; the price of the bucket form is a threshold up to (hi - lo) / 32 lower, ~20 % more candidates.)
-  unsigned* hist = reinterpret_cast<unsigned*>(srt);
-  for (int q = 0; q < Q; ++q) {
-    float v[4], lo = INFINITY, hi = -INFINITY;
+  // The k-th largest of the nwg maxima per needle (k of them are k distinct rows at or above it), exactly, by one wave and without LDS:
+  // every lane holds four of the <= 256 maxima as orderable bit patterns (all Q x 4 loads in flight together), and the answers are built
+  // bit by bit from the top, all needles in the same round - res |= bit while at least k patterns are >= the trial value (32 rounds of
+  // four compares + ballots per needle).  (First form: a 64-bucket histogram per needle, one needle after the other with the loads inside
+  // the loop; its bucket edge also sat up to a bucket below the exact value: ~20 % more candidates.)
+  unsigned ov[NQ][4];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = lane + 64 * u;
-      v[u] = e < nwg ? __hip_atomic_load(a.wgmax + (long)q * nwg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : NAN;
-      if (e < nwg) { lo = fminf(lo, v[u]); hi = fmaxf(hi, v[u]); }
+      ov[q][u] = (q < Q && e < nwg) ? orderable(__hip_atomic_load(a.wgmax + (long)q * nwg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
     }
+  unsigned res[NQ];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
-    const float width = (hi - lo) * (1.f / 64.f), inv = width > 0.f ? 1.f / width : 0.f;
-    hist[lane] = 0u;
-    __syncthreads();
+  for (int q = 0; q < NQ; ++q) res[q] = 0u;
+#pragma unroll 1
+  for (int b = 31; b >= 0; --b) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (lane + 64 * u < nwg) { int bkt = (int)((v[u] - lo) * inv); bkt = bkt < 0 ? 0 : (bkt > 63 ? 63 : bkt); atomicAdd(&hist[bkt], 1u); }
-    __syncthreads();
-    unsigned suf = hist[lane];                                   // maxima in buckets >= lane: suffix sum over the lanes
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const unsigned t = (unsigned)__shfl_down((int)suf, off, 64); if (lane + off < 64) suf += t; }
-    const unsigned long long ok = __ballot(suf >= (unsigned)a.k);      // lane 0 always qualifies (nwg >= k)
-    const int top = 63 - __builtin_clzll(ok | 1ull);
-    if (lane == 0) a.tau[q] = lo + (float)(top - 1) * width - a.eps2;
-    __syncthreads();
+    for (int q = 0; q < NQ; ++q) {
+      const unsigned t = res[q] | (1u << b);
+      const int c = __popcll(__ballot(ov[q][0] >= t)) + __popcll(__ballot(ov[q][1] >= t)) + __popcll(__ballot(ov[q][2] >= t)) + __popcll(__ballot(ov[q][3] >= t));
+      if (c >= a.k) res[q] = t;
+    }
   }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (lane == 0 && q < Q) a.tau[q] = res[q] ? unorderable(res[q]) - a.eps2 : -INFINITY;
 }
+// Selection of the small path (one workgroup of 256 per needle): second cut, exact re-score of what is left, sort, results and a completion word
+// straight into the caller's (pinned host) block.  Round 4, second form - batched_select_kernel (1024 threads) spent most of its 26 us in block
+// barriers: a bitonic sort of 1024 per-thread maxima (55 steps) to find the cut, 8 dependent loads per row and needle round, a second sort.  Here:
+//   cut     a histogram of the candidates' approximate scores over [tau, 1] in 2048 bins (LDS atomics), a suffix count over the bins, the lowest bin
+//           edge with k candidates at or above it (minus one bin: the float rounding of a bin index) minus the 2 eps margin - every row of the
+//           exact top k is at or above it (as for batched_select_kernel's cut: k rows with approximate score >= E have exact scores >= E - eps);
+//   scores  the needle staged in LDS once, the row 16 vectors per round; cos_keys_kernel's arithmetic (fp32 products, sequential sums);
+//   done    every thread's stores fenced at system scope, then ONE word per needle = the call's sequence number: the host polls it (no stream
+//           synchronisation: ~10 us of wake-up per search).
+constexpr int SSEL_BINS = 2048, SSEL_MAX = 256;
+template <bool ACCF>
+__global__ __launch_bounds__(256) void small_select_kernel(const float* __restrict__ emb, int d, const unsigned* __restrict__ cand_idx,
+                                                          const float* __restrict__ cand_sc, const unsigned* __restrict__ counts, int nwg, int k,
+                                                          long* __restrict__ idx, float* __restrict__ score, unsigned* __restrict__ status,
+                                                          float margin2, SmallQ qr, const float* __restrict__ tau, unsigned* __restrict__ done, unsigned seq) {
+  typedef typename std::conditional<ACCF, float, double>::type acc_t;
+  __shared__ unsigned hist[SSEL_BINS];
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[SSEL_MAX];
+  __shared__ unsigned rows[SSEL_MAX];
+  __shared__ __attribute__((aligned(16))) float ndl[BD_MAX];
+  __shared__ unsigned wtot[4];
+  __shared__ unsigned list_n, over, cutbin;
+  __shared__ float sh_w22;
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned* cnt = counts + (long)q * nwg;
+  const unsigned* ci = cand_idx + (long)q * nwg * ASLOT;
+  const float* cs = cand_sc + (long)q * nwg * ASLOT;
+  const float* nd = emb + qr.rows[q] * (long)d;
+  const float lo = tau[q];
+  bool fail = !(lo > -INFINITY);                                    // no threshold (fewer than k sample maxima): the unfiltered search decides
+  for (int i = tid; i < SSEL_BINS; i += 256) hist[i] = 0u;
+  if (tid == 0) { list_n = 0u; over = 0u; cutbin = 0u; }
+  for (int c = tid; c < d; c += 256) ndl[c] = nd[c];
+  __syncthreads();
+  if (tid == 255) {                                                 // 1 / (|needle|^2 + 1e-12) in needle_prep_kernel's arithmetic, from the staged copy
+    acc_t t = 0;                                                    // (read from global memory by this one thread it was 7 dependent rounds: ~10 us)
+    for (int i = 0; i < d; ++i) { const float v = ndl[i]; t += v * v; }
+    float w = (float)t;
+    w = w + 1e-12f;
+    sh_w22 = 1.f / w;
+  }
+  const float span = 1.0001f - lo, inv = span > 0.f ? (float)SSEL_BINS / span : 0.f, width = span / (float)SSEL_BINS;
+  // pass 1: histogram of the approximate scores (a list's entries are contiguous: four per 16-byte load)
+  unsigned o = 0u;
+  if (!fail)
+    for (int g = tid; g < nwg; g += 256) {
+      const unsigned c0 = cnt[g];
+      if (c0 > (unsigned)ASLOT) o = 1u;
+      const unsigned c = min(c0, (unsigned)ASLOT);
+      for (unsigned e0 = 0; e0 < c; e0 += 4) {
+        const float4 va = *reinterpret_cast<const float4*>(cs + (long)g * ASLOT + e0);
+        const float v[4] = {va.x, va.y, va.z, va.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e0 + u < c) { int b = (int)((v[u] - lo) * inv); b = b < 0 ? 0 : (b > SSEL_BINS - 1 ? SSEL_BINS - 1 : b); atomicAdd(&hist[b], 1u); }
+      }
+    }
+  if (o) over = 1u;
+  __syncthreads();
+  fail = fail || over != 0u;
+  // suffix count over the bins: thread t owns bins 8 t .. 8 t + 7; S(t) = candidates in bins >= 8 t
+  unsigned own = 0u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) own += hist[8 * tid + j];
+  unsigned suf = own;                                               // suffix sum over the lanes of the wave, then the waves above
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned t = (unsigned)__shfl_down((int)suf, off, 64); if (lane + off < 64) suf += t; }
+  if (lane == 0) wtot[wave] = suf;
+  __syncthreads();
+  for (int w = wave + 1; w < 4; ++w) suf += wtot[w];
+  const unsigned above = suf - own;                                 // candidates in bins >= 8 (t + 1)
+  if (suf >= (unsigned)k && above < (unsigned)k) {                  // exactly one thread when there are k candidates at all (else the cut stays at bin 0)
+    unsigned run = above;
+    for (int j = 7; j >= 0; --j) { run += hist[8 * tid + j]; if (run >= (unsigned)k) { cutbin = (unsigned)(8 * tid + j); break; } }
+  }
+  __syncthreads();
+  const float tau2 = lo + ((float)cutbin - 1.f) * width - margin2;
+  // pass 2: the candidates at or above the cut
+  if (!fail)
+    for (int g = tid; g < nwg; g += 256) {
+      const unsigned c = min(cnt[g], (unsigned)ASLOT);
+      for (unsigned e0 = 0; e0 < c; e0 += 4) {
+        const float4 va = *reinterpret_cast<const float4*>(cs + (long)g * ASLOT + e0);
+        const float v[4] = {va.x, va.y, va.z, va.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e0 + u < c && v[u] >= tau2) { const unsigned pos = atomicAdd(&list_n, 1u); if (pos < (unsigned)SSEL_MAX) rows[pos] = ci[(long)g * ASLOT + e0 + u]; }
+      }
+    }
+  __syncthreads();
+  const unsigned m = list_n;
+  fail = fail || m > (unsigned)SSEL_MAX || m < (unsigned)k;
+  if (!fail) {
+    // exact scores, cos_keys_kernel's arithmetic: fp32 products, sequential sums over the columns, the same w22 / w32 steps
+    const float w22q = sh_w22;
+    if ((unsigned)tid < m) {
+      const long row = rows[tid];
+      const float* b = emb + row * (long)d;
+      acc_t s1 = 0, s3 = 0;
+      if ((d & 3) == 0) {
+        const int n4 = d >> 2;
+#pragma unroll 1
+        for (int c0 = 0; c0 < n4; c0 += 16) {
+          float4 bv4[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) bv4[u] = reinterpret_cast<const float4*>(b)[c0 + u < n4 ? c0 + u : n4 - 1];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) if (c0 + u < n4) {
+            const float4 nv = reinterpret_cast<const float4*>(ndl)[c0 + u];
+            const float bb[4] = {bv4[u].x, bv4[u].y, bv4[u].z, bv4[u].w}, nn[4] = {nv.x, nv.y, nv.z, nv.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { s3 += (acc_t)(bb[jj] * bb[jj]); s1 += (acc_t)(nn[jj] * bb[jj]); }
+          }
+        }
+      } else
+      for (int c = 0; c < d; ++c) { const float bv = b[c]; s3 += (acc_t)(bv * bv); s1 += (acc_t)(ndl[c] * bv); }
+      float w32 = (float)s3;
+      w32 = w32 + 1e-12f;
+      w32 = 1.f / w32;
+      float w = w22q * w32;
+      w = sqrtf(w);
+      const float sc = (float)s1 * w;
+      keys[tid] = ((unsigned long long)orderable(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)row);
+    }
+    int P = 64; while (P < (int)m) P <<= 1;
+    if (tid >= (int)m && tid < P) keys[tid] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+      for (int st = size >> 1; st > 0; st >>= 1) {
+        if (tid < P / 2) {
+          const int l0 = ((tid / st) * st * 2) + (tid % st), h0 = l0 + st;
+          const bool desc = ((l0 & size) == 0);
+          const unsigned long long x = keys[l0], y = keys[h0];
+          if ((x < y) == desc) { keys[l0] = y; keys[h0] = x; }
+        }
+        __syncthreads();
+      }
+    for (int r = tid; r < k; r += 256) {
+      const unsigned long long key = keys[r];
+      idx[(long)q * k + r] = (long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+      if (score) score[(long)q * k + r] = unorderable((uint32_t)(key >> 32));
+    }
+  } else if (tid == 0 && status) *status = 1u;
+  // completion: the results (and the status word) are visible to the host before the needle's word carries this call's sequence number
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0 && done) __hip_atomic_store(done + q, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 bool cosine_topk_small_path(long N, int d, int Q, int k) {
   static const bool on = !getenv("GR_SEARCH_NO_APPROX");
   const int d4 = d / 4;
@@ -913,7 +1072,7 @@ static void launch_keys(bool accf, int mode, int nq, unsigned nb, hipStream_t s,
 // status_dev (nullable): receives 0, or 1 when the filtered path dropped candidates (rerun with unfiltered = 1)
 int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_dev, int Q, int k,
                        long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s, unsigned* status_dev, int unfiltered,
-                       const long* query_rows_host, unsigned* arrival_counter) {
+                       const long* query_rows_host, unsigned* arrival_counter, unsigned* done_words, unsigned seq) {
   if (k > 1024 || k < 1 || k > N || N >= 0xFFFFFFFFl || d < 1 || d > 4096 * 4) return -1;
   { static const char* e = getenv("GR_SEARCH_DEBUG"); if (e) g_search_debug = atoi(e); }
   // workspace carve: needles [Q][d] | w22 [Q] | counts [Q] | keys A | keys B | keys C
@@ -948,10 +1107,17 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
       KtScope kt("cos_approx_kernel", 2.0 * N * d * Q, 4.0 * N * d, s);
       launch_approx<1>(d / 4, Q, (unsigned)awgs, s, emb, N, 1L, qr, a);
     }
-    KtScope kt("batched_select_kernel", 0.0, 0.0, s);
-    if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, (long)awgs, k, idx_out, score_out, status_dev, ASLOT, a.eps2, qr, 1);
-    else hipLaunchKernelGGL(batched_select_kernel<false>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, (long)awgs, k, idx_out, score_out, status_dev, ASLOT, a.eps2, qr, 1);
-    return 0;
+    static const bool old_select = getenv("GR_SEARCH_OLD_SELECT") != nullptr;       // A/B: round 4's first selection kernel (no completion words: the caller synchronises)
+    if (old_select || k > SSEL_MAX / 2) {
+      KtScope kt("batched_select_kernel", 0.0, 0.0, s);
+      if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, (long)awgs, k, idx_out, score_out, status_dev, ASLOT, a.eps2, qr, 1);
+      else hipLaunchKernelGGL(batched_select_kernel<false>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, (long)awgs, k, idx_out, score_out, status_dev, ASLOT, a.eps2, qr, 1);
+      return 0;
+    }
+    KtScope kt("small_select_kernel", 0.0, 0.0, s);
+    if (accf) hipLaunchKernelGGL(small_select_kernel<true>, dim3(Q), dim3(256), 0, s, emb, d, cidx, csc, wcnt, awgs, k, idx_out, score_out, status_dev, a.eps2, qr, tau, done_words, seq);
+    else hipLaunchKernelGGL(small_select_kernel<false>, dim3(Q), dim3(256), 0, s, emb, d, cidx, csc, wcnt, awgs, k, idx_out, score_out, status_dev, a.eps2, qr, tau, done_words, seq);
+    return done_words ? 2 : 0;        // 2: the needles' completion words will carry `seq`
   }
   if (accf) hipLaunchKernelGGL(needle_prep_kernel<true>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
   else hipLaunchKernelGGL(needle_prep_kernel<false>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
