@@ -681,7 +681,7 @@ __global__ __launch_bounds__(1024) void batched_select_kernel(const float* __res
 // them).  The exact op order (fp32 products summed sequentially in fp64) is only needed for rows that can make the top k, so this path, like the
 // batched one above, lets a cheap APPROXIMATE score decide which rows those are and scores only them exactly (batched_select_kernel):
 //   cos_approx_kernel: one wave per workgroup, thread = row, tiles of 64 whole rows - 64 * d * 4 contiguous bytes - brought HBM -> LDS by LDS-DMA
-//   (two tiles per workgroup: the next one is requested as soon as the current one has landed), the needles' values next to them; fp32 FMA sums in
+//   (one tile per workgroup, five or six workgroups per CU: APPROX_NB below), the needles' values next to them; fp32 FMA sums in
 //   any order.  |approximate - exact as computed| <= (2 d + 16) 2^-24 =: eps  (both are within (d + 8) 2^-24 of the real cosine: each product and
 //   each of the few fp32 steps behind the sums rounds by 2^-24 relative, and sum |a_i b_i| <= |a| |b|), so with margins of 2 eps at the two cuts
 //   no row of the exact top k is lost: indices and scores stay bit-identical to the exact search.
@@ -689,16 +689,16 @@ __global__ __launch_bounds__(1024) void batched_select_kernel(const float* __res
 //   agent-scope release / acquire around it) takes the k-th largest of those S / 64 maxima (k of them are k distinct rows at or above it) minus
 //   2 eps as the needle's threshold tau: one launch instead of needle_prep + sample + bound.  MODE 1: every row, (row, score) pairs >= tau into
 //   the workgroup's own entries.
-constexpr int APPROX_NB = 2;          // LDS tiles per workgroup of the main pass (ring; see cos_approx_kernel).  3 was measured (round 4): two workgroups per CU instead of
-                                      // three, each with two tiles in flight - 101 -> 120 us at d = 100: the pass is bound by what ONE wave gets through (25 DMA instructions
-                                      // + 150 LDS reads + 600 FMAs per tile), so waves per CU count for more than bytes in flight per wave
-constexpr int ASLOT = 96;             // entries per (persistent workgroup, needle): expected ~7 at cfg5 (5200 candidates over 768 workgroups)
-constexpr int APPROX_WGS_MAX = 768;   // at most 3 one-wave workgroups per CU (two 25.6 KB tiles each at d = 100); wider rows: what fits 160 KB of LDS
-static int approx_wgs(int d, int Q) {        // ONE resident round: a grid of 768 where only two workgroups fit a CU ran its last third alone (d = 128: 335 us)
+constexpr int APPROX_NB = 1;          // LDS tiles per workgroup of the main pass.  Round 4 measured all three (d = 100, same box): 2 tiles (the next one streams in behind the
+                                      // current one's arithmetic), 3 workgroups per CU: 101 us; 3 tiles, 2 per CU: 120 us; ONE tile, 5 per CU: 83 us (d = 32: 46 -> 31 us).  The
+                                      // pass is bound by what one wave gets through (25 DMA instructions + 150 LDS reads + 600 FMAs per tile, each step waiting for the one
+                                      // before), so the LDS buys more as resident waves than as tiles in flight behind one wave.
+constexpr int ASLOT = 96;             // entries per (persistent workgroup, needle): expected ~4 at cfg5 (5200 candidates over 1280 workgroups)
+static int approx_wgs(int d, int Q) {        // ONE resident round (up to 6 one-wave workgroups per CU): a grid larger than what fits ran its last part alone (d = 128: 335 us)
   const int d4 = d / 4, v = (d4 & 1) ? d4 : d4 + 1;
   const int nq = Q <= 2 ? 2 : (Q <= 5 ? 5 : 8);      // the instantiation launch_approx_nq picks
   const size_t lds = (size_t)APPROX_NB * 64 * v * 16 + (size_t)nq * d * 4 + 256 + 64;
-  int per_cu = (int)((size_t)160 * 1024 / lds); if (per_cu > 3) per_cu = 3; if (per_cu < 1) per_cu = 1;
+  int per_cu = (int)((size_t)160 * 1024 / lds); if (per_cu > 6) per_cu = 6; if (per_cu < 1) per_cu = 1;
   return 256 * per_cu;
 }
 struct ApproxArgs {
@@ -907,21 +907,30 @@ __global__ __launch_bounds__(256) void small_select_kernel(const float* __restri
     sh_w22 = 1.f / w;
   }
   const float span = 1.0001f - lo, inv = span > 0.f ? (float)SSEL_BINS / span : 0.f, width = span / (float)SSEL_BINS;
-  // pass 1: histogram of the approximate scores (a list's entries are contiguous: four per 16-byte load)
+  // pass 1: histogram of the approximate scores.  The lists were written by the pass before, on other XCDs: every load here is a trip to the
+  // fabric (~1.5 us) - a thread's counts are requested together, then the first eight entries of all its lists together (an average list holds
+  // four); a loop of count -> entries -> next list was 10 dependent trips per thread, most of this kernel.
+  constexpr int LPT = 8;                                            // lists per thread (nwg <= 2048)
+  unsigned lc[LPT]; float4 la[LPT], lb[LPT];
   unsigned o = 0u;
-  if (!fail)
-    for (int g = tid; g < nwg; g += 256) {
-      const unsigned c0 = cnt[g];
-      if (c0 > (unsigned)ASLOT) o = 1u;
-      const unsigned c = min(c0, (unsigned)ASLOT);
-      for (unsigned e0 = 0; e0 < c; e0 += 4) {
-        const float4 va = *reinterpret_cast<const float4*>(cs + (long)g * ASLOT + e0);
-        const float v[4] = {va.x, va.y, va.z, va.w};
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (e0 + u < c) { int b = (int)((v[u] - lo) * inv); b = b < 0 ? 0 : (b > SSEL_BINS - 1 ? SSEL_BINS - 1 : b); atomicAdd(&hist[b], 1u); }
-      }
-    }
+  for (int j = 0; j < LPT; ++j) { const int g = tid + 256 * j; lc[j] = (!fail && g < nwg) ? cnt[g] : 0u; }
+#pragma unroll
+  for (int j = 0; j < LPT; ++j) {
+    const int g = tid + 256 * j;
+    if (lc[j] > (unsigned)ASLOT) { o = 1u; lc[j] = (unsigned)ASLOT; }
+    la[j] = lc[j] > 0u ? *reinterpret_cast<const float4*>(cs + (long)g * ASLOT) : make_float4(0.f, 0.f, 0.f, 0.f);
+    lb[j] = lc[j] > 4u ? *reinterpret_cast<const float4*>(cs + (long)g * ASLOT + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto bin_of = [&](float v) { int b_ = (int)((v - lo) * inv); return b_ < 0 ? 0 : (b_ > SSEL_BINS - 1 ? SSEL_BINS - 1 : b_); };
+#pragma unroll
+  for (int j = 0; j < LPT; ++j) {
+    const int g = tid + 256 * j;
+    const float v[8] = {la[j].x, la[j].y, la[j].z, la[j].w, lb[j].x, lb[j].y, lb[j].z, lb[j].w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if ((unsigned)u < lc[j]) atomicAdd(&hist[bin_of(v[u])], 1u);
+    for (unsigned e = 8; e < lc[j]; ++e) atomicAdd(&hist[bin_of(cs[(long)g * ASLOT + e])], 1u);      // (2 % of the lists)
+  }
   if (o) over = 1u;
   __syncthreads();
   fail = fail || over != 0u;
@@ -942,18 +951,17 @@ __global__ __launch_bounds__(256) void small_select_kernel(const float* __restri
   }
   __syncthreads();
   const float tau2 = lo + ((float)cutbin - 1.f) * width - margin2;
-  // pass 2: the candidates at or above the cut
-  if (!fail)
-    for (int g = tid; g < nwg; g += 256) {
-      const unsigned c = min(cnt[g], (unsigned)ASLOT);
-      for (unsigned e0 = 0; e0 < c; e0 += 4) {
-        const float4 va = *reinterpret_cast<const float4*>(cs + (long)g * ASLOT + e0);
-        const float v[4] = {va.x, va.y, va.z, va.w};
+  // pass 2: the candidates at or above the cut (their scores are still in registers)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (e0 + u < c && v[u] >= tau2) { const unsigned pos = atomicAdd(&list_n, 1u); if (pos < (unsigned)SSEL_MAX) rows[pos] = ci[(long)g * ASLOT + e0 + u]; }
-      }
-    }
+  for (int j = 0; j < LPT; ++j) {
+    const int g = tid + 256 * j;
+    const float v[8] = {la[j].x, la[j].y, la[j].z, la[j].w, lb[j].x, lb[j].y, lb[j].z, lb[j].w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if ((unsigned)u < lc[j] && v[u] >= tau2) { const unsigned pos = atomicAdd(&list_n, 1u); if (pos < (unsigned)SSEL_MAX) rows[pos] = ci[(long)g * ASLOT + u]; }
+    for (unsigned e = 8; e < lc[j]; ++e)
+      if (cs[(long)g * ASLOT + e] >= tau2) { const unsigned pos = atomicAdd(&list_n, 1u); if (pos < (unsigned)SSEL_MAX) rows[pos] = ci[(long)g * ASLOT + e]; }
+  }
   __syncthreads();
   const unsigned m = list_n;
   fail = fail || m > (unsigned)SSEL_MAX || m < (unsigned)k;
@@ -967,12 +975,12 @@ __global__ __launch_bounds__(256) void small_select_kernel(const float* __restri
       if ((d & 3) == 0) {
         const int n4 = d >> 2;
 #pragma unroll 1
-        for (int c0 = 0; c0 < n4; c0 += 16) {
-          float4 bv4[16];
+        for (int c0 = 0; c0 < n4; c0 += 32) {                      // the whole row in one round of loads (d <= 128)
+          float4 bv4[32];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) bv4[u] = reinterpret_cast<const float4*>(b)[c0 + u < n4 ? c0 + u : n4 - 1];
+          for (int u = 0; u < 32; ++u) bv4[u] = reinterpret_cast<const float4*>(b)[c0 + u < n4 ? c0 + u : n4 - 1];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) if (c0 + u < n4) {
+          for (int u = 0; u < 32; ++u) if (c0 + u < n4) {
             const float4 nv = reinterpret_cast<const float4*>(ndl)[c0 + u];
             const float bb[4] = {bv4[u].x, bv4[u].y, bv4[u].z, bv4[u].w}, nn[4] = {nv.x, nv.y, nv.z, nv.w};
 #pragma unroll
