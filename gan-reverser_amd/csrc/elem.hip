@@ -1415,6 +1415,20 @@ void launch_downsum2(const float* gup, float* gin, int B, int C, int Hs, int Ws,
 __global__ void scale_copy_kernel(const float* src, float* dst, long n, float scale) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
 }
+__global__ __launch_bounds__(256) void zero_regions_kernel(ZeroJobs jobs) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int j = 0; j < jobs.n; ++j) {
+    uint4* p = reinterpret_cast<uint4*>(jobs.ptr[j]);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < jobs.n16[j]; i += (long)gridDim.x * blockDim.x) p[i] = z;
+  }
+}
+void launch_zero_regions(const ZeroJobs& jobs, hipStream_t s) {
+  long tot = 0; for (int j = 0; j < jobs.n; ++j) tot += jobs.n16[j];
+  if (tot <= 0) return;
+  long blocks = (tot + 255) / 256; if (blocks > 4096) blocks = 4096;
+  KtScope kt("zero_regions_kernel", 0.0, 16.0 * (double)tot, s);
+  hipLaunchKernelGGL(zero_regions_kernel, dim3((unsigned)blocks), dim3(256), 0, s, jobs);
+}
 void launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s) {
   long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n, scale);

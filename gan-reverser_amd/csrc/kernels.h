@@ -367,6 +367,10 @@ void launch_spread_verdict(unsigned* chmax, int C, unsigned* word, int side, hip
 void launch_pair_spread(const float* a, const float* b, int C, unsigned* word, hipStream_t s);
 void launch_l2_distance_rows(const float* a, const float* b, long n, long d, double* out, hipStream_t s);
 void launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s);
+// several regions zeroed by ONE launch (each a multiple of 16 bytes, 16-byte aligned): the fills a training step needs - the scale slots of both
+// nets, the gradient vector - were three hipMemsetAsync kernels of ~6 us each at batch 256
+struct ZeroJobs { void* ptr[4]; long n16[4]; int n; };
+void launch_zero_regions(const ZeroJobs& jobs, hipStream_t s);
 void launch_upsample2(const float* x, float* up, int B, int C, int Ho, int Wo, hipStream_t s);       // nearest x2, [B,C,Ho/2,Wo/2] -> [B,C,Ho,Wo]
 void launch_downsum2(const float* gup, float* gin, int B, int C, int Hs, int Ws, hipStream_t s);   // its backward: sum of each 2x2 block
 

@@ -441,6 +441,7 @@ struct gr_net {
   uint64_t prepped_version[3] = {0, 0, 0};
   unsigned* amax = nullptr;          // f16x3 scale tracking, groups of [nst] slots: x | y | kb | dy | dz | w  (AMAX_GROUPS)
   bool dy_slots_zeroed = false, w_slots_zeroed = false;   // set by forward_impl's single fill, consumed by backward / weight prep
+  int amax_prezeroed_groups = 0;     // > 0: the caller (gr_train_r_step's one fill per step) has just zeroed that many slot groups: the next forward skips its own fill
   bool keep_fp32 = false;            // range-guarded host calls: no lean (operand-ready only) tensors, so a backward can still fall back to bf16x6
   bool last_fwd_fell_back = false;   // the last guarded forward ran on bf16x6: its backward does too
   unsigned guard_sides = 0;           // the largest spreads (bits: activation side | weight side << 16) the last guarded forward measured
@@ -988,10 +989,11 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
   if (f16) {
     const bool w_too = n->training && n->prepped_version[2] != n->params_version;
     const size_t groups = w_too ? AMAX_GROUPS : (n->training ? AG_W : AG_KB);      // x xt y | kb dy dz | w
-    HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst * groups, c->stream));
+    if ((size_t)n->amax_prezeroed_groups < groups) HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst * groups, c->stream));
     n->dy_slots_zeroed = groups >= (size_t)AG_W;
     n->w_slots_zeroed = groups == (size_t)AMAX_GROUPS;
   }
+  n->amax_prezeroed_groups = 0;
   r = prep_weights(n); if (r) return r;
   {
     // Dropout noise of every stage, drawn in one launch (injected masks - tests - are consumed instead)
@@ -1754,13 +1756,30 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   }
   if (tm) (void)hipEventRecord(c->ev[0], c->stream);
   g->training = false;                                         // train_r.lua:70  MODEL_G:evaluate()
+  rn->training = true;
+  {
+    // ONE fill per step: the f16x3 scale slots of both nets (what their forwards would each zero themselves) and R's gradient vector
+    // (train_r.lua:143 gradParameters:zero()) - three hipMemsetAsync kernels of ~6 us each at batch 256 otherwise
+    ZeroJobs z{}; z.n = 0;
+    static const bool one_fill = !getenv("GR_NO_STEP_FILL");       // A/B control: every forward zeroes its own slots, the gradients get their own fill
+    if (c->conv_mode == 2 && one_fill) {
+      const int gg = AG_KB;                                                                      // G: evaluate() mode
+      const int gr_ = rn->prepped_version[2] != rn->params_version ? AMAX_GROUPS : AG_W;         // R: training; the w group when the weight images are stale
+      z.ptr[z.n] = g->amax; z.n16[z.n++] = (long)(sizeof(unsigned) * AMAX_WORDS * g->st.size() * gg / 16);
+      z.ptr[z.n] = rn->amax; z.n16[z.n++] = (long)(sizeof(unsigned) * AMAX_WORDS * rn->st.size() * gr_ / 16);
+      g->amax_prezeroed_groups = gg; rn->amax_prezeroed_groups = gr_;
+    }
+    if (one_fill && rn->n_params % 4 == 0 && ((uintptr_t)rn->grads & 15) == 0) { z.ptr[z.n] = rn->grads; z.n16[z.n++] = (long)(rn->n_params / 4); }
+    else { r = gr_net_zero_grads(rn); if (r) return r; }
+    g_kphase = 1;
+    launch_zero_regions(z, c->stream);
+    LAUNCHCHK(c);
+  }
   g_kphase = 1;
   { PhaseRange pr("G forward"); r = forward_impl(g, noise_dev, B); } if (r) return r;          // train_r.lua:139
   const float* images = g->st.back().out;
   if (tm) (void)hipEventRecord(c->ev[1], c->stream);
-  rn->training = true;
   g_kphase = 2;
-  r = gr_net_zero_grads(rn); if (r) return r;                  // :143
   { PhaseRange pr("R forward"); r = forward_impl(rn, images, B); } if (r) return r;            // :146
   if (tm) (void)hipEventRecord(c->ev[2], c->stream);
   g_kphase = 3;
