@@ -1529,6 +1529,15 @@ __device__ __forceinline__ void conv_p16_quad_body(const ConvArgs& a, const uint
       for (int i = 0; i < a.nchunks; ++i) __builtin_amdgcn_s_sleep(8);  // a.nchunks (unused otherwise on this path) = the delay in units of 8 x 64 clocks
     }
   }
+  // PO: the evaluate()-mode BatchNorm coefficients of this workgroup's CT channels wait in LDS behind the operand image (the epilogue's 4 values per
+  // channel as lane-dependent global loads - 64 per lane and 32-channel block, a round trip each - cost more than the multiplies of a 64-channel layer)
+  float* bnp = reinterpret_cast<float*>(smem_raw + (size_t)LBUF * 16);
+  if constexpr (PO) {
+    if (a.ep.mean && tid < CT) {
+      const int o = min(o0 + tid, a.Cout - 1);
+      bnp[tid] = a.ep.mean[o]; bnp[CT + tid] = a.ep.invstd[o]; bnp[2 * CT + tid] = a.ep.gamma[o]; bnp[3 * CT + tid] = a.ep.beta[o];
+    }
+  }
   if (!(dbg & 4)) GR_P16_DMA(0)
   for (int ch = 0; ch < nchunks; ++ch) {
     dma_publish_barrier();                                           // the image holds chunk ch
@@ -1637,6 +1646,68 @@ __device__ __forceinline__ void conv_p16_quad_body(const ConvArgs& a, const uint
     const bool want_max = a.amax_out != nullptr;
     float sc16 = 1.f;
     if constexpr (PO) sc16 = pow2f(f16_scale_exp(absmax_read(a.p16_scale)));
+    if constexpr (PO) {      // (PO kernels write the operand-ready image only: the launcher passes no fp32 destination)
+      // Operand-ready output ONLY (the evaluate()-mode chain: nobody reads the fp32 tensor) - straight from the accumulators, no LDS.  A lane
+      // holds, of every 8-channel group g of a 32-channel block, the four channels 8 g + 4 h .. + 3 of ITS pixel; lane l + 32 holds the other
+      // four of the same pixel.  Per group the epilogue's values are split and packed into two dwords per term; v_permlane32_swap then
+      // trades halves between the lane pair - groups (p, p + 2): the low lane ends with all of group p, the high lane with all of group
+      // p + 2 - and every lane stores whole 16-byte vectors: 32 consecutive pixels x 16 bytes per half-wave and (group, term) plane.
+      // (First form of the round: the LDS staging image read back column by column - 128 ds_write + 128 ds_read per lane and block, 0.30 ms
+      // of cfg5's 1.25 ms in these kernels went to the epilogue.)
+      const int Gout = a.Cout >> 3;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                            // channel groups pp and pp + 2 of the block: the pair that trades halves
+          unsigned X[NG][2][4];                                     // [pixel group][group pp / pp + 2][hi.x, hi.y, lo.x, lo.y]
+#pragma unroll
+          for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int r = 4 * (pp + 2 * gi) + j;
+              const int chl = (r & 3) + 8 * (r >> 2) + 4 * h, cl = mt * 32 + chl;
+              float v4[NG];
+              if (a.ep.mean) {
+                const float bm = bnp[cl], bi = bnp[CT + cl], bg = bnp[2 * CT + cl], bb = bnp[3 * CT + cl];
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng) v4[ng] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(acc[mt][ng][r], bm), bi), bg), bb);
+              } else {
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng) v4[ng] = acc[mt][ng][r];
+              }
+              conv_act_block<NG>(a.ep, v4);
+#pragma unroll
+              for (int ng = 0; ng < NG; ++ng) {
+                if (want_max && pin[ng] && o0 + mt * 32 + chl < a.Cout) omax = fmaxf(omax, fabsf(v4[ng]));
+                const float sv = v4[ng] * sc16;                     // split8_f16's roundings
+                const _Float16 h0 = (_Float16)sv; const float rr = sv - (float)h0; const _Float16 h1 = (_Float16)rr;
+                const unsigned u0 = __builtin_bit_cast(unsigned short, h0), u1 = __builtin_bit_cast(unsigned short, h1);
+                if (j & 1) { X[ng][gi][j >> 1] |= u0 << 16; X[ng][gi][2 + (j >> 1)] |= u1 << 16; }
+                else { X[ng][gi][j >> 1] = u0; X[ng][gi][2 + (j >> 1)] = u1; }
+              }
+            }
+#pragma unroll
+          for (int ng = 0; ng < NG; ++ng) {
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+              const auto sw = __builtin_amdgcn_permlane32_swap(X[ng][0][d4], X[ng][1][d4], false, false);      // vdst lanes 32-63 <-> src lanes 0-31
+              X[ng][0][d4] = sw[0]; X[ng][1][d4] = sw[1];
+#endif
+            }
+            const int grp = (o0 + mt * 32) / 8 + (h ? pp + 2 : pp);
+            if (pin[ng] && grp < Gout) {
+              const int p = (wave * NG + ng) * 32 + l31; int prr, pc; tile_pixel<TW>(p, prr, pc);
+              const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
+              uint4* dst = a.p16_out + ((size_t)(b + img) * Gout + grp) * 2 * HW + (size_t)(y0 + pr) * W + (x0 + pc);
+              store4(dst, make_uint4(X[ng][0][0], X[ng][0][1], X[ng][1][0], X[ng][1][1]), false);
+              store4(dst + HW, make_uint4(X[ng][0][2], X[ng][0][3], X[ng][1][2], X[ng][1][3]), false);
+            }
+          }
+        }
+      }
+    }
+    if constexpr (!PO) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (plain) {
@@ -1656,34 +1727,7 @@ __device__ __forceinline__ void conv_p16_quad_body(const ConvArgs& a, const uint
           for (int ng = 0; ng < NG; ++ng) stg[chl * RS + ng * 32 + l31] = v4[ng];
         }
       }
-      if constexpr (PO) {
-        // Operand-ready output: item = (8-channel group g of this 32-channel block, pixel pxl of the wave's 32 * NG): the 8 channel rows of
-        // the staging image at one pixel column (consecutive lanes = consecutive pixels: conflict-free reads), split into the two fp16 term
-        // vectors, two 16-byte stores; a wave-instruction covers 64 consecutive pixels of one (group, term) plane on a 32-wide plane.
-        constexpr int NPX = 32 * NG, ITEMS = 4 * NPX / 64;
-        const int Gout = a.Cout >> 3;
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-          const int it = i * 64 + lane, g = it / NPX, pxl = it - g * NPX;
-          float x8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) x8[j] = stg[(8 * g + j) * RS + pxl];
-          int prr, pc; tile_pixel<TW>(wave * NPX + pxl, prr, pc);
-          const int img = NI > 1 ? prr / IH : 0, pr = NI > 1 ? prr - img * IH : prr;
-          const int y = y0 + pr, x = x0 + pc, o8 = o0 + mt * 32 + 8 * g;
-          if (y < H && x < W && b + img < a.B && o8 < a.Cout) {
-            uint4 t0, t1;
-            split8_f16(x8, sc16, t0, t1);
-            uint4* dst = a.p16_out + ((size_t)(b + img) * Gout + (o8 >> 3)) * 2 * HW + (size_t)y * W + x;
-            store4(dst, t0, false); store4(dst + HW, t1, false);
-            if (want_max && !a.out) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) omax = fmaxf(omax, fabsf(x8[j]));
-            }
-          }
-        }
-      }
-      if (!PO || a.out) {
+      {
 #pragma unroll
       for (int i = 0; i < 32 / CPI; ++i) {
         const int chl = CPI * i + hq, o = o0 + mt * 32 + chl;
@@ -1694,6 +1738,7 @@ __device__ __forceinline__ void conv_p16_quad_body(const ConvArgs& a, const uint
         }
       }
       }
+    }
     }
   }
   if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GR_STAMP() if (tid == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[nstamp++] = t_; stamps[31] = nstamp; } }
@@ -2463,11 +2508,13 @@ static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin,
   static const std::string name = "conv3x3_p16_quad_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ", " + std::to_string(NG) + ", " + std::to_string(MT) + ">";   // as rocprofv3 prints it (default template arguments included)
   const double px = (double)a.B * a.H * a.W;
   if (a.p16_out) {      // evaluate() mode: the result leaves operand-ready (same kernel body, its own symbol)
+    const size_t lds_po = lds + 16 * CT;                            // + the BatchNorm coefficients of the CT channels
+    static_assert((MT == 1 ? 4 : 2) * (16 * (size_t)LBUF + 16 * CT) <= 160 * 1024, "PO: the coefficient block fits beside the images of a CU's workgroups");
     static bool attr_po = false;
-    if (!attr_po) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_quad_po_kernel<TW, NI, NG, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_po = true; }
+    if (!attr_po) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_quad_po_kernel<TW, NI, NG, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_po); attr_po = true; }
     static const std::string name_po = "conv3x3_p16_quad_po_kernel<" + std::to_string(TW) + ", " + std::to_string(NI) + ", " + std::to_string(NG) + ", " + std::to_string(MT) + ">";
     KtScope kt(name_po.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-    hipLaunchKernelGGL((conv3x3_p16_quad_po_kernel<TW, NI, NG, MT>), dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
+    hipLaunchKernelGGL((conv3x3_p16_quad_po_kernel<TW, NI, NG, MT>), dim3(a.n_tiles), dim3(256), lds_po, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
     return a.stat_tiles;
   }
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
