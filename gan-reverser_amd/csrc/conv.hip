@@ -1921,6 +1921,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
   }
   const int wq = dxq * 64 + hh * 32 + l15;
   constexpr int LBUF = 2 * 2 * PSL + WV;                           // uint4s of one (patch, weights) image
+  // the epilogue's per-channel values (bias, evaluate()-mode BatchNorm coefficients of the workgroup's 32 channels) wait in LDS behind the
+  // images: as lane-dependent global loads inside the epilogue they were 40 round trips per pixel block, repeated for each of the blocks
+  float* epar = reinterpret_cast<float*>(smem_raw + (size_t)(DB ? 2 : 1) * LBUF * 16);
+  if (tid < 32) {
+    const int o = min(o0 + tid, a.Cout - 1);
+    epar[tid] = a.bias ? a.bias[o] : 0.f;
+    if (a.ep.mean) { epar[32 + tid] = a.ep.mean[o]; epar[64 + tid] = a.ep.invstd[o]; epar[96 + tid] = a.ep.gamma[o]; epar[128 + tid] = a.ep.beta[o]; }
+  }
   GR_UP_LOAD(0)
   if (COMPACT) {                                                   // the padding slots, once (both images when double-buffered)
     for (int i = tid; i < (DB ? 2 : 1) * LBUF; i += NT) if (i % LBUF < 2 * 2 * PSL) patch[i] = make_uint4(0, 0, 0, 0);
@@ -1970,10 +1978,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_up2_f16x3_kernel(ConvArgs a, c
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int o = min(o0 + mb * 16 + q * 4 + r, a.Cout - 1);
-        const float bvv = a.bias ? a.bias[o] : 0.f;
+        const int cl = mb * 16 + q * 4 + r;                          // bias and BatchNorm coefficients from the LDS block (epar)
+        const float bvv = epar[cl];
         float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
-        if (has_bn) { mean = a.ep.mean[o]; invstd = a.ep.invstd[o]; gam = a.ep.gamma[o]; bet = a.ep.beta[o]; }
+        if (has_bn) { mean = epar[32 + cl]; invstd = epar[64 + cl]; gam = epar[96 + cl]; bet = epar[128 + cl]; }
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
           float t = ldexpf(acc[ph >> 1][ph & 1][mb][nb][r], -ktot) + bvv;
@@ -2033,6 +2041,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, 
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
   const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
   const int y0 = ty * TR, x0 = tx * TW, o0 = ot * 32;
+  // the epilogue's per-channel values in LDS behind the image (conv3x3_up2_f16x3_kernel: epar)
+  float* epar = reinterpret_cast<float*>(smem_raw + (size_t)(PVP + WV) * 16);
+  if (tid < 32) {
+    const int o = min(o0 + tid, a.Cout - 1);
+    epar[tid] = a.bias ? a.bias[o] : 0.f;
+    if (a.ep.mean) { epar[32 + tid] = a.ep.mean[o]; epar[64 + tid] = a.ep.invstd[o]; epar[96 + tid] = a.ep.gamma[o]; epar[128 + tid] = a.ep.beta[o]; }
+  }
   const int Hs = a.H >> 1, Ws = a.W >> 1;                        // source plane
   const size_t HWs = (size_t)Hs * Ws;
   const float* in_base = a.in + (size_t)b * a.Cin * HWs;
@@ -2147,10 +2162,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, 
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int o = min(o0 + mb * 16 + q * 4 + r, a.Cout - 1);
-        const float bvv = a.bias ? a.bias[o] : 0.f;
+        const int cl = mb * 16 + q * 4 + r;                          // bias and BatchNorm coefficients from the LDS block (epar)
+        const float bvv = epar[cl];
         float mean = 0.f, invstd = 1.f, gam = 1.f, bet = 0.f;
-        if (has_bn) { mean = a.ep.mean[o]; invstd = a.ep.invstd[o]; gam = a.ep.gamma[o]; bet = a.ep.beta[o]; }
+        if (has_bn) { mean = epar[32 + cl]; invstd = epar[64 + cl]; gam = epar[96 + cl]; bet = epar[128 + cl]; }
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
           float t = ldexpf(acc[ph >> 1][ph & 1][mb][nb][r], -ktot) + bvv;
@@ -2236,7 +2251,7 @@ static void launch_conv_up2_db(ConvArgs a, const void* wup, hipStream_t s) {
   const int Hs = a.H / 2, Ws = a.W / 2;
   a.tiles_x = (Ws + TW - 1) / TW; a.tiles_y = NI > 1 ? 1 : (Hs + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / 32;
-  const size_t lds = (DB ? 2 : 1) * 16 * (size_t)(2 * 2 * PSL + 2 * 2 * 8 * 2 * 32);
+  const size_t lds = (DB ? 2 : 1) * 16 * (size_t)(2 * 2 * PSL + 2 * 2 * 8 * 2 * 32) + 5 * 32 * 4;     // + the epilogue's per-channel block
   const int grid = ((a.B + NI - 1) / NI) * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2_f16x3_kernel<TW, NI, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
@@ -2249,7 +2264,7 @@ static void launch_conv_up2_db(ConvArgs a, const void* wup, hipStream_t s) {
 template <int TW, int NI>
 static void launch_conv_up2_t(const ConvArgs& a, const void* wup, hipStream_t s) {
   constexpr int IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), PSL = (PS + 15) / 16 * 16;
-  constexpr bool FITS = 2 * 16 * (2 * 2 * PSL + 2 * 2 * 8 * 2 * 32) <= 160 * 1024;    // two LDS images where they fit (not the 8-wide tile)
+  constexpr bool FITS = 2 * 16 * (2 * 2 * PSL + 2 * 2 * 8 * 2 * 32) + 5 * 32 * 4 <= 160 * 1024;    // two LDS images where they fit (not the 8-wide tile)
   static int db = -1;
   if (db < 0) { const char* e = getenv("GR_UP2_DB"); db = e ? atoi(e) : 1; }
   if (FITS && db) launch_conv_up2_db<TW, NI, FITS>(a, wup, s);
@@ -2262,7 +2277,7 @@ static void launch_conv_up2q(ConvArgs a, const void* wup, hipStream_t s) {
   a.tiles_x = (Ws + TW - 1) / TW; a.tiles_y = (Hs + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / 32;
   a.nchunks = g_up2_stagger;
-  const size_t lds = 16 * (size_t)(PVP + 2 * 2 * 8 * 2 * 32);
+  const size_t lds = 16 * (size_t)(PVP + 2 * 2 * 8 * 2 * 32) + 5 * 32 * 4;       // + the epilogue's per-channel block
   const int grid = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_up2q_f16x3_kernel<TW, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
