@@ -496,7 +496,7 @@ __device__ __forceinline__ void conv_fewin_body(const ConvArgs& a, const float* 
 template <int CI>
 __global__ __launch_bounds__(256) void conv3x3_fewin_kernel(ConvArgs a, const float* __restrict__ w_native) { conv_fewin_body<CI, false>(a, w_native); }
 template <int CI>
-__global__ __launch_bounds__(256) void conv3x3_fewin_p16o_kernel(ConvArgs a, const float* __restrict__ w_native) { conv_fewin_body<CI, true>(a, w_native); }
+__global__ __launch_bounds__(256, 4) void conv3x3_fewin_p16o_kernel(ConvArgs a, const float* __restrict__ w_native) { conv_fewin_body<CI, true>(a, w_native); }
 bool conv_fewin_applies(int Cin, int W, bool up) { return Cin <= 3 && !up && W % 4 == 0 && W >= 4; }
 bool conv_fewin_p16_out_supported(int Cout, int H, int W) { return Cout % 8 == 0 && Cout <= 256 && W % 4 == 0; }
 void launch_conv3x3_fewin(const float* in, const float* w_native, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
