@@ -266,7 +266,7 @@ def search_cfg5(ctx):
                 batched_1024=batched,
                 note="ms = one gr_cosine_topk_dev call: three launches (fp32 filter over a strided sample with the bound folded in, fp32 filter over "
                      "the table by LDS-DMA tiles, exact re-score + sort of the survivors), the 5 x 50 results written by the last kernel into pinned "
-                     "host memory, one host wait")
+                     "host memory behind one completion word per needle, which the host polls")
 
 
 def embed_cfg5(ctx, rows, with_oracle=True, train_steps=300):
