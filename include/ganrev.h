@@ -177,6 +177,11 @@ int gr_get_conv_mode(gr_ctx* ctx);
 /* kernel-selection thresholds (process-wide).  "p16_min_tiles" (default 256): smallest tile count at which a convolution takes the
  * operand-ready (P16) kernel; tests set 1 to exercise that path on small shapes. */
 int gr_set_tuning(gr_ctx* ctx, const char* key, int value);
+/* "eval_p16" (default 1; f16x3 arithmetic): in evaluate() mode (apply_r.lua:120-153: MODEL_R:forward on generated images) a stage hands its output to the
+ * next 3x3 convolution as that convolution's operand-ready image (fp16 hi / lo vectors written by the convolution epilogue or the pooling stage's pipeline
+ * kernel, scaled by an a-priori bound from the weights' per-channel L1 norms and the measured maximum of the stage's input) instead of as an fp32 tensor.
+ * Same 1e-4 parity bar; a pure function of the stage's input and parameters (chunks, batch sizes and the host-memory calls agree bit for bit).  0 keeps
+ * the fp32 tensors between the stages (gr_net_layer_output can then read them; a gr_net_backward_* after an evaluate()-mode forward needs them). */
 /* "sync_bn" (default 0): synchronised BatchNorm under data parallelism (optional).  With a communicator (or the host-exchange
  * hook) on the context, every training-mode BatchNorm adds its per-channel batch sums over the ranks - (sum y, sum y^2) in the forward,
  * (sum dz, sum dz (y - mean)) in the backward, 2 x C doubles each - before it uses them, so that P ranks of B images compute what ONE
