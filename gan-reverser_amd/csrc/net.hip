@@ -439,7 +439,7 @@ struct gr_net {
   uint8_t* mask_stage = nullptr; size_t mask_stage_cap = 0;
   PrepJob* jobs_dev[3] = {nullptr, nullptr, nullptr}; int njobs[3] = {0, 0, 0};   // [0] fp32 k-major images, [1] bf16x6, [2] f16x3 split images
   uint64_t prepped_version[3] = {0, 0, 0};
-  unsigned* amax = nullptr;          // f16x3 scale tracking, groups of [nst] slots: x | y | kb | dy | dz | w  (AMAX_GROUPS)
+  unsigned* amax = nullptr;          // f16x3 scale tracking, groups of [nst] slots: x xt y | kb dy dz | w  (AG_*, AMAX_GROUPS)
   bool dy_slots_zeroed = false, w_slots_zeroed = false;   // set by forward_impl's single fill, consumed by backward / weight prep
   int amax_prezeroed_groups = 0;     // > 0: the caller (gr_train_r_step's one fill per step) has just zeroed that many slot groups: the next forward skips its own fill
   bool keep_fp32 = false;            // range-guarded host calls: no lean (operand-ready only) tensors, so a backward can still fall back to bf16x6
@@ -1855,8 +1855,8 @@ extern "C" int gr_cosine_topk_dev(gr_ctx* c, const float* emb, int64_t N, int d,
     if (lr < 0) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
     LAUNCHCHK(c);
     // The selection kernel publishes one completion word per needle behind its results (system-scope release): poll them instead of
-    // synchronising the stream - the wake-up of hipStreamSynchronize costs ~10 us of a 0.13 ms search.  Bounded: after 20 ms the stream is
-    // synchronised after all (a fault shows up there).
+    // synchronising the stream (measured: 1-3 us of a 0.15 ms search).  Bounded: after 20 ms the stream is synchronised after all (a fault
+    // shows up there).
     static const bool poll_on = !getenv("GR_SEARCH_NO_POLL");
     bool seen = false;
     if (lr == 2 && poll_on) {
