@@ -707,6 +707,7 @@ struct ApproxArgs {
   unsigned* cand_idx; float* cand_sc; unsigned* counts;   // main pass: [Q][nwg][ASLOT], [Q][nwg]
   unsigned* status;
   int Q, k, accf; float eps2;
+  int dbg;                                       // diagnostic ablations of the sample launch (GR_SEARCH_DEBUG bits 8, 16, 32: results then rely on an earlier call's thresholds)
 };
 template <int D4, int NQ, int MODE>
 __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict__ emb, long N, long stride, SmallQ qr, ApproxArgs a) {
@@ -755,6 +756,7 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
   for (int q = 0; q < NQ; ++q) { tauq[q] = (MODE == 1 && q < Q) ? a.tau[q] : INFINITY; cnt[q] = 0u; wmax[q] = -INFINITY; }
   int buf = 0;
   for (long t = wg; t < ntiles; t += nwg, buf = buf + 1 == NB ? 0 : buf + 1) {
+    if (MODE == 0 && (a.dbg & 32)) break;                         // ablation: no sample tile
     if (NB == 1) request(t, 0);                                   // (the sample: one tile per workgroup)
     // tile t has landed once at most the requests issued AFTER it are outstanding: V per tile already requested behind it (vmcnt counts in issue order)
     if (NB >= 3 && t + (long)(NB - 2) * nwg < ntiles) {
@@ -825,6 +827,7 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
     if (lane == 0 && q < Q) a.wgmax[(long)q * nwg + wg] = m;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (a.dbg & 16) return;                                          // ablation: no arrival, no threshold
   unsigned arrived = 0u;
   if (lane == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -836,6 +839,7 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next search
+  if (a.dbg & 8) return;                                           // ablation: the last workgroup's threshold computation
   // The k-th largest of the nwg maxima per needle (k of them are k distinct rows at or above it), exactly, by one wave and without LDS:
   // every lane holds four of the <= 256 maxima as orderable bit patterns (all Q x 4 loads in flight together), and the answers are built
   // bit by bit from the top, all needles in the same round - res |= bit while at least k patterns are >= the trial value (32 rounds of
@@ -849,11 +853,24 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
       const int e = lane + 64 * u;
       ov[q][u] = (q < Q && e < nwg) ? orderable(__hip_atomic_load(a.wgmax + (long)q * nwg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
     }
+  // (rounds: from the highest bit in which ANY two of the patterns differ - the bits above it are common to all of them and to the answer - down to
+  // bit 8: the threshold ends up at most 2^-15 of itself low, which costs nothing; 16-18 rounds instead of 32 - the loop was 8 of the tail's 12 us)
   unsigned res[NQ];
+  int top = 0;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) res[q] = 0u;
+  for (int q = 0; q < NQ; ++q) {
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (q < Q && lane + 64 * u < nwg) { lo = min(lo, ov[q][u]); hi = max(hi, ov[q][u]); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64)); hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64)); }
+    const unsigned diff = lo ^ hi;                                  // (q >= Q: lo = ~0, hi = 0: ignored below)
+    const int tb = (q < Q && diff) ? 31 - __builtin_clz(diff) : -1;
+    res[q] = (q < Q && tb < 31) ? (hi >> (tb + 1)) << (tb + 1) : 0u;    // the common prefix
+    top = max(top, tb);
+  }
 #pragma unroll 1
-  for (int b = 31; b >= 0; --b) {
+  for (int b = top; b >= 8; --b) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const unsigned t = res[q] | (1u << b);
@@ -1106,7 +1123,7 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
     SmallQ qr{}; for (int q = 0; q < AQ_MAX; ++q) qr.rows[q] = query_rows_host[q < Q ? q : 0];
     ApproxArgs a{};
     a.needles = needles; a.w22 = w22; a.wgmax = wgmax; a.counter = counter; a.tau = tau; a.cand_idx = cidx; a.cand_sc = csc; a.counts = wcnt;
-    a.status = status_dev; a.Q = Q; a.k = k; a.accf = accf; a.eps2 = 2.f * (float)(2 * d + 16) * 5.9604645e-8f;
+    a.status = status_dev; a.Q = Q; a.k = k; a.accf = accf; a.eps2 = 2.f * (float)(2 * d + 16) * 5.9604645e-8f; a.dbg = g_search_debug;
     {
       KtScope kt("cos_approx_kernel (sample + bound)", 0.0, 4.0 * S * d, s);
       launch_approx<0>(d / 4, Q, swg, s, emb, S, stride, qr, a);
