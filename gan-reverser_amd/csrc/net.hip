@@ -874,7 +874,7 @@ static PostArgs post_args(gr_net* n, Stage& s, int B) {
 // 20 bits per entry of the smallest channel, ~1e-6 of that channel's maximum.
 // (Until round 3 the two largest spreads of EITHER side were added.  Two BatchNorm layers never multiply each other, and Torch's
 // default gamma ~ U(0, 1) spreads 8-14 bits over 64-512 channels: two of five default-initialised R nets tripped that rule at
-// their first step and trained on bf16x6 for nothing - tools/debug_guard_trip.py.)
+// their first step and trained on bf16x6 for nothing - tools/debug/debug_guard_trip.py.)
 enum { GUARD_BUDGET_BITS = 20 };
 static bool guard_over_budget(unsigned word) { return (word & 0xffffu) + (word >> 16) > (unsigned)GUARD_BUDGET_BITS; }
 static unsigned guard_merge(unsigned t, unsigned u) {        // per side, the larger of both words' entries

@@ -436,7 +436,7 @@ def test_dead_channels_between_two_guard_scans_in_the_device_loop(ctx, oracle, c
     dead channel's lost bits change downstream is below 1e-10.  Asserted: (1) a step that runs with such weights BETWEEN two scans
     (t = 2: no scan due; in f16x3 mode the context must still be on f16x3 afterwards) meets every parity bar against the oracle -
     images, recovered noise, loss, and every RAW gradient tensor at 1e-4 of its module's largest entry (measured on MI355X: 4-7e-6
-    in f32, bf16x6 and f16x3 alike - tools/debug_dead.py; the dead channels' own gradients are ~35, amplified by that 316, so the
+    in f32, bf16x6 and f16x3 alike - tools/debug/debug_dead.py; the dead channels' own gradients are ~35, amplified by that 316, so the
     comparison is made before the clamp, which would otherwise hide them all at +-1); (2) f16x3 only: the next due scan (t = 65)
     sees the spread and moves the context to bf16x6, counted once."""
     import ganrev._lib as L

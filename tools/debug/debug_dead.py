@@ -1,7 +1,7 @@
 """Dead-channel case of tests/test_gpu_parity.py::test_dead_channels_between_two_guard_scans_in_the_device_loop in every arithmetic:
 per-module gradient error against the oracle (diagnostic)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "gan-reverser_amd"), ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 import ganrev._lib as L

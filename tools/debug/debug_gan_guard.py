@@ -1,6 +1,6 @@
 """Does DeviceGame's parameter scan trip the f16x3 range guard on the synthetic G / D2 of the GAN tests? (diagnostic)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "gan-reverser_amd"), ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 import ganrev._lib as L

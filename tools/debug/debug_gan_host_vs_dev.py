@@ -1,6 +1,6 @@
 """test_device_resident_gan_batch_matches_the_host_mirror, per module: where do the host mirror and the device game differ? (diagnostic)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "gan-reverser_amd"), ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 import ganrev._lib as L

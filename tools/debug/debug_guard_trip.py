@@ -1,6 +1,6 @@
 """Does train_r's guard trip on the small default nets of tests/test_gpu_parity.py::test_train_r_reads_and_writes_torch7_checkpoints?"""
 import os, sys, tempfile
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gan-reverser_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "gan-reverser_amd"))
 import numpy as np
 import ganrev._lib as L
 from ganrev import models, synth, t7, train_r

@@ -2,7 +2,7 @@
 """Per-parameter-tensor gradient differences vs the oracle for one R case in every arithmetic mode (diagnostic for pooling
 near-tie flips: a flip shows up only in tensors upstream of the pooling layer and in every mode-independent position)."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (os.path.join(ROOT, "gan-reverser_amd"), ROOT, os.path.join(ROOT, "tests")): sys.path.insert(0, p)
 import numpy as np
 import ganrev._lib as L
