@@ -17,6 +17,7 @@ struct GemmArgs {
   int M, N, K, klen, nsplit, accumulate;
   ConvEpilogue ep;       // optional per-column epilogue (evaluate()-mode BatchNorm over the N features + activation); nsplit == 1 only
   int has_ep;
+  int vec_store;         // big kernel: whole blocks leave through the LDS transpose (16-byte stores); 0 = the dword stores (GR_GEMM_DWORD_STORES: A/B control)
   unsigned* amax_out;    // nullable (nsplit == 1): max|C| folded into this f16x3 scale slot
   const unsigned *amax_a, *amax_b;   // f16x3 kernel: scale slots (max|A|, max|B|)
 };
@@ -90,6 +91,61 @@ __device__ __forceinline__ void gemm_store_block(const GemmArgs& a, const f32x16
   for (int r = 0; r < 16; ++r) {
     const int dm = (r & 3) + 8 * (r >> 2);
     if (full || mb + dm < a.M) { c0[(long)dm * a.ldc] = v[r]; omax = fmaxf(omax, fabsf(v[r])); }
+  }
+}
+
+// The same block through a per-wave LDS transpose: 16-byte stores.  The accumulator layout gives one dword per lane and store - 16 store
+// instructions per block, each two 128-byte row pieces: store-ISSUE-bound (the convolution kernels met the same wall: conv.hip, "Output stores
+// through an LDS transpose"): G.fc at cfg3, a 268 MB output stream behind a K = 100 product, ran at 1.85 TB/s, and a third of an fc1 launch
+// was its split-K slab going out dword by dword.  Here a wave writes the block's 32 x 32 values to its own staging rows (stride 36 floats)
+// and reads them back four consecutive columns per lane: 4 store instructions of 8 rows x 128 bytes.  For blocks that lie whole inside the
+// matrix, with N and ldc multiples of 4 and no accumulation into C; everything else takes gemm_store_block.  mb0 = the block's first row.
+__device__ __forceinline__ bool gemm_block_vec_ok(const GemmArgs& a, int mb0, int nb0) {
+  return a.vec_store && !a.accumulate && mb0 + 32 <= a.M && nb0 + 32 <= a.N && (a.N & 3) == 0 && (a.ldc & 3) == 0 && (((uintptr_t)a.C | (uintptr_t)a.slab) & 15) == 0;
+}
+__device__ __forceinline__ void gemm_store_block_vec(const GemmArgs& a, const f32x16& acc, int mb0, int nb0, int shift, float& omax, float* stg, int lane) {
+  const int l31 = lane & 31, h = lane >> 5, n = nb0 + l31;
+  float v[16];
+  if (a.nsplit > 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = ldexpf(acc[r], shift);
+  } else {
+    const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = ldexpf(acc[r], shift) + bias;
+    if (a.has_ep) {
+      if (a.ep.mean) {
+        const float mean = a.ep.mean[n], invstd = a.ep.invstd[n], gamma = a.ep.gamma[n], beta = a.ep.beta[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v[r], mean), invstd), gamma), beta);
+      }
+      switch (a.ep.act) {
+        case ACT_RELU:
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+          break;
+        case ACT_LEAKYRELU:
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = v[r] > 0.f ? v[r] : __fmul_rn(v[r], a.ep.slope);
+          break;
+        case ACT_NONE: break;
+        default:
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = gemm_activation(a.ep, v[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = v[r];
+  float* base = a.nsplit > 1 ? a.slab + ((size_t)blockIdx.z * a.M + mb0) * a.N + nb0 : a.C + (long)mb0 * a.ldc + nb0;
+  const long ld = a.nsplit > 1 ? (long)a.N : a.ldc;
+  const int c4 = (lane & 7) * 4, r0 = lane >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = r0 + 8 * i;
+    const float4 t = *reinterpret_cast<const float4*>(stg + row * 36 + c4);       // (a wave's LDS operations execute in order: no barrier)
+    *reinterpret_cast<float4*>(base + (long)row * ld + c4) = t;
+    if (a.nsplit == 1) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
   }
 }
 
@@ -383,11 +439,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_big_kernel(GemmArgs a) {
     __syncthreads();
   }
   float omax = 0.f;
+  float* stg = reinterpret_cast<float*>(As) + wave * (32 * 36);      // the operand images are dead (the loop ends on a barrier): 4.6 KB of staging per wave
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      gemm_store_block(a, acc[i][j], m0 + wm * 64 + i * 32 + 4 * h, n0 + wn * 64 + j * 32 + l31, -(ka + kb), omax);
+    for (int i = 0; i < 2; ++i) {
+      const int mb0 = m0 + wm * 64 + i * 32, nb0 = n0 + wn * 64 + j * 32;
+      if (gemm_block_vec_ok(a, mb0, nb0)) gemm_store_block_vec(a, acc[i][j], mb0, nb0, -(ka + kb), omax, stg, lane);
+      else gemm_store_block(a, acc[i][j], mb0 + 4 * h, nb0 + l31, -(ka + kb), omax);
+    }
   if (a.amax_out && a.nsplit == 1) absmax_commit(omax, a.amax_out);
 }
 
@@ -440,6 +500,8 @@ void launch_gemm(const float* A, long rsA, long ksA, const float* Bm, long rsB, 
                  const unsigned* amax_a, const unsigned* amax_b) {
   GemmArgs a{};
   if (ep) { a.ep = *ep; a.has_ep = 1; }
+  static const int vec_store = getenv("GR_GEMM_DWORD_STORES") ? 0 : 1;
+  a.vec_store = vec_store;
   a.amax_out = amax_out; a.amax_a = amax_a; a.amax_b = amax_b;
   const bool f16 = amax_a != nullptr && amax_b != nullptr;
   static const bool big_on = !getenv("GR_GEMM_SMALL_TILES");
