@@ -693,12 +693,15 @@ constexpr int APPROX_NB = 1;          // LDS tiles per workgroup of the main pas
                                       // current one's arithmetic), 3 workgroups per CU: 101 us; 3 tiles, 2 per CU: 120 us; ONE tile, 5 per CU: 83 us (d = 32: 46 -> 31 us).  The
                                       // pass is bound by what one wave gets through (25 DMA instructions + 150 LDS reads + 600 FMAs per tile, each step waiting for the one
                                       // before), so the LDS buys more as resident waves than as tiles in flight behind one wave.
+constexpr bool APPROX_HALF = true;    // main pass: 32-row tiles, two lanes per row (cos_approx_kernel): eight workgroups per CU instead of five; same box at d = 100 / 128 / 32:
+                                      // 83 -> 75, 108 -> 96, 31.5 -> 28.7 us (75 us for 400 MB = 5.7 TB/s with the event timer's overhead in it)
 constexpr int ASLOT = 96;             // entries per (persistent workgroup, needle): expected ~4 at cfg5 (5200 candidates over 1280 workgroups)
-static int approx_wgs(int d, int Q) {        // ONE resident round (up to 6 one-wave workgroups per CU): a grid larger than what fits ran its last part alone (d = 128: 335 us)
+static int approx_wgs(int d, int Q) {        // ONE resident round (up to 8 one-wave workgroups per CU): a grid larger than what fits ran its last part alone (d = 128: 335 us)
   const int d4 = d / 4, v = (d4 & 1) ? d4 : d4 + 1;
   const int nq = Q <= 2 ? 2 : (Q <= 5 ? 5 : 8);      // the instantiation launch_approx_nq picks
-  const size_t lds = (size_t)APPROX_NB * 64 * v * 16 + (size_t)nq * d * 4 + 256 + 64;
-  int per_cu = (int)((size_t)160 * 1024 / lds); if (per_cu > 6) per_cu = 6; if (per_cu < 1) per_cu = 1;
+  const int tr = APPROX_HALF ? 32 : 64, nj = (tr * v + 63) / 64;
+  const size_t lds = (size_t)APPROX_NB * 64 * nj * 16 + (size_t)nq * d * 4 + 256 + 64;
+  int per_cu = (int)((size_t)160 * 1024 / lds); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;      // (8 x 256 = 2048 lists per needle: small_select_kernel's LPT)
   return 256 * per_cu;
 }
 struct ApproxArgs {
@@ -714,23 +717,28 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
   constexpr int V = (D4 & 1) ? D4 : D4 + 1, d = D4 * 4;      // vectors per LDS row: odd, so that the 16 lanes of a ds_read_b128 group hit 64 distinct banks
   // NB tiles per workgroup in a ring: while one is multiplied, NB - 1 are in flight (APPROX_NB: two; three lost)
   constexpr int NB = MODE == 0 ? 1 : APPROX_NB;
-  __shared__ __attribute__((aligned(16))) uint4 tile[NB][64 * V];
+  // HALF (the main pass): tiles of 32 rows, TWO lanes per row - lane l and l + 32 take the two halves of the row's columns and add their partial
+  // sums through v_permlane32_swap.  A tile is then 12.8 KB at d = 100 and eight one-wave workgroups fit a CU instead of five: the pass is bound by
+  // what one wave gets through (APPROX_NB), so the same bytes split over twice the waves move faster.
+  constexpr bool HALF = MODE == 1 && APPROX_HALF;
+  constexpr int TR = HALF ? 32 : 64, NJ = (TR * V + 63) / 64;            // rows per tile; DMA instructions per tile (the last one partly parked)
+  __shared__ __attribute__((aligned(16))) uint4 tile[NB][64 * NJ];
   __shared__ __attribute__((aligned(16))) float4 nd[NQ * D4];
   const int lane = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x, Q = a.Q;
   const size_t bytes = (size_t)N * (MODE == 0 ? stride : 1) * d * 4;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(emb), 0, (int)(bytes < 0x7FFFF000ul ? bytes : 0x7FFFF000ul), 0x00020000);
   // DMA instruction j of a tile covers LDS vectors 64 j + lane = (row, column vector) of the padded row-major tile; the pad column is parked out of range
-  int voff[V];
+  int voff[NJ];
 #pragma unroll
-  for (int j = 0; j < V; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int e = 64 * j + lane, r = e / V, c4 = e - r * V;
-    voff[j] = c4 < D4 ? (int)(((long)r * (MODE == 0 ? stride : 1) * d + 4 * c4) * 4) : (int)0x7FFFF000;
+    voff[j] = (c4 < D4 && r < TR) ? (int)(((long)r * (MODE == 0 ? stride : 1) * d + 4 * c4) * 4) : (int)0x7FFFF000;
   }
-  const long ntiles = (N + 63) / 64;
+  const long ntiles = (N + TR - 1) / TR;
   auto request = [&](long t, int buf) {
-    const int soff = (int)(t * 64 * (MODE == 0 ? stride : 1) * d * 4);      // (rows past N lie past the descriptor's range: zeros)
+    const int soff = (int)(t * TR * (MODE == 0 ? stride : 1) * d * 4);      // (rows past N lie past the descriptor's range: zeros)
 #pragma unroll
-    for (int j = 0; j < V; ++j) lds_dma16(rs, &tile[buf][64 * j], voff[j], soff);
+    for (int j = 0; j < NJ; ++j) lds_dma16(rs, &tile[buf][64 * j], voff[j], soff);
   };
 #pragma unroll
   for (int j = 0; j < NB - 1; ++j)
@@ -760,16 +768,54 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
     if (NB == 1) request(t, 0);                                   // (the sample: one tile per workgroup)
     // tile t has landed once at most the requests issued AFTER it are outstanding: V per tile already requested behind it (vmcnt counts in issue order)
     if (NB >= 3 && t + (long)(NB - 2) * nwg < ntiles) {
-      if (NB == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(V <= 63 ? V : 0) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * V <= 63 ? 2 * V : 0) : "memory");
-    } else if (NB >= 4 && t + nwg < ntiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(V <= 63 ? V : 0) : "memory");
+      if (NB == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NJ <= 63 ? NJ : 0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NJ <= 63 ? 2 * NJ : 0) : "memory");
+    } else if (NB >= 4 && t + nwg < ntiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NJ <= 63 ? NJ : 0) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                 // (one wave: orders the LDS-DMA writes before the reads below for the compiler too)
     if (NB > 1 && t + (long)(NB - 1) * nwg < ntiles) request(t + (long)(NB - 1) * nwg, buf == 0 ? NB - 1 : buf - 1);   // into the buffer the previous round multiplied
-    const uint4* row = &tile[buf][lane * V];
+    const uint4* row = &tile[buf][(HALF ? (lane & 31) : lane) * V];
     float s3 = 0.f, s1[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) s1[q] = 0.f;
+    if constexpr (HALF) {
+      // this lane's half of the columns: [cbeg, cbeg + ncol), four vectors per round; slots past ncol (d = 100: 13 + 12 columns) read a valid
+      // column and are multiplied away
+      constexpr int CH = (D4 + 1) / 2;
+      const int hf = lane >> 5, cbeg = hf * CH, ncol = hf ? D4 - CH : CH;
+#pragma unroll 1
+      for (int c0 = 0; c0 < CH; c0 += 4) {
+        float4 b[4], n[NQ][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int cc = c0 + u < ncol ? cbeg + c0 + u : cbeg;
+          b[u] = __builtin_bit_cast(float4, row[cc]);
+          if (c0 + u >= ncol) b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) n[q][u] = nd[q * D4 + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s3 = fmaf(b[u].x, b[u].x, s3); s3 = fmaf(b[u].y, b[u].y, s3); s3 = fmaf(b[u].z, b[u].z, s3); s3 = fmaf(b[u].w, b[u].w, s3);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            s1[q] = fmaf(n[q][u].x, b[u].x, s1[q]); s1[q] = fmaf(n[q][u].y, b[u].y, s1[q]); s1[q] = fmaf(n[q][u].z, b[u].z, s1[q]); s1[q] = fmaf(n[q][u].w, b[u].w, s1[q]);
+          }
+        }
+      }
+      // the two halves of a row: every lane ends with the row's full sums (a + b = b + a: both lanes hold the same bits)
+      auto pair_sum = [&](float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+        return v + __builtin_bit_cast(float, lane < 32 ? sw[1] : sw[0]);
+#else
+        return v;
+#endif
+      };
+      s3 = pair_sum(s3);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) s1[q] = pair_sum(s1[q]);
+    } else {
     // UB column vectors per round: their (NQ + 1) x UB LDS reads are in flight together, then the FMAs (a fully unrolled row - 150 reads at
     // d = 100, five needles - took all 512 registers and spilled)
     constexpr int UB = (D4 % 5 == 0) ? 5 : 4;
@@ -792,14 +838,15 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
         }
       }
     }
-    const long i = t * 64 + lane;
+    }
+    const long i = t * TR + (HALF ? (lane & 31) : lane);
     const float w32 = 1.f / (s3 + 1e-12f);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const float v = s1[q] * sqrtf(w22a[q] * w32);
       if (MODE == 0) { if (i < N) wmax[q] = fmaxf(wmax[q], v); }
       else {
-        const bool hit = i < N && q < Q && v >= tauq[q];
+        const bool hit = (!HALF || lane < 32) && i < N && q < Q && v >= tauq[q];
         const unsigned long long m = __ballot(hit);
         if (m) {
           const unsigned pos = cnt[q] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
