@@ -381,8 +381,9 @@ size_t cosine_topk_workspace_bytes(long N, int d, int Q, int k);
 // query_rows_host (nullable): the same rows in host memory - a handful of needles (cosine_topk_small_path) travel in the kernel arguments
 int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_dev, int Q, int k,
                        long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s, unsigned* status_dev = nullptr, int unfiltered = 0,
-                       const long* query_rows_host = nullptr, unsigned* arrival_counter = nullptr,    // arrival_counter: one zeroed device word the caller owns (the sample launch's last-workgroup hand-over leaves it at 0 again)
+                       const long* query_rows_host = nullptr, unsigned* arrival_counter = nullptr,    // arrival_counter: SEARCH_STATE_WORDS zeroed device words the caller owns (word 0: the sample launch's arrival counter, words 16..: its histogram bins; both are left at 0 again)
                        unsigned* done_words = nullptr, unsigned seq = 0);   // small path: done_words[q] (host-visible) receives seq once needle q's results are written; the call then returns 2
+constexpr int SEARCH_STATE_WORDS = 16 + 8 * 1024;
 bool cosine_topk_small_path(long N, int d, int Q, int k);     // the filtered search takes the fp32-filter path (query rows by value, no device copy of them needed)
 
 // ---------------------------------------------------------------- k-means + nearest-centroid pass (apply_r.lua:197-217)

@@ -53,6 +53,7 @@ struct gr_ctx {
   long guard_scans = 0, guard_fallbacks = 0;
   long search_reruns = 0;              // searches whose sample-bound filter overflowed and ran again unfiltered
   void* pin = nullptr; size_t pin_bytes = 0;   // pinned staging for small results (search)
+  unsigned* search_state = nullptr;    // device words of the small search path (kernels.h SEARCH_STATE_WORDS)
   unsigned* pin_done = nullptr; unsigned search_seq = 0;   // per-needle completion words of the small search path (pinned, 64 bytes) and the sequence number they carry
   hipEvent_t ev_guard = nullptr; bool guard_pending = false;   // device-resident trainer: sampled scans, verdict read one call later
   bool guard_tripped = false;          // ... which found a hostile range: the context stays on bf16x6
@@ -238,6 +239,7 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   if (c->sync_buf) (void)hipFree(c->sync_buf);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->pin_done) (void)hipHostFree(c->pin_done);
+  if (c->search_state) (void)hipFree(c->search_state);
   if (c->ev_guard) (void)hipEventDestroy(c->ev_guard);
   (void)hipFree(c->d_loss); (void)hipFree(c->amax); (void)hipHostFree(c->h_loss);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1850,7 +1852,11 @@ extern "C" int gr_cosine_topk_dev(gr_ctx* c, const float* emb, int64_t N, int d,
     HIPCHK(c, hipHostGetDevicePointer(&done_dev, c->pin_done, 0));
     if (++c->search_seq == 0u) c->search_seq = 1u;                                  // never 0: a fresh block reads 0
     const unsigned seq = c->search_seq;
-    const int lr = launch_cosine_topk(emb, N, d, d_q, Q, k, p_idx, p_sc, accf, c->ws, c->stream, p_status, 0, qrows, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->d_loss) + 32),
+    if (!c->search_state) {       // the sample launch's arrival counter and histogram: zero now, left zero by every search
+      HIPCHK(c, hipMalloc((void**)&c->search_state, sizeof(unsigned) * SEARCH_STATE_WORDS));
+      HIPCHK(c, hipMemsetAsync(c->search_state, 0, sizeof(unsigned) * SEARCH_STATE_WORDS, c->stream));
+    }
+    const int lr = launch_cosine_topk(emb, N, d, d_q, Q, k, p_idx, p_sc, accf, c->ws, c->stream, p_status, 0, qrows, c->search_state,
                                       static_cast<unsigned*>(done_dev), seq);
     if (lr < 0) return fail(c, GR_ERR_UNSUPPORTED, "cosine_topk: unsupported size");
     LAUNCHCHK(c);

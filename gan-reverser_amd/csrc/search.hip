@@ -693,6 +693,7 @@ constexpr int APPROX_NB = 1;          // LDS tiles per workgroup of the main pas
                                       // current one's arithmetic), 3 workgroups per CU: 101 us; 3 tiles, 2 per CU: 120 us; ONE tile, 5 per CU: 83 us (d = 32: 46 -> 31 us).  The
                                       // pass is bound by what one wave gets through (25 DMA instructions + 150 LDS reads + 600 FMAs per tile, each step waiting for the one
                                       // before), so the LDS buys more as resident waves than as tiles in flight behind one wave.
+constexpr int SBINS = 1024;           // bins of the sample's histogram of workgroup maxima over [-1, 1] (cos_approx_kernel, MODE 0)
 constexpr bool APPROX_HALF = true;    // main pass: 32-row tiles, two lanes per row (cos_approx_kernel): eight workgroups per CU instead of five; same box at d = 100 / 128 / 32:
                                       // 83 -> 75, 108 -> 96, 31.5 -> 28.7 us (75 us for 400 MB = 5.7 TB/s with the event timer's overhead in it)
 constexpr int ASLOT = 96;             // entries per (persistent workgroup, needle): expected ~4 at cfg5 (5200 candidates over 1280 workgroups)
@@ -706,7 +707,7 @@ static int approx_wgs(int d, int Q) {        // ONE resident round (up to 8 one-
 }
 struct ApproxArgs {
   float* needles; float* w22;                    // [Q][d], [Q]: written by workgroup 0 of the sample launch for the selection kernel (exact: needle_prep's arithmetic)
-  float* wgmax; unsigned* counter; float* tau;   // sample: [Q][nwg] maxima, arrival counter, [Q] thresholds
+  unsigned* hist; unsigned* counter; float* tau;  // sample: [AQ_MAX][SBINS] histogram of the workgroups' maxima (zero between searches), arrival counter, [Q] thresholds
   unsigned* cand_idx; float* cand_sc; unsigned* counts;   // main pass: [Q][nwg][ASLOT], [Q][nwg]
   unsigned* status;
   int Q, k, accf; float eps2;
@@ -865,69 +866,61 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
     }
     return;
   }
-  // MODE 0: this workgroup's maxima, then the arrival; the last workgroup turns the nwg maxima per needle into tau
+  // MODE 0: this workgroup's maximum per needle goes into a histogram over [-1, 1] (one agent-scope atomic add per needle: performed at the memory side,
+  // nothing to write back - no release fence), then the arrival; the LAST workgroup reads the SBINS bins per needle (16 per lane, all needles' loads in
+  // flight together), takes a suffix count over the lanes and the lower edge of the bin that holds the k-th largest maximum - k distinct rows at or above
+  // it - minus 2 eps as the threshold tau, and leaves the bins zero for the next search.  A bin is 2 / SBINS = 0.002 wide: tau sits that much low at
+  // most (a few per cent more candidates).  (Earlier forms of the round kept the maxima themselves: plain stores + a release fence per workgroup, then an
+  // exact k-th by a 64-bucket estimate or a bitwise radix select on the last wave - 12 of the launch's 22 us went to that tail.)
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     float m = wmax[q];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if (lane == 0 && q < Q) a.wgmax[(long)q * nwg + wg] = m;
+    if (lane == 0 && q < Q) {
+      int bin = (int)((m + 1.f) * (0.5f * (float)SBINS));               // (-inf: a workgroup without rows lands in bin 0)
+      bin = bin < 0 ? 0 : (bin > SBINS - 1 ? SBINS - 1 : bin);
+      __hip_atomic_fetch_add(a.hist + q * SBINS + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (a.dbg & 16) return;                                          // ablation: no arrival, no threshold
   unsigned arrived = 0u;
-  if (lane == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (lane == 0) arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   arrived = (unsigned)__shfl((int)arrived, 0, 64);
   if (arrived != (unsigned)nwg - 1u) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next search
-  if (a.dbg & 8) return;                                           // ablation: the last workgroup's threshold computation
-  // The k-th largest of the nwg maxima per needle (k of them are k distinct rows at or above it), exactly, by one wave and without LDS:
-  // every lane holds four of the <= 256 maxima as orderable bit patterns (all Q x 4 loads in flight together), and the answers are built
-  // bit by bit from the top, all needles in the same round - res |= bit while at least k patterns are >= the trial value (32 rounds of
-  // four compares + ballots per needle).  (First form: a 64-bucket histogram per needle, one needle after the other with the loads inside
-  // the loop; its bucket edge also sat up to a bucket below the exact value: ~20 % more candidates.)
-  unsigned ov[NQ][4];
+  if (a.dbg & 8) return;                                           // ablation: the last workgroup's threshold computation (leaves the bins dirty)
+  constexpr int BPL = SBINS / 64;                                  // bins per lane: lane L owns bins [BPL L, BPL L + BPL)
+  unsigned hb[NQ][BPL];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = lane + 64 * u;
-      ov[q][u] = (q < Q && e < nwg) ? orderable(__hip_atomic_load(a.wgmax + (long)q * nwg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
-    }
-  // (rounds: from the highest bit in which ANY two of the patterns differ - the bits above it are common to all of them and to the answer - down to
-  // bit 8: the threshold ends up at most 2^-15 of itself low, which costs nothing; 16-18 rounds instead of 32 - the loop was 8 of the tail's 12 us)
-  unsigned res[NQ];
-  int top = 0;
+    for (int u = 0; u < BPL; ++u)
+      hb[q][u] = q < Q ? __hip_atomic_load(a.hist + q * SBINS + BPL * lane + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    if (q >= Q) break;
+    unsigned own = 0u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (q < Q && lane + 64 * u < nwg) { lo = min(lo, ov[q][u]); hi = max(hi, ov[q][u]); }
+    for (int u = 0; u < BPL; ++u) own += hb[q][u];
+    unsigned suf = own;                                            // maxima in bins >= BPL * lane
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { lo = min(lo, (unsigned)__shfl_xor((int)lo, off, 64)); hi = max(hi, (unsigned)__shfl_xor((int)hi, off, 64)); }
-    const unsigned diff = lo ^ hi;                                  // (q >= Q: lo = ~0, hi = 0: ignored below)
-    const int tb = (q < Q && diff) ? 31 - __builtin_clz(diff) : -1;
-    res[q] = (q < Q && tb < 31) ? (hi >> (tb + 1)) << (tb + 1) : 0u;    // the common prefix
-    top = max(top, tb);
-  }
-#pragma unroll 1
-  for (int b = top; b >= 8; --b) {
+    for (int off = 1; off < 64; off <<= 1) { const unsigned t = (unsigned)__shfl_down((int)suf, off, 64); if (lane + off < 64) suf += t; }
+    const unsigned above = suf - own;
+    const unsigned total = (unsigned)__shfl((int)suf, 0, 64);
+    if (suf >= (unsigned)a.k && above < (unsigned)a.k) {           // exactly one lane when there are k maxima at all
+      unsigned run = above; int bsel = 0;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const unsigned t = res[q] | (1u << b);
-      const int c = __popcll(__ballot(ov[q][0] >= t)) + __popcll(__ballot(ov[q][1] >= t)) + __popcll(__ballot(ov[q][2] >= t)) + __popcll(__ballot(ov[q][3] >= t));
-      if (c >= a.k) res[q] = t;
+      for (int u = BPL - 1; u >= 0; --u) { run += hb[q][u]; if (run >= (unsigned)a.k) { bsel = BPL * lane + u; break; } }
+      a.tau[q] = -1.f + (float)bsel * (2.f / (float)SBINS) - a.eps2 - 2.4e-7f;      // (2.4e-7: the rounding of m + 1 in the bin index can lift a maximum just below an edge into the bin above it)
     }
-  }
+    if (total < (unsigned)a.k && lane == 0) a.tau[q] = -INFINITY;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
-    if (lane == 0 && q < Q) a.tau[q] = res[q] ? unorderable(res[q]) - a.eps2 : -INFINITY;
+    for (int u = 0; u < BPL; ++u) a.hist[q * SBINS + BPL * lane + u] = 0u;
+  }
 }
 // Selection of the small path (one workgroup of 256 per needle): second cut, exact re-score of what is left, sort, results and a completion word
 // straight into the caller's (pinned host) block.  Round 4, second form - batched_select_kernel (1024 threads) spent most of its 26 us in block
@@ -1162,14 +1155,14 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
     // keys A = maxima [Q][256] | tau [8] | arrival counter | candidate rows [Q][wgs][ASLOT] | scores | counts [Q][wgs]
     const long S = SAMPLE_ROWS, stride = N / S;
     const unsigned swg = (unsigned)(S / 64);
-    float* wgmax = reinterpret_cast<float*>(keysA); float* tau = wgmax + (size_t)AQ_MAX * 256; unsigned* counter = arrival_counter;     // (the context's: zero between searches)
+    float* wgmax = reinterpret_cast<float*>(keysA); float* tau = wgmax + (size_t)AQ_MAX * 256; unsigned* counter = arrival_counter; unsigned* hist = arrival_counter + 16;     // (the context's: zero between searches)
     unsigned* pad_ = reinterpret_cast<unsigned*>(tau + AQ_MAX);
     const int awgs = approx_wgs(d, Q);
     unsigned* cidx = pad_ + 8; float* csc = reinterpret_cast<float*>(cidx + (size_t)Q * awgs * ASLOT);
     unsigned* wcnt = reinterpret_cast<unsigned*>(csc + (size_t)Q * awgs * ASLOT);
     SmallQ qr{}; for (int q = 0; q < AQ_MAX; ++q) qr.rows[q] = query_rows_host[q < Q ? q : 0];
     ApproxArgs a{};
-    a.needles = needles; a.w22 = w22; a.wgmax = wgmax; a.counter = counter; a.tau = tau; a.cand_idx = cidx; a.cand_sc = csc; a.counts = wcnt;
+    a.needles = needles; a.w22 = w22; a.hist = hist; a.counter = counter; a.tau = tau; a.cand_idx = cidx; a.cand_sc = csc; a.counts = wcnt;
     a.status = status_dev; a.Q = Q; a.k = k; a.accf = accf; a.eps2 = 2.f * (float)(2 * d + 16) * 5.9604645e-8f; a.dbg = g_search_debug;
     {
       KtScope kt("cos_approx_kernel (sample + bound)", 0.0, 4.0 * S * d, s);
