@@ -555,6 +555,24 @@ __global__ __launch_bounds__(1024) void batched_tau_kernel(const float* __restri
   // stored divided by sqrt(w22): cos_mfma_kernel compares (dot * sqrt(w32)) with it; the rounding of the division is far inside the 2 BERR slack
   if (threadIdx.x == 0) tau[q] = kth ? (unorderable(kth) - 2.f * GR_BERR) / sw22s[q] : -INFINITY;
 }
+// the same threshold by ONE wave per needle (four needles per workgroup): the <= 256 sample maxima as orderable bit patterns, four per lane, and the exact
+// k-th largest built bit by bit from the top (res |= bit while at least k patterns are >= the trial value) - no LDS, no block barriers (the 1024-thread
+// bitonic sort above took 23 us for 1024 needles)
+__global__ __launch_bounds__(256) void batched_tau_wave_kernel(const float* __restrict__ samp, int S, int Q, int k, const float* __restrict__ sw22s, float* __restrict__ tau) {
+  const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  unsigned ov[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int e = lane + 64 * u; ov[u] = e < S ? orderable(samp[(long)q * S + e]) : 0u; }
+  unsigned res = 0u;
+#pragma unroll 1
+  for (int b = 31; b >= 0; --b) {
+    const unsigned t = res | (1u << b);
+    const int c = __popcll(__ballot(ov[0] >= t)) + __popcll(__ballot(ov[1] >= t)) + __popcll(__ballot(ov[2] >= t)) + __popcll(__ballot(ov[3] >= t));
+    if (c >= k) res = t;
+  }
+  if (lane == 0) tau[q] = res ? (unorderable(res) - 2.f * GR_BERR) / sw22s[q] : -INFINITY;
+}
 // per needle: second cut on the approximate scores, exact re-score of what is left, sort, decode
 template <bool ACCF>
 __global__ __launch_bounds__(1024) void batched_select_kernel(const float* __restrict__ emb, int d, const float* __restrict__ needles,
@@ -932,31 +950,37 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
 //   done    every thread's stores fenced at system scope, then ONE word per needle = the call's sequence number: the host polls it (no stream
 //           synchronisation: 1-3 us per search, measured).
 constexpr int SSEL_BINS = 2048, SSEL_MAX = 256;
-template <bool ACCF>
-__global__ __launch_bounds__(256) void small_select_kernel(const float* __restrict__ emb, int d, const unsigned* __restrict__ cand_idx,
-                                                          const float* __restrict__ cand_sc, const unsigned* __restrict__ counts, int nwg, int k,
-                                                          long* __restrict__ idx, float* __restrict__ score, unsigned* __restrict__ status,
-                                                          float margin2, SmallQ qr, const float* __restrict__ tau, unsigned* __restrict__ done, unsigned seq) {
+// NT threads (256: the small path's <= 2048 lists per needle; 512: the batched path's N / 256 lists), SLOT entries per list, FROM_ROWS: the needle is row
+// qr.rows[q] of the table and its norm is formed here (small path) / the needle and its 1 / (|a|^2 + 1e-12) come from needle_prep_kernel's arrays (batched);
+// lo_scale (nullable): tau[q] * lo_scale[q] is the lower edge of the candidates' scores (the batched path stores tau divided by sqrt(w22)).
+template <bool ACCF, int NT, int SLOT_, bool FROM_ROWS>
+__global__ __launch_bounds__(NT) void small_select_kernel(const float* __restrict__ emb, int d, const unsigned* __restrict__ cand_idx,
+                                                         const float* __restrict__ cand_sc, const unsigned* __restrict__ counts, int nwg, int k,
+                                                         long* __restrict__ idx, float* __restrict__ score, unsigned* __restrict__ status,
+                                                         float margin2, SmallQ qr, const float* __restrict__ tau, unsigned* __restrict__ done, unsigned seq,
+                                                         const float* __restrict__ needles, const float* __restrict__ w22, const float* __restrict__ lo_scale) {
   typedef typename std::conditional<ACCF, float, double>::type acc_t;
   __shared__ unsigned hist[SSEL_BINS];
   __shared__ __attribute__((aligned(16))) unsigned long long keys[SSEL_MAX];
   __shared__ unsigned rows[SSEL_MAX];
   __shared__ __attribute__((aligned(16))) float ndl[BD_MAX];
-  __shared__ unsigned wtot[4];
+  __shared__ unsigned wtot[NT / 64];
   __shared__ unsigned list_n, over, cutbin;
   __shared__ float sh_w22;
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned* cnt = counts + (long)q * nwg;
+  constexpr int ASLOT = SLOT_;                                     // (shadows the small path's constant: this instantiation's list length)
   const unsigned* ci = cand_idx + (long)q * nwg * ASLOT;
   const float* cs = cand_sc + (long)q * nwg * ASLOT;
-  const float* nd = emb + qr.rows[q] * (long)d;
-  const float lo = tau[q];
+  const float* nd = FROM_ROWS ? emb + qr.rows[q] * (long)d : needles + (long)q * d;
+  const float lo = lo_scale ? tau[q] * lo_scale[q] - 1e-6f : tau[q];
   bool fail = !(lo > -INFINITY);                                    // no threshold (fewer than k sample maxima): the unfiltered search decides
-  for (int i = tid; i < SSEL_BINS; i += 256) hist[i] = 0u;
+  for (int i = tid; i < SSEL_BINS; i += NT) hist[i] = 0u;
   if (tid == 0) { list_n = 0u; over = 0u; cutbin = 0u; }
-  for (int c = tid; c < d; c += 256) ndl[c] = nd[c];
+  for (int c = tid; c < d; c += NT) ndl[c] = nd[c];
   __syncthreads();
-  if (tid == 255) {                                                 // 1 / (|needle|^2 + 1e-12) in needle_prep_kernel's arithmetic, from the staged copy
+  if (!FROM_ROWS) { if (tid == NT - 1) sh_w22 = w22[q]; }
+  else if (tid == NT - 1) {                                                 // 1 / (|needle|^2 + 1e-12) in needle_prep_kernel's arithmetic, from the staged copy
     acc_t t = 0;                                                    // (read from global memory by this one thread it was 7 dependent rounds: ~10 us)
     for (int i = 0; i < d; ++i) { const float v = ndl[i]; t += v * v; }
     float w = (float)t;
@@ -971,10 +995,10 @@ __global__ __launch_bounds__(256) void small_select_kernel(const float* __restri
   unsigned lc[LPT]; float4 la[LPT], lb[LPT];
   unsigned o = 0u;
 #pragma unroll
-  for (int j = 0; j < LPT; ++j) { const int g = tid + 256 * j; lc[j] = (!fail && g < nwg) ? cnt[g] : 0u; }
+  for (int j = 0; j < LPT; ++j) { const int g = tid + NT * j; lc[j] = (!fail && g < nwg) ? cnt[g] : 0u; }
 #pragma unroll
   for (int j = 0; j < LPT; ++j) {
-    const int g = tid + 256 * j;
+    const int g = tid + NT * j;
     if (lc[j] > (unsigned)ASLOT) { o = 1u; lc[j] = (unsigned)ASLOT; }
     la[j] = lc[j] > 0u ? *reinterpret_cast<const float4*>(cs + (long)g * ASLOT) : make_float4(0.f, 0.f, 0.f, 0.f);
     lb[j] = lc[j] > 4u ? *reinterpret_cast<const float4*>(cs + (long)g * ASLOT + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -982,7 +1006,7 @@ __global__ __launch_bounds__(256) void small_select_kernel(const float* __restri
   auto bin_of = [&](float v) { int b_ = (int)((v - lo) * inv); return b_ < 0 ? 0 : (b_ > SSEL_BINS - 1 ? SSEL_BINS - 1 : b_); };
 #pragma unroll
   for (int j = 0; j < LPT; ++j) {
-    const int g = tid + 256 * j;
+    const int g = tid + NT * j;
     const float v[8] = {la[j].x, la[j].y, la[j].z, la[j].w, lb[j].x, lb[j].y, lb[j].z, lb[j].w};
 #pragma unroll
     for (int u = 0; u < 8; ++u) if ((unsigned)u < lc[j]) atomicAdd(&hist[bin_of(v[u])], 1u);
@@ -991,27 +1015,28 @@ __global__ __launch_bounds__(256) void small_select_kernel(const float* __restri
   if (o) over = 1u;
   __syncthreads();
   fail = fail || over != 0u;
-  // suffix count over the bins: thread t owns bins 8 t .. 8 t + 7; S(t) = candidates in bins >= 8 t
+  // suffix count over the bins: thread t owns bins BPT t .. BPT t + BPT - 1; S(t) = candidates in bins >= BPT t
+  constexpr int BPT = SSEL_BINS / NT;
   unsigned own = 0u;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) own += hist[8 * tid + j];
+  for (int j = 0; j < BPT; ++j) own += hist[BPT * tid + j];
   unsigned suf = own;                                               // suffix sum over the lanes of the wave, then the waves above
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const unsigned t = (unsigned)__shfl_down((int)suf, off, 64); if (lane + off < 64) suf += t; }
   if (lane == 0) wtot[wave] = suf;
   __syncthreads();
-  for (int w = wave + 1; w < 4; ++w) suf += wtot[w];
+  for (int w = wave + 1; w < NT / 64; ++w) suf += wtot[w];
   const unsigned above = suf - own;                                 // candidates in bins >= 8 (t + 1)
   if (suf >= (unsigned)k && above < (unsigned)k) {                  // exactly one thread when there are k candidates at all (else the cut stays at bin 0)
     unsigned run = above;
-    for (int j = 7; j >= 0; --j) { run += hist[8 * tid + j]; if (run >= (unsigned)k) { cutbin = (unsigned)(8 * tid + j); break; } }
+    for (int j = BPT - 1; j >= 0; --j) { run += hist[BPT * tid + j]; if (run >= (unsigned)k) { cutbin = (unsigned)(BPT * tid + j); break; } }
   }
   __syncthreads();
   const float tau2 = lo + ((float)cutbin - 1.f) * width - margin2;
   // pass 2: the candidates at or above the cut (their scores are still in registers)
 #pragma unroll
   for (int j = 0; j < LPT; ++j) {
-    const int g = tid + 256 * j;
+    const int g = tid + NT * j;
     const float v[8] = {la[j].x, la[j].y, la[j].z, la[j].w, lb[j].x, lb[j].y, lb[j].z, lb[j].w};
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -1067,16 +1092,18 @@ __global__ __launch_bounds__(256) void small_select_kernel(const float* __restri
         }
         __syncthreads();
       }
-    for (int r = tid; r < k; r += 256) {
+    for (int r = tid; r < k; r += NT) {
       const unsigned long long key = keys[r];
       idx[(long)q * k + r] = (long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
       if (score) score[(long)q * k + r] = unorderable((uint32_t)(key >> 32));
     }
   } else if (tid == 0 && status) *status = 1u;
   // completion: the results (and the status word) are visible to the host before the needle's word carries this call's sequence number
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0 && done) __hip_atomic_store(done + q, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (done) {                                                      // (uniform: only the small path hands its results to a polling host)
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done + q, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 bool cosine_topk_small_path(long N, int d, int Q, int k) {
@@ -1180,8 +1207,8 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
       return 0;
     }
     KtScope kt("small_select_kernel", 0.0, 0.0, s);
-    if (accf) hipLaunchKernelGGL(small_select_kernel<true>, dim3(Q), dim3(256), 0, s, emb, d, cidx, csc, wcnt, awgs, k, idx_out, score_out, status_dev, a.eps2, qr, tau, done_words, seq);
-    else hipLaunchKernelGGL(small_select_kernel<false>, dim3(Q), dim3(256), 0, s, emb, d, cidx, csc, wcnt, awgs, k, idx_out, score_out, status_dev, a.eps2, qr, tau, done_words, seq);
+    if (accf) hipLaunchKernelGGL((small_select_kernel<true, 256, ASLOT, true>), dim3(Q), dim3(256), 0, s, emb, d, cidx, csc, wcnt, awgs, k, idx_out, score_out, status_dev, a.eps2, qr, tau, done_words, seq, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+    else hipLaunchKernelGGL((small_select_kernel<false, 256, ASLOT, true>), dim3(Q), dim3(256), 0, s, emb, d, cidx, csc, wcnt, awgs, k, idx_out, score_out, status_dev, a.eps2, qr, tau, done_words, seq, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     return done_words ? 2 : 0;        // 2: the needles' completion words will carry `seq`
   }
   if (accf) hipLaunchKernelGGL(needle_prep_kernel<true>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
@@ -1212,15 +1239,22 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
       KtScope kt("cos_mfma_kernel (sample)", 2.0 * S * d * Q, 4.0 * S * d, s);
       GR_MFMA(0, (unsigned)((S + 255) / 256), S, stride, (const float*)nullptr, samp, (unsigned*)nullptr, (float*)nullptr, (unsigned*)nullptr);
     }
-    {
+    static const bool old_tail = getenv("GR_BATCHED_OLD_TAIL") != nullptr;      // A/B: round 4's first threshold and selection kernels (bitonic sorts of 1024 per-thread maxima)
+    if (old_tail || swg > 256) {
       KtScope kt("batched_tau_kernel", 0.0, 4.0 * swg * Q, s);
       hipLaunchKernelGGL(batched_tau_kernel, dim3(Q), dim3(1024), 0, s, samp, swg, k, sw22s, tau);
+    } else {
+      KtScope kt("batched_tau_wave_kernel", 0.0, 4.0 * swg * Q, s);
+      hipLaunchKernelGGL(batched_tau_wave_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s, samp, (int)swg, Q, k, sw22s, tau);
     }
     {
       KtScope kt("cos_mfma_kernel", 2.0 * N * d * Q, 4.0 * N * d, s);
       GR_MFMA(1, (unsigned)nwg, N, 1L, (const float*)tau, (float*)nullptr, cidx, csc, wcnt);
     }
 #undef GR_MFMA
+    // (the histogram-cut selection kernel of the small path, instantiated for these lists - small_select_kernel<ACCF, 512, BSLOT, false>, tau scaled by sqrt(w22) -
+    // was measured here: 109 us against this kernel's 101 for 1024 needles.  Both read 3907 sixty-four-byte lists per needle, 70 % of them non-empty, one DRAM
+    // line each: 256 MB of scattered reads set the time, not the barriers of the sort; not used)
     KtScope kt("batched_select_kernel", 0.0, 0.0, s);
     if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev, BSLOT, 2.f * GR_BERR, SmallQ{}, 0);
     else hipLaunchKernelGGL(batched_select_kernel<false>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev, BSLOT, 2.f * GR_BERR, SmallQ{}, 0);
