@@ -1754,6 +1754,182 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_po_kern
   conv_p16_quad_body<TW, NI, NG, MT, true>(a, wsplit, xin);
 }
 
+// tile row of 16-pixel block nb (0..3) of wave `wave` in the 256-pixel tilings of the P16 kernels (tile_pixel<16>: a wave's two 32-pixel groups pair rows 8 apart)
+template <int TW>
+__device__ __forceinline__ int prow_of_block(int wave, int nb) { int prr, pc; tile_pixel<TW>((wave * 2 + (nb >> 1)) * 32 + 16 * (nb & 1), prr, pc); return prr; }
+// ---------------------------------------------------------------- the same layer on v_mfma_f32_16x16x32_f16: 16x16 planes, 32-channel chunks
+// VERDICT round 3, item 2.  The shape probe (tools/build_probe.sh) priced the instruction shape at -7...-8 % per launch for the kernel above; K = 32 needs
+// 32-channel chunks, whose image (patch 43 KB + weights 37 KB for 256 pixels x 32 output channels) is 78 KB: for the ONE instantiation that already runs
+// 256-pixel x 32-channel tiles - conv3x3_p16_quad_kernel<16, 1, 2, 1>, the dominant kernel at batch 256 - that still leaves two workgroups per CU (four
+// before), the LDS reads per FLOP unchanged and half as many chunk hand-overs.  (64-channel tiles or 512-pixel tiles do not fit twice: §4.00.)
+//   K index of the instruction = 8 q + e, q = lane / 16: q & 1 = which 8-channel group of a 16-channel sub-chunk, q >> 1 = which sub-chunk - so the operand
+//   images are the kernel above's, two sub-chunks side by side: patch [term][4 groups][PS] (plane stride a multiple of 16 vectors: the four lane quarters of a
+//   ds_read_b128 then start at the same 16-byte slot), weights [2 sub-chunks][term][9 taps][2 halves][32 o] = two consecutive chunk images of the prep kernel.
+//   A operand (weights): lane -> output channel 16 mb + lane % 16; B operand (patch): lane -> pixel x = lane % 16 of row nb's tile row; accumulator block
+//   [mb][nb] (16 o x 16 px): lane holds o = 16 mb + 4 q + i, i = 0..3, at pixel x.  A wave owns four tile rows (the kernel above's pixel order: tile_pixel)
+//   and both 16-channel blocks: 8 blocks, 32 accumulator registers; per tap 4 + 8 operand reads for 24 instructions of 16 cycles (12 for 6 x 32 before).
+// Epilogue: scale back + bias, BatchNorm statistics of the stored values (sums over a wave's 64 pixels by DPP inside the 16-lane rows, the four waves added in
+// fp64 in wave order: a fixed order), then the kernel above's LDS transpose to 16-byte stores.  Training-mode output only (raw y; no fused epilogue, no PO).
+constexpr int K32_PS = (18 * 18 + 15) / 16 * 16;      // 336: patch plane stride (vectors)
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
+  static_assert(TW == 16, "one 16x16 image per tile");
+  constexpr int NW = 4, TR = 16, PR = TR + 2, PC = TW + 2, PS0 = PR * PC, PS = K32_PS, CT = 32, MB = 2, NB = 4;
+  constexpr int PV = 2 * 4 * PS, PVP = (PV + 63) / 64 * 64, WR16 = 2 * 9 * 2, WV = 2 * WR16 * CT, LBUF = PVP + WV;
+  constexpr int NPI = PVP / 64, NPS = (NPI + NW - 1) / NW, NWI = WV / 64, NWS = (NWI + NW - 1) / NW;
+  static_assert(2 * LBUF * 16 <= 160 * 1024, "two workgroups per CU");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint4* lds = reinterpret_cast<uint4*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int G = a.Cin >> 3;
+  int bid = xcd_remap(blockIdx.x, a.n_tiles);
+  const int tile = bid / a.n_otiles;
+  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+  const int b = bid;                                             // one image per tile
+  const int o0 = ot * CT;
+  const int nchunks = a.Cin / 32;
+  const size_t xbytes = (size_t)a.B * G * 2 * HW * 16;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(xin), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wsplit), 0, (int)((size_t)(a.Cin / 16) * WR16 * a.cout_pad * 16), 0x00020000);
+  const int ktot = f16_scale_exp(absmax_read(a.amax_in)) + f16_scale_exp(absmax_read(a.amax_w));
+  int voff[NPS], woff[NWS];
+#pragma unroll
+  for (int j = 0; j < NPS; ++j) {
+    const int e = 64 * (wave + NW * j) + lane;
+    const int p8 = e / PS, pos = e - p8 * PS, t = p8 >> 2, grp = p8 & 3;      // plane p8 = term * 4 + group
+    const int rr = pos / PC, c = pos - rr * PC;
+    const int yy = rr - 1, xx = c - 1;
+    const bool inb = e < PV && pos < PS0 && yy >= 0 && yy < H && xx >= 0 && xx < W && b < a.B;
+    voff[j] = inb ? (((b * G + grp) * 2 + t) * HW + yy * W + xx) * 16 : (int)0x7FFFF000;
+  }
+#pragma unroll
+  for (int j = 0; j < NWS; ++j) {          // weight vector f of the [2 sub-chunks][36 rows][32 o] image
+    const int f = 64 * (wave + NW * j) + lane, cc = f / (WR16 * CT), rem = f - cc * (WR16 * CT), r = rem / CT, col = rem - r * CT;
+    woff[j] = f < WV ? ((cc * WR16 + r) * a.cout_pad + o0 + col) * 16 : (int)0x7FFFF000;
+  }
+#define GR_K32_DMA(ch_)                                                                                   \
+  {                                                                                                       \
+    const int psoff_ = (ch_) * HW * 128;                               /* 4 groups x 2 terms x HW vectors */ \
+    _Pragma("unroll") for (int j = 0; j < NPS; ++j) {                                                     \
+      const int i_ = wave + NW * j;                                                                       \
+      if (i_ < NPI) lds_dma16(rin, lds + 64 * i_, voff[j], psoff_);                                       \
+    }                                                                                                     \
+    const int wsoff_ = (ch_) * 2 * WR16 * a.cout_pad * 16;                                                \
+    _Pragma("unroll") for (int j = 0; j < NWS; ++j) {                                                     \
+      const int r_ = wave + NW * j;                                                                       \
+      if (r_ < NWI) lds_dma16(rwt, lds + PVP + 64 * r_, woff[j], wsoff_);                                 \
+    }                                                                                                     \
+  }
+  f32x4 acc[MB][NB];
+  int pix[NB], prow[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    int prr, pc; tile_pixel<TW>((wave * 2 + (nb >> 1)) * 32 + 16 * (nb & 1), prr, pc);      // the 16 pixels of block nb: one tile row (pc = 0)
+    prow[nb] = prr;
+    pix[nb] = q * PS + prr * PC + l15;
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint4* patch = lds; const uint4* wts = lds + PVP;
+  const int wq = ((q >> 1) * WR16 + (q & 1)) * CT + l15;           // this lane's weight column: sub-chunk q >> 1, channel half q & 1, output channel l15 (+ 16 mb)
+  GR_K32_DMA(0)
+  for (int ch = 0; ch < nchunks; ++ch) {
+    dma_publish_barrier();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = (tap / 3) * PC + (tap % 3);
+      uint4 av[MB][2], bv[NB][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) av[mb][t] = wts[wq + ((t * 9 + tap) * 2) * CT + mb * 16];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb][t] = patch[t * 4 * PS + pix[nb] + toff];
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          f32x4 c_ = acc[mb][nb];
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][1]), __builtin_bit_cast(f16x8, bv[nb][0]), c_, 0, 0, 0);
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][0]), __builtin_bit_cast(f16x8, bv[nb][1]), c_, 0, 0, 0);
+          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][0]), __builtin_bit_cast(f16x8, bv[nb][0]), c_, 0, 0, 0);
+          acc[mb][nb] = c_;
+        }
+    }
+    __syncthreads();
+    if (ch + 1 < nchunks) GR_K32_DMA(ch + 1)
+  }
+#undef GR_K32_DMA
+  // scale back + bias: lane holds channel chl = 16 mb + 4 q + i of pixel (prow[nb], l15)
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = o0 + mb * 16 + 4 * q + i;
+      const float bvv = (a.bias && o < a.Cout) ? a.bias[o] : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i] = ldexpf(acc[mb][nb][i], -ktot) + bvv;
+    }
+  const bool inimg = b < a.B;
+  if (a.stat_part) {
+    // per (wave, channel): the 64 pixels = four per lane over the 16 lanes of the channel's DPP row; then the four waves in fp64, in wave order
+    float* wsum = reinterpret_cast<float*>(smem_raw);            // [4 waves][2][32 channels]  (the operand image is dead: every wave is past the last chunk's barrier)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sv = 0.f, qv = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { const float v = inimg ? acc[mb][nb][i] : 0.f; sv += v; qv += v * v; }
+        // sum over the 16 lanes of the row (row_shr 1, 2, 4, 8 with zero fill: lane 15 of the row ends with the total, in a fixed order)
+        sv += dpp_take<0x111, 0xF>(sv); sv += dpp_take<0x112, 0xF>(sv); sv += dpp_take<0x114, 0xF>(sv); sv += dpp_take<0x118, 0xF>(sv);
+        qv += dpp_take<0x111, 0xF>(qv); qv += dpp_take<0x112, 0xF>(qv); qv += dpp_take<0x114, 0xF>(qv); qv += dpp_take<0x118, 0xF>(qv);
+        if (l15 == 15) { const int chl = mb * 16 + 4 * q + i; wsum[(wave * 2 + 0) * 32 + chl] = sv; wsum[(wave * 2 + 1) * 32 + chl] = qv; }
+      }
+    __syncthreads();
+    if (tid < 64) {
+      const int wh = tid >> 5, chl = tid & 31;
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += (double)wsum[(w * 2 + wh) * 32 + chl];
+      const int o = o0 + chl;
+      if (o < a.Cout) a.stat_part[((size_t)o * a.stat_tiles + tile) * 2 + wh] = t;
+    }
+    __syncthreads();
+  }
+  // output stores through the per-wave LDS transpose of the kernel above: [channel][pixel of the wave's 64] -> four consecutive pixels of a channel per lane
+  float omax = 0.f;
+  {
+    constexpr int RS = 64 + 4, NQ = 16, CPI = 64 / NQ;
+    static_assert(NW * 32 * RS * 4 <= LBUF * 16, "staging fits the operand image");
+    float* stg = reinterpret_cast<float*>(smem_raw) + wave * 32 * RS;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg[(mb * 16 + 4 * q + i) * RS + nb * 16 + l15] = acc[mb][nb][i];
+    const int kq = lane % NQ, hq = lane / NQ;                     // pixel quad kq of the wave's 64 pixels (block kq / 4, x = 4 (kq % 4)), channel row hq + CPI i
+    const int yq = prow_of_block<TW>(wave, kq >> 2), xq = 4 * (kq & 3);
+    float* outq = a.out + ((size_t)b * a.Cout * H + yq) * W + xq;
+    const bool want_max = a.amax_out != nullptr;
+#pragma unroll
+    for (int i2 = 0; i2 < 32 / CPI; ++i2) {
+      const int chl = CPI * i2 + hq, o = o0 + chl;
+      const float4 v = *reinterpret_cast<const float4*>(stg + chl * RS + 4 * kq);
+      if (inimg && o < a.Cout) {
+        store4(outq + (size_t)o * H * W, v, a.nt_out != 0);
+        if (want_max) omax = absmax4(omax, v);
+      }
+    }
+  }
+  if (a.amax_out) absmax_commit(omax, a.amax_out);
+}
+
 // Epilogue stores of the up-sampling kernels.  A lane ends with the 2x2 outputs of its source pixel (x, y): two float2 per channel,
 // 8 bytes per lane - store-issue-bound (MI355X_MICROARCH.md: a dwordx2-per-lane store tail runs at ~7 B/clk/CU, dwordx4 halves it;
 // ablation round 3: the stores are 34-39 us of G.convB's 246 at cfg2), and rocprofv3's WRITE_SIZE reads 2.4x the bytes for them.
@@ -2556,6 +2732,21 @@ static int launch_conv_p16_t(ConvArgs a, const void* wsplit, const void* xin, hi
   return a.stat_tiles;
 }
 bool conv_p16_out_supported(int Cout) { return g_p16_variant == 1 && Cout % 8 == 0; }
+// 16x16 planes, one image per tile, 32-channel chunks on v_mfma_f32_16x16x32_f16 (conv3x3_p16_k32_kernel): training-mode output only
+static int launch_conv_p16_k32(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {
+  constexpr int PVP = (2 * 4 * K32_PS + 63) / 64 * 64, LBUF = PVP + 2 * 36 * 32;
+  a.tiles_x = 1; a.tiles_y = 1;
+  a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / 32;
+  const size_t lds = 16 * (size_t)LBUF;
+  a.n_tiles = a.B * a.n_otiles;
+  a.stat_tiles = a.B;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_k32_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  const double px = (double)a.B * a.H * a.W;
+  KtScope kt("conv3x3_p16_k32_kernel<16>", 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+  hipLaunchKernelGGL(conv3x3_p16_k32_kernel<16>, dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
+  return a.stat_tiles;
+}
 void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
                         hipStream_t s, const ConvEpilogue* ep, const unsigned* amax_in, const unsigned* amax_w, unsigned* amax_out,
                         double* stat_part, int* stat_tiles, const P16Out* p16o) {
@@ -2571,7 +2762,10 @@ void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias
   const long two_img_tiles = (long)((B + 1) / 2) * (round_up(Cout, 32) / 64);
   int nt;
   static const int narrow = getenv("GR_P16_NARROW") ? atoi(getenv("GR_P16_NARROW")) : 1;     // 32-channel output tiles on single-image tiles: four workgroups per CU (six launches 0.303 -> 0.294 ms at cfg2: small, the L2 -> LDS traffic doubles)
-  if (H == 16 && W == 16) nt = (single && g_p16_variant == 1 && two_img_tiles < 512) ? (narrow ? launch_conv_p16_quad<16, 1, 2, 1>(a, wsplit, x_p16, s) : launch_conv_p16_quad<16, 1, 2>(a, wsplit, x_p16, s))
+  static const int k32 = getenv("GR_P16_K32") ? atoi(getenv("GR_P16_K32")) : 1;      // 32-channel chunks on the 16x16x32 MFMA where the single-image narrow tiles run (0: the 32x32x16 kernel, the A/B control)
+  const bool plain_out = a.ep.mean == nullptr && a.ep.act == ACT_NONE && !a.p16_out && out != nullptr;
+  if (H == 16 && W == 16 && k32 && single && narrow && g_p16_variant == 1 && two_img_tiles < 512 && Cin % 32 == 0 && plain_out && !g_p16_debug) nt = launch_conv_p16_k32(a, wsplit, x_p16, s);
+  else if (H == 16 && W == 16) nt = (single && g_p16_variant == 1 && two_img_tiles < 512) ? (narrow ? launch_conv_p16_quad<16, 1, 2, 1>(a, wsplit, x_p16, s) : launch_conv_p16_quad<16, 1, 2>(a, wsplit, x_p16, s))
                                                                                   : launch_conv_p16_t<16, 2>(a, wsplit, x_p16, s);
   else {
     static const int half32 = getenv("GR_P16_HALF32") ? atoi(getenv("GR_P16_HALF32")) : 0;     // 256-pixel tiles (8 rows x 32) on wider planes
