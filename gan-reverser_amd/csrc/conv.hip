@@ -1754,9 +1754,6 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_po_kern
   conv_p16_quad_body<TW, NI, NG, MT, true>(a, wsplit, xin);
 }
 
-// tile row of 16-pixel block nb (0..3) of wave `wave` in the 256-pixel tilings of the P16 kernels (tile_pixel<16>: a wave's two 32-pixel groups pair rows 8 apart)
-template <int TW>
-__device__ __forceinline__ int prow_of_block(int wave, int nb) { int prr, pc; tile_pixel<TW>((wave * 2 + (nb >> 1)) * 32 + 16 * (nb & 1), prr, pc); return prr; }
 // ---------------------------------------------------------------- the same layer on v_mfma_f32_16x16x32_f16: 16x16 planes, 32-channel chunks
 // VERDICT round 3, item 2.  The shape probe (tools/build_probe.sh) priced the instruction shape at -7...-8 % per launch for the kernel above; K = 32 needs
 // 32-channel chunks, whose image (patch 43 KB + weights 37 KB for 256 pixels x 32 output channels) is 78 KB: for the ONE instantiation that already runs
@@ -1770,11 +1767,12 @@ __device__ __forceinline__ int prow_of_block(int wave, int nb) { int prr, pc; ti
 //   and both 16-channel blocks: 8 blocks, 32 accumulator registers; per tap 4 + 8 operand reads for 24 instructions of 16 cycles (12 for 6 x 32 before).
 // Epilogue: scale back + bias, BatchNorm statistics of the stored values (sums over a wave's 64 pixels by DPP inside the 16-lane rows, the four waves added in
 // fp64 in wave order: a fixed order), then the kernel above's LDS transpose to 16-byte stores.  Training-mode output only (raw y; no fused epilogue, no PO).
-constexpr int K32_PS = (18 * 18 + 15) / 16 * 16;      // 336: patch plane stride (vectors)
+template <int TW> constexpr int k32_ps() { return ((256 / TW + 2) * (TW + 2) + 15) / 16 * 16; }      // patch plane stride (vectors): 336 (16 x 16 tile) / 352 (8 rows x 32)
+// TW = 32: tiles of 8 rows x 32 on planes whose width is a multiple of 32 - the image is then 80 KiB exactly (patch 44 KB + weights 36.9 KB): still two per CU
 template <int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
-  static_assert(TW == 16, "one 16x16 image per tile");
-  constexpr int NW = 4, TR = 16, PR = TR + 2, PC = TW + 2, PS0 = PR * PC, PS = K32_PS, CT = 32, MB = 2, NB = 4;
+  static_assert(TW == 16 || TW == 32, "one 16x16 image, or 8 rows of a 32-wide tile column");
+  constexpr int NW = 4, TR = 256 / TW, PR = TR + 2, PC = TW + 2, PS0 = PR * PC, PS = k32_ps<TW>(), CT = 32, MB = 2, NB = 4;
   constexpr int PV = 2 * 4 * PS, PVP = (PV + 63) / 64 * 64, WR16 = 2 * 9 * 2, WV = 2 * WR16 * CT, LBUF = PVP + WV;
   constexpr int NPI = PVP / 64, NPS = (NPI + NW - 1) / NW, NWI = WV / 64, NWS = (NWI + NW - 1) / NW;
   static_assert(2 * LBUF * 16 <= 160 * 1024, "two workgroups per CU");
@@ -1786,8 +1784,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
   int bid = xcd_remap(blockIdx.x, a.n_tiles);
   const int tile = bid / a.n_otiles;
   const int ot = bid % a.n_otiles; bid /= a.n_otiles;
-  const int b = bid;                                             // one image per tile
-  const int o0 = ot * CT;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
+  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * CT;
   const int nchunks = a.Cin / 32;
   const size_t xbytes = (size_t)a.B * G * 2 * HW * 16;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(xin), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
@@ -1799,7 +1798,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
     const int e = 64 * (wave + NW * j) + lane;
     const int p8 = e / PS, pos = e - p8 * PS, t = p8 >> 2, grp = p8 & 3;      // plane p8 = term * 4 + group
     const int rr = pos / PC, c = pos - rr * PC;
-    const int yy = rr - 1, xx = c - 1;
+    const int yy = y0 + rr - 1, xx = x0 + c - 1;
     const bool inb = e < PV && pos < PS0 && yy >= 0 && yy < H && xx >= 0 && xx < W && b < a.B;
     voff[j] = inb ? (((b * G + grp) * 2 + t) * HW + yy * W + xx) * 16 : (int)0x7FFFF000;
   }
@@ -1822,12 +1821,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
     }                                                                                                     \
   }
   f32x4 acc[MB][NB];
-  int pix[NB], prow[NB];
+  int pix[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    int prr, pc; tile_pixel<TW>((wave * 2 + (nb >> 1)) * 32 + 16 * (nb & 1), prr, pc);      // the 16 pixels of block nb: one tile row (pc = 0)
-    prow[nb] = prr;
-    pix[nb] = q * PS + prr * PC + l15;
+    int prr, pc; tile_pixel<TW>((wave * 2 + (nb >> 1)) * 32 + 16 * (nb & 1), prr, pc);      // the 16 pixels of block nb: one tile row from column pc (0 or 16)
+    pix[nb] = q * PS + prr * PC + pc + l15;
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
@@ -1864,7 +1862,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
     if (ch + 1 < nchunks) GR_K32_DMA(ch + 1)
   }
 #undef GR_K32_DMA
-  // scale back + bias: lane holds channel chl = 16 mb + 4 q + i of pixel (prow[nb], l15)
+  // scale back + bias: lane holds channel chl = 16 mb + 4 q + i of pixel l15 of block nb
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -1914,7 +1912,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
 #pragma unroll
         for (int i = 0; i < 4; ++i) stg[(mb * 16 + 4 * q + i) * RS + nb * 16 + l15] = acc[mb][nb][i];
     const int kq = lane % NQ, hq = lane / NQ;                     // pixel quad kq of the wave's 64 pixels (block kq / 4, x = 4 (kq % 4)), channel row hq + CPI i
-    const int yq = prow_of_block<TW>(wave, kq >> 2), xq = 4 * (kq & 3);
+    int prrq, pcq; tile_pixel<TW>(wave * 64 + 4 * kq, prrq, pcq);
+    const int yq = y0 + prrq, xq = x0 + pcq;
     float* outq = a.out + ((size_t)b * a.Cout * H + yq) * W + xq;
     const bool want_max = a.amax_out != nullptr;
 #pragma unroll
@@ -2732,19 +2731,21 @@ static int launch_conv_p16_t(ConvArgs a, const void* wsplit, const void* xin, hi
   return a.stat_tiles;
 }
 bool conv_p16_out_supported(int Cout) { return g_p16_variant == 1 && Cout % 8 == 0; }
-// 16x16 planes, one image per tile, 32-channel chunks on v_mfma_f32_16x16x32_f16 (conv3x3_p16_k32_kernel): training-mode output only
+// 256-pixel x 32-channel tiles, 32-channel chunks on v_mfma_f32_16x16x32_f16 (conv3x3_p16_k32_kernel): training-mode output only
+template <int TW>
 static int launch_conv_p16_k32(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {
-  constexpr int PVP = (2 * 4 * K32_PS + 63) / 64 * 64, LBUF = PVP + 2 * 36 * 32;
-  a.tiles_x = 1; a.tiles_y = 1;
+  constexpr int TR = 256 / TW, PVP = (2 * 4 * k32_ps<TW>() + 63) / 64 * 64, LBUF = PVP + 2 * 36 * 32;
+  a.tiles_x = (a.W + TW - 1) / TW; a.tiles_y = (a.H + TR - 1) / TR;
   a.cout_pad = round_up(a.Cout, 32); a.n_otiles = a.cout_pad / 32;
   const size_t lds = 16 * (size_t)LBUF;
-  a.n_tiles = a.B * a.n_otiles;
-  a.stat_tiles = a.B;
+  a.n_tiles = a.B * a.tiles_x * a.tiles_y * a.n_otiles;
+  a.stat_tiles = a.n_tiles / a.n_otiles;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_k32_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_k32_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static const std::string name = "conv3x3_p16_k32_kernel<" + std::to_string(TW) + ">";
   const double px = (double)a.B * a.H * a.W;
-  KtScope kt("conv3x3_p16_k32_kernel<16>", 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL(conv3x3_p16_k32_kernel<16>, dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
+  KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
+  hipLaunchKernelGGL(conv3x3_p16_k32_kernel<TW>, dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
   return a.stat_tiles;
 }
 void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
@@ -2764,7 +2765,8 @@ void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias
   static const int narrow = getenv("GR_P16_NARROW") ? atoi(getenv("GR_P16_NARROW")) : 1;     // 32-channel output tiles on single-image tiles: four workgroups per CU (six launches 0.303 -> 0.294 ms at cfg2: small, the L2 -> LDS traffic doubles)
   static const int k32 = getenv("GR_P16_K32") ? atoi(getenv("GR_P16_K32")) : 1;      // 32-channel chunks on the 16x16x32 MFMA where the single-image narrow tiles run (0: the 32x32x16 kernel, the A/B control)
   const bool plain_out = a.ep.mean == nullptr && a.ep.act == ACT_NONE && !a.p16_out && out != nullptr;
-  if (H == 16 && W == 16 && k32 && single && narrow && g_p16_variant == 1 && two_img_tiles < 512 && Cin % 32 == 0 && plain_out && !g_p16_debug) nt = launch_conv_p16_k32(a, wsplit, x_p16, s);
+  if (H == 16 && W == 16 && k32 && single && narrow && g_p16_variant == 1 && two_img_tiles < 512 && Cin % 32 == 0 && plain_out && !g_p16_debug) nt = launch_conv_p16_k32<16>(a, wsplit, x_p16, s);
+  else if (k32 >= 2 && !(H == 16 && W == 16) && g_p16_variant == 1 && W % 32 == 0 && H % 8 == 0 && Cin % 32 == 0 && plain_out && !g_p16_debug) nt = launch_conv_p16_k32<32>(a, wsplit, x_p16, s);      // experiment: 8-row tiles of 32-wide planes
   else if (H == 16 && W == 16) nt = (single && g_p16_variant == 1 && two_img_tiles < 512) ? (narrow ? launch_conv_p16_quad<16, 1, 2, 1>(a, wsplit, x_p16, s) : launch_conv_p16_quad<16, 1, 2>(a, wsplit, x_p16, s))
                                                                                   : launch_conv_p16_t<16, 2>(a, wsplit, x_p16, s);
   else {
