@@ -234,13 +234,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 // has one 32-row tile per CU: 4 waves per CU, every chunk's load latency exposed; cfg2: 57 -> 47.5 us with two groups, 38.8
 // with four, 3.5 TB/s).
 template <int CO, int KS = 1, int TW = 32>
-__global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, const float* __restrict__ w_native) {
+__global__ __launch_bounds__(256, (TW == 64 && CO <= 3) ? 4 : 3) void conv3x3_fewout_kernel(ConvArgs a, const float* __restrict__ w_native) {
+  // TW = 64 (later in round 4): chunks of FOUR channels (a 21 KB patch) and four waves per SIMD instead of eight channels and three - the kernel is
+  // bound by what its resident waves get through between two barriers, not by the barriers: 0.341 -> 0.31 ms at cfg3 (same box); five waves per
+  // SIMD spill (0.70 ms), two-channel chunks at six even more (1.38 ms).
   // TW = 64 (round 4): a 64-wide plane as ONE tile column.  With 32-wide tiles every workgroup's two halo columns (4-byte loads at x0 - 1
   // and x0 + 32) pull the NEIGHBOUR tile's whole 128-byte line of every patch row out of the fabric - horizontally adjacent tiles run on
   // different XCDs (round-robin dispatch), so the neighbour's L2 copy does not help: G's last convolution at cfg3 fetched 1981 MB per launch
   // for 1074 MB of input (request-size counters, profiles/r04_traffic_two_ways_cfg3.txt) at 5.1 TB/s - it was traffic-bound, not LDS-bound.
   constexpr int SPR = TW / 4;                              // 4-pixel strips per tile row
-  constexpr int TRr = 1024 / TW / KS, CK = 8, PR = TRr + 2, PCS = TW + 8, PS = PR * PCS;   // interior columns at [4, TW + 4), halo at 3 and TW + 4
+  constexpr int TRr = 1024 / TW / KS, CK = (TW == 64 ? 4 : 8), PR = TRr + 2, PCS = TW + 8, PS = PR * PCS;   // interior columns at [4, TW + 4), halo at 3 and TW + 4
   constexpr int NV = (CK * PR * SPR + 255) / 256;          // float4 loads per thread per chunk (interior)
   constexpr int NHL = (CK * PR * 2 + 255) / 256;           // scalar loads per thread per chunk (halo columns)
   // the chunk's weights sit in LDS next to the patch ([ci][o][tap], rows padded to float4s) and are read back as broadcast
@@ -291,8 +294,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
       wreg[1] = (wl_c2 < CK && wl_e2 < CO * 9 && ci2 < a.Cin) ? w_native[((size_t)(wl_e2 / 9) * a.Cin + ci2) * 9 + wl_e2 % 9] : 0.f; \
     }                                                                                            \
   }
+  const int nch = (a.Cin + CK - 1) / CK;
   GR_FO_LOAD(0)
-  for (int ch = 0; ch < a.nchunks; ++ch) {
+  for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + 256 * i, q = f % SPR, rr = (f / SPR) % PR, cil = (f / SPR) / PR;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_fewout_kernel(ConvArgs a, cons
     if (wl_c < CK) wsh[wl_c * WS + wl_e] = wreg[0];
     if (wl_c2 < CK) wsh[wl_c2 * WS + wl_e2] = wreg[1];
     __syncthreads();
-    if (ch + 1 < a.nchunks) GR_FO_LOAD(ch + 1)
+    if (ch + 1 < nch) GR_FO_LOAD(ch + 1)
 #pragma unroll 2
     for (int cil = kg * (CK / KS); cil < (kg + 1) * (CK / KS); ++cil) {
       const int ci = ch * CK + cil;
