@@ -7,8 +7,8 @@ python bench.py --gpus N --steps K --warmup W
   N > 1 without a torch.distributed.run environment: this process (which never touches a GPU) starts the N ranks itself
   (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>) and exits with their code.
   N > 1 under torch.distributed.run (RANK / WORLD_SIZE set): one rank per GPU, gradients over RCCL.
-Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline`, `cpu_baseline`, and per arithmetic mode
-(`modes`: f16x3 = headline, bf16x6, f32) the same timed loop with its own roofline.
+Rank 0 prints ONE compact JSON line on stdout (< 4 KB; contract in the task statement) carrying `roofline`, `cpu_baseline`, `f32_row`, `cfg3` and
+`search_cfg5` summaries; the full result (per arithmetic mode tables, per-kernel tables, notes) goes to gpurun_out/bench_detail.json and stderr.
 """
 import argparse
 import json
@@ -700,6 +700,104 @@ def run_workload(args, wl_key, modes, ctx, rank, world, shared_gpu, traffic, tra
     return out
 
 
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The line the driver parses.  VERDICT round 4: a 23 KB line was cut by the driver's 8 KB stdout tail and left BENCH_r04.parsed null.
+# Rank 0 therefore prints ONE compact stdout line (< 4 KB, strict JSON); everything else (mode tables, per-kernel tables, notes)
+# goes to gpurun_out/bench_detail.json (and to stderr as one line, so a driver that keeps stderr still has it).
+HEADLINE_MAX_BYTES = 4096
+DETAIL_FILE = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+_SHORT_DTYPE = {"f16x3": "f32 via f16x3 split (3 fp16 MFMA products, fp32 accumulate)", "bf16x6": "f32 via bf16x6 split (6 bf16 MFMA products, fp32 accumulate)", "f32": "f32"}
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def headline(out, conv_mode="f16x3"):
+    """The compact line: exactly the contract's keys + roofline + cpu_baseline + the strict-precision row, cfg3 and cfg5 summaries
+    (VERDICT round 4, item 1).  Pure function of the full result dict (tests/test_host_logic.py feeds it a canned one)."""
+    cfgkeys = ("workload", "global_batch", "per_gpu_batch", "parallelism", "bn")
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline")}
+    line["dtype"] = out["dtype"] if len(str(out.get("dtype", ""))) <= 100 else _SHORT_DTYPE.get(conv_mode, conv_mode)
+    if out.get("range_guard_tripped") or "range guard" in str(out.get("dtype", "")):
+        line["dtype"] = "f32 via bf16x6 split (range guard moved the context off f16x3 during the timed steps)"
+    line["data"] = out.get("data", "synthetic")
+    line["config"] = _pick(out.get("config", {}), cfgkeys)
+    line["rccl_ranks"] = out.get("rccl_ranks", 1)
+    roof = out.get("roofline") or {}
+    line["roofline"] = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "algorithmic_gflop_per_launch"))
+    if isinstance(roof.get("sustained"), dict):
+        line["roofline"]["frac_of_bare_loop"] = roof["sustained"].get("frac_of_bare_loop")
+    line["r_convs"] = _pick(out.get("r_convs") or {}, ("ms_per_step", "algorithmic_gflop", "tflops"))
+    if line["r_convs"].get("tflops") and roof.get("peak"):
+        line["r_convs"]["frac"] = round(line["r_convs"]["tflops"] / roof["peak"], 4)
+    line["elementwise_ms"] = (out.get("elementwise") or {}).get("ms_per_step")
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "by_threads")) if cb else None
+    if cb:
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:120]
+    f32 = out.get("f32_row")
+    line["f32_row"] = _pick(f32, ("images_per_sec", "ms_per_step", "roofline_kernel", "roofline_frac", "r_convs_frac_of_fp32_mfma_peak")) if f32 else None
+    c3 = out.get("cfg3")
+    if c3:
+        r3 = c3.get("roofline") or {}
+        line["cfg3"] = dict(_pick(c3, ("images_per_sec", "ms_per_step")), roofline_kernel=r3.get("kernel"), roofline_frac=r3.get("frac"),
+                            roofline_avg_launch_ms=r3.get("avg_launch_ms"), traffic=r3.get("traffic"),
+                            r_convs_ms=(c3.get("r_convs") or {}).get("ms_per_step"), elementwise_ms=(c3.get("elementwise") or {}).get("ms_per_step"))
+    s5 = out.get("search_cfg5")
+    if s5:
+        emb, bat = s5.get("embed") or {}, s5.get("batched_1024") or {}
+        line["search_cfg5"] = dict(_pick(s5, ("n", "d", "k", "ms", "hbm_frac", "exact_match")), embed_images_per_sec=emb.get("images_per_sec"),
+                                   embed_error=(str(emb["error"])[:120] if emb.get("error") else None), batched_ms=bat.get("ms"), batched_tflops=bat.get("mfma_tflops"),
+                                   pipeline_corpus_exact_match=(s5.get("search_on_pipeline_corpus") or {}).get("exact_match"))
+    g = out.get("gan_step")
+    if g:
+        line["gan_step"] = {"error": str(g["error"])[:120]} if "error" in g else {b: (g.get(b) or {}).get("ms_per_batch") for b in ("batch32", "batch256")}
+    line["detail"] = "gpurun_out/bench_detail.json (and stderr): mode tables, per-kernel tables, notes"
+    return line
+
+
+def headline_text(out, conv_mode="f16x3"):
+    line = headline(out, conv_mode)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    for drop in ("gan_step", "elementwise_ms", "r_convs", "detail"):      # never reached with today's keys; a guard, not a plan
+        if len(text) < HEADLINE_MAX_BYTES:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= HEADLINE_MAX_BYTES:
+        raise SystemExit(f"bench.py: headline is {len(text)} bytes (limit {HEADLINE_MAX_BYTES})")
+    return text
+
+
+def _finite(o):
+    """NaN / Infinity are not JSON: they become null with the path recorded (the line must parse strictly)."""
+    import math
+    if isinstance(o, float) and not math.isfinite(o):
+        return None
+    if isinstance(o, dict):
+        return {str(k): _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
+def emit(out, args):
+    out = _finite(out)
+    detail = json.dumps(out, allow_nan=False)
+    try:
+        os.makedirs(os.path.dirname(DETAIL_FILE), exist_ok=True)
+        with open(DETAIL_FILE, "w") as f:
+            f.write(detail + "\n")
+    except OSError as e:
+        print(f"bench.py: could not write {DETAIL_FILE}: {e}", file=sys.stderr)
+    print("bench_detail " + detail, file=sys.stderr)
+    sys.stderr.flush()
+    print(headline_text(out, args.conv_mode))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -857,7 +955,7 @@ def main():
             ctx.comm_destroy()
         dist.destroy_process_group()
     if out is not None and not args.quiet_child:
-        print(json.dumps(out))
+        emit(out, args)
 
 
 if __name__ == "__main__":

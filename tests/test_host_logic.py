@@ -289,6 +289,43 @@ def test_bench_launches_its_own_ranks():
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
 
 
+def test_bench_headline_is_compact_strict_json():
+    """the LAST stdout line of bench.py must be a compact (< 4 KB), strictly valid JSON object carrying the contract's keys,
+    `roofline` and `cpu_baseline`; the tables go to a side file.  Built here from a canned full result (a committed copy of round 4's 23 KB line) and from the
+    same result with hostile values (NaN, a tripped range guard, failed side legs, pathologically long notes)."""
+    import copy, json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    full = json.load(open(os.path.join(root, "tests", "golden", "bench_result_canned.json")))
+    assert len(json.dumps(full)) > 20000                       # the size that broke the driver
+    text = bench.headline_text(full)
+    assert len(text) < 4096 and "\n" not in text
+    line = json.loads(text, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))      # NaN / Infinity would raise
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "rccl_ranks", "roofline", "cpu_baseline", "f32_row", "cfg3", "search_cfg5"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["config"]["workload"] == full["config"]["workload"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "algorithmic_gflop_per_launch"):
+        assert line["roofline"][k] == full["roofline"][k], k
+    for k in ("value", "unit", "cores", "kind"):
+        assert line["cpu_baseline"][k] == full["cpu_baseline"][k], k
+    assert line["cfg3"]["images_per_sec"] == full["cfg3"]["images_per_sec"] and line["cfg3"]["roofline_frac"] == full["cfg3"]["roofline"]["frac"]
+    assert line["search_cfg5"]["exact_match"] is True and line["f32_row"]["ms_per_step"] == full["f32_row"]["ms_per_step"]
+    assert "model" not in line["config"]
+    # hostile variant
+    bad = copy.deepcopy(full)
+    bad["last_loss"] = float("nan"); bad["roofline"]["traffic"] = float("inf")
+    bad["dtype"] = "x" * 3000; bad["cpu_baseline"]["sample"] = "y" * 5000
+    bad["gan_step"] = {"error": "RuntimeError: " + "z" * 5000}
+    bad["search_cfg5"]["embed"] = {"error": "boom"}
+    bad = bench._finite(bad)
+    t2 = bench.headline_text(bad)
+    l2 = json.loads(t2)
+    assert len(t2) < 4096 and l2["roofline"]["traffic"] is None and l2["search_cfg5"]["embed_error"] == "boom" and len(l2["dtype"]) < 120
+    json.dumps(bad, allow_nan=False)                           # the detail file is strict JSON too
+
+
 def test_oracle_act_side_hook_moves_exactly_the_forced_elements():
     """go_net_force_act_side: forcing the side the oracle would take anyway changes nothing; flipping one LeakyReLU input's side
     changes gradInput of the activation by gout * (1 - slope) at that element only (seen through a 1x1 identity-free net:
