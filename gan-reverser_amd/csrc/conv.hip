@@ -571,12 +571,12 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.up = up ? 1 : 0;
   a.nchunks = L.cin_pad / CONV_CK; a.cout_pad = L.cout_pad;
   if (w_native && Cout <= 4 && !up && W % 4 == 0 && W >= 16) {
-    static const int fo_split = getenv("GR_FEWOUT_SPLIT") ? atoi(getenv("GR_FEWOUT_SPLIT")) : 4;     // 0: 32-row tiles, 1: two channel groups on 16-row tiles, 4: four on 8-row tiles
+    static const int fo_split = GR_KNOB("GR_FEWOUT_SPLIT", 4);     // 0: 32-row tiles, 1: two channel groups on 16-row tiles, 4: four on 8-row tiles
     // (decided by the plane alone, not by the batch: a row must get the same bits whatever batch it travels in)
     const bool ks2 = fo_split && H % 16 == 0 && ((W + 31) / 32) * ((H + 31) / 32) < 4;      // small planes: too few 32-row tiles per image to fill the chip
     const bool ks4 = fo_split == 4 && ks2 && H % 8 == 0;
     // planes whose width is a multiple of 64: one 64-wide x 16-row tile per workgroup (no halo columns fetched from a neighbour's lines)
-    static const bool fo_wide = !getenv("GR_FEWOUT_NO_WIDE");
+    static const bool fo_wide = !GR_KNOB_SET("GR_FEWOUT_NO_WIDE");
     const bool wide64 = fo_wide && !ks2 && W % 64 == 0;
     a.tiles_x = wide64 ? W / 64 : (W + 31) / 32; a.tiles_y = wide64 ? (H + 15) / 16 : (ks4 ? H / 8 : (ks2 ? H / 16 : (H + 31) / 32)); a.n_otiles = 1;
     const int grid = B * a.tiles_x * a.tiles_y;
@@ -608,7 +608,7 @@ void launch_conv3x3(const float* in, const float* wt, const float* bias, float* 
     return;
   }
   static int variant = -1;
-  if (variant < 0) { const char* e = getenv("GR_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
+  if (variant < 0) { variant = GR_KNOB("GR_CONV_VARIANT", 0); }
   const bool big_img = (long)H * W >= 512;            // a 512-pixel tile needs at least that many pixels per image
   if (L.cout_pad % 64 != 0) { launch_conv_mt<1, 2>(a, s); return; }
   // measured on MI355X (B=256): 512-pixel tiles (NG=4) beat 256-pixel ones on 32x32 planes (G.convB 1333 -> 1198 us);
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_p16_wide_kernel(ConvArgs a, co
     _Pragma("unroll") for (int ng = 0; ng < NG; ++ng) acc[mt][ng] = split_mma<NTERM>(av_[mt], bv_[ng], acc[mt][ng]);
 #define GR_BF_PIN() __builtin_amdgcn_sched_group_barrier(0x100, (MT + NG) * NTERM, 0); __builtin_amdgcn_sched_group_barrier(0x008, MT * NG * 3, 0);
   float omax = 0.f;
-  const int dbg = a.up;                                              // diagnostic bit mask (0 in production): see g_p16_debug
+  const int dbg = GR_DBG(a.up);                                              // diagnostic bit mask (0 in production): see g_p16_debug
   int L = blockIdx.x;
   Geo g = tile_geo(L);
   int voff[NPS];
@@ -1455,7 +1455,7 @@ __device__ __forceinline__ void conv_p16_quad_body(const ConvArgs& a, const uint
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int H = a.H, W = a.W, HW = H * W;
   const int G = a.Cin >> 3;
-  const int dbg = a.up;
+  const int dbg = GR_DBG(a.up);
   int bid = xcd_remap(blockIdx.x, a.n_tiles);
   const int tile = bid / a.n_otiles;
   const int ot = bid % a.n_otiles; bid /= a.n_otiles;
@@ -2239,7 +2239,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_up2q_f16x3_kernel(ConvArgs a, 
   const int kin = f16_scale_exp(absmax_read(a.amax_in));
   const int ktot = kin + f16_scale_exp(absmax_read(a.amax_w)) - 2;   // summed weights: up to 4 max|w|
   const float sc_in = pow2f(kin);
-  const int dbg = a.up >> 1;            // diagnostic ablations (gr_set_tuning "up2_debug"; outputs are then wrong by design): 1 no stores, 2 no MFMA, 4 no activation staging, 8 no weight DMA
+  const int dbg = GR_DBG(a.up >> 1);            // diagnostic ablations (gr_set_tuning "up2_debug"; outputs are then wrong by design): 1 no stores, 2 no MFMA, 4 no activation staging, 8 no weight DMA
   int voff[NSL], eoff[NSL];
 #pragma unroll
   for (int s = 0; s < NSL; ++s) {
@@ -2445,7 +2445,7 @@ static void launch_conv_up2_t(const ConvArgs& a, const void* wup, hipStream_t s)
   constexpr int IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), PSL = (PS + 15) / 16 * 16;
   constexpr bool FITS = 2 * 16 * (2 * 2 * PSL + 2 * 2 * 8 * 2 * 32) + 5 * 32 * 4 <= 160 * 1024;    // two LDS images where they fit (not the 8-wide tile)
   static int db = -1;
-  if (db < 0) { const char* e = getenv("GR_UP2_DB"); db = e ? atoi(e) : 1; }
+  if (db < 0) { db = GR_KNOB("GR_UP2_DB", 1); }
   if (FITS && db) launch_conv_up2_db<TW, NI, FITS>(a, wup, s);
   else launch_conv_up2_db<TW, NI, false>(a, wup, s);
 }
@@ -2576,7 +2576,7 @@ static void launch_conv_split_wide_db(ConvArgs a, const void* wsplit, hipStream_
   // persistent workgroups: one per CU with two LDS images, two with one (a multiple of 8 so that a workgroup's tiles stay
   // on its XCD); GR_CONV_PERSIST=0 launches one workgroup per tile
   static int persist = -1;
-  if (persist < 0) { const char* e = getenv("GR_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
+  if (persist < 0) { persist = GR_KNOB("GR_CONV_PERSIST", 1); }
   const int resident = 256 * (DB ? 1 : 2);
   const int grid = (persist && a.n_tiles > resident) ? resident : a.n_tiles;
   static bool attr_set = false;
@@ -2591,7 +2591,7 @@ template <int TW, int NI, int NTERM>
 static void launch_conv_split_wide(const ConvArgs& a, const void* wsplit, hipStream_t s) {
   // two f16x3 images fit the 160 KB LDS (152-157 KB): double-buffered; three-term bf16 images do not
   static int db = -1;
-  if (db < 0) { const char* e = getenv("GR_CONV_DB"); db = e ? atoi(e) : 1; }
+  if (db < 0) { db = GR_KNOB("GR_CONV_DB", 1); }
   if (NTERM == 2 && db) launch_conv_split_wide_db<TW, NI, 2, true>(a, wsplit, s);
   else launch_conv_split_wide_db<TW, NI, NTERM, false>(a, wsplit, s);
 }
@@ -2604,9 +2604,9 @@ static int launch_conv3x3_split_n(ConvArgs a, const void* wsplit, hipStream_t s)
   a.stat_part = nullptr;
   ConvArgs aw = a; aw.stat_part = const_cast<double*>(want_stats);      // only the 512-pixel kernels fill it
   static int variant = -1;
-  if (variant < 0) { const char* e = getenv("GR_BF16X6_VARIANT"); variant = e ? atoi(e) : 0; }
+  if (variant < 0) { variant = GR_KNOB("GR_BF16X6_VARIANT", 0); }
   const bool wide = round_up(Cout, 32) % 64 == 0 && variant != 1;      // 64 output channels per workgroup (8 waves share one patch)
-  static const bool stack8 = !getenv("GR_NO_STACK8");
+  static const bool stack8 = !GR_KNOB_SET("GR_NO_STACK8");
   // four 8x8 images per tile - while that still leaves half a workgroup per CU (batch 32 of the GAN game: 32 workgroups stacked, 0.38 -> 0.45 ms;
   // batch 256: 1.37 -> 0.5 ms)
   const long st_tiles = (B + 3) / 4, cp32 = round_up(Cout, 32) / 32;
@@ -2665,16 +2665,16 @@ void launch_conv3x3_split(const float* in, const void* wsplit, const float* bias
 
 // f16x3 convolution on an operand-ready (P16) activation: see conv3x3_p16_wide_kernel
 int g_p16_debug = 0;
-int g_up2_quad = getenv("GR_UP2_QUAD") ? atoi(getenv("GR_UP2_QUAD")) : 1;
-int g_up2_stagger = getenv("GR_UP2_STAGGER") ? atoi(getenv("GR_UP2_STAGGER")) : 0;
-int g_nt_stores = getenv("GR_NT_STORES") ? atoi(getenv("GR_NT_STORES")) : 0;      // kernels.h store4: which kernels store non-temporally (measured: no effect; off)
+int g_up2_quad = GR_KNOB("GR_UP2_QUAD", 1);
+int g_up2_stagger = GR_KNOB("GR_UP2_STAGGER", 0);
+int g_nt_stores = GR_KNOB("GR_NT_STORES", 0);      // kernels.h store4: which kernels store non-temporally (measured: no effect; off)
 int g_up2_debug = 0;       // diagnostic ablations of conv3x3_up2q_f16x3_kernel (gr_set_tuning "up2_debug")
 void* g_p16_stamps = nullptr;     // diagnostic: device buffer of 32 x 8 bytes per workgroup (gr_debug_stamps)
 int g_stack8_min_wgs = 128;     // smallest grid at which 8x8 planes are stacked four to a tile (gr_set_tuning("stack8_min_wgs"): tests force the path)
 int g_p16_min_tiles = 128;      // below half a workgroup per CU the 256-pixel-tile kernels fill the chip better (gr_set_tuning("p16_min_tiles"): tests force the path)
 bool conv_p16_supported(int B, int Cin, int Cout, int H, int W) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("GR_NO_P16"); on = e ? 0 : 1; }
+  if (on < 0) { on = GR_KNOB_SET("GR_NO_P16") ? 0 : 1; }
   if (!on || Cin % 16 != 0 || (H * W) % 256 != 0 || round_up(Cout, 32) % 64 != 0 || (size_t)B * Cin * H * W * 4 >= 0x7FFFF000ul) return false;
   const long otiles = round_up(Cout, 32) / 64;
   if (H == 16 && W == 16) return (long)((B + 1) / 2) * otiles >= g_p16_min_tiles;
@@ -2694,7 +2694,7 @@ static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin,
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI, NG, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true;
-    if (getenv("GR_DEBUG_OCC")) {
+    if (GR_KNOB_SET("GR_DEBUG_OCC")) {
       int nb = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&conv3x3_p16_quad_kernel<TW, NI, NG, MT>), 256, lds);
       fprintf(stderr, "conv3x3_p16_quad_kernel<%d, %d> (NG %d): %zu B LDS per workgroup, occupancy query says %d workgroups per CU\n", TW, NI, NG, lds, nb);
     }
@@ -2763,18 +2763,18 @@ void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias
   a.amax_in = amax_in; a.amax_w = amax_w; a.amax_out = amax_out;
   a.stat_part = stat_tiles ? stat_part : nullptr;
   // 16x16 planes: two-image tiles when they still give two workgroups per CU, single-image tiles otherwise
-  static const int single = getenv("GR_P16_SINGLE") ? atoi(getenv("GR_P16_SINGLE")) : 1;
+  static const int single = GR_KNOB("GR_P16_SINGLE", 1);
   const long two_img_tiles = (long)((B + 1) / 2) * (round_up(Cout, 32) / 64);
   int nt;
-  static const int narrow = getenv("GR_P16_NARROW") ? atoi(getenv("GR_P16_NARROW")) : 1;     // 32-channel output tiles on single-image tiles: four workgroups per CU (six launches 0.303 -> 0.294 ms at cfg2: small, the L2 -> LDS traffic doubles)
-  static const int k32 = getenv("GR_P16_K32") ? atoi(getenv("GR_P16_K32")) : 1;      // 32-channel chunks on the 16x16x32 MFMA where the single-image narrow tiles run (0: the 32x32x16 kernel, the A/B control)
+  static const int narrow = GR_KNOB("GR_P16_NARROW", 1);     // 32-channel output tiles on single-image tiles: four workgroups per CU (six launches 0.303 -> 0.294 ms at cfg2: small, the L2 -> LDS traffic doubles)
+  static const int k32 = GR_KNOB("GR_P16_K32", 1);      // 32-channel chunks on the 16x16x32 MFMA where the single-image narrow tiles run (0: the 32x32x16 kernel, the A/B control)
   const bool plain_out = a.ep.mean == nullptr && a.ep.act == ACT_NONE && !a.p16_out && out != nullptr;
   if (H == 16 && W == 16 && k32 && single && narrow && g_p16_variant == 1 && two_img_tiles < 512 && Cin % 32 == 0 && plain_out && !g_p16_debug) nt = launch_conv_p16_k32<16>(a, wsplit, x_p16, s);
   else if (k32 >= 2 && !(H == 16 && W == 16) && g_p16_variant == 1 && W % 32 == 0 && H % 8 == 0 && Cin % 32 == 0 && plain_out && !g_p16_debug) nt = launch_conv_p16_k32<32>(a, wsplit, x_p16, s);      // experiment: 8-row tiles of 32-wide planes
   else if (H == 16 && W == 16) nt = (single && g_p16_variant == 1 && two_img_tiles < 512) ? (narrow ? launch_conv_p16_quad<16, 1, 2, 1>(a, wsplit, x_p16, s) : launch_conv_p16_quad<16, 1, 2>(a, wsplit, x_p16, s))
                                                                                   : launch_conv_p16_t<16, 2>(a, wsplit, x_p16, s);
   else {
-    static const int half32 = getenv("GR_P16_HALF32") ? atoi(getenv("GR_P16_HALF32")) : 0;     // 256-pixel tiles (8 rows x 32) on wider planes
+    static const int half32 = GR_KNOB("GR_P16_HALF32", 0);     // 256-pixel tiles (8 rows x 32) on wider planes
     const long tiles512 = (long)B * ((H + 15) / 16) * ((W + 31) / 32) * (round_up(Cout, 32) / 64);
     nt = (half32 && g_p16_variant == 1 && H % 8 == 0 && tiles512 < half32) ? launch_conv_p16_quad<32, 1, 2>(a, wsplit, x_p16, s) : launch_conv_p16_t<32, 1>(a, wsplit, x_p16, s);
   }
@@ -4014,7 +4014,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
 // GR_WGRAD_PP: 1 (default) = the ping-pong kernel on 16-wide planes only, 2 = everywhere, 0 = never.  Measured at cfg2 per launch:
 // 16-wide 52 -> 50 us, and the slab reduction 16.5 -> 10.8 us; 32-wide 70 -> 98 us (its 34 KB x patch per 64 pixels makes the
 // load phase longer than the multiply phase, and strict alternation then idles the matrix pipe more than chance did).
-static int wgrad_pp_mode() { static int v = -1; if (v < 0) { const char* e = getenv("GR_WGRAD_PP"); v = e ? atoi(e) : 1; } return v; }
+static int wgrad_pp_mode() { static int v = -1; if (v < 0) { v = GR_KNOB("GR_WGRAD_PP", 1); } return v; }
 static bool wgrad_pp(int W) { const int m = wgrad_pp_mode(); return m == 2 || (m == 1 && W == 16); }
 template <int W_>
 static void launch_wgrad_p16_pp_t(const WgradP16Args& a, int grid, size_t lds, hipStream_t s) {
@@ -4040,7 +4040,7 @@ static void wgrad_geometry(int B, int Cin, int Cout, int H, int W, WgradArgs& a,
   // measured (B=256): 32-wide planes 512 splits (two workgroups per CU overlap convert/store with MFMAs), 16-wide planes 256
   // measured (f16x3): 512 partial blocks pay off on 32-wide planes once there are many row steps per block (cfg3: 1.75 vs 1.93 ms),
   // 256 otherwise (cfg2: the slab round trip of the extra blocks costs more than the overlap gains, -0.02 ms)
-  else if (split) { const char* e = getenv("GR_WGRAD_SPLITS"); want = (e ? atoi(e) : ((TW == 32 && (long)B * H * a.tiles_x >= 16384) ? 512 : 256)) / (a.n_ob * a.n_cb); }
+  else if (split) { want = GR_KNOB("GR_WGRAD_SPLITS", ((TW == 32 && (long)B * H * a.tiles_x >= 16384) ? 512 : 256)) / (a.n_ob * a.n_cb); }
   if (want < 1) want = 1;
   if (want > a.tiles_total) want = a.tiles_total;
   a.nsplit = (int)want;
@@ -4069,14 +4069,14 @@ static void launch_wgrad_split(const WgradArgs& a, int TW, int rps, int wv, int 
 
 bool conv_wgrad_p16_supported(int B, int Cin, int Cout, int H, int W) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("GR_NO_P16_WGRAD"); on = e ? 0 : 1; }
+  if (on < 0) { on = GR_KNOB_SET("GR_NO_P16_WGRAD") ? 0 : 1; }
   return on && Cin % 64 == 0 && Cout % 64 == 0 && (W == 16 || W == 32 || W == 64) && (H * W) % 256 == 0 &&
          (size_t)B * (Cin > Cout ? Cin : Cout) * H * W * 4 < 0x7FFFF000ul;
 }
 static int wgrad_p16_splits(int B, int Cin, int Cout, int H, int W) {
   const int blocks = (Cin / 64) * (Cout / 64);
   static int wgs_env = -1;
-  if (wgs_env < 0) { const char* e = getenv("GR_WGRAD_P16_WGS"); wgs_env = e ? atoi(e) : 0; }
+  if (wgs_env < 0) { wgs_env = GR_KNOB("GR_WGRAD_P16_WGS", 0); }
   const int wgs = wgs_env ? wgs_env : (wgrad_pp(W) ? 256 : 512);      // ping-pong: ONE eight-wave workgroup per CU; else two four-wave ones
   int want = wgs / blocks; if (want < 1) want = 1;
   const long units = (long)B * H * W / 64;
@@ -4099,8 +4099,8 @@ void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, 
   a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.n_ob = Cout / 64; a.n_cb = Cin / 64; a.cinp = Cin; a.coutp = Cout;
   a.nsplit = wgrad_p16_splits(B, Cin, Cout, H, W); a.units = (int)((long)B * H * W / 64);
   a.amax_x = amax_x; a.amax_dy = amax_dy;
-  { static const int plain = getenv("GR_WGRAD_PLAIN_ORDER") ? atoi(getenv("GR_WGRAD_PLAIN_ORDER")) : 0; a.plain_order = plain; }
-  { static const int dynt = getenv("GR_WGRAD_DY_NT") ? atoi(getenv("GR_WGRAD_DY_NT")) : 0; a.dy_nt = dynt; }
+  { static const int plain = GR_KNOB("GR_WGRAD_PLAIN_ORDER", 0); a.plain_order = plain; }
+  { static const int dynt = GR_KNOB("GR_WGRAD_DY_NT", 0); a.dy_nt = dynt; }
   const int grid = a.nsplit * a.n_ob * a.n_cb;
   const double px = (double)B * H * W;
   {
@@ -4132,7 +4132,7 @@ void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* work
     {
       const int grid_ = a.nsplit * a.n_ob * a.n_cb;
       static int wv = -1;
-      if (wv < 0) { const char* e = getenv("GR_WGRAD_VARIANT"); wv = e ? atoi(e) : 2; }   // 2: rolling-window kernel; 1: per-tile kernel (AGPR accumulators)
+      if (wv < 0) { wv = GR_KNOB("GR_WGRAD_VARIANT", 2); }   // 2: rolling-window kernel; 1: per-tile kernel (AGPR accumulators)
       const int TRr = 32 / TW;
       int rps = 0;                                                 // rows per segment of the rolling-window kernel
       if (wv == 2 && H % TRr == 0) {

@@ -263,14 +263,14 @@ static void convk_direct(const float* in, const float* w, const float* bias, flo
   // two images per workgroup (each weight load used twice) measured SLOWER at the D network's shape, 430 vs 364 us (84 instead
   // of 50 VGPRs, twice the LDS): the scalar cache is not what bounds the one-image kernel.  Kept behind a switch.
   // measured (GAN batch, D network's shape): batch 32 - 290 -> 83 us per launch sliced; batch 256 (1024+ workgroups) - 364 us either way
-  static const int sliced_env = getenv("GR_CONVK_SLICED") ? atoi(getenv("GR_CONVK_SLICED")) : -1;
+  static const int sliced_env = GR_KNOB("GR_CONVK_SLICED", -1);
   const bool sliced = sliced_env >= 0 ? sliced_env != 0 : (long)tiles_x * tiles_y * (CoP / COT) * B < 1024;
   if (sliced) {
     dim3 grid(tiles_x * tiles_y, CoP / COT, B);
     convk_direct_sliced_kernel<K, COT, KC_KS><<<grid, 256 * KC_KS, 0, s>>>(in, wt, bias, out, cin_eff, cout_eff, CoP, H, W, tiles_x);
     return;
   }
-  static const bool two_images = getenv("GR_CONVK_NI2") != nullptr;
+  static const bool two_images = GR_KNOB_SET("GR_CONVK_NI2");
   if (two_images && (long)tiles_x * tiles_y * (CoP / COT) * ((B + 1) / 2) >= 512) {
     dim3 grid(tiles_x * tiles_y, CoP / COT, (B + 1) / 2);
     convk_direct_kernel<K, COT, 2><<<grid, 256, 0, s>>>(in, wt, bias, out, B, cin_eff, cout_eff, CoP, H, W, tiles_x);

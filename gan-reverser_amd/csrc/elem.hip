@@ -55,7 +55,7 @@ __device__ __forceinline__ void post_specialize(PostArgs& f) {
   if (CB == 11) { f.act = ACT_ELU; f.has_bn = 1; f.m1.kind = MASK_SCALE; f.pool = 1; f.m2.kind = MASK_NONE; }
 }
 inline int post_combo(const PostArgs& f) {
-  static const bool on = !getenv("GR_POST_GENERIC");
+  static const bool on = !GR_KNOB_SET("GR_POST_GENERIC");
   if (!on) return 0;
   if (!f.has_bn && f.m2.kind == MASK_NONE) {
     if (f.act == ACT_PRELU && f.m1.kind == MASK_NONE && !f.pool) return 4;
@@ -211,7 +211,7 @@ __device__ __forceinline__ float4 ld4_maybe_nt(const float* p, bool nt) {
   if (nt) { const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
   return *reinterpret_cast<const float4*>(p);
 }
-inline int post_nt_mode() { static const int m = getenv("GR_POST_NT") ? atoi(getenv("GR_POST_NT")) : -1; return m; }   // -1: the size rule; else bit 0 pass A, 1 pass B, 2 forward
+inline int post_nt_mode() { static const int m = GR_KNOB("GR_POST_NT", -1); return m; }   // -1: the size rule; else bit 0 pass A, 1 pass B, 2 forward
 inline bool post_big(const PostArgs& f) { return 4.0 * f.B * f.C * f.H * f.W >= 128.0 * 1024 * 1024; }
 
 template <int CB>
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void to_p16_kernel(const float* __restrict__ x
 // LDS tile of the 8-channel-group pipeline kernels: 2 = 256 pixels (9 KB per workgroup, eight workgroups per CU; default), 1 = 512,
 // 0 = 1024 (34 KB, four per CU).  Measured per step, pass B / forward: cfg2 0.228 / 0.148 -> 0.207 / 0.135 -> 0.199 / 0.139 ms,
 // cfg3 1.74 / 1.09 -> 1.23 / 0.80 -> 1.21 / 0.81 ms.
-static int g8_half_tiles() { static int v = -1; if (v < 0) { const char* e = getenv("GR_G8_HALF_TILES"); v = e ? atoi(e) : 2; } return v; }
+static int g8_half_tiles() { static int v = -1; if (v < 0) { v = GR_KNOB("GR_G8_HALF_TILES", 2); } return v; }
 void launch_to_p16(const float* x, void* p16, int B, int C, int HW, const unsigned* slot, hipStream_t s) {
   long blocks = ((long)B * (C / 8) * (HW / 4) + 255) / 256;
   if (blocks > 16384) blocks = 16384;
@@ -865,7 +865,8 @@ __global__ __launch_bounds__(256) void post_backward_b_vec_kernel(PostBwdArgs a,
 // dy_p16[b][g][term][pixel], scaled by the power of two of the bound K * max|dz| (K from the forward's statistics, max|dz| from
 // pass A) that it also leaves in amax_dy, and as fp32 only when a consumer still needs that (a.dy != null).
 template <int PXT, int CB>
-__global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, int splits, int slices, double n, int dbg) {
+__global__ __launch_bounds__(256) void post_backward_b_g8_kernel(PostBwdArgs a, int splits, int slices, double n, int dbg_) {
+  const int dbg = GR_DBG(dbg_);
   post_specialize<CB>(a.f);
   constexpr int RSB = PXT * 2 + 64;
   __shared__ __attribute__((aligned(16))) unsigned char img[16 * RSB];

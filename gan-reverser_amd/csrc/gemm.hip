@@ -500,11 +500,11 @@ void launch_gemm(const float* A, long rsA, long ksA, const float* Bm, long rsB, 
                  const unsigned* amax_a, const unsigned* amax_b) {
   GemmArgs a{};
   if (ep) { a.ep = *ep; a.has_ep = 1; }
-  static const int vec_store = getenv("GR_GEMM_DWORD_STORES") ? 0 : 1;
+  static const int vec_store = GR_KNOB_SET("GR_GEMM_DWORD_STORES") ? 0 : 1;
   a.vec_store = vec_store;
   a.amax_out = amax_out; a.amax_a = amax_a; a.amax_b = amax_b;
   const bool f16 = amax_a != nullptr && amax_b != nullptr;
-  static const bool big_on = !getenv("GR_GEMM_SMALL_TILES");
+  static const bool big_on = !GR_KNOB_SET("GR_GEMM_SMALL_TILES");
   bool big = f16 && big_on && M >= 128 && N >= 128;
   a.A = A; a.Bm = Bm; a.C = C; a.slab = reinterpret_cast<float*>(workspace); a.bias = bias;
   a.rsA = rsA; a.ksA = ksA; a.rsB = rsB; a.ksB = ksB; a.ldc = ldc;

@@ -4,6 +4,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
+// ---------------------------------------------------------------- knobs
+// The SHIPPING library (make: libganrev.so) reads three environment variables (GR_CONV_MODE, GR_RANGE_GUARD, GR_SIDE_WGRAD: net.hip, gr_init) and
+// answers the gr_set_tuning keys include/ganrev.h documents; nothing else selects kernels at run time.  Every other switch - A/B controls of
+// variants that lost their measurement, and ablation bits that make kernels compute WRONG results by design (no stores, no MFMA, no DMA ...) - exists
+// only in the ablation build (make ablate: libganrev_ablate.so, -DGR_ABLATE), where GR_KNOB reads the environment; in the shipping build it is its
+// default, a compile-time constant the optimiser folds away, and GR_DBG(x) is 0 inside the kernels.  
+#ifdef GR_ABLATE
+#define GR_KNOB(name, def) (getenv(name) ? atoi(getenv(name)) : (def))
+#define GR_KNOB_SET(name) (getenv(name) != nullptr)
+#define GR_DBG(x) (x)
+#else
+#define GR_KNOB(name, def) (def)
+#define GR_KNOB_SET(name) (false)
+#define GR_DBG(x) 0
+#endif
+
 namespace gr {
 
 // ---------------------------------------------------------------- conv3x3 (implicit GEMM on fp32 MFMA)

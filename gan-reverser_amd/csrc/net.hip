@@ -27,6 +27,8 @@ struct gr_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   ncclComm_t comm = nullptr;
+  ncclComm_t stat_comm = nullptr;             // synchronised BatchNorm's own communicator (ncclCommSplit of comm): its collectives run on the COMPUTE stream while the gradient
+                                              // buckets run on comm_stream - two streams never share one communicator
   int nranks = 1, rank = 0;
   hipStream_t comm_stream = nullptr;          // gradient buckets are reduced here, behind the rest of backward
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
@@ -66,7 +68,7 @@ struct gr_ctx {
 
 // ---- per-kernel event timer (gr_set_timing(ctx, 2)) -------------------------------------------------------------
 namespace gr { KernelTimer* g_ktimer = nullptr; }
-static int g_eval_p16 = getenv("GR_NO_EVAL_P16") ? 0 : 1;      // gr_set_tuning "eval_p16"
+static int g_eval_p16 = GR_KNOB_SET("GR_NO_EVAL_P16") ? 0 : 1;      // gr_set_tuning "eval_p16"
 static int g_kphase = 0;      // which part of gr_train_r_step is launching: 0 outside, 1 G forward, 2 R forward, 3 loss, 4 R backward, 5 Adam
 struct EventTimer : gr::KernelTimer {
   struct Rec { std::string name; int phase; double flops, bytes; hipEvent_t e0, e1; bool ok; };
@@ -150,7 +152,16 @@ static int small_allreduce(gr_ctx* c, void* buf, long count, int kind) {
     return rc ? fail(c, GR_ERR_COMM, "host exchange hook failed (%d)", rc) : GR_OK;
   }
   if (!c->comm) return GR_OK;
-  NCCLCHK(c, ncclAllReduce(buf, buf, (size_t)count, kind == 0 ? ncclFloat : (kind == 1 ? ncclDouble : ncclUint32), kind == 2 ? ncclMax : ncclSum, c->comm, c->stream));
+  NCCLCHK(c, ncclAllReduce(buf, buf, (size_t)count, kind == 0 ? ncclFloat : (kind == 1 ? ncclDouble : ncclUint32), kind == 2 ? ncclMax : ncclSum, c->stat_comm ? c->stat_comm : c->comm, c->stream));
+  return GR_OK;
+}
+// Collective (every rank reaches it at the same point: gr_comm_init with sync_bn already on, or gr_set_tuning "sync_bn" with a communicator): the
+// BatchNorm statistics get a communicator of their own.  Without it the statistics all-reduces (compute stream) and the gradient buckets (comm_stream)
+// would interleave on ONE communicator from two streams; RCCL serialises that correctly only as long as every rank issues in the same host order -
+// true here by construction, but never run with a peer on this pool, so it is not relied on.
+static int ensure_stat_comm(gr_ctx* c) {
+  if (!c->comm || c->stat_comm || !c->sync_bn) return GR_OK;
+  NCCLCHK(c, ncclCommSplit(c->comm, 0, c->rank, &c->stat_comm, nullptr));
   return GR_OK;
 }
 static int statsync_sum(void* user, double* buf, long count) { gr_ctx* c = static_cast<gr_ctx*>(user); const int r = small_allreduce(c, buf, count, 1); if (r && !c->coll_rc) c->coll_rc = r; return r; }
@@ -159,9 +170,14 @@ static int statsync_max(void* user, unsigned* buf, long count) { gr_ctx* c = sta
 static const StatSync* stat_sync(gr_ctx* c, StatSync& ss, int C, double n_local) {
   if (!c->sync_bn || !have_peers(c)) return nullptr;
   if ((size_t)C * 2 > c->sync_cap) {
-    if (c->sync_buf) { if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr; (void)hipFree(c->sync_buf); c->sync_buf = nullptr; c->sync_cap = 0; }
+    // a failure here must NOT fall back to per-rank statistics: the peers would enter an all-reduce this rank never issues.  The error
+    // is parked in coll_rc, which every caller of stat_sync returns before it issues anything else.
+    if (c->sync_buf) {
+      if (hipStreamSynchronize(c->stream) != hipSuccess) { if (!c->coll_rc) c->coll_rc = fail(c, GR_ERR_HIP, "sync-BN: stream synchronise failed before regrowing the statistics buffer"); return nullptr; }
+      (void)hipFree(c->sync_buf); c->sync_buf = nullptr; c->sync_cap = 0;
+    }
     const size_t cap = (size_t)(C > 2048 ? C : 2048) * 2;
-    if (hipMalloc((void**)&c->sync_buf, sizeof(double) * cap) != hipSuccess) return nullptr;
+    if (hipMalloc((void**)&c->sync_buf, sizeof(double) * cap) != hipSuccess) { c->sync_buf = nullptr; if (!c->coll_rc) c->coll_rc = fail(c, GR_ERR_HIP, "sync-BN: statistics buffer allocation failed (%zu bytes)", sizeof(double) * cap); return nullptr; }
     c->sync_cap = cap;
   }
   ss.sum = statsync_sum; ss.max_u32 = statsync_max; ss.user = c; ss.buf = c->sync_buf;
@@ -212,7 +228,7 @@ extern "C" int gr_init(int device, gr_ctx** out) {
   (void)hipMemsetAsync(c->d_loss, 0, 64, c->stream);
   memset(c->h_loss, 0, 64);
   { const char* d = getenv("GR_RANGE_GUARD"); if (d) c->range_guard = atoi(d); }
-  { const char* d = getenv("GR_P16_DEBUG"); if (d) gr::g_p16_debug = atoi(d); }      // diagnostic ablations (tools/ablate_p16.py)
+  gr::g_p16_debug = GR_KNOB("GR_P16_DEBUG", 0);      // diagnostic ablations (probe build only: tools/ablate_p16.py)
   { const char* m = getenv("GR_CONV_MODE"); if (m) c->conv_mode = (!strcmp(m, "f32") || !strcmp(m, "0")) ? 0 : ((!strcmp(m, "bf16x6") || !strcmp(m, "1")) ? 1 : 2); }
   (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   (void)hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
@@ -229,6 +245,7 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   if (!c) return GR_ERR_INVALID;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stat_comm) { ncclCommDestroy(c->stat_comm); c->stat_comm = nullptr; }
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
   if (c->ws) (void)hipFree(c->ws);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
@@ -274,6 +291,7 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!c || !key) return GR_ERR_INVALID;
   if (!strcmp(key, "p16_min_tiles")) { gr::g_p16_min_tiles = value; return GR_OK; }
   if (!strcmp(key, "stack8_min_wgs")) { gr::g_stack8_min_wgs = value; return GR_OK; }      // four 8x8 images per convolution tile from this many workgroups on (default 128)
+#ifdef GR_ABLATE   // ablation build only (make ablate): variants that lost their A/B, and ablation bits that make kernels compute wrong results by design
   if (!strcmp(key, "p16_stagger")) { gr::g_p16_stagger = value; return GR_OK; }
   if (!strcmp(key, "p16_variant")) { gr::g_p16_variant = value; return GR_OK; }
   if (!strcmp(key, "p16_debug")) { gr::g_p16_debug = value; return GR_OK; }
@@ -281,10 +299,11 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!strcmp(key, "nt_stores")) { gr::g_nt_stores = value; return GR_OK; }        // bit mask: which kernels store their outputs non-temporally (kernels.h)
   if (!strcmp(key, "up2_stagger")) { gr::g_up2_stagger = value; return GR_OK; }   // start delay of a CU's second workgroup, x 512 clocks
   if (!strcmp(key, "up2_quad")) { gr::g_up2_quad = value; return GR_OK; }       // 1 (default): four-wave up-sampling kernel where it applies; 0: eight-wave     // diagnostic ablations (outputs are then wrong by design)
+#endif
   if (!strcmp(key, "eval_p16")) { g_eval_p16 = value; return GR_OK; }           // evaluate()-mode stages hand their output over operand-ready (1, default) or as fp32 (0: the A/B control)
   if (!strcmp(key, "side_wgrad")) { c->side_wgrad = value; return GR_OK; }
   // synchronised BatchNorm under data parallelism: per-channel batch sums are all-reduced, fwd and bwd (include/ganrev.h)
-  if (!strcmp(key, "sync_bn")) { c->sync_bn = value != 0; return GR_OK; }          // weight gradients on the side stream (1) or in line (0, default)
+  if (!strcmp(key, "sync_bn")) { c->sync_bn = value != 0; return ensure_stat_comm(c); }   // (collective when a communicator exists: every rank sets it at the same point)
   // f16x3 range guard on / off.  Off also clears a tripped trainer guard AND drops a verdict still in flight: that verdict is about the
   // nets scanned by an earlier gr_train_r_step and must not trip the context under whoever trains next on it.
   if (!strcmp(key, "range_guard")) { c->range_guard = value; if (!value) { c->guard_tripped = false; c->guard_pending = false; } return GR_OK; }
@@ -778,17 +797,17 @@ static int ensure_batch(gr_net* n, int B) {
 static bool fewout_applies(const Stage& s) {
   // GR_FEWOUT_MAX=0 sends the few-output layers to the MFMA split kernels too (A/B, round 3: G's last convolution 0.388 -> 0.53 ms at cfg3,
   // 39 -> 73 us at cfg2 - a 32-channel output block for 1-3 real channels)
-  static const int maxc = getenv("GR_FEWOUT_MAX") ? atoi(getenv("GR_FEWOUT_MAX")) : 4;
+  static const int maxc = GR_KNOB("GR_FEWOUT_MAX", 4);
   return s.ksz == 3 && s.Cout <= maxc && !s.up && s.W % 4 == 0 && s.W >= 16;
 }
 // f16x3 GEMM for the large nn.Linear layers (R.fc1: 90-97 % of R's parameters); small ones stay on the fp32 MFMA kernel
 static bool use_f16_gemm(gr_net* n, const Stage& s) {
-  static const bool on = !getenv("GR_NO_F16_GEMM");
+  static const bool on = !GR_KNOB_SET("GR_NO_F16_GEMM");
   return on && n->ctx->conv_mode == 2 && s.kind == ST_LINEAR && (int64_t)s.Cin * s.Cout >= (1 << 20);
 }
 // the 5x5 layer of the D network (models.lua:297) on the f16x3 split kernel (round 4; bf16x6 / f32 modes keep convk.hip's fp32 VALU kernels)
 static bool convk_split(gr_net* n, const Stage& s) {
-  static const bool on = !getenv("GR_NO_CONV5_SPLIT");
+  static const bool on = !GR_KNOB_SET("GR_NO_CONV5_SPLIT");
   return on && n->ctx->conv_mode == 2 && s.kind == ST_CONV && s.ksz == 5 && !s.up && !s.fullconv && s.ws_fwd && conv5x5_split_supported(s.Cin, s.Cout, s.H, s.W);
 }
 static bool use_bf16x6(gr_net* n, const Stage& s) { return (n->ctx->conv_mode >= 1 && s.kind == ST_CONV && s.ksz == 3 && !fewout_applies(s)) || convk_split(n, s); }   // either split flavour
@@ -977,6 +996,8 @@ static int guard_scan_activation(gr_ctx* c, const float* t, int B, int C, int H,
 
 static int forward_stages(gr_net* n, const float* in_dev, int B) {
   gr_ctx* c = n->ctx;
+  const int prezeroed_groups = n->amax_prezeroed_groups;      // consumed on EVERY path out of this call (an early error return must not leave it set for a later forward)
+  n->amax_prezeroed_groups = 0;
   HIPCHK(c, hipSetDevice(c->device));
   int r = ensure_batch(n, B); if (r) return r;
   const float* x = in_dev;
@@ -991,11 +1012,10 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
   if (f16) {
     const bool w_too = n->training && n->prepped_version[2] != n->params_version;
     const size_t groups = w_too ? AMAX_GROUPS : (n->training ? AG_W : AG_KB);      // x xt y | kb dy dz | w
-    if ((size_t)n->amax_prezeroed_groups < groups) HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst * groups, c->stream));
+    if ((size_t)prezeroed_groups < groups) HIPCHK(c, hipMemsetAsync(n->amax, 0, sizeof(unsigned) * AMAX_WORDS * nst * groups, c->stream));
     n->dy_slots_zeroed = groups >= (size_t)AG_W;
     n->w_slots_zeroed = groups == (size_t)AMAX_GROUPS;
   }
-  n->amax_prezeroed_groups = 0;
   r = prep_weights(n); if (r) return r;
   {
     // Dropout noise of every stage, drawn in one launch (injected masks - tests - are consumed instead)
@@ -1052,10 +1072,10 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
         ep.act = s.act; ep.slope = s.slope; epp = &ep; dst = s.out; s.fused_epilogue = true;
       }
       // training-mode BatchNorm: the conv epilogue also leaves the per-channel (sum, sum of squares) of what it stores
-      static const bool epi_stats_on = !getenv("GR_NO_EPI_STATS");
+      static const bool epi_stats_on = !GR_KNOB_SET("GR_NO_EPI_STATS");
       const bool want_stats = epi_stats_on && n->training && s.has_bn && s.stat_part && !s.fused_epilogue;
       int stat_tiles = 0;
-      static const bool fewin_on = !getenv("GR_NO_FEWIN");
+      static const bool fewin_on = !GR_KNOB_SET("GR_NO_FEWIN");
       const bool is_fewin = fewin_on && !s.fullconv && conv_fewin_applies(s.Cin, s.W, s.up);
       const bool in_p16 = f16 && !s.up && s.x_p16 && s.x_p16_gen == n->amax_gen && use_bf16x6(n, s);      // this stage's input arrived operand-ready
       // evaluate() mode, f16x3 (round 4: apply_r.lua:145-153's corpus pipeline): the next convolution's input leaves THIS stage operand-ready
@@ -1088,7 +1108,7 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
         if (last_writer && nx) nx->amax_x_fwd = n->amax_gen;
       } else if (use_bf16x6(n, s)) {
         const int nterm = c->conv_mode == 2 ? 2 : 3;
-        static const bool up2_on = !getenv("GR_NO_UP2");
+        static const bool up2_on = !GR_KNOB_SET("GR_NO_UP2");
         if (nterm == 2 && in_p16) {
           // the previous stage's pipeline kernel left this stage's input operand-ready, scaled by the bound in amax_x
           launch_conv3x3_p16(s.x_p16, s.ws_fwd, n->params + s.b_off, dst, B, s.Cin, s.Cout, s.H, s.W, c->stream, epp, s.amax_x, s.amax_w, conv_amax_out,
@@ -1161,6 +1181,7 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
           bdp = &bd; s.kb_gen = n->amax_gen;
         }
         StatSync ss; const StatSync* sync = stat_sync(c, ss, s.Cout, (double)B * s.H * s.W);
+        if (c->coll_rc) { r = c->coll_rc; c->coll_rc = 0; return r; }
         if (sync) {     // synchronised BatchNorm: the ranks' per-channel (sum, sum of squares) are added before the statistics are formed
           launch_pair_sums(s.stat_part, s.stat_tiles_last, s.stat_tiles_last, s.Cout, sync->buf, c->stream);
           r = small_allreduce(c, sync->buf, 2L * s.Cout, 1); if (r) return r;
@@ -1189,7 +1210,7 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
     // The fp32 copy of the stage output has one more reader than the next convolution's forward: that convolution's weight
     // gradient.  When it will take the operand-ready image too (every condition is fixed by the shapes and this forward), the
     // fp32 tensor is not written at all: the pipeline kernel writes 4 bytes per element, as it did before it wrote two formats.
-    static const bool lean_on = !getenv("GR_P16_KEEP_FP32");
+    static const bool lean_on = !GR_KNOB_SET("GR_P16_KEEP_FP32");
     s.out_skipped = lean_on && !n->keep_fp32 && p16_out && nx->has_bn && n->dy_p16 && post_g8_supported(nx->Cout, nx->H, nx->W, nx->pool, true) &&
                     conv_wgrad_p16_supported(B, nx->Cin, nx->Cout, nx->H, nx->W) && nx->stat_part;
     if (post_p16) s.out_skipped = true;               // evaluate(): nothing else reads the fp32 tensor
@@ -1411,7 +1432,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
     pb.dy_p16 = dy_p16 ? dyp : nullptr; pb.amax_dz = dy_p16 ? s.amax_dz : nullptr; pb.kb = s.amax_kb;
     if (s.kind == ST_CONV && si > 0 && n->st[si - 1].out_skipped && !wgrad_p16)
       return fail(c, GR_ERR_STATE, "stage %d: the forward left this stage's input operand-ready only (f16x3); backward in another arithmetic mode needs a new forward", si);
-    static const bool lean_on = !getenv("GR_P16_KEEP_FP32");
+    static const bool lean_on = !GR_KNOB_SET("GR_P16_KEEP_FP32");
     if (lean_on && !n->keep_fp32 && wgrad_p16 && (dgrad_p16 || !need_gin)) pb.dy = nullptr;      // no fp32 reader of dy is left
     if (s.act == ACT_PRELU) {
       // nn.PReLU accGradParameters: the stage ends at the PReLU, so g is its gradOutput and the raw main-op output (the stage
@@ -1674,11 +1695,15 @@ extern "C" int gr_comm_init(gr_ctx* c, const void* idb, int nranks, int rank) {
   ncclUniqueId id; memcpy(&id, idb, sizeof id);
   NCCLCHK(c, ncclCommInitRank(&c->comm, nranks, id, rank));
   c->nranks = nranks; c->rank = rank;
-  return GR_OK;
+  return ensure_stat_comm(c);
 }
 extern "C" int gr_comm_destroy(gr_ctx* c) {
   if (!c) return GR_ERR_INVALID;
-  if (c->comm) { HIPCHK(c, hipStreamSynchronize(c->stream)); NCCLCHK(c, ncclCommDestroy(c->comm)); c->comm = nullptr; }
+  if (c->comm) {
+    HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    if (c->stat_comm) { NCCLCHK(c, ncclCommDestroy(c->stat_comm)); c->stat_comm = nullptr; }
+    NCCLCHK(c, ncclCommDestroy(c->comm)); c->comm = nullptr;
+  }
   c->nranks = 1; c->rank = 0;
   return GR_OK;
 }
@@ -1763,7 +1788,7 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
     // ONE fill per step: the f16x3 scale slots of both nets (what their forwards would each zero themselves) and R's gradient vector
     // (train_r.lua:143 gradParameters:zero()) - three hipMemsetAsync kernels of ~6 us each at batch 256 otherwise
     ZeroJobs z{}; z.n = 0;
-    static const bool one_fill = !getenv("GR_NO_STEP_FILL");       // A/B control: every forward zeroes its own slots, the gradients get their own fill
+    static const bool one_fill = !GR_KNOB_SET("GR_NO_STEP_FILL");       // A/B control: every forward zeroes its own slots, the gradients get their own fill
     if (c->conv_mode == 2 && one_fill) {
       const int gg = AG_KB;                                                                      // G: evaluate() mode
       const int gr_ = rn->prepped_version[2] != rn->params_version ? AMAX_GROUPS : AG_W;         // R: training; the w group when the weight images are stale
@@ -1838,7 +1863,7 @@ extern "C" int gr_cosine_topk_dev(gr_ctx* c, const float* emb, int64_t N, int d,
     HIPCHK(c, hipHostMalloc(&c->pin, res_bytes * 2));
     c->pin_bytes = res_bytes * 2;
   }
-  static const bool filter_on = !getenv("GR_SEARCH_UNFILTERED");
+  static const bool filter_on = !GR_KNOB_SET("GR_SEARCH_UNFILTERED");
   // A handful of needles (the reference's five): their rows travel in the kernel arguments and the kernels write idx | scores | status
   // straight into the pinned result block (host memory the device can address): no upload, no copy-out - launches, one wait.
   if (filter_on && cosine_topk_small_path(N, d, Q, k)) {
@@ -1863,7 +1888,7 @@ extern "C" int gr_cosine_topk_dev(gr_ctx* c, const float* emb, int64_t N, int d,
     // The selection kernel publishes one completion word per needle behind its results (system-scope release): poll them instead of
     // synchronising the stream (measured: 1-3 us of a 0.15 ms search).  Bounded: after 20 ms the stream is synchronised after all (a fault
     // shows up there).
-    static const bool poll_on = !getenv("GR_SEARCH_NO_POLL");
+    static const bool poll_on = !GR_KNOB_SET("GR_SEARCH_NO_POLL");
     bool seen = false;
     if (lr == 2 && poll_on) {
       volatile unsigned* dw = c->pin_done;
@@ -2002,7 +2027,7 @@ static int conv_split_once(gr_ctx* c, const float* w, int cin, int cout, bool bw
 }
 extern "C" int gr_conv3_forward_dev(gr_ctx* c, const float* in, const float* w, const float* bias, float* out, int B, int cin, int cout, int h, int wd, int up) {
   if (!c || !in || !w || !out) return GR_ERR_INVALID;
-  if (c->conv_mode == 2 && up && conv_up2_supported(cin, cout, h, wd) && !getenv("GR_NO_UP2")) {
+  if (c->conv_mode == 2 && up && conv_up2_supported(cin, cout, h, wd) && !GR_KNOB_SET("GR_NO_UP2")) {
     // the fused up-sampling layer as four 2x2 convolutions (the path a net takes for such a stage in f16x3 mode)
     void* wup = nullptr;
     HIPCHK(c, hipMalloc(&wup, conv_weight_up2_bytes(cin, cout)));
@@ -2079,7 +2104,7 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   HIPCHK(c, hipMalloc((void**)&x, sizeof(float) * nin)); HIPCHK(c, hipMalloc((void**)&y, sizeof(float) * nout));
   HIPCHK(c, hipMalloc((void**)&w, sizeof(float) * nw)); HIPCHK(c, hipMalloc((void**)&gw, sizeof(float) * nw));
   launch_fill_normal(x, (long)nin, 11, c->stream); launch_fill_normal(y, (long)nout, 12, c->stream); launch_fill_normal(w, (long)nw, 13, c->stream);
-  if (getenv("GR_BENCH_ZERO")) {   // DVFS diagnostic: all-zero operands draw less power (MI355X_MICROARCH.md, DVFS give-back item 1)
+  if (GR_KNOB_SET("GR_BENCH_ZERO")) {   // DVFS diagnostic: all-zero operands draw less power (MI355X_MICROARCH.md, DVFS give-back item 1)
     (void)hipMemsetAsync(x, 0, sizeof(float) * nin, c->stream); (void)hipMemsetAsync(y, 0, sizeof(float) * nout, c->stream); (void)hipMemsetAsync(w, 0, sizeof(float) * nw, c->stream);
   }
   (void)hipMemsetAsync(gw, 0, sizeof(float) * nw, c->stream);
@@ -2090,7 +2115,7 @@ extern "C" int gr_bench_conv3(gr_ctx* c, int which, int B, int cin, int cout, in
   if (split) { r = conv_split_once(c, w, cin, cout, which == 1, &wsp); if (r) return r; }
   r = ensure_ws(c, conv_wgrad_workspace_bytes(B, cin, cout, h, wd, c->conv_mode)); if (r) return r;
   // f16x3 scales: taken once outside the timed loop (in a net the producing kernel tracks them), or per launch with GR_BENCH_ABSMAX
-  const bool amax_each = getenv("GR_BENCH_ABSMAX") != nullptr;
+  const bool amax_each = GR_KNOB_SET("GR_BENCH_ABSMAX");
   if (c->conv_mode == 2) { launch_absmax(x, (long)nin, c->amax, c->stream); launch_absmax(y, (long)nout, c->amax + AMAX_WORDS, c->stream); }
   void* wup = nullptr;
   if (which == 3) {      // fused up-sampling layer: x is the source plane [B, cin, h/2, wd/2] (a quarter of the buffer), y the output

@@ -74,7 +74,8 @@ template <bool ACCF, int MODE, int NQ, int DC>
 __global__ __launch_bounds__(ROWS) void cos_keys_kernel(const float* __restrict__ emb, long N, int d,
                                                          const float* __restrict__ needles, const float* __restrict__ w22,
                                                          int q0, unsigned long long* __restrict__ keys, long stride,
-                                                         const unsigned long long* __restrict__ bound, unsigned* __restrict__ counts, int dbg) {
+                                                         const unsigned long long* __restrict__ bound, unsigned* __restrict__ counts, int dbg_) {
+  const int dbg = GR_DBG(dbg_);
   typedef typename std::conditional<ACCF, float, double>::type acc_t;
   constexpr int TS = ((DC / 4) & 1) ? DC + 8 : DC + 4;
   __shared__ __attribute__((aligned(16))) float tile[ROWS * TS];
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
   for (int q = 0; q < NQ; ++q) { tauq[q] = (MODE == 1 && q < Q) ? a.tau[q] : INFINITY; cnt[q] = 0u; wmax[q] = -INFINITY; }
   int buf = 0;
   for (long t = wg; t < ntiles; t += nwg, buf = buf + 1 == NB ? 0 : buf + 1) {
-    if (MODE == 0 && (a.dbg & 32)) break;                         // ablation: no sample tile
+    if (MODE == 0 && (GR_DBG(a.dbg) & 32)) break;                         // ablation: no sample tile
     if (NB == 1) request(t, 0);                                   // (the sample: one tile per workgroup)
     // tile t has landed once at most the requests issued AFTER it are outstanding: V per tile already requested behind it (vmcnt counts in issue order)
     if (NB >= 3 && t + (long)(NB - 2) * nwg < ntiles) {
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (a.dbg & 16) return;                                          // ablation: no arrival, no threshold
+  if (GR_DBG(a.dbg) & 16) return;                                          // ablation: no arrival, no threshold
   unsigned arrived = 0u;
   if (lane == 0) arrived = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   arrived = (unsigned)__shfl((int)arrived, 0, 64);
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(64) void cos_approx_kernel(const float* __restrict_
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next search
-  if (a.dbg & 8) return;                                           // ablation: the last workgroup's threshold computation (leaves the bins dirty)
+  if (GR_DBG(a.dbg) & 8) return;                                           // ablation: the last workgroup's threshold computation (leaves the bins dirty)
   constexpr int BPL = SBINS / 64;                                  // bins per lane: lane L owns bins [BPL L, BPL L + BPL)
   unsigned hb[NQ][BPL];
 #pragma unroll
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(NT) void small_select_kernel(const float* __restric
 }
 
 bool cosine_topk_small_path(long N, int d, int Q, int k) {
-  static const bool on = !getenv("GR_SEARCH_NO_APPROX");
+  static const bool on = !GR_KNOB_SET("GR_SEARCH_NO_APPROX");
   const int d4 = d / 4;
   return on && Q >= 1 && Q <= AQ_MAX && (d & 3) == 0 && (d4 == 8 || d4 == 16 || d4 == 25 || d4 == 32) && N >= FILTER_MIN_ROWS && k <= 128 &&
          (size_t)N * d * 4 < 0x7FFFF000ul;
@@ -1132,7 +1133,16 @@ static long chunks_of(long n) { return (n + CHUNK - 1) / CHUNK; }
 
 size_t cosine_topk_workspace_bytes(long N, int d, int Q, int k) {
   const long n1 = chunks_of(N) * k, n2 = chunks_of(n1) * k;
-  return sizeof(float) * ((size_t)Q * d + Q + 8) + sizeof(unsigned) * (size_t)(Q + 8) + 1024 + sizeof(unsigned long long) * (size_t)Q * (N + n1 + n2);
+  size_t keys = sizeof(unsigned long long) * (size_t)Q * (N + n1 + n2);
+  if (cosine_topk_small_path(N, d, Q, k)) {
+    // the small-needle path carves its candidate lists out of the key area (launch_cosine_topk): maxima [AQ_MAX][256] | tau [AQ_MAX] | pad 8 |
+    // rows [Q][wgs][ASLOT] | scores [Q][wgs][ASLOT] | counts [Q][wgs].  Below ~197 K rows that is MORE than the keys (out-of-bounds
+    // device writes on a fresh context at 131072 <= N < 197 K) - the workspace is the larger of the two layouts.
+    const size_t awgs = (size_t)approx_wgs(d, Q);
+    const size_t small = sizeof(float) * ((size_t)AQ_MAX * 256 + AQ_MAX) + sizeof(unsigned) * 8 + (size_t)Q * awgs * ((size_t)ASLOT * 8 + 4) + 256;
+    if (small > keys) keys = small;
+  }
+  return sizeof(float) * ((size_t)Q * d + Q + 8) + sizeof(unsigned) * (size_t)(Q + 8) + 1024 + keys;
 }
 
 int g_search_debug = 0;      // diagnostic ablations (GR_SEARCH_DEBUG: 1 no global loads, 2 no arithmetic, 4 no epilogue; results are then wrong by design)
@@ -1166,7 +1176,7 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
                        long* idx_out, float* score_out, int accf, void* workspace, hipStream_t s, unsigned* status_dev, int unfiltered,
                        const long* query_rows_host, unsigned* arrival_counter, unsigned* done_words, unsigned seq) {
   if (k > 1024 || k < 1 || k > N || N >= 0xFFFFFFFFl || d < 1 || d > 4096 * 4) return -1;
-  { static const char* e = getenv("GR_SEARCH_DEBUG"); if (e) g_search_debug = atoi(e); }
+  g_search_debug = GR_KNOB("GR_SEARCH_DEBUG", 0);
   // workspace carve: needles [Q][d] | w22 [Q] | counts [Q] | keys A | keys B | keys C
   char* w = reinterpret_cast<char*>(workspace);
   float* needles = reinterpret_cast<float*>(w); w += sizeof(float) * (size_t)Q * d;
@@ -1199,7 +1209,7 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
       KtScope kt("cos_approx_kernel", 2.0 * N * d * Q, 4.0 * N * d, s);
       launch_approx<1>(d / 4, Q, (unsigned)awgs, s, emb, N, 1L, qr, a);
     }
-    static const bool old_select = getenv("GR_SEARCH_OLD_SELECT") != nullptr;       // A/B: round 4's first selection kernel (no completion words: the caller synchronises)
+    static const bool old_select = GR_KNOB_SET("GR_SEARCH_OLD_SELECT");       // A/B: round 4's first selection kernel (no completion words: the caller synchronises)
     if (old_select || k > SSEL_MAX / 2) {
       KtScope kt("batched_select_kernel", 0.0, 0.0, s);
       if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, (long)awgs, k, idx_out, score_out, status_dev, ASLOT, a.eps2, qr, 1);
@@ -1213,8 +1223,8 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
   }
   if (accf) hipLaunchKernelGGL(needle_prep_kernel<true>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
   else hipLaunchKernelGGL(needle_prep_kernel<false>, dim3((Q + 63) / 64), dim3(64), 0, s, emb, d, query_rows_dev, Q, needles, w22, counts, status_dev);
-  static const bool batched_on = !getenv("GR_SEARCH_NO_BATCHED");
-  static const int batch_min_q = getenv("GR_BATCH_MIN_Q") ? atoi(getenv("GR_BATCH_MIN_Q")) : BATCH_MIN_Q;
+  static const bool batched_on = !GR_KNOB_SET("GR_SEARCH_NO_BATCHED");
+  static const int batch_min_q = GR_KNOB("GR_BATCH_MIN_Q", BATCH_MIN_Q);
   if (filter && batched_on && Q >= batch_min_q && Q <= BQ_MAX && d <= BD_MAX && k <= 128 && N >= 2 * BSAMPLE_ROWS) {      // (k distinct workgroup maxima must exist: 256 workgroups)
     // keys A = sample scores [Q][S] | tau [Qpad] | sqrt(w22) [Qpad] | bf16 needles [Qpad][KS] | candidate rows [Q][nwg][BSLOT] | scores | counts [Q][nwg]
     // sample: BSAMPLE_ROWS strided rows in workgroups of 256; each leaves its maximum per needle, tau from the k-th largest of those
@@ -1239,7 +1249,7 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
       KtScope kt("cos_mfma_kernel (sample)", 2.0 * S * d * Q, 4.0 * S * d, s);
       GR_MFMA(0, (unsigned)((S + 255) / 256), S, stride, (const float*)nullptr, samp, (unsigned*)nullptr, (float*)nullptr, (unsigned*)nullptr);
     }
-    static const bool old_tail = getenv("GR_BATCHED_OLD_TAIL") != nullptr;      // A/B: round 4's first threshold and selection kernels (bitonic sorts of 1024 per-thread maxima)
+    static const bool old_tail = GR_KNOB_SET("GR_BATCHED_OLD_TAIL");      // A/B: round 4's first threshold and selection kernels (bitonic sorts of 1024 per-thread maxima)
     if (old_tail || swg > 256) {
       KtScope kt("batched_tau_kernel", 0.0, 4.0 * swg * Q, s);
       hipLaunchKernelGGL(batched_tau_kernel, dim3(Q), dim3(1024), 0, s, samp, swg, k, sw22s, tau);

@@ -98,7 +98,10 @@ int gr_net_get_mask(gr_net* net, int layer_index, uint8_t* keep_host, int64_t n)
 /* m:forward(input) -> m.output   (train_r.lua:139,146; utils/nn_utils.lua:18) */
 int gr_net_forward_host(gr_net* net, const float* in_host, int batch, float* out_host);
 int gr_net_forward_dev(gr_net* net, const float* in_dev, int batch, float* out_dev /*nullable: result stays in m.output*/);
-float* gr_net_output_dev(gr_net* net);                     /* m.output (device), valid until the next forward */
+float* gr_net_output_dev(gr_net* net);                     /* m.output (device), valid until the next forward.  After an evaluate()-mode gr_net_forward_dev with a
+                                                            * non-null out_dev the last stage wrote out_dev ITSELF (no copy): m.output then IS the caller's buffer and is
+                                                            * valid only while the caller keeps out_dev alive (Torch7: the caller's tensor).  Same for gr_net_layer_output
+                                                            * of the last layer. */
 /* NN_UTILS.forwardBatched(model, input, batchSize) (utils/nn_utils.lua:5-33; apply_r.lua:146,152,153) on device-resident rows:
  * in_dev [rows x in] -> out_dev [rows x out] in chunks of `batch` rows (the last one ragged).  In evaluate() mode each chunk's last
  * kernel writes its rows of out_dev itself: the reference's per-row copy loop (utils/nn_utils.lua:25-28) has no counterpart.

@@ -916,6 +916,32 @@ def test_full_size_cfg5_search_bit_exact(ctx, oracle):
     assert 999_999 in idx[2, :2]
 
 
+def test_search_small_needle_path_on_a_fresh_context(oracle):
+    """the five-needle path carves its candidate lists (8 x 256 lists of 96 entries per needle, ~1.58 MB) out of the key area of the
+    workspace, which below ~197 K rows used to be SMALLER than the lists - out-of-bounds device writes on a context whose workspace no bigger search had grown.
+    A fresh context per table, d = 100 / 32 / 128, Q = 5 (and 8, the most lists), k = 50: bit-exact against the oracle and no rerun."""
+    import os
+    import ganrev._lib as L
+    from ganrev import synth
+    oracle.set_threads(max(1, min(32, os.cpu_count() or 1)))
+    for N, d, Q, k in ((131_072, 100, 5, 50), (160_000, 100, 5, 50), (131_073, 32, 8, 128), (140_001, 128, 8, 50)):
+        c = L.Context(0)
+        try:
+            emb = synth.normal((N, d), N % 1000 + d)
+            q = (np.arange(Q, dtype=np.int64) * 100 + 100) % N
+            q[-1] = N - 1
+            r0 = c.search_reruns()
+            idx, sc = c.cosine_topk(emb, q, k)
+            ridx, rsc = oracle.cosine_topk(emb, q, k)
+            assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc), (N, d, Q, k)
+            assert c.search_reruns() == r0
+            # device-resident table, the polled five-needle call (gr_cosine_topk_dev) on the same fresh context
+            idx2, sc2 = c.cosine_topk(emb, q[:5], k)
+            assert np.array_equal(idx2, ridx[:5]) and np.array_equal(sc2, rsc[:5])
+        finally:
+            c.close()
+
+
 def test_bce_criterion_vs_oracle(ctx, oracle):
     """nn.BCECriterion (train.lua:173's CRITERION, used by adversarial.lua): loss to 1e-12 relative (the device's log), gradInput bit-exact (IEEE +, -, x, /
     in double on both sides), through the criterion class the reference scripts use."""
