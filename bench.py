@@ -787,11 +787,11 @@ def emit(out, args):
     out = _finite(out)
     detail = json.dumps(out, allow_nan=False)
     try:
-        os.makedirs(os.path.dirname(DETAIL_FILE), exist_ok=True)
-        with open(DETAIL_FILE, "w") as f:
+        os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+        with open(args.detail, "w") as f:
             f.write(detail + "\n")
     except OSError as e:
-        print(f"bench.py: could not write {DETAIL_FILE}: {e}", file=sys.stderr)
+        print(f"bench.py: could not write {args.detail}: {e}", file=sys.stderr)
     print("bench_detail " + detail, file=sys.stderr)
     sys.stderr.flush()
     print(headline_text(out, args.conv_mode))
@@ -821,6 +821,7 @@ def main():
     ap.add_argument("--modes", default=",".join(MODES), help="arithmetic modes timed in this invocation (the headline mode is always run)")
     ap.add_argument("--traffic", default="live", choices=["live", "file", "off"],
                     help="roofline.traffic: measured in this run by rocprofv3 --pmc children (N = 1), read from profiles/traffic.json, or omitted")
+    ap.add_argument("--detail", default=DETAIL_FILE, help="file the FULL result (mode tables, per-kernel tables, notes) is written to; stdout carries the compact headline only")
     ap.add_argument("--quiet-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus < 1:

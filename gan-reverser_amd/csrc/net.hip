@@ -36,10 +36,12 @@ struct gr_ctx {
   // weight gradients run beside the rest of backward (backward_impl): their own stream, workspace and events
   hipStream_t side_stream = nullptr; void* ws2 = nullptr; size_t ws2_bytes = 0;
   hipEvent_t ev_dy_ready = nullptr, ev_wgrad_done[2] = {nullptr, nullptr};
-  int side_wgrad = 0;                  // gr_set_tuning "side_wgrad" / GR_SIDE_WGRAD=1.  Off by default: measured +1.1 % at cfg2 (2.331 -> 2.304 ms) - the
-                                       // MFMA kernels take the whole register file of a CU (2 waves x 256 VGPRs per SIMD), so the pipeline kernels of the main
-                                       // stream cannot become resident beside a weight gradient and only kernel tails overlap - not worth per-kernel
-                                       // timings that no longer add up to the step
+  int side_wgrad = -1;                 // gr_set_tuning "side_wgrad" / GR_SIDE_WGRAD: 1 on, 0 off, -1 (default) by size.  The MFMA kernels take the whole register file of a
+                                       // CU (2 waves x 256 VGPRs per SIMD), so nothing becomes resident beside a weight gradient and only kernel tails overlap.  Round 5,
+                                       // same box, interleaved (profiles/r05_ab_side_wgrad_*.txt): cfg2 1.976 -> 1.998 ms (slower: the tails are a few us and two streams
+                                       // cost an event hand-over per stage), cfg3 12.005 -> 11.875 ms (faster: the slab write + reduction tail of a 0.3 ms launch hides
+                                       // behind the data gradient).  Auto = on for stages of >= 2^26 activations (cfg3's layers; cfg2's have 2^24).  Bit-identical
+                                       // either way.  Per-kernel timing (gr_set_timing 2) forces it off, so that kernel durations are not inflated by overlap.
   double* d_loss = nullptr;     // device scalar (64-byte block: +0 the loss, +16 the range guard's alarm word, +32 the search's arrival counter)
   double* h_loss = nullptr;     // pinned host scalar
   bool timing = false;
@@ -1497,7 +1499,8 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       // The weight gradient has no consumer before Adam / the gradient all-reduce: it runs on the side stream, beside this
       // stage's data gradient and the memory-bound pipeline kernels of the stages after it (they leave the matrix pipe idle).
       // Its own workspace; the dy pair it reads is not rewritten before ev_wgrad_done[dk] (waited for two stages on).
-      const bool side = c->side_wgrad && c->side_stream != nullptr;
+      const bool side_want = c->side_wgrad < 0 ? (int64_t)B * vol3(s.Cout, s.H, s.W) >= ((int64_t)1 << 26) : c->side_wgrad != 0;
+      const bool side = side_want && c->side_stream != nullptr && gr::g_ktimer == nullptr;
       hipStream_t ws_ = side ? c->side_stream : c->stream;
       void* wsp_ = c->ws;
       if (side) {

@@ -353,7 +353,7 @@ template <int MODE, int NK>
 __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restrict__ emb, long N, int d, long stride,
                                                           const unsigned short* __restrict__ nb16, const float* __restrict__ sw22s, int Q,
                                                           const float* __restrict__ tau, float* __restrict__ out,
-                                                          unsigned* __restrict__ cand_idx, float* __restrict__ cand_sc, unsigned* __restrict__ counts) {
+                                                          unsigned* __restrict__ cand_idx, float* __restrict__ cand_sc, unsigned* __restrict__ counts, int qcap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int KP = NK * 16, KS = KP + 8;                      // bf16 elements per staged row; KS / 8 is odd: conflict-free 16-byte reads
   constexpr int TV = 64 * KS / 8, NTV = (TV + 255) / 256;         // 16-byte vectors of one needle tile, per thread
@@ -362,9 +362,14 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
   float* sw22t = sw32s + 256;                                                    // [2][64]
   float* taut = sw22t + 128;                                                     // [2][64]
   unsigned* lds_cnt = reinterpret_cast<unsigned*>(taut + 128);                   // [Q] (MODE 1)
+  // MODE 1: a queue of passing (needle, row, score) entries per WAVE, [4][qcap] x 8 bytes behind the counters (launcher: whatever two workgroups per CU leave, 0 = none)
+  const int dbg = GR_DBG(qcap >> 16);                                            // ablation build: GR_BATCHED_DEBUG bits 1 no epilogue, 2 no MFMA, 4 no row loads (results wrong by design)
+  qcap &= 0xffff;
+  unsigned* wg_ovf = lds_cnt + (((Q > 128 ? Q : 128) + 1) & ~1);                  // [2]: some wave's queue overflowed
+  unsigned long long* wqueue = reinterpret_cast<unsigned long long*>(wg_ovf + 2) + (size_t)(threadIdx.x >> 6) * qcap;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const long r0 = (long)blockIdx.x * 256;
-  if (MODE == 1) for (int q = tid; q < Q; q += 256) lds_cnt[q] = 0u;
+  if (MODE == 1) { for (int q = tid; q < Q; q += 256) lds_cnt[q] = 0u; if (tid == 0) *wg_ovf = 0u; }
   if (MODE == 0 && tid < 128) lds_cnt[tid] = 0u;               // two slots of 64 per-needle maxima (orderable bits; 0 = below everything)
   // stage the row tile as bf16 (zero columns past d, zero rows past N): float4 loads when the rows are 16-byte aligned
   if ((d & 3) == 0) {
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
 #pragma unroll
       for (int u = 0; u < HALF; ++u) {
         const int e = tid + 256 * (part * HALF + u), r = e / C4, c = (e - r * C4) * 4;
-        const bool ok = e < TOT && c < d && r0 + r < N;
+        const bool ok = e < TOT && c < d && r0 + r < N && !(dbg & 4);
         const long row = ok ? (MODE == 0 ? (r0 + r) * stride : r0 + r) : 0;
         v[u] = *reinterpret_cast<const float4*>(emb + row * (long)d + (ok ? c : 0));
         if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -432,7 +437,11 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
   for (int rb = 0; rb < 2; ++rb) s32[rb] = (MODE == 1 && r0 + 64 * wave + 32 * rb + l31 >= N) ? NAN : sw32s[64 * wave + 32 * rb + l31];   // (a NaN score passes no threshold)
   uint4* ndA = reinterpret_cast<uint4*>(rowsB);                 // [2][TV]
   const uint4* nsrc = reinterpret_cast<const uint4*>(nb16);
-  const int ntiles = (Q + 63) / 64;
+  const int ntiles_all = (Q + 63) / 64;
+  // MODE 0 (the sample): gridDim.y workgroups share a row tile and walk disjoint runs of needle tiles.  One workgroup per CU walking all 16 tiles of 1024
+  // needles is a chain of 16 barrier-to-barrier steps (68 us for 13 GFLOP, round 4); four per row tile re-read 26 MB of sample rows from L2 and take a quarter
+  // of the steps each.  MODE 1 always walks every tile (gridDim.y = 1).
+  const int nt0 = MODE == 0 ? (int)((long)blockIdx.y * ntiles_all / gridDim.y) : 0, ntiles = MODE == 0 ? (int)((long)(blockIdx.y + 1) * ntiles_all / gridDim.y) : ntiles_all;
   uint4 pre[NTV]; float pre_w = 0.f, pre_t = 0.f;
   auto fetch = [&](int nt) {
 #pragma unroll
@@ -444,8 +453,8 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
     for (int u = 0; u < NTV; ++u) { const int e = tid + 256 * u; if (e < TV) ndA[buf * TV + e] = pre[u]; }
     if (tid < 64) { sw22t[buf * 64 + tid] = pre_w; if (MODE == 1) taut[buf * 64 + tid] = pre_t; }
   };
-  fetch(0); commit(0);
-  for (int nt = 0; nt < ntiles; ++nt) {
+  if (nt0 < ntiles) { fetch(nt0); commit(nt0 & 1); }
+  for (int nt = nt0; nt < ntiles; ++nt) {
     const int q0 = nt * 64, cur = nt & 1;
     __syncthreads();                                            // tile nt is published; tile nt - 1's buffer is free
     if (nt + 1 < ntiles) fetch(nt + 1);
@@ -457,6 +466,7 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][rb][r] = 0.f;
+    if (!(dbg & 2))
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
       uint4 a[2];
@@ -477,11 +487,64 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) pv[nb][rq] = *reinterpret_cast<const float4*>((MODE == 1 ? taut : sw22t) + cur * 64 + 32 * nb + 8 * rq + 4 * h);
     float vmax0[2][16];                                         // MODE 0: this lane's maximum per needle over its two row blocks
-    if (MODE == 0 && tid < 64 && nt > 0) {                      // the previous tile's maxima are complete (the barrier above): out they go, slot cleared
+    if (MODE == 0 && tid < 64 && nt > nt0) {                    // the previous tile's maxima are complete (the barrier above): out they go, slot cleared
       const int qp = (nt - 1) * 64 + tid;
       if (qp < Q) out[(long)qp * gridDim.x + blockIdx.x] = unorderable(lds_cnt[(cur ^ 1) * 64 + tid]) * sw22t[(cur ^ 1) * 64 + tid];
       lds_cnt[(cur ^ 1) * 64 + tid] = 0u;
     }
+    if (MODE == 1 && (dbg & 1)) {
+    } else if (MODE == 1 && qcap > 0) {
+      // Round 5.  0.5 % of the 64 x 64 values of a wave's tile pass their threshold, so ~17 of the 64 (needle block, row block, register) positions have a
+      // passing lane somewhere in the wave.  Round 4 entered the hit path at each of them - an LDS atomic WITH return, a wait, an LDS read, two scattered
+      // stores: ~300 cycles each, one after the other, 5000 cycles per tile against 900 for its 28 MFMAs (243 TFLOP/s = 0.098 of the bf16 peak).  Now a
+      // position with a hit costs a wave vote, a prefix count and ONE fire-and-forget 8-byte LDS write into the wave's own queue (no atomic, no wait: the
+      // position is scalar base + mbcnt); the queue is drained once per tile, one entry per lane, so the atomics and stores of all ~20 entries overlap.
+      // An entry that does not fit the queue takes the old path on the spot: nothing is dropped here that round 4 kept.
+      unsigned qn = 0u;                                          // wave-uniform: passing values so far (may exceed qcap: see below)
+      const unsigned lo_base = ((unsigned)(64 * wave + l31) << 8) | (unsigned)(4 * h);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            // four positions (one float4 of thresholds) per scalar branch: their compares are independent VALU work, the four wave votes are OR-ed on the
+            // scalar unit.  One position at a time, a vote waited for its compare and the branch for the vote: ~30 cycles per position, 64 positions per tile
+            // (ablation, 1 M x 100 against 1024 needles: this epilogue was 200 us of the pass's 443; skeleton 131, row loads 34, MFMA 77).
+            const float4 p4 = pv[nb][rq];
+            const float pqs[4] = {p4.x, p4.y, p4.z, p4.w};
+            float v[4]; unsigned long long bal[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = acc[nb][rb][4 * rq + j] * s32[rb]; bal[j] = __ballot(v[j] >= pqs[j]); }   // (the threshold is +inf past Q; rows past N carry a NaN scale: never true)
+            if (__builtin_expect((bal[0] | bal[1] | bal[2] | bal[3]) != 0ull, 0)) {      // out of line: a group without a hit falls through
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (bal[j]) {
+                  const unsigned pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(bal[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal[j], 0u));
+                  if (v[j] >= pqs[j] && pos < (unsigned)qcap) {
+                    unsigned lo = lo_base;
+                    asm volatile("" : "+v"(lo));                 // (keeps the 64 per-position constants from being hoisted out of the tile loop into 64 live registers: spills)
+                    wqueue[pos] = ((unsigned long long)__float_as_uint(v[j]) << 32) | (lo + (unsigned)(((32 * rb) << 8) | (32 * nb + j + 8 * rq)));
+                  }
+                  qn += (unsigned)__popcll(bal[j]);
+                }
+            }
+          }
+      }
+      // a wave whose tile passes more values than its queue holds (never on tables the sample describes: ~20 expected, 256 slots) marks the workgroup: its
+      // counts are then reported as overflowed for every needle and the call reruns on the unbatched path, exactly as for an overflowing candidate list
+      if (qn > (unsigned)qcap && lane == 0) *wg_ovf = 1u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (LDS operations of one wave execute in order; this keeps the compiler from moving the reads up)
+      const unsigned nq = qn < (unsigned)qcap ? qn : (unsigned)qcap;
+      for (unsigned e = lane; e < nq; e += 64) {
+        const unsigned long long ent = wqueue[e];
+        const unsigned lo = (unsigned)ent, ql = lo & 63u, rowl = lo >> 8;
+        const float v = __uint_as_float((unsigned)(ent >> 32));
+        const int q = q0 + (int)ql;
+        const unsigned p2 = atomicAdd(&lds_cnt[q], 1u);
+        if (p2 < (unsigned)BSLOT) { const long at2 = ((long)q * gridDim.x + blockIdx.x) * BSLOT + p2; cand_idx[at2] = (unsigned)(r0 + rowl); cand_sc[at2] = v * sw22t[cur * 64 + ql]; }
+      }
+    } else {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       const long i = r0 + 64 * wave + 32 * rb + l31;
@@ -500,6 +563,7 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
           }
         }
     }
+    }
     if (MODE == 0) {
       // the sample leaves ONE value per (workgroup, needle): the maximum over the workgroup's 256 rows (their k-th largest over the
       // workgroups bounds the k-th largest sample score from below - k distinct rows at or above it - without writing S x Q scores).
@@ -517,14 +581,15 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
     }
     if (nt + 1 < ntiles) commit(cur ^ 1);
   }
-  if (MODE == 0) {
+  if (MODE == 0 && nt0 < ntiles) {
     __syncthreads();
     const int lastb = (ntiles - 1) & 1, qp = (ntiles - 1) * 64 + tid;
     if (tid < 64 && qp < Q) out[(long)qp * gridDim.x + blockIdx.x] = unorderable(lds_cnt[lastb * 64 + tid]) * sw22t[lastb * 64 + tid];
   }
   if (MODE == 1) {
     __syncthreads();
-    for (int q = tid; q < Q; q += 256) counts[(long)q * gridDim.x + blockIdx.x] = lds_cnt[q];
+    const unsigned ovf = *wg_ovf;
+    for (int q = tid; q < Q; q += 256) counts[(long)q * gridDim.x + blockIdx.x] = ovf ? (unsigned)BSLOT + 1u : lds_cnt[q];
   }
 }
 
@@ -1234,20 +1299,26 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
     unsigned short* nb16 = reinterpret_cast<unsigned short*>(sw22s + Qpad);
     unsigned* cidx = reinterpret_cast<unsigned*>(nb16 + (size_t)Qpad * KS); float* csc = reinterpret_cast<float*>(cidx + (size_t)Q * nwg * BSLOT);
     unsigned* wcnt = reinterpret_cast<unsigned*>(csc + (size_t)Q * nwg * BSLOT);
-    const size_t lds = (size_t)256 * KS * 2 + sizeof(float) * (256 + 128 + 128) + sizeof(unsigned) * (size_t)(Q > 128 ? Q : 128);
+    const size_t lds0 = (size_t)256 * KS * 2 + sizeof(float) * (256 + 128 + 128) + sizeof(unsigned) * (size_t)((((Q > 128 ? Q : 128) + 1) & ~1) + 2);
+    // the main pass's per-wave hit queues: what two workgroups per CU leave of the LDS, at most 256 entries per wave (~20 expected per tile); none below 32
+    int qcap = (int)(((size_t)80 * 1024 - lds0) / (4 * 8)); qcap = qcap > 256 ? 256 : (qcap < 32 ? 0 : qcap & ~31);
+    qcap = GR_KNOB("GR_BATCHED_QCAP", qcap);                   // ablation build: 0 = round 4's direct hit path
+    const size_t lds = lds0 + (size_t)4 * 8 * qcap;
+    qcap |= GR_KNOB("GR_BATCHED_DEBUG", 0) << 16;
     hipLaunchKernelGGL(needles_bf16_kernel, dim3((unsigned)(((long)Qpad * KS + 255) / 256)), dim3(256), 0, s, needles, w22, Q, Qpad, d, KS, nb16, sw22s, tau);
-#define GR_MFMA(MODE_, grid_, N_, stride_, tau_, out_, ci_, cs_, wc_)                                                                  \
+#define GR_MFMA(MODE_, grid_, gy_, N_, stride_, tau_, out_, ci_, cs_, wc_)                                                                  \
     do {                                                                                                                              \
       switch (NK) {                                                                                                                   \
-        case 2: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 2>), dim3(grid_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_); break; \
-        case 4: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 4>), dim3(grid_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_); break; \
-        case 7: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 7>), dim3(grid_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_); break; \
-        default: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 8>), dim3(grid_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_); break; \
+        case 2: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 2>), dim3(grid_, gy_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_, qcap); break; \
+        case 4: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 4>), dim3(grid_, gy_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_, qcap); break; \
+        case 7: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 7>), dim3(grid_, gy_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_, qcap); break; \
+        default: (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cos_mfma_kernel<MODE_, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); hipLaunchKernelGGL((cos_mfma_kernel<MODE_, 8>), dim3(grid_, gy_), dim3(256), lds, s, emb, N_, d, stride_, nb16, sw22s, Q, tau_, out_, ci_, cs_, wc_, qcap); break; \
       }                                                                                                                               \
     } while (0)
     {
       KtScope kt("cos_mfma_kernel (sample)", 2.0 * S * d * Q, 4.0 * S * d, s);
-      GR_MFMA(0, (unsigned)((S + 255) / 256), S, stride, (const float*)nullptr, samp, (unsigned*)nullptr, (float*)nullptr, (unsigned*)nullptr);
+      const int tiles_q = (Q + 63) / 64, gy = GR_KNOB("GR_BATCHED_SAMPLE_Y", tiles_q >= 16 ? 4 : (tiles_q >= 4 ? 2 : 1));
+      GR_MFMA(0, (unsigned)((S + 255) / 256), (unsigned)gy, S, stride, (const float*)nullptr, samp, (unsigned*)nullptr, (float*)nullptr, (unsigned*)nullptr);
     }
     static const bool old_tail = GR_KNOB_SET("GR_BATCHED_OLD_TAIL");      // A/B: round 4's first threshold and selection kernels (bitonic sorts of 1024 per-thread maxima)
     if (old_tail || swg > 256) {
@@ -1259,7 +1330,7 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
     }
     {
       KtScope kt("cos_mfma_kernel", 2.0 * N * d * Q, 4.0 * N * d, s);
-      GR_MFMA(1, (unsigned)nwg, N, 1L, (const float*)tau, (float*)nullptr, cidx, csc, wcnt);
+      GR_MFMA(1, (unsigned)nwg, 1u, N, 1L, (const float*)tau, (float*)nullptr, cidx, csc, wcnt);
     }
 #undef GR_MFMA
     // (the histogram-cut selection kernel of the small path, instantiated for these lists - small_select_kernel<ACCF, 512, BSLOT, false>, tau scaled by sqrt(w22) -

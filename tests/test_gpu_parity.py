@@ -519,7 +519,7 @@ def test_side_stream_weight_gradients_change_nothing(ctx):
             res.append((R._net.get_params(), R._net.get_grads()))
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     finally:
-        ctx.set_tuning("side_wgrad", 0)
+        ctx.set_tuning("side_wgrad", -1)     # the library default: by stage size
         ctx.set_conv_mode(prev)
 
 

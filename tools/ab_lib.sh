@@ -5,10 +5,10 @@ WL=${1:-cfg3}; N=${2:-2}; F=${3:-.}
 for i in $(seq 1 $N); do
   for arm in A B; do
     if [ $arm = A ]; then cp tools/probe/libganrev_base.so gan-reverser_amd/ganrev/libganrev.so; else cp tools/probe/libganrev_new.so gan-reverser_amd/ganrev/libganrev.so; fi
-    python bench.py --workload $WL --modes f16x3 --steps 20 --warmup 5 --no-cpu-baseline --no-search --no-gan --no-sustained --traffic off > /tmp/ab_$arm.json 2>/dev/null
+    python bench.py --workload $WL --modes f16x3 --steps 20 --warmup 5 --no-cpu-baseline --no-search --no-gan --no-sustained --traffic off --detail /tmp/ab_$arm.json > /dev/null 2>&1
     python - $arm "$F" <<'PY'
 import json, re, sys
-d = json.loads([l for l in open(f"/tmp/ab_{sys.argv[1]}.json") if l.startswith("{")][-1])
+d = json.load(open(f"/tmp/ab_{sys.argv[1]}.json"))
 rows = [f"{k.split('_kernel')[0][8:] + k.split('_kernel')[1]}={v['ms_per_step']:.4f}" for k, v in d["kernels"].items() if re.search(sys.argv[2], k)][:8]
 print(f"  {sys.argv[1]} {d['ms_per_step']:.4f} ms/step  ew {d['elementwise']['ms_per_step']:.3f}  " + "  ".join(rows))
 PY

@@ -62,12 +62,9 @@ def main():
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     traffic[workload] = {k: v["hbm_bytes_corrected"] for k, v in summary.items()}
     json.dump(traffic, open(tpath, "w"), indent=1)
-    for f in (f"bench_prof_{workload}.log",):
-        p = os.path.join(ROOT, "gpurun_out", f)
-        if os.path.exists(p):
-            lines = [l for l in open(p, errors="replace") if l.startswith("{")]
-            if lines:
-                open(os.path.join(out, f"{tag}_{workload}_bench_under_rocprof.json"), "w").write(lines[-1])
+    p = os.path.join(ROOT, "gpurun_out", f"bench_prof_{workload}.json")      # the FULL result of the profiled run (bench.py --detail)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(out, f"{tag}_{workload}_bench_under_rocprof.json"))
     print("wrote", sorted(os.listdir(out)))
 
 
