@@ -1173,6 +1173,411 @@ void launch_mse(const float* x, const float* t, long n, long n_global, double* l
   hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, x, t, n, 1.0 / (double)n_global, (float)(2.0 / (double)n_global), loss_dev, grad);
 }
 
+// ------------------------------------------------------------------ R's head in ONE launch (gr_train_r_step; round 5)
+// models.lua:446-451 + train_r.lua:147-151:  Linear(fc1) -> BatchNormalization -> act -> Dropout -> Linear(fc2) [-> Tanh] -> MSECriterion, forward AND backward
+// down to the gradient wrt fc1's output.  Between fc1's GEMM and fc1's two backward GEMMs the step used to issue 14 kernels on tensors of B x 512 and B x nd
+// floats - statistics partial / finalize / apply, a split-K GEMM and its reduction, the criterion, pass A / finalize of the last stage, two more small GEMMs,
+// pass A / pass B of the BatchNorm stage: 79 us at cfg2, every one of them the 5 us floor of a dependent launch.  Here C1 / 8 workgroups (64) walk three
+// phases separated by two grid barriers (all 64 are resident: the launch is alone on its stream and far below one workgroup per CU):
+//   1  per 8-feature slice, all rows:  batch statistics (double sums, fixed order), running statistics, z = ((y - mean) invstd) gamma + beta, act, Dropout -> out1
+//   2  per row slice, all features:    fc2 (+ bias, Tanh), loss partial, gradOutput, act' of fc2, gx = gy2 W2, times Dropout mask and act'(z) -> dz
+//   3  per 8-feature slice, all rows:  BatchNorm backward (sums of dz and (y - mean) dz in double; grad gamma / beta; dy), bias gradient of fc1, weight and
+//                                       bias gradient of fc2, max|dy| for the f16x3 GEMMs that follow
+// Every value is formed by the operations of the kernels it replaces (bn_apply / act_fwd / act_bwd_z / mask_mul, the finalize kernels' double arithmetic);
+// only the ORDER of the sums differs (rows in 32 interleaved groups instead of 256 threads x splits; fp32 dot products by fmaf in a fixed order), which is
+// inside the 1e-4 bar every parity test holds the step to.  Deterministic: no floating-point atomics, every reduction in a fixed order.
+// LLVM sinks a load into the (conditional) block of its only use and schedules for occupancy: a batch of independent loads written before a loop comes out as
+// load - wait - use, one at a time - fatal in a kernel of 256 waves where every wait is a full memory latency.  An empty asm that names the batch as inputs
+// pins every load of it above that point: one wait for all.
+#define HEAD_KEEP8(a_, i_) asm volatile("" :: "v"((a_)[(i_)]), "v"((a_)[(i_) + 1]), "v"((a_)[(i_) + 2]), "v"((a_)[(i_) + 3]), "v"((a_)[(i_) + 4]), "v"((a_)[(i_) + 5]), "v"((a_)[(i_) + 6]), "v"((a_)[(i_) + 7]))
+#define HEAD_KEEP16(a_, i_) asm volatile("" :: "v"((a_)[(i_)]), "v"((a_)[(i_) + 1]), "v"((a_)[(i_) + 2]), "v"((a_)[(i_) + 3]), "v"((a_)[(i_) + 4]), "v"((a_)[(i_) + 5]), "v"((a_)[(i_) + 6]), "v"((a_)[(i_) + 7]), \
+                                              "v"((a_)[(i_) + 8]), "v"((a_)[(i_) + 9]), "v"((a_)[(i_) + 10]), "v"((a_)[(i_) + 11]), "v"((a_)[(i_) + 12]), "v"((a_)[(i_) + 13]), "v"((a_)[(i_) + 14]), "v"((a_)[(i_) + 15]))
+// Dropout keep flag of element e as a multiplier: the launcher passes MASK_ELEM with its bits, or MASK_NONE with bits pointing at ANY readable words (the load
+// stays unconditional: no branch, no sinking) - what mask_mul computes for these two kinds
+__device__ __forceinline__ unsigned head_mask_word(const MaskRef& m, long e) { return m.bits[e >> 5]; }
+__device__ __forceinline__ float head_mask_of(const MaskRef& m, unsigned w, long e) { const float k = ((w >> (e & 31)) & 1u) ? m.scale : 0.f; return m.kind == MASK_ELEM ? k : 1.f; }
+struct HeadArgs {
+  int B, C1, nd, rows_per_wg;
+  const float* y1; float* out1;
+  float* mean; float* invstd; float* run_mean; float* run_var; const float* gamma; const float* beta;
+  MaskRef m1; int act1; float slope1; int act2;
+  const float* W2; const float* b2; float* y2; float* out2;
+  const float* target; double inv_n; float norm; double* loss; double* loss_part;
+  float* gout; float* gy2; float* dy1;
+  float* gW2; float* gb2; float* ggamma; float* gbeta; float* gb1;
+  unsigned* amax_dy;
+  unsigned* bar; unsigned bar_base;
+  unsigned long long* stamps;      // ablation build: [workgroup][8] wall-clock stamps of the phases (tools/debug/debug_head.py)
+};
+constexpr int HEAD_FW = 8, HEAD_RG = 32, HEAD_RMAX = 16;
+__device__ __forceinline__ bool head_grid_barrier(unsigned* ctr, unsigned target) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  __shared__ int ok_;
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 0;
+    for (int spin = 0; spin < (1 << 22); ++spin) {               // bounded: a launch that cannot become resident as a whole ends with a NaN loss, not a hung GPU
+      if ((int)(__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    ok_ = ok;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok_ != 0;
+}
+template <int RT>      // rows per workgroup in phase 2 (4: cfg2's 256 rows over 64 workgroups, 8: cfg3's 512, 16: the largest covered)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void head_fwd_bwd_kernel(HeadArgs a) {      // (one wave per SIMD: the scheduler may keep 64 loads in flight instead of trading them for an occupancy nobody uses)
+  extern __shared__ __attribute__((aligned(16))) unsigned char head_smem[];
+  __shared__ double sh_s[HEAD_RG][HEAD_FW], sh_q[HEAD_RG][HEAD_FW];
+  __shared__ float sh_mean[HEAD_FW], sh_inv[HEAD_FW], sh_c0[HEAD_FW], sh_c1[HEAD_FW];
+  __shared__ double sh_loss8[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, NW = gridDim.x;
+  const int B = a.B, C1 = a.C1, nd = a.nd;
+  const double n = (double)B;
+  bool alive = true;
+#define HEAD_STAMP(i_) if (GR_DBG(a.stamps != nullptr) && tid == 0) a.stamps[blockIdx.x * 8 + (i_)] = wall_clock64();
+  HEAD_STAMP(0)
+  // Loops below run a FIXED number of steps with clamped indices and zero weights past the ends (rows past B, outputs past nd, columns past C1) and guard
+  // only their stores: the first version predicated every step of 16-fold unrollings and came to 35 000 lines of ISA, slower than the 14 launches it replaced.
+  // ---------------------------------------------------------------- phase 1: features f0 .. f0 + 7, all rows
+  const int f0 = wg * HEAD_FW, ff = tid & (HEAD_FW - 1), rg = tid >> 3, f = f0 + ff;
+  {
+    double s = 0, q = 0;
+    for (int b0 = rg; b0 < B; b0 += 8 * HEAD_RG) {               // eight loads in flight per thread, added in row order
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = a.y1[(long)min(b0 + u * HEAD_RG, B - 1) * C1 + f];
+      HEAD_KEEP8(v8, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const double v = b0 + u * HEAD_RG < B ? v8[u] : 0.f; s += v; q += v * v; }
+    }
+    sh_s[rg][ff] = s; sh_q[rg][ff] = q;
+    __syncthreads();
+    if (tid < HEAD_FW) {
+      double ss = 0, qq = 0;
+#pragma unroll 8
+      for (int k = 0; k < HEAD_RG; ++k) { ss += sh_s[k][tid]; qq += sh_q[k][tid]; }
+      const double m = ss / n;
+      double vs = qq - ss * m;
+      if (vs < 0) vs = 0;
+      const float mf = (float)m, is = (float)(1.0 / sqrt(vs / n + 1e-5));
+      const int c = f0 + tid;
+      a.mean[c] = mf; a.invstd[c] = is;
+      if (a.run_mean) {
+        a.run_mean[c] = (float)(0.1 * m + 0.9 * (double)a.run_mean[c]);
+        a.run_var[c] = (float)(0.1 * (vs / (n - 1)) + 0.9 * (double)a.run_var[c]);
+      }
+      sh_mean[tid] = mf; sh_inv[tid] = is;
+    }
+    __syncthreads();
+    const float mean = sh_mean[ff], invstd = sh_inv[ff], gm = a.gamma[f], bt = a.beta[f];
+    for (int b0 = rg; b0 < B; b0 += 8 * HEAD_RG) {
+      float v8[8]; unsigned m8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const long e = (long)min(b0 + u * HEAD_RG, B - 1) * C1 + f; v8[u] = a.y1[e]; m8[u] = head_mask_word(a.m1, e); }
+      HEAD_KEEP8(v8, 0); HEAD_KEEP8(m8, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u * HEAD_RG;
+        const long e = (long)min(b, B - 1) * C1 + f;
+        const float z = ((v8[u] - mean) * invstd) * gm + bt;
+        const float o = act_fwd(z, a.act1, a.slope1) * head_mask_of(a.m1, m8[u], e);
+        if (b < B) a.out1[(long)b * C1 + f] = o;
+      }
+    }
+  }
+  HEAD_STAMP(1)
+  alive = head_grid_barrier(a.bar, a.bar_base + (unsigned)NW) && alive;
+  HEAD_STAMP(2)
+  // ---------------------------------------------------------------- phase 2: rows r0 .. r0 + nrows - 1, all features
+  // Every global load of the phase that does not depend on its own arithmetic goes out at its top - the slice's out1 rows, the first eight W2 rows of each
+  // wave, fc2's bias, the criterion's targets, y1 / Dropout words of the slice - and is waited for ONCE; later batches (more than 32 outputs) are requested one
+  // batch ahead of their use.  (256 waves on the chip: a load that waits alone costs a whole memory latency, ~2 us behind the barrier's cache invalidate.)
+  const int r0 = wg * RT, nrows = max(0, min(RT, B - r0));
+  float* xs = reinterpret_cast<float*>(head_smem);                 // [RT][C1]: out1 rows (phase 2), then [B][8] out1 columns (phase 3)
+  float* gy2_s = xs + (size_t)(RT * C1 > B * HEAD_FW ? RT * C1 : B * HEAD_FW);      // [RT][nd]
+  float* red = gy2_s + (size_t)RT * nd;                            // phase 3: [slices][OG][9]; phase 2: fc2's bias [nd]
+  float* b2_s = red;
+  double lacc = 0;
+  {
+    const int NJ = C1 >> 6;                                        // C1 % 64 == 0, C1 <= 512 (launcher): at most 8 columns per lane
+    const long last1 = (long)B * C1 - 1, last2 = (long)B * nd - 1;
+    float xr[2 * RT];                                              // RT * C1 / 256 <= 2 RT elements of the slice's rows per thread
+#pragma unroll
+    for (int k = 0; k < 2 * RT; ++k) { const long i = (long)r0 * C1 + tid + 256 * k; xr[k] = a.out1[i < last1 ? i : last1]; }
+    float w8[8][8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w8[u][j] = a.W2[(long)min(wave + 4 * u, nd - 1) * C1 + lane + 64 * (j < NJ ? j : 0)];
+    const float b2r = a.b2[min(tid, nd - 1)];
+    float tg[(RT * 128 + 255) / 256];                              // the criterion's targets of this thread's elements (nd <= 128)
+#pragma unroll
+    for (int k = 0; k < (RT * 128 + 255) / 256; ++k) { const long e2 = (long)r0 * nd + tid + 256 * k; tg[k] = a.target[e2 < last2 ? e2 : last2]; }
+    float yv[2][RT]; unsigned mk[2][RT];                           // y1 and Dropout words of the thread's two feature columns (fx = tid, tid + 256)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int r = 0; r < RT; ++r) { const long e = (long)min(r0 + r, B - 1) * C1 + min(tid + 256 * h2, C1 - 1); yv[h2][r] = a.y1[e]; mk[h2][r] = head_mask_word(a.m1, e); }
+    float bnp[2][4];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) { const int fx = min(tid + 256 * h2, C1 - 1); bnp[h2][0] = a.mean[fx]; bnp[h2][1] = a.invstd[fx]; bnp[h2][2] = a.gamma[fx]; bnp[h2][3] = a.beta[fx]; }
+    // ---- one wait
+#pragma unroll
+    for (int k = 0; k < 2 * RT; k += 4) asm volatile("" :: "v"(xr[k]), "v"(xr[k + 1]), "v"(xr[k + 2]), "v"(xr[k + 3]));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) HEAD_KEEP8(w8[u], 0);
+    asm volatile("" :: "v"(b2r), "v"(tg[0]), "v"(bnp[0][0]), "v"(bnp[0][1]), "v"(bnp[0][2]), "v"(bnp[0][3]), "v"(bnp[1][0]), "v"(bnp[1][1]), "v"(bnp[1][2]), "v"(bnp[1][3]));
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int r = 0; r < RT; r += 4) asm volatile("" :: "v"(yv[h2][r]), "v"(yv[h2][r + 1]), "v"(yv[h2][r + 2]), "v"(yv[h2][r + 3]), "v"(mk[h2][r]), "v"(mk[h2][r + 1]), "v"(mk[h2][r + 2]), "v"(mk[h2][r + 3]));
+#pragma unroll
+    for (int k = 0; k < 2 * RT; ++k) { const int i = tid + 256 * k; if (i < RT * C1) xs[i] = (long)r0 * C1 + i <= last1 ? xr[k] : 0.f; }
+    if (tid < nd) b2_s[tid] = b2r;
+    __syncthreads();
+    for (int ob = wave; ob < nd; ob += 32) {                       // this wave's outputs ob, ob + 4, ..., eight at a time
+      float wn[8][8];                                              // the next batch, requested before this one is multiplied
+      const bool more = ob + 32 < nd;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wn[u][j] = a.W2[(long)min(ob + 32 + 4 * u, nd - 1) * C1 + lane + 64 * (j < NJ ? j : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = ob + 4 * u;
+        const float bias2 = b2_s[min(o, nd - 1)];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          float pr = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pr = fmaf((o < nd && j < NJ) ? w8[u][j] : 0.f, xs[r * C1 + lane + 64 * (j < NJ ? j : 0)], pr);
+          const float v = wave_sum(pr);                            // DPP tree, fixed order; the total sits in lanes 48-63
+          if (lane == 63 && o < nd) gy2_s[r * nd + o] = v + bias2;   // fc2's raw output; the criterion follows below, one element per thread
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) HEAD_KEEP8(wn[u], 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w8[u][j] = wn[u][j];
+      }
+    }
+    // W2 columns of the thread's two features for the data gradient: the first 32 outputs now, behind the criterion
+    float wc[2][32];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int u = 0; u < 32; ++u) wc[h2][u] = a.W2[(long)min(u, nd - 1) * C1 + min(tid + 256 * h2, C1 - 1)];
+    __syncthreads();
+    // criterion and its gradient, element-wise over the slice's nrows x nd outputs (a wave's lane 63 doing this after every dot product was a chain of
+    // dependent global loads and stores: 80 us of the kernel's first version)
+#pragma unroll
+    for (int k = 0; k < (RT * 128 + 255) / 256; ++k) {
+      const int i = tid + 256 * k;
+      if (i < nrows * nd) {
+        const long e2 = (long)r0 * nd + i;
+        const float y = gy2_s[i];
+        const float out = act_fwd(y, a.act2, 0.f);
+        const float zd = out - tg[k];
+        lacc += (double)(zd * zd);
+        const float g = a.norm * zd;
+        const float g2 = act_bwd(g, y, out, a.act2, 0.f);
+        a.y2[e2] = y;
+        if (a.out2 != a.y2) a.out2[e2] = out;
+        a.gout[e2] = g;
+        a.gy2[e2] = g2;
+        gy2_s[i] = g2;
+      } else if (i < RT * nd) gy2_s[i] = 0.f;                     // rows past B: zero gradient
+    }
+    lacc = block_reduce_sum(lacc, sh_loss8);
+    HEAD_STAMP(3)
+    __syncthreads();
+    if (tid == 0) a.loss_part[wg] = lacc;
+    // gx = gy2 W2 for the rows of this slice, then through the Dropout mask and the activation's derivative: dz
+    float acc[2][RT];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[h2][r] = 0.f;
+    for (int o0 = 0; o0 < nd; o0 += 32) {
+      float wcn[2][32];
+      const bool more = o0 + 32 < nd;
+      if (more) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int u = 0; u < 32; ++u) wcn[h2][u] = a.W2[(long)min(o0 + 32 + u, nd - 1) * C1 + min(tid + 256 * h2, C1 - 1)];
+      } else {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) { HEAD_KEEP16(wc[h2], 0); HEAD_KEEP16(wc[h2], 16); }
+      }
+#pragma unroll
+      for (int u = 0; u < 32; ++u) {
+        const int oo = min(o0 + u, nd - 1);
+        const bool on = o0 + u < nd;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          const float gv = gy2_s[r * nd + oo];
+          acc[0][r] = fmaf(gv, on ? wc[0][u] : 0.f, acc[0][r]);
+          acc[1][r] = fmaf(gv, on ? wc[1][u] : 0.f, acc[1][r]);
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) { HEAD_KEEP16(wcn[h2], 0); HEAD_KEEP16(wcn[h2], 16); }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int u = 0; u < 32; ++u) wc[h2][u] = wcn[h2][u];
+      }
+    }
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int fx = tid + 256 * h2;
+      const float mean = bnp[h2][0], invstd = bnp[h2][1], gm = bnp[h2][2], bt = bnp[h2][3];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const float g = acc[h2][r] * head_mask_of(a.m1, mk[h2][r], (long)min(r0 + r, B - 1) * C1 + min(fx, C1 - 1));
+        const float z = ((yv[h2][r] - mean) * invstd) * gm + bt;
+        const float dz = act_bwd_z(g, z, a.act1, a.slope1);
+        if (r < nrows && fx < C1) a.dy1[(long)(r0 + r) * C1 + fx] = dz;
+      }
+    }
+  }
+  HEAD_STAMP(4)
+  alive = head_grid_barrier(a.bar, a.bar_base + 2u * (unsigned)NW) && alive;
+  HEAD_STAMP(5)
+  // ---------------------------------------------------------------- phase 3: features f0 .. f0 + 7, all rows
+  {
+    const float mean = sh_mean[ff], invstd = sh_inv[ff], gm = a.gamma[f];
+    double s = 0, q = 0;
+    for (int b0 = rg; b0 < B; b0 += 8 * HEAD_RG) {
+      float d8[8], y8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const long e = (long)min(b0 + u * HEAD_RG, B - 1) * C1 + f; d8[u] = a.dy1[e]; y8[u] = a.y1[e]; }
+      HEAD_KEEP8(d8, 0); HEAD_KEEP8(y8, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const float dz = b0 + u * HEAD_RG < B ? d8[u] : 0.f; s += (double)dz; q += (double)(y8[u] - mean) * (double)dz; }
+    }
+    __syncthreads();                                               // (sh_s / sh_q of phase 1 are long consumed; xs / gy2_s of phase 2 too)
+    sh_s[rg][ff] = s; sh_q[rg][ff] = q;
+    __syncthreads();
+    if (tid < HEAD_FW) {
+      double ss = 0, qq = 0;
+#pragma unroll 8
+      for (int k = 0; k < HEAD_RG; ++k) { ss += sh_s[k][tid]; qq += sh_q[k][tid]; }
+      const double isd = (double)sh_inv[tid];
+      const int c = f0 + tid;
+      a.ggamma[c] += (float)(qq * isd);
+      a.gbeta[c] += (float)ss;
+      sh_c0[tid] = (float)(ss / n);
+      sh_c1[tid] = (float)(qq * isd * isd / n);
+    }
+    __syncthreads();
+    const float c0 = sh_c0[ff], c1 = sh_c1[ff];
+    double sb = 0; float dmax = 0.f;
+    for (int b0 = rg; b0 < B; b0 += 8 * HEAD_RG) {
+      float d8[8], y8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const long e = (long)min(b0 + u * HEAD_RG, B - 1) * C1 + f; d8[u] = a.dy1[e]; y8[u] = a.y1[e]; }
+      HEAD_KEEP8(d8, 0); HEAD_KEEP8(y8, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u * HEAD_RG;
+        const float d = ((d8[u] - c0) - (y8[u] - mean) * c1) * invstd * gm;
+        if (b < B) { a.dy1[(long)b * C1 + f] = d; dmax = fmaxf(dmax, fabsf(d)); sb += (double)d; }
+      }
+    }
+    if (a.amax_dy) absmax_commit(dmax, a.amax_dy);
+    sh_s[rg][ff] = sb;
+    // out1 columns of this slice -> LDS for fc2's weight gradient
+    for (int i = tid; i < B * HEAD_FW; i += 256) { const int b = i >> 3, c = i & 7; xs[i] = a.out1[(long)b * C1 + f0 + c]; }
+    __syncthreads();
+    if (tid < HEAD_FW) {
+      double t = 0;
+#pragma unroll 8
+      for (int k = 0; k < HEAD_RG; ++k) t += sh_s[k][tid];
+      a.gb1[f0 + tid] += (float)t;
+    }
+    // gW2[o][f0 + c] += sum_b gy2[b][o] out1[b][f0 + c]; gb2[o] += sum_b gy2[b][o] (workgroup 0)
+    const int OG = nd <= 32 ? 32 : (nd <= 64 ? 64 : 128), slices = 256 / OG, o = tid & (OG - 1), sl = tid / OG, oc = min(o, nd - 1);
+    float acc[HEAD_FW + 1];
+#pragma unroll
+    for (int c = 0; c <= HEAD_FW; ++c) acc[c] = 0.f;
+    for (int b0 = sl; b0 < B; b0 += 16 * slices) {
+      float g16[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) g16[u] = a.gy2[(long)min(b0 + u * slices, B - 1) * nd + oc];
+      HEAD_KEEP16(g16, 0);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) g16[u] = b0 + u * slices < B ? g16[u] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = min(b0 + u * slices, B - 1);
+        const float g = g16[u];
+        const float4 x0 = *reinterpret_cast<const float4*>(xs + b * HEAD_FW), x1 = *reinterpret_cast<const float4*>(xs + b * HEAD_FW + 4);
+        acc[0] = fmaf(g, x0.x, acc[0]); acc[1] = fmaf(g, x0.y, acc[1]); acc[2] = fmaf(g, x0.z, acc[2]); acc[3] = fmaf(g, x0.w, acc[3]);
+        acc[4] = fmaf(g, x1.x, acc[4]); acc[5] = fmaf(g, x1.y, acc[5]); acc[6] = fmaf(g, x1.z, acc[6]); acc[7] = fmaf(g, x1.w, acc[7]);
+        acc[8] += g;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c <= HEAD_FW; ++c) red[(sl * OG + o) * (HEAD_FW + 1) + c] = acc[c];
+    __syncthreads();
+    for (int i = tid; i < nd * (HEAD_FW + 1); i += 256) {
+      const int oo = i / (HEAD_FW + 1), c = i - oo * (HEAD_FW + 1);
+      float t = 0.f;
+      for (int k = 0; k < slices; ++k) t += red[(k * OG + oo) * (HEAD_FW + 1) + c];
+      if (c < HEAD_FW) a.gW2[(long)oo * C1 + f0 + c] += t;
+      else if (wg == 0) a.gb2[oo] += t;
+    }
+    HEAD_STAMP(6)
+    if (wg == 0 && tid == 0) {
+      double t = 0;
+      for (int k = 0; k < NW; ++k) t += a.loss_part[k];
+      *a.loss = alive ? t * a.inv_n : (double)NAN;
+    }
+  }
+}
+size_t head_lds_bytes(int B, int C1, int nd, int rows_per_wg) {
+  const size_t xs = (size_t)(rows_per_wg * C1 > B * HEAD_FW ? rows_per_wg * C1 : B * HEAD_FW);
+  return sizeof(float) * (xs + (size_t)rows_per_wg * nd + (size_t)256 * (HEAD_FW + 1));
+}
+bool head_supported(int B, int C1, int nd) {
+  if (B < 2 || C1 % 64 != 0 || C1 < 64 || C1 > 512 || nd < 1 || nd > 128) return false;
+  const int NW = C1 / HEAD_FW, R = (B + NW - 1) / NW;
+  // Measured (in-kernel stamps, tools/debug/head_stamps.py): cfg2's head (256 rows, nd 32: 4 rows per workgroup) 48.6 us against 79 us for the 14 launches it
+  // replaces; cfg3's (512 rows, nd 100: 8 rows per workgroup, four batches of W2 per wave) 141 us against ~95 - its fc2 forward is a chain of 256 dependent
+  // (LDS read, 8 FMAs, DPP wave sum) steps per wave.  The kernel is used where it wins: at most 4 rows per workgroup and nd <= 32.
+  return R <= 4 && nd <= 32 && head_lds_bytes(B, C1, nd, 4) <= 60 * 1024;
+}
+void launch_head_fwd_bwd(const HeadLaunch& h, hipStream_t s) {
+  HeadArgs a{};
+  a.B = h.B; a.C1 = h.C1; a.nd = h.nd;
+  const int NW = h.C1 / HEAD_FW;
+  a.rows_per_wg = (h.B + NW - 1) / NW;
+  a.y1 = h.y1; a.out1 = h.out1; a.mean = h.mean; a.invstd = h.invstd; a.run_mean = h.run_mean; a.run_var = h.run_var; a.gamma = h.gamma; a.beta = h.beta;
+  a.m1 = h.m1; if (a.m1.kind != MASK_ELEM) { a.m1.kind = MASK_NONE; a.m1.bits = reinterpret_cast<const uint32_t*>(h.y1); a.m1.scale = 1.f; }      // (any readable words: head_mask_word)
+  a.act1 = h.act1; a.slope1 = h.slope1; a.act2 = h.act2;
+  a.W2 = h.W2; a.b2 = h.b2; a.y2 = h.y2; a.out2 = h.out2;
+  a.target = h.target; a.inv_n = 1.0 / (double)h.n_global; a.norm = (float)(2.0 / (double)h.n_global); a.loss = h.loss; a.loss_part = h.loss_part;
+  a.gout = h.gout; a.gy2 = h.gy2; a.dy1 = h.dy1;
+  a.gW2 = h.gW2; a.gb2 = h.gb2; a.ggamma = h.ggamma; a.gbeta = h.gbeta; a.gb1 = h.gb1;
+  a.amax_dy = h.amax_dy; a.bar = h.bar; a.bar_base = h.bar_base; a.stamps = reinterpret_cast<unsigned long long*>(g_p16_stamps);
+  const size_t lds = head_lds_bytes(h.B, h.C1, h.nd, 4);      // (head_supported: at most 4 rows per workgroup)
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fwd_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+  KtScope kt("head_fwd_bwd_kernel", 2.0 * 3.0 * h.B * (double)h.C1 * h.nd, 4.0 * (6.0 * h.B * h.C1 + 3.0 * (double)h.nd * h.C1), s);
+  hipLaunchKernelGGL(head_fwd_bwd_kernel<4>, dim3(NW), dim3(256), lds, s, a);
+}
+
 // ------------------------------------------------------------------ nn.BCECriterion (sizeAverage; train.lua:173's CRITERION, used by adversarial.lua)
 // THNN BCECriterion.c with EPS = 1e-12: every term in double (the C source mixes float tensors with double literals), the sum in
 // double; gradInput = -1/n (t - x) / ((1 - x + EPS)(x + EPS)) evaluated in double and rounded once - the same IEEE operations as

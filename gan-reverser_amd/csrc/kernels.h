@@ -355,6 +355,21 @@ void launch_prelu_grad(const float* g, const float* z, long n, double* part, flo
 
 // ---------------------------------------------------------------- criterion / optimiser / misc
 void launch_mse(const float* x, const float* t, long n, long n_global, double* loss_dev, float* grad, hipStream_t s);
+// R's head in one launch (elem.hip, head_fwd_bwd_kernel): BatchNorm + act + Dropout of the fc1 stage, fc2 [+ Tanh], MSE, and their backward down to fc1's dy
+struct HeadLaunch {
+  int B, C1, nd; long n_global;
+  const float* y1; float* out1;                                  // fc1: raw output (bias added), stage output
+  float *mean, *invstd, *run_mean, *run_var; const float *gamma, *beta;
+  MaskRef m1; int act1; float slope1; int act2;                  // fc1 stage: Dropout mask, activation; fc2 stage: ACT_NONE or ACT_TANH
+  const float *W2, *b2; float *y2, *out2;                        // fc2: weights [nd][C1], bias, raw output, stage output (== y2 without an activation)
+  const float* target; double* loss; double* loss_part;          // the criterion's target, device loss, [C1 / 8] partial sums
+  float *gout, *gy2, *dy1;                                       // gradOutput of the net [B][nd], gradient wrt fc2's raw output, wrt fc1's raw output [B][C1]
+  float *gW2, *gb2, *ggamma, *gbeta, *gb1;                       // accumulated into (accGradParameters)
+  unsigned* amax_dy;                                             // f16x3: max|dy1| slot of fc1's backward GEMMs (nullable)
+  unsigned* bar; unsigned bar_base;                              // grid-barrier arrival counter (monotonic; the launch adds 2 x C1 / 8) and its value before this launch
+};
+bool head_supported(int B, int C1, int nd);
+void launch_head_fwd_bwd(const HeadLaunch& h, hipStream_t s);
 void launch_add_inplace(float* y, const float* x, long n, hipStream_t s);        // y += x
 void launch_bce(const float* x, const float* t, long n, double* loss_dev, float* grad, hipStream_t s);      // nn.BCECriterion (sizeAverage)
 struct AdamConsts { float b1, b2, c1, c2, eps, step, l1, l2, clamp; int use_penalty, use_clamp; };

@@ -36,6 +36,10 @@ struct gr_ctx {
   // weight gradients run beside the rest of backward (backward_impl): their own stream, workspace and events
   hipStream_t side_stream = nullptr; void* ws2 = nullptr; size_t ws2_bytes = 0;
   hipEvent_t ev_dy_ready = nullptr, ev_wgrad_done[2] = {nullptr, nullptr};
+  // R's head in one launch (gr_train_r_step, elem.hip head_fwd_bwd_kernel): grid-barrier counter (monotonic) and per-workgroup loss partials
+  unsigned* head_bar = nullptr; unsigned head_bar_count = 0; double* head_loss_part = nullptr;
+  int fused_head = 1;                  // gr_set_tuning "fused_head" (1 default; 0 = the stage-by-stage path: the A/B control and what every other entry point runs)
+  hipEvent_t ev_prep_go = nullptr, ev_prep_done = nullptr;    // ablation build: R's per-step preparation on the side stream beside G's forward (GR_PREP_OVERLAP=1; it lost its A/B)
   int side_wgrad = -1;                 // gr_set_tuning "side_wgrad" / GR_SIDE_WGRAD: 1 on, 0 off, -1 (default) by size.  The MFMA kernels take the whole register file of a
                                        // CU (2 waves x 256 VGPRs per SIMD), so nothing becomes resident beside a weight gradient and only kernel tails overlap.  Round 5,
                                        // same box, interleaved (profiles/r05_ab_side_wgrad_*.txt): cfg2 1.976 -> 1.998 ms (slower: the tails are a few us and two streams
@@ -235,8 +239,10 @@ extern "C" int gr_init(int device, gr_ctx** out) {
   (void)hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
   (void)hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&c->ev_dy_ready, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_prep_go, hipEventDisableTiming); (void)hipEventCreateWithFlags(&c->ev_prep_done, hipEventDisableTiming);
   for (auto& e : c->ev_wgrad_done) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   { const char* e = getenv("GR_SIDE_WGRAD"); if (e) c->side_wgrad = atoi(e); }
+  { const char* e = getenv("GR_FUSED_HEAD"); if (e) c->fused_head = atoi(e) != 0; }
   (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
   *out = c;
@@ -253,6 +259,10 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
   if (c->ws2) (void)hipFree(c->ws2);
   if (c->ev_dy_ready) (void)hipEventDestroy(c->ev_dy_ready);
+  if (c->head_bar) (void)hipFree(c->head_bar);
+  if (c->head_loss_part) (void)hipFree(c->head_loss_part);
+  if (c->ev_prep_go) (void)hipEventDestroy(c->ev_prep_go);
+  if (c->ev_prep_done) (void)hipEventDestroy(c->ev_prep_done);
   for (auto& e : c->ev_wgrad_done) if (e) (void)hipEventDestroy(e);
   if (c->guard_chmax) (void)hipFree(c->guard_chmax);
   if (c->sync_buf) (void)hipFree(c->sync_buf);
@@ -304,6 +314,7 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
 #endif
   if (!strcmp(key, "eval_p16")) { g_eval_p16 = value; return GR_OK; }           // evaluate()-mode stages hand their output over operand-ready (1, default) or as fp32 (0: the A/B control)
   if (!strcmp(key, "side_wgrad")) { c->side_wgrad = value; return GR_OK; }
+  if (!strcmp(key, "fused_head")) { c->fused_head = value != 0; return GR_OK; }   // gr_train_r_step: R's last two stages + the criterion, forward and backward, in one launch
   // synchronised BatchNorm under data parallelism: per-channel batch sums are all-reduced, fwd and bwd (include/ganrev.h)
   if (!strcmp(key, "sync_bn")) { c->sync_bn = value != 0; return ensure_stat_comm(c); }   // (collective when a communicator exists: every rank sets it at the same point)
   // f16x3 range guard on / off.  Off also clears a tripped trainer guard AND drops a verdict still in flight: that verdict is about the
@@ -464,6 +475,8 @@ struct gr_net {
   uint64_t prepped_version[3] = {0, 0, 0};
   unsigned* amax = nullptr;          // f16x3 scale tracking, groups of [nst] slots: x xt y | kb dy dz | w  (AG_*, AMAX_GROUPS)
   bool dy_slots_zeroed = false, w_slots_zeroed = false;   // set by forward_impl's single fill, consumed by backward / weight prep
+  bool head_fused = false;           // gr_train_r_step: this forward stops after fc1's GEMM and this backward starts at fc1's GEMMs - the head kernel does what lies between
+  int begun_B = 0;                   // > 0: forward_begin has already run for the next forward of this batch size (gr_train_r_step ran it on the side stream)
   int amax_prezeroed_groups = 0;     // > 0: the caller (gr_train_r_step's one fill per step) has just zeroed that many slot groups: the next forward skips its own fill
   bool keep_fp32 = false;            // range-guarded host calls: no lean (operand-ready only) tensors, so a backward can still fall back to bf16x6
   bool last_fwd_fell_back = false;   // the last guarded forward ran on bf16x6: its backward does too
@@ -996,13 +1009,15 @@ static int guard_scan_activation(gr_ctx* c, const float* t, int B, int C, int H,
   return guard_scan(c, t, B, C, hw, (long)C * hw, hw, 0);
 }
 
-static int forward_stages(gr_net* n, const float* in_dev, int B) {
+// The per-forward preparation that depends on nothing but the parameters and the batch size: counters, the one fill of the f16x3 scale slots, the weight
+// images / maxima of the current parameters, the Dropout noise.  Launches on c->stream - gr_train_r_step points that at the side stream for R, so that these
+// three to four small launches (25 us at cfg2: each is a launch-latency floor, not work) run beside G's forward instead of between G and R.
+static int forward_begin(gr_net* n, int B) {
   gr_ctx* c = n->ctx;
   const int prezeroed_groups = n->amax_prezeroed_groups;      // consumed on EVERY path out of this call (an early error return must not leave it set for a later forward)
   n->amax_prezeroed_groups = 0;
   HIPCHK(c, hipSetDevice(c->device));
   int r = ensure_batch(n, B); if (r) return r;
-  const float* x = in_dev;
   n->fwd_counter++;
   n->amax_gen++;
   const bool f16 = c->conv_mode == 2;
@@ -1042,6 +1057,18 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
     launch_gen_mask_batch(jobs, n->seed, n->fwd_counter, c->stream);
     LAUNCHCHK(c);
   }
+  n->begun_B = B;
+  return GR_OK;
+}
+
+static int forward_stages(gr_net* n, const float* in_dev, int B) {
+  gr_ctx* c = n->ctx;
+  int r = GR_OK;
+  if (n->begun_B != B) { r = forward_begin(n, B); if (r) { n->begun_B = 0; return r; } }
+  n->begun_B = 0;
+  const float* x = in_dev;
+  const bool f16 = c->conv_mode == 2;
+  const size_t nst = n->st.size();
   for (size_t si = 0; si < nst; ++si) {
     Stage& s = n->st[si];
     // f16x3: the kernel that writes this stage's output also tracks its max|.| for the convolution that consumes it
@@ -1164,6 +1191,12 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
       launch_gemm(x, s.Cin, 1, n->params + s.w_off, s.Cin, 1, s.y, s.Cout, n->params + s.b_off, false, B, s.Cout, s.Cin, c->ws, c->stream);
     }
     LAUNCHCHK(c);
+    if (n->head_fused && si + 2 == nst) {      // fc1's raw output is complete: the head kernel (gr_train_r_step) takes it from here, through fc2, the criterion and back
+      s.eval_ready = false;
+      Stage& s2 = n->st[si + 1];
+      s2.x_in = s.out; s2.fused_epilogue = false; s2.out_skipped = false; s2.out = s2.has_post ? s2.out : s2.y;
+      break;
+    }
     if (!s.has_post) { s.out = s.y; x = s.out; continue; }
     const float* yv = s.kind == ST_ELEM ? x : s.y;
     PostArgs pa = post_args(n, s, B);
@@ -1406,6 +1439,10 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
   for (int si = (int)n->st.size() - 1; si >= 0; --si) {
     Stage& s = n->st[si];
     if (s.has_bn && !n->training) return fail(c, GR_ERR_STATE, "backward through BatchNormalization requires training mode");
+    // gr_train_r_step's head kernel has already run fc2's whole backward and fc1's pipeline backward (dy of fc1 sits in its dy buffer, max|dy| in its slot,
+    // the gradients of fc2, of the BatchNorm and of fc1's bias are accumulated): fc1's two GEMMs are what is left of these two stages
+    if (n->head_fused && si + 1 == (int)n->st.size()) continue;
+    const bool head_here = n->head_fused && si + 2 == (int)n->st.size();
     const float* x = si == 0 ? in_dev : s.x_in;
     const bool need_gin = si > 0 || gin_dev != nullptr;
     float* gin = (si == 0 && gin_dev) ? gin_dev : n->g_buf[si & 1];
@@ -1436,13 +1473,13 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
       return fail(c, GR_ERR_STATE, "stage %d: the forward left this stage's input operand-ready only (f16x3); backward in another arithmetic mode needs a new forward", si);
     static const bool lean_on = !GR_KNOB_SET("GR_P16_KEEP_FP32");
     if (lean_on && !n->keep_fp32 && wgrad_p16 && (dgrad_p16 || !need_gin)) pb.dy = nullptr;      // no fp32 reader of dy is left
-    if (s.act == ACT_PRELU) {
+    if (s.act == ACT_PRELU && !head_here) {
       // nn.PReLU accGradParameters: the stage ends at the PReLU, so g is its gradOutput and the raw main-op output (the stage
       // input for an element-wise stage) its input
       int r = ensure_ws(c, prelu_grad_workspace_bytes()); if (r) return r;
       launch_prelu_grad(g, s.kind == ST_ELEM ? x : s.y, (long)B * vol3(s.Cout, s.H, s.W), static_cast<double*>(c->ws), n->grads + s.slope_off, c->stream);
     }
-    {
+    if (!head_here) {
       StatSync ss;
       launch_post_backward(pb, c->stream, &bias_jobs, s.has_bn ? stat_sync(c, ss, s.Cout, (double)B * s.H * s.W) : nullptr);       // bias gradients of several stages are summed by one launch
       if (c->coll_rc) { const int rc = c->coll_rc; c->coll_rc = 0; return rc; }
@@ -1755,6 +1792,32 @@ extern "C" int gr_broadcast_params(gr_net* n, int root) {
 }
 
 // ------------------------------------------------------------------ the whole train_r.lua:138-170 iteration
+// Can R's last two stages run in the head kernel?  Linear -> BatchNorm -> activation -> [Dropout] followed by Linear [-> Tanh], training mode, per-rank
+// BatchNorm statistics (synchronised BatchNorm adds a collective between the phases: stage-by-stage path), shapes the kernel covers.  Fills every field of
+// the launch that depends on the net only.
+static bool head_plan(gr_net* n, int B, HeadLaunch& h) {
+  gr_ctx* c = n->ctx;
+  const size_t nst = n->st.size();
+  if (nst < 3 || !n->training || (c->sync_bn && have_peers(c)) || n->keep_fp32) return false;
+  Stage& s1 = n->st[nst - 2]; Stage& s2 = n->st[nst - 1];
+  if (s1.kind != ST_LINEAR || s2.kind != ST_LINEAR || !s1.has_post || !s1.has_bn || s1.pool || s1.m2 >= 0 || s1.H != 1 || s1.W != 1) return false;
+  if (s1.act == ACT_PRELU || s2.has_bn || s2.pool || s2.m1 >= 0 || s2.m2 >= 0 || !(s2.act == ACT_NONE || s2.act == ACT_TANH)) return false;
+  if (s2.Cin != s1.Cout || !head_supported(B, s1.Cout, s2.Cout) || B > n->capB) return false;      // (gr_train_r_step has sized the buffers: ensure_batch)
+  bool need = false;
+  const MaskRef m1 = mask_ref(n, s1.m1, need);
+  if (!(m1.kind == MASK_NONE || m1.kind == MASK_ELEM)) return false;
+  const int i1 = (int)nst - 2, i2 = (int)nst - 1;
+  h.B = B; h.C1 = s1.Cout; h.nd = s2.Cout;
+  h.y1 = s1.y; h.out1 = s1.out;
+  h.mean = s1.mean; h.invstd = s1.invstd; h.run_mean = s1.run_mean; h.run_var = s1.run_var; h.gamma = n->params + s1.g_off; h.beta = n->params + s1.be_off;
+  h.m1 = m1; h.act1 = s1.act; h.slope1 = s1.slope; h.act2 = s2.act;
+  h.W2 = n->params + s2.w_off; h.b2 = n->params + s2.b_off; h.y2 = s2.y; h.out2 = s2.has_post ? s2.out : s2.y;
+  h.gout = n->gout_buf; h.gy2 = (i2 & 1) ? n->dy_buf_b : n->dy_buf; h.dy1 = (i1 & 1) ? n->dy_buf_b : n->dy_buf;
+  h.gW2 = n->grads + s2.w_off; h.gb2 = n->grads + s2.b_off; h.ggamma = n->grads + s1.g_off; h.gbeta = n->grads + s1.be_off; h.gb1 = n->grads + s1.b_off;
+  h.amax_dy = (c->conv_mode == 2 && use_f16_gemm(n, s1)) ? s1.amax_dy : nullptr;
+  return h.y1 && h.out1 && h.y2 && h.out2 && h.gout && h.gy2 && h.dy1;
+}
+
 extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, int B, int GB, const gr_hyper* h, int t, double* loss_out) {
   if (!g || !rn || !noise_dev || !h || B <= 0 || GB < B || t < 1) return GR_ERR_INVALID;
   gr_ctx* c = rn->ctx;
@@ -1806,15 +1869,50 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
     LAUNCHCHK(c);
   }
   g_kphase = 1;
-  { PhaseRange pr("G forward"); r = forward_impl(g, noise_dev, B); } if (r) return r;          // train_r.lua:139
+  // R's preparation for this step (weight images and maxima of the parameters Adam just wrote, Dropout noise) depends on nothing G computes and could run on
+  // the side stream beside G's forward.  Measured (round 5, same box, interleaved: profiles/r05_ab_prep_overlap_cfg2.txt): the step gets SLOWER, 1.920-1.942 ->
+  // 1.960-1.968 ms at cfg2 - the three launches cost 25 us in line, the two event hand-overs and the small kernels' workgroups squeezing in between G's
+  // matrix-pipe-filling workgroups cost more.  Ablation build only (GR_PREP_OVERLAP=1); the shipping library runs them in line.
+  static const int prep_overlap = GR_KNOB("GR_PREP_OVERLAP", 0);
+  const bool prep_side = prep_overlap && c->side_stream != nullptr && gr::g_ktimer == nullptr && rn->capB >= B;
+  if (prep_side) {
+    HIPCHK(c, hipEventRecord(c->ev_prep_go, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->ev_prep_go, 0));
+    hipStream_t main_stream = c->stream;
+    c->stream = c->side_stream;
+    g_kphase = 2;
+    r = forward_begin(rn, B);
+    g_kphase = 1;
+    c->stream = main_stream;
+    if (r) { rn->begun_B = 0; return r; }
+    HIPCHK(c, hipEventRecord(c->ev_prep_done, c->side_stream));
+  }
+  { PhaseRange pr("G forward"); r = forward_impl(g, noise_dev, B); } if (r) { rn->begun_B = 0; return r; }          // train_r.lua:139
+  if (prep_side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prep_done, 0));
   const float* images = g->st.back().out;
   if (tm) (void)hipEventRecord(c->ev[1], c->stream);
   g_kphase = 2;
-  { PhaseRange pr("R forward"); r = forward_impl(rn, images, B); } if (r) return r;            // :146
+  HeadLaunch hl{};
+  r = ensure_batch(rn, B); if (r) return r;                    // (the plan below takes buffer addresses)
+  rn->head_fused = c->fused_head && head_plan(rn, B, hl);
+  { PhaseRange pr("R forward"); r = forward_impl(rn, images, B); } if (r) { rn->head_fused = false; return r; }            // :146
   if (tm) (void)hipEventRecord(c->ev[2], c->stream);
   g_kphase = 3;
   {
   PhaseRange pr("loss");
+  if (rn->head_fused) {
+    // fc1's BatchNorm / activation / Dropout, fc2, the criterion (:147,150) and their backward down to fc1's dy: one launch (elem.hip, head_fwd_bwd_kernel)
+    if (!c->head_bar) {
+      if (hipMalloc((void**)&c->head_bar, 256) != hipSuccess || hipMalloc((void**)&c->head_loss_part, sizeof(double) * 512) != hipSuccess) { rn->head_fused = false; return fail(c, GR_ERR_HIP, "head kernel: allocation failed"); }
+      HIPCHK(c, hipMemsetAsync(c->head_bar, 0, 256, c->stream));
+      c->head_bar_count = 0;
+    }
+    if (!head_plan(rn, B, hl)) { rn->head_fused = false; return fail(c, GR_ERR_STATE, "head kernel: the plan changed during the forward"); }   // (again: the forward may have re-allocated the Dropout bits)
+    hl.n_global = (long)GB * nd; hl.target = noise_dev; hl.loss = c->d_loss; hl.loss_part = c->head_loss_part;
+    hl.bar = c->head_bar; hl.bar_base = c->head_bar_count;
+    c->head_bar_count += 2u * (unsigned)(hl.C1 / 8);
+    launch_head_fwd_bwd(hl, c->stream);
+  } else
   launch_mse(rn->st.back().out, noise_dev, (long)B * nd, (long)GB * nd, c->d_loss, rn->gout_buf, c->stream);  // :147,150
   LAUNCHCHK(c);
   if (c->xchg) { r = small_allreduce(c, c->d_loss, 1, 1); if (r) return r; }
@@ -1828,7 +1926,9 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   // the penalty and the clamp are non-linear in g (train_r.lua:154-165): the SUM over ranks comes first.  It is issued
   // bucket by bucket from inside backward on the comm stream; the compute stream waits for it only here.
   g_kphase = 4;
-  { PhaseRange pr(c->comm ? "R backward + all-reduce" : "R backward"); r = backward_impl(rn, images, rn->gout_buf, B, nullptr, /*reduce=*/true); } if (r) return r;   // :151
+  { PhaseRange pr(c->comm ? "R backward + all-reduce" : "R backward"); r = backward_impl(rn, images, rn->gout_buf, B, nullptr, /*reduce=*/true); }   // :151
+  rn->head_fused = false;
+  if (r) return r;
   if (tm) (void)hipEventRecord(c->ev[4], c->stream);
 
   if (tm) (void)hipEventRecord(c->ev[5], c->stream);

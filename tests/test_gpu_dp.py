@@ -74,10 +74,23 @@ def test_dp_two_shards_in_process_vs_grouped_oracle(ctx, oracle, conv_mode, name
         ctx.upload(D.shard(noise, r), dn)
         for li, k in masks.items():
             rnet.set_mask(li, D.shard(k.reshape(GB, -1), r).ravel())
+        # (a0) the fused entry point as it ships (round 5: R's head - fc1's pipeline, fc2, the criterion and their backward - in ONE launch,
+        #      head_fwd_bwd_kernel): same operations per value as the stage-by-stage path, sums in another order -> compared at the gradient bar, not bit for bit
+        loss_head = L.train_r_step(gnet, rnet, dn, B, GB, free, D.T_STEP)
+        raw_head = rnet.get_grads()
+        rnet.set_params(theta0); rnet.set_adam_state(zeros, zeros)
+        for li, k in masks.items():
+            rnet.set_mask(li, D.shard(k.reshape(GB, -1), r).ravel())
         # (a) the fused entry point with the GLOBAL normaliser; no communicator: its Adam sees the local gradient only, so the
-        #     penalty-free hyper-parameters keep the raw local gradient readable afterwards
-        losses.append(L.train_r_step(gnet, rnet, dn, B, GB, free, D.T_STEP))
+        #     penalty-free hyper-parameters keep the raw local gradient readable afterwards.  Stage by stage (fused_head 0): (b) below must reproduce it bit for bit
+        ctx.set_tuning("fused_head", 0)
+        try:
+            losses.append(L.train_r_step(gnet, rnet, dn, B, GB, free, D.T_STEP))
+        finally:
+            ctx.set_tuning("fused_head", 1)
         raw.append(rnet.get_grads())
+        assert abs(loss_head - losses[-1]) <= 1e-6 * max(1.0, abs(losses[-1])), (loss_head, losses[-1])
+        assert_grads_close(R, raw_head, raw[-1], 1e-4, 1e-3, f"shard {r}: head kernel vs stage-by-stage step")
         images.append(ctx.download(gnet.lib.gr_net_output_dev(gnet.h), (B,) + dims))
         preds.append(ctx.download(rnet.lib.gr_net_output_dev(rnet.h), (B, nd)))
         for m, li, (c, h, w) in pool_layers(R, oR):

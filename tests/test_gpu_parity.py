@@ -493,6 +493,54 @@ def test_dead_channels_between_two_guard_scans_in_the_device_loop(ctx, oracle, c
         ctx.set_tuning("range_guard", 0); ctx.set_tuning("range_guard", 1)     # clears the tripped state
 
 
+@pytest.mark.parametrize("dims,nd,B,method", [((1, 32, 32), 32, 64, "normal"), ((1, 32, 32), 32, 37, "uniform"), ((1, 32, 32), 32, 256, "normal")])
+def test_head_kernel_equals_the_stage_by_stage_step(ctx, conv_mode, dims, nd, B, method):
+    """gr_train_r_step runs R's last two stages, the criterion and their backward (models.lua:446-454, train_r.lua:147-151) in ONE launch (head_fwd_bwd_kernel,
+    gr_set_tuning "fused_head" 1 = default) instead of 14.  Same operations per value, only the order of the sums differs: one step from the same state with
+    the kernel on and off must agree - loss to 1e-6 relative, recovered noise to 1e-6, every raw gradient tensor to 1e-4 of its module's largest entry (a 1e-7 difference in
+    fc1's dy passes through six BatchNorm backwards on its way to conv1) - and the kernel must really have run (and not run when switched off).  The oracle comparison of the
+    step itself is test_train_r_steps_vs_oracle / test_full_size_step_vs_oracle (which now run the head kernel)."""
+    import ganrev._lib as L
+    from ganrev import models, synth
+    G = models.create_G(dims, nd); synth.init_params(G, 1)
+    R = models.create_R(dims, nd, noiseMethod=method); synth.init_params(R, 2)
+    G.evaluate(); G.forward(synth.normal((2, nd), 1))
+    R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
+    theta0 = R._net.get_params()
+    noise = synth.normal((B, nd), 5) if method == "normal" else synth.uniform((B, nd), 5, -1, 1)
+    dn = ctx.upload(noise)
+    hyper = L.Hyper(l2=0.0, clamp=1e30)            # raw gradients: penalty and clamp would hide differences
+    res = []
+    try:
+        for fused in (1, 0):
+            ctx.set_tuning("fused_head", fused)
+            R._net.set_params(theta0); R._net.adam_reset(); R._net.set_seed(11)
+            ctx.set_timing(2)
+            loss = L.train_r_step(G._net, R._net, dn, B, B, hyper, 1)
+            names = {k["kernel"] for k in ctx.kernel_times()}
+            ctx.set_timing(0)
+            assert ("head_fwd_bwd_kernel" in names) == bool(fused), sorted(names)
+            out = ctx.download(R._net.lib.gr_net_output_dev(R._net.h), (B, nd))
+            res.append((loss, out, R._net.get_grads(), R._net.get_params()))
+        (l1, o1, g1, p1), (l0, o0, g0, p0) = res
+        assert abs(l1 - l0) <= 1e-6 * max(1.0, abs(l0)), (l1, l0)
+        assert np.abs(o1 - o0).max() <= 1e-6, np.abs(o1 - o0).max()
+        off = 0
+        for m in R.leaves():
+            sizes = [t.size for t in m.param_arrays()]
+            if not sizes:
+                continue
+            scale = max(float(np.abs(g0[off:off + sum(sizes)]).max()), 1e-12)      # the module's largest entry (a bias in front of a BatchNorm holds rounding residue only)
+            for n_ in sizes:
+                a, b = g1[off:off + n_], g0[off:off + n_]
+                assert np.abs(a - b).max() <= 1e-4 * scale, (m.typename, n_, float(np.abs(a - b).max()), scale)
+                off += n_
+        assert off == g0.size
+    finally:
+        ctx.set_tuning("fused_head", 1)
+        ctx.free(dn)
+
+
 def test_side_stream_weight_gradients_change_nothing(ctx):
     """gr_set_tuning "side_wgrad" 1 runs R's convolution weight gradients on a second stream beside the rest of backward (dy
     double-buffered, events both ways).  Same kernels, same operands, same order inside each kernel: three training steps

@@ -173,14 +173,20 @@ def test_sync_bn_through_a_one_rank_rccl_communicator_changes_no_bit(ctx, oracle
             rnet.set_mask(li, D.shard(k.reshape(B * D.WORLD, -1), 0).ravel())
         loss = L.train_r_step(gnet, rnet, dn, B, B, L.Hyper(), 1)
         return loss, rnet.get_grads(), rnet.get_params(), [rnet.get_bn_running(i) for i in range(rnet.n_bn())]
-    plain = one_step()
-    ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+    # (the synchronised step runs stage by stage - a collective sits between the head's statistics and their use - so the plain step it is compared
+    #  with bit for bit does too: fused_head 0; the head kernel itself is held to the stage-by-stage step in test_head_kernel_equals_the_stage_by_stage_step)
+    ctx.set_tuning("fused_head", 0)
     try:
-        ctx.set_tuning("sync_bn", 1)
-        synced = one_step()
+        plain = one_step()
+        ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+        try:
+            ctx.set_tuning("sync_bn", 1)
+            synced = one_step()
+        finally:
+            ctx.set_tuning("sync_bn", 0)
+            ctx.comm_destroy()
     finally:
-        ctx.set_tuning("sync_bn", 0)
-        ctx.comm_destroy()
+        ctx.set_tuning("fused_head", 1)
     ctx.free(dn)
     assert plain[0] == synced[0]
     assert np.array_equal(plain[1], synced[1]) and np.array_equal(plain[2], synced[2])
