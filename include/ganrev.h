@@ -177,8 +177,23 @@ int gr_train_r_step(gr_net* gnet, gr_net* rnet, const float* noise_dev, int batc
  * 0 = exact fp32 on v_mfma_f32_32x32x2_f32.  Also settable with the environment variable GR_CONV_MODE=f32|bf16x6|f16x3 before gr_init. */
 int gr_set_conv_mode(gr_ctx* ctx, int mode);
 int gr_get_conv_mode(gr_ctx* ctx);
-/* kernel-selection thresholds (process-wide).  "p16_min_tiles" (default 256): smallest tile count at which a convolution takes the
- * operand-ready (P16) kernel; tests set 1 to exercise that path on small shapes. */
+/* Runtime knobs.  These are ALL the keys the shipping library answers (anything else: GR_ERR_INVALID); environment variables read once in gr_init:
+ * GR_CONV_MODE (f32 | bf16x6 | f16x3, default f16x3), GR_RANGE_GUARD (0 | 1), GR_SIDE_WGRAD (-1 | 0 | 1), GR_FUSED_HEAD (0 | 1).  Every other GR_* switch
+ * of earlier rounds - A/B controls of variants that lost their measurement, ablation bits that make kernels compute wrong results by design - exists only in
+ * the ablation build (make -C gan-reverser_amd/csrc ablate -> libganrev_ablate.so, never loaded by the tests or bench.py).
+ *   "p16_min_tiles"  (default 128, process-wide) smallest tile count at which a 3x3 convolution takes the operand-ready (P16) kernels; tests set 1 to
+ *                    exercise that path on small shapes
+ *   "stack8_min_wgs" (default 128, process-wide) smallest grid at which 8x8 planes are stacked four to a convolution tile; tests force the path
+ *   "eval_p16"       (default 1) evaluate()-mode stages hand their output to the next convolution operand-ready - see below
+ *   "side_wgrad"     (default -1 = by stage size: on from 2^26 activations) R's convolution weight gradients on a second stream beside the rest of backward;
+ *                    bit-identical either way (measured: cfg3 -1.1 %, cfg2 +1.1 %: profiles/r05_ab_side_wgrad_*.txt)
+ *   "fused_head"     (default 1) gr_train_r_step runs R's last two stages (Linear -> BatchNormalization -> ELU -> Dropout -> Linear [-> Tanh], models.lua:446-454),
+ *                    the criterion (train_r.lua:147-151) and their backward in ONE launch where that wins (at most 4 rows per workgroup of 8 features:
+ *                    batch <= 256 at 512 features, and nd <= 32); same operations per value as the stage-by-stage path, sums in another order (1e-6 on the
+ *                    loss, 1e-4 of a module's largest entry on the gradients: tests/test_gpu_parity.py::test_head_kernel_equals_the_stage_by_stage_step).
+ *                    0 = stage by stage: what gr_net_forward_* / gr_net_backward_* compute, bit for bit
+ *   "sync_bn"        (default 0) synchronised BatchNorm under data parallelism - see below
+ *   "range_guard"    (default 1) the f16x3 range guard - see below */
 int gr_set_tuning(gr_ctx* ctx, const char* key, int value);
 /* "eval_p16" (default 1; f16x3 arithmetic): in evaluate() mode (apply_r.lua:120-153: MODEL_R:forward on generated images) a stage hands its output to the
  * next 3x3 convolution as that convolution's operand-ready image (fp16 hi / lo vectors written by the convolution epilogue or the pooling stage's pipeline

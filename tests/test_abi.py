@@ -108,3 +108,33 @@ def test_lua_ffi_cdef_matches_the_header():
         fields = lambda body: [(_param_type(d.split(",")[0]).replace("*", ""), len(d.split(","))) for d in body.split(";") if d.strip()]
         flat = lambda body: [t for t, n in fields(body) for _ in range(n)]
         assert flat(a) == flat(b), f"{struct}: {flat(a)} != {flat(b)}"
+
+
+def test_every_runtime_knob_is_documented_and_the_shipping_library_reads_few_environment_variables():
+    """the shipping library keeps <= 10 documented runtime knobs.  Every gr_set_tuning key of the non-ablation build must be
+    described in include/ganrev.h's comment on gr_set_tuning, every environment variable gr_init reads must be named there and in README.md, and the kernels'
+    sources may call getenv at most 10 times (everything else is GR_KNOB: a constant outside the ablation build)."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "gan-reverser_amd", "csrc")
+    net = open(os.path.join(csrc, "net.hip")).read()
+    body = net[net.index('extern "C" int gr_set_tuning('):]
+    body = body[:body.index("\n}\n")]
+    shipping = re.sub(r"#ifdef GR_ABLATE.*?#endif", "", body, flags=re.S)
+    keys = re.findall(r'!strcmp\(key, "(\w+)"\)', shipping)
+    assert 1 <= len(keys) <= 10, keys
+    header = open(os.path.join(root, "include", "ganrev.h")).read()
+    doc = header[header.index("/* Runtime knobs."):header.index("int gr_set_tuning(")]
+    readme = open(os.path.join(root, "README.md")).read()
+    for k in keys:
+        assert f'"{k}"' in doc, f"gr_set_tuning key {k} is not documented in include/ganrev.h"
+        assert f"`{k}`" in readme, f"gr_set_tuning key {k} is not listed in README.md"
+    n_getenv, envs = 0, set()
+    for f in os.listdir(csrc):
+        if f.endswith(".hip"):
+            src = open(os.path.join(csrc, f)).read()
+            n_getenv += len(re.findall(r"\bgetenv\(", src))
+            envs |= set(re.findall(r'getenv\("(GR_\w+)"\)', src))
+    assert n_getenv <= 10, n_getenv
+    for e in envs:
+        assert e in doc and e in readme, f"environment variable {e} is read by the library but not documented"

@@ -1202,7 +1202,27 @@ def test_fused_step_equals_decomposed_and_comm_path(ctx, oracle, conv_mode):
     from ganrev.parallel import DeviceTrainer
     dims, nd, B = (1, 32, 32), 32, 8
     results = []
-    for mode in ("fused", "decomposed", "fused+comm"):
+    # bit for bit: gr_train_r_step on its stage-by-stage path (fused_head 0).  With the head kernel (the default) the same values come out of sums in another
+    # order: that path is held to this one in test_head_kernel_equals_the_stage_by_stage_step and to the oracle in test_train_r_steps_vs_oracle.
+    ctx.set_tuning("fused_head", 0)
+    try:
+        _fused_decomposed_comm(ctx, dims, nd, B, results)
+    finally:
+        ctx.set_tuning("fused_head", 1)
+    for other in results[1:]:
+        assert results[0][0] == other[0], "loss trajectories differ"
+        assert np.array_equal(results[0][1], other[1]) and np.array_equal(results[0][2], other[2])
+    # and with the head kernel: fused == fused + comm, bit for bit (the communicator must not change what the kernel computes)
+    results = []
+    _fused_decomposed_comm(ctx, dims, nd, B, results, modes=("fused", "fused+comm"))
+    assert results[0][0] == results[1][0] and np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
+
+
+def _fused_decomposed_comm(ctx, dims, nd, B, results, modes=("fused", "decomposed", "fused+comm")):
+    import ganrev._lib as L
+    from ganrev import models, synth
+    from ganrev.parallel import DeviceTrainer
+    for mode in modes:
         G = models.create_G(dims, nd); synth.init_params(G, 5)
         R = models.create_R(dims, nd); synth.init_params(R, 6)
         G.evaluate(); G.forward(synth.normal((2, nd), 1))
@@ -1220,9 +1240,6 @@ def test_fused_step_equals_decomposed_and_comm_path(ctx, oracle, conv_mode):
         finally:
             if mode == "fused+comm":
                 ctx.comm_destroy()
-    for other in results[1:]:
-        assert results[0][0] == other[0], "loss trajectories differ"
-        assert np.array_equal(results[0][1], other[1]) and np.array_equal(results[0][2], other[2])
 
 
 def test_apply_r_pipeline_vs_oracle(oracle, conv_mode):
