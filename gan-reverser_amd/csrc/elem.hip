@@ -772,18 +772,25 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
     // four float4 groups per thread and round: all their loads are issued before the first is used (a block owns only ~1024
     // groups - four per thread - so without this every thread waits out one memory round trip per group); post_bwd_load4 /
     // post_bwd_dz_of are the two halves of post_bwd_dz4, same operations in the same order
-    for (unsigned j0 = threadIdx.x; j0 < tot; j0 += 1024) {
-      BwdRaw r[4]; unsigned ee[4];
+    // Round 5: a block may own several rounds of 1024 groups (launcher: fewer, longer blocks on tensors the Infinity Cache holds); round k + 1 is requested
+    // before round k is worked on, so a thread's memory latency hides behind its own arithmetic as well as behind the other waves'
+    BwdRaw r[4], rn[4]; unsigned ee[4], een[4];
+    auto request = [&](unsigned j0, BwdRaw* rr, unsigned* e_) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const unsigned j = j0 + 256u * u;
         if (j < tot) {
           const unsigned bb = udivp(j, q4), i = j - bb * q4;
           const unsigned bc = (unsigned)(b0 + bb) * f.C + c, pbase = bc * HW, obase = bc * HWo;
-          ee[u] = pbase + i * 4;
-          r[u] = post_bwd_load4(a, bc, ee[u], i, obase, wq, Wo);
+          e_[u] = pbase + i * 4;
+          rr[u] = post_bwd_load4(a, bc, e_[u], i, obase, wq, Wo);
         }
       }
+    };
+    if (threadIdx.x < tot) request(threadIdx.x, r, ee);
+    for (unsigned j0 = threadIdx.x; j0 < tot; j0 += 1024) {
+      const bool more = j0 + 1024 < tot;
+      if (more) request(j0 + 1024, rn, een);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (j0 + 256u * u < tot) {
@@ -797,6 +804,10 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
           s += (double)((dz.x + dz.y) + (dz.z + dz.w));
           q += (double)(((yv.x - mean) * dz.x + (yv.y - mean) * dz.y) + ((yv.z - mean) * dz.z + (yv.w - mean) * dz.w));
         }
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { r[u] = rn[u]; ee[u] = een[u]; }
       }
     }
   }
@@ -1037,6 +1048,10 @@ void launch_post_backward(const PostBwdArgs& a0, hipStream_t s, BiasJobs* defer,
   const bool vec = (f.pool ? (f.W % 8 == 0 && f.H % 2 == 0) : (f.W % 4 == 0)) && f.H * f.W >= 64 && pre < 4.0e9;
   if (vec) {
     splits = batch_splits(n, f.B);
+    {
+      static const int div = GR_KNOB("GR_PASSA_SPLIT_DIV", 1);
+      if (div > 1 && !post_big(a0.f)) { int s2 = splits / div; if (s2 < 1) s2 = 1; const int per = (f.B + s2 - 1) / s2; splits = (f.B + per - 1) / per; }
+    }
     KtScope kt("post_backward_a_vec_kernel", 0.0, 4.0 * ((f.has_bn ? 1.0 : 2.0) * pre + post), s);   // with BN: dz is not stored
     with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL(post_backward_a_vec_kernel<decltype(cb)::value>, dim3(f.C, splits), dim3(256), 0, s, a, splits); });
   } else {
