@@ -1773,6 +1773,15 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void conv3x3_p16_quad_po_kern
 // fp64 in wave order: a fixed order), then the kernel above's LDS transpose to 16-byte stores.  Training-mode output only (raw y; no fused epilogue, no PO).
 template <int TW> constexpr int k32_ps() { return ((256 / TW + 2) * (TW + 2) + 15) / 16 * 16; }      // patch plane stride (vectors): 336 (16 x 16 tile) / 352 (8 rows x 32)
 // TW = 32: tiles of 8 rows x 32 on planes whose width is a multiple of 32 - the image is then 80 KiB exactly (patch 44 KB + weights 36.9 KB): still two per CU
+// Round 5: the kernel WALKS its units (pixel tile x 32-channel block) blockIdx.x, blockIdx.x + gridDim.x, ... - with one workgroup
+// per unit (gridDim.x = n_tiles, what rounds 3-4 launched) every unit paid its own prologue: the first chunk's 80 KB requested, and waited for, with the
+// workgroup's waves idle, while its CU partner may be in its own epilogue.  A workgroup that goes on to a next unit requests that unit's first PATCH (43 KB,
+// the larger half) as soon as its last chunk is multiplied - before the epilogue, which stages through the WEIGHT half of the image (36 KB: it fits) - and the
+// first weights right after the epilogue's last LDS read.  The epilogue's barriers wait for LDS operations only (s_waitcnt lgkmcnt(0); s_barrier), not for the
+// request in flight.  Launcher: gridDim.x = min(n_tiles, 2 per CU), a multiple of 8, so that a workgroup's units stay on its XCD's run of logical tiles.
+__device__ __forceinline__ void lds_only_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 template <int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, const uint4* __restrict__ wsplit, const uint4* __restrict__ xin) {
   static_assert(TW == 16 || TW == 32, "one 16x16 image, or 8 rows of a 32-wide tile column");
@@ -1782,155 +1791,178 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
   static_assert(2 * LBUF * 16 <= 160 * 1024, "two workgroups per CU");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint4* lds = reinterpret_cast<uint4*>(smem_raw);
+  unsigned char* wregion = smem_raw + (size_t)PVP * 16;           // the weight half of the image: the epilogue's staging area
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
   const int H = a.H, W = a.W, HW = H * W;
   const int G = a.Cin >> 3;
-  int bid = xcd_remap(blockIdx.x, a.n_tiles);
-  const int tile = bid / a.n_otiles;
-  const int ot = bid % a.n_otiles; bid /= a.n_otiles;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y; const int b = bid / a.tiles_y;
-  const int y0 = ty * TR, x0 = tx * TW, o0 = ot * CT;
   const int nchunks = a.Cin / 32;
   const size_t xbytes = (size_t)a.B * G * 2 * HW * 16;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(xin), 0, (int)(xbytes < 0x7FFFF000ul ? xbytes : 0x7FFFF000ul), 0x00020000);
   const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wsplit), 0, (int)((size_t)(a.Cin / 16) * WR16 * a.cout_pad * 16), 0x00020000);
   const int ktot = f16_scale_exp(absmax_read(a.amax_in)) + f16_scale_exp(absmax_read(a.amax_w));
   int voff[NPS], woff[NWS];
+  int tile, y0, x0, o0, b;
+  auto unit_geometry = [&](int u) {                               // unit u -> tile / channel block, and the per-lane DMA offsets of its operand image
+    int bid = xcd_remap(u, a.n_tiles);
+    tile = bid / a.n_otiles;
+    const int ot = bid % a.n_otiles; bid /= a.n_otiles;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y; b = bid / a.tiles_y;
+    y0 = ty * TR; x0 = tx * TW; o0 = ot * CT;
 #pragma unroll
-  for (int j = 0; j < NPS; ++j) {
-    const int e = 64 * (wave + NW * j) + lane;
-    const int p8 = e / PS, pos = e - p8 * PS, t = p8 >> 2, grp = p8 & 3;      // plane p8 = term * 4 + group
-    const int rr = pos / PC, c = pos - rr * PC;
-    const int yy = y0 + rr - 1, xx = x0 + c - 1;
-    const bool inb = e < PV && pos < PS0 && yy >= 0 && yy < H && xx >= 0 && xx < W && b < a.B;
-    voff[j] = inb ? (((b * G + grp) * 2 + t) * HW + yy * W + xx) * 16 : (int)0x7FFFF000;
-  }
+    for (int j = 0; j < NPS; ++j) {
+      const int e = 64 * (wave + NW * j) + lane;
+      const int p8 = e / PS, pos = e - p8 * PS, t = p8 >> 2, grp = p8 & 3;      // plane p8 = term * 4 + group
+      const int rr = pos / PC, c = pos - rr * PC;
+      const int yy = y0 + rr - 1, xx = x0 + c - 1;
+      const bool inb = e < PV && pos < PS0 && yy >= 0 && yy < H && xx >= 0 && xx < W && b < a.B;
+      voff[j] = inb ? (((b * G + grp) * 2 + t) * HW + yy * W + xx) * 16 : (int)0x7FFFF000;
+    }
 #pragma unroll
-  for (int j = 0; j < NWS; ++j) {          // weight vector f of the [2 sub-chunks][36 rows][32 o] image
-    const int f = 64 * (wave + NW * j) + lane, cc = f / (WR16 * CT), rem = f - cc * (WR16 * CT), r = rem / CT, col = rem - r * CT;
-    woff[j] = f < WV ? ((cc * WR16 + r) * a.cout_pad + o0 + col) * 16 : (int)0x7FFFF000;
-  }
-#define GR_K32_DMA(ch_)                                                                                   \
+    for (int j = 0; j < NWS; ++j) {          // weight vector f of the [2 sub-chunks][36 rows][32 o] image
+      const int f = 64 * (wave + NW * j) + lane, cc = f / (WR16 * CT), rem = f - cc * (WR16 * CT), r = rem / CT, col = rem - r * CT;
+      woff[j] = f < WV ? ((cc * WR16 + r) * a.cout_pad + o0 + col) * 16 : (int)0x7FFFF000;
+    }
+  };
+#define GR_K32_DMA_PATCH(ch_)                                                                             \
   {                                                                                                       \
     const int psoff_ = (ch_) * HW * 128;                               /* 4 groups x 2 terms x HW vectors */ \
     _Pragma("unroll") for (int j = 0; j < NPS; ++j) {                                                     \
       const int i_ = wave + NW * j;                                                                       \
       if (i_ < NPI) lds_dma16(rin, lds + 64 * i_, voff[j], psoff_);                                       \
     }                                                                                                     \
+  }
+#define GR_K32_DMA_WEIGHTS(ch_)                                                                           \
+  {                                                                                                       \
     const int wsoff_ = (ch_) * 2 * WR16 * a.cout_pad * 16;                                                \
     _Pragma("unroll") for (int j = 0; j < NWS; ++j) {                                                     \
       const int r_ = wave + NW * j;                                                                       \
       if (r_ < NWI) lds_dma16(rwt, lds + PVP + 64 * r_, woff[j], wsoff_);                                 \
     }                                                                                                     \
   }
-  f32x4 acc[MB][NB];
   int pix[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     int prr, pc; tile_pixel<TW>((wave * 2 + (nb >> 1)) * 32 + 16 * (nb & 1), prr, pc);      // the 16 pixels of block nb: one tile row from column pc (0 or 16)
     pix[nb] = q * PS + prr * PC + pc + l15;
   }
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint4* patch = lds; const uint4* wts = lds + PVP;
   const int wq = ((q >> 1) * WR16 + (q & 1)) * CT + l15;           // this lane's weight column: sub-chunk q >> 1, channel half q & 1, output channel l15 (+ 16 mb)
-  GR_K32_DMA(0)
-  for (int ch = 0; ch < nchunks; ++ch) {
-    dma_publish_barrier();
+  int u = blockIdx.x;
+  if (u >= a.n_tiles) return;
+  unit_geometry(u);
+  GR_K32_DMA_PATCH(0)
+  GR_K32_DMA_WEIGHTS(0)
+  for (;;) {
+    f32x4 acc[MB][NB];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int toff = (tap / 3) * PC + (tap % 3);
-      uint4 av[MB][2], bv[NB][2];
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nchunks; ++ch) {
+      dma_publish_barrier();
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) av[mb][t] = wts[wq + ((t * 9 + tap) * 2) * CT + mb * 16];
+      for (int tap = 0; tap < 9; ++tap) {
+        const int toff = (tap / 3) * PC + (tap % 3);
+        uint4 av[MB][2], bv[NB][2];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bv[nb][t] = patch[t * 4 * PS + pix[nb] + toff];
-      }
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+          for (int mb = 0; mb < MB; ++mb) av[mb][t] = wts[wq + ((t * 9 + tap) * 2) * CT + mb * 16];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          f32x4 c_ = acc[mb][nb];
-          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][1]), __builtin_bit_cast(f16x8, bv[nb][0]), c_, 0, 0, 0);
-          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][0]), __builtin_bit_cast(f16x8, bv[nb][1]), c_, 0, 0, 0);
-          c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][0]), __builtin_bit_cast(f16x8, bv[nb][0]), c_, 0, 0, 0);
-          acc[mb][nb] = c_;
+          for (int nb = 0; nb < NB; ++nb) bv[nb][t] = patch[t * 4 * PS + pix[nb] + toff];
         }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            f32x4 c_ = acc[mb][nb];
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][1]), __builtin_bit_cast(f16x8, bv[nb][0]), c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][0]), __builtin_bit_cast(f16x8, bv[nb][1]), c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[mb][0]), __builtin_bit_cast(f16x8, bv[nb][0]), c_, 0, 0, 0);
+            acc[mb][nb] = c_;
+          }
+      }
+      __syncthreads();
+      if (ch + 1 < nchunks) { GR_K32_DMA_PATCH(ch + 1) GR_K32_DMA_WEIGHTS(ch + 1) }
     }
-    __syncthreads();
-    if (ch + 1 < nchunks) GR_K32_DMA(ch + 1)
-  }
-#undef GR_K32_DMA
-  // scale back + bias: lane holds channel chl = 16 mb + 4 q + i of pixel l15 of block nb
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = o0 + mb * 16 + 4 * q + i;
-      const float bvv = (a.bias && o < a.Cout) ? a.bias[o] : 0.f;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i] = ldexpf(acc[mb][nb][i], -ktot) + bvv;
-    }
-  const bool inimg = b < a.B;
-  if (a.stat_part) {
-    // per (wave, channel): the 64 pixels = four per lane over the 16 lanes of the channel's DPP row; then the four waves in fp64, in wave order
-    float* wsum = reinterpret_cast<float*>(smem_raw);            // [4 waves][2][32 channels]  (the operand image is dead: every wave is past the last chunk's barrier)
+    // this unit's geometry is needed by the epilogue; the next unit's patch request needs the next unit's offsets: keep the former in scalars
+    const int e_tile = tile, e_y0 = y0, e_x0 = x0, e_o0 = o0, e_b = b;
+    const int un = u + (int)gridDim.x;
+    const bool more = un < a.n_tiles;
+    if (more) { unit_geometry(un); GR_K32_DMA_PATCH(0) }          // lands in the patch half while the epilogue works in the weight half
+    // scale back + bias: lane holds channel chl = 16 mb + 4 q + i of pixel l15 of block nb
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float sv = 0.f, qv = 0.f;
+        const int o = e_o0 + mb * 16 + 4 * q + i;
+        const float bvv = (a.bias && o < a.Cout) ? a.bias[o] : 0.f;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) { const float v = inimg ? acc[mb][nb][i] : 0.f; sv += v; qv += v * v; }
-        // sum over the 16 lanes of the row (row_shr 1, 2, 4, 8 with zero fill: lane 15 of the row ends with the total, in a fixed order)
-        sv += dpp_take<0x111, 0xF>(sv); sv += dpp_take<0x112, 0xF>(sv); sv += dpp_take<0x114, 0xF>(sv); sv += dpp_take<0x118, 0xF>(sv);
-        qv += dpp_take<0x111, 0xF>(qv); qv += dpp_take<0x112, 0xF>(qv); qv += dpp_take<0x114, 0xF>(qv); qv += dpp_take<0x118, 0xF>(qv);
-        if (l15 == 15) { const int chl = mb * 16 + 4 * q + i; wsum[(wave * 2 + 0) * 32 + chl] = sv; wsum[(wave * 2 + 1) * 32 + chl] = qv; }
+        for (int nb = 0; nb < NB; ++nb) acc[mb][nb][i] = ldexpf(acc[mb][nb][i], -ktot) + bvv;
       }
-    __syncthreads();
-    if (tid < 64) {
-      const int wh = tid >> 5, chl = tid & 31;
-      double t = 0.0;
+    const bool inimg = e_b < a.B;
+    if (a.stat_part) {
+      // per (wave, channel): the 64 pixels = four per lane over the 16 lanes of the channel's DPP row; then the four waves in fp64, in wave order
+      float* wsum = reinterpret_cast<float*>(wregion);             // [4 waves][2][32 channels]  (the weight image is dead: every wave is past the last chunk's barrier)
 #pragma unroll
-      for (int w = 0; w < NW; ++w) t += (double)wsum[(w * 2 + wh) * 32 + chl];
-      const int o = o0 + chl;
-      if (o < a.Cout) a.stat_part[((size_t)o * a.stat_tiles + tile) * 2 + wh] = t;
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float sv = 0.f, qv = 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) { const float v = inimg ? acc[mb][nb][i] : 0.f; sv += v; qv += v * v; }
+          // sum over the 16 lanes of the row (row_shr 1, 2, 4, 8 with zero fill: lane 15 of the row ends with the total, in a fixed order)
+          sv += dpp_take<0x111, 0xF>(sv); sv += dpp_take<0x112, 0xF>(sv); sv += dpp_take<0x114, 0xF>(sv); sv += dpp_take<0x118, 0xF>(sv);
+          qv += dpp_take<0x111, 0xF>(qv); qv += dpp_take<0x112, 0xF>(qv); qv += dpp_take<0x114, 0xF>(qv); qv += dpp_take<0x118, 0xF>(qv);
+          if (l15 == 15) { const int chl = mb * 16 + 4 * q + i; wsum[(wave * 2 + 0) * 32 + chl] = sv; wsum[(wave * 2 + 1) * 32 + chl] = qv; }
+        }
+      lds_only_barrier();
+      if (tid < 64) {
+        const int wh = tid >> 5, chl = tid & 31;
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += (double)wsum[(w * 2 + wh) * 32 + chl];
+        const int o = e_o0 + chl;
+        if (o < a.Cout) a.stat_part[((size_t)o * a.stat_tiles + e_tile) * 2 + wh] = t;
+      }
+      lds_only_barrier();
     }
-    __syncthreads();
-  }
-  // output stores through the per-wave LDS transpose of the kernel above: [channel][pixel of the wave's 64] -> four consecutive pixels of a channel per lane
-  float omax = 0.f;
-  {
-    constexpr int RS = 64 + 4, NQ = 16, CPI = 64 / NQ;
-    static_assert(NW * 32 * RS * 4 <= LBUF * 16, "staging fits the operand image");
-    float* stg = reinterpret_cast<float*>(smem_raw) + wave * 32 * RS;
+    // output stores through the per-wave LDS transpose of the kernel above: [channel][pixel of the wave's 64] -> four consecutive pixels of a channel per lane
+    float omax = 0.f;
+    {
+      constexpr int RS = 64 + 4, NQ = 16, CPI = 64 / NQ;
+      static_assert(NW * 32 * RS * 4 <= WV * 16, "staging fits the weight half of the operand image");
+      float* stg = reinterpret_cast<float*>(wregion) + wave * 32 * RS;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stg[(mb * 16 + 4 * q + i) * RS + nb * 16 + l15] = acc[mb][nb][i];
-    const int kq = lane % NQ, hq = lane / NQ;                     // pixel quad kq of the wave's 64 pixels (block kq / 4, x = 4 (kq % 4)), channel row hq + CPI i
-    int prrq, pcq; tile_pixel<TW>(wave * 64 + 4 * kq, prrq, pcq);
-    const int yq = y0 + prrq, xq = x0 + pcq;
-    float* outq = a.out + ((size_t)b * a.Cout * H + yq) * W + xq;
-    const bool want_max = a.amax_out != nullptr;
+          for (int i = 0; i < 4; ++i) stg[(mb * 16 + 4 * q + i) * RS + nb * 16 + l15] = acc[mb][nb][i];
+      const int kq = lane % NQ, hq = lane / NQ;                     // pixel quad kq of the wave's 64 pixels (block kq / 4, x = 4 (kq % 4)), channel row hq + CPI i
+      int prrq, pcq; tile_pixel<TW>(wave * 64 + 4 * kq, prrq, pcq);
+      const int yq = e_y0 + prrq, xq = e_x0 + pcq;
+      float* outq = a.out + ((size_t)e_b * a.Cout * H + yq) * W + xq;
+      const bool want_max = a.amax_out != nullptr;
 #pragma unroll
-    for (int i2 = 0; i2 < 32 / CPI; ++i2) {
-      const int chl = CPI * i2 + hq, o = o0 + chl;
-      const float4 v = *reinterpret_cast<const float4*>(stg + chl * RS + 4 * kq);
-      if (inimg && o < a.Cout) {
-        store4(outq + (size_t)o * H * W, v, a.nt_out != 0);
-        if (want_max) omax = absmax4(omax, v);
+      for (int i2 = 0; i2 < 32 / CPI; ++i2) {
+        const int chl = CPI * i2 + hq, o = e_o0 + chl;
+        const float4 v = *reinterpret_cast<const float4*>(stg + chl * RS + 4 * kq);
+        if (inimg && o < a.Cout) {
+          store4(outq + (size_t)o * H * W, v, a.nt_out != 0);
+          if (want_max) omax = absmax4(omax, v);
+        }
       }
     }
+    if (a.amax_out) absmax_commit(omax, a.amax_out);
+    if (!more) break;
+    lds_only_barrier();                                            // every wave has read its staged values: the weight half is free
+    GR_K32_DMA_WEIGHTS(0)
+    u = un;
   }
-  if (a.amax_out) absmax_commit(omax, a.amax_out);
+#undef GR_K32_DMA_PATCH
+#undef GR_K32_DMA_WEIGHTS
 }
 
 // Epilogue stores of the up-sampling kernels.  A lane ends with the 2x2 outputs of its source pixel (x, y): two float2 per channel,
@@ -2749,7 +2781,11 @@ static int launch_conv_p16_k32(ConvArgs a, const void* wsplit, const void* xin, 
   static const std::string name = "conv3x3_p16_k32_kernel<" + std::to_string(TW) + ">";
   const double px = (double)a.B * a.H * a.W;
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
-  hipLaunchKernelGGL(conv3x3_p16_k32_kernel<TW>, dim3(a.n_tiles), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
+  // two resident workgroups per CU walk the units (a multiple of 8 workgroups: blockIdx.x & 7 = the XCD, and xcd_remap keys the unit's place on that);
+  // GR_K32_PERSIST=0 (ablation build): one workgroup per unit, as in rounds 3-4
+  static const int persist = GR_KNOB("GR_K32_PERSIST", 1);
+  const int grid = (persist && a.n_tiles > 512) ? 512 : a.n_tiles;
+  hipLaunchKernelGGL(conv3x3_p16_k32_kernel<TW>, dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
   return a.stat_tiles;
 }
 void launch_conv3x3_p16(const void* x_p16, const void* wsplit, const float* bias, float* out, int B, int Cin, int Cout, int H, int W,
