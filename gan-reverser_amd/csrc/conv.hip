@@ -3883,7 +3883,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_p16_kernel(WgradP16Args 
 // has the matrix pipe to itself and a loading half always has a full multiply phase to hide its DMA behind.  Each half
 // accumulates its own part of the workgroup's pixel range; at the end half B's accumulators go through LDS into half A's, so
 // the kernel leaves HALF as many slabs (one per CU instead of two): half the slab write and half the reduction.
-template <int W_>
+// FREE (round 5): the halves do NOT alternate - each runs load -> multiply over its own chunks behind a barrier of its own four waves (an LDS arrival counter:
+// gfx950 has no named barriers), exactly as two four-wave workgroups of conv3x3_wgrad_p16_kernel would, and they meet only for the hand-over at the end.  On
+// 32-wide planes strict alternation lost (70 -> 98 us: the load phase is longer than the multiply phase); free-running halves keep the four-wave kernel's
+// timing and still leave ONE slab per CU instead of two - half the slab write and half the reduction.
+__device__ __forceinline__ void half_barrier(unsigned* cnt, unsigned& target, int lane) {
+  target += 4u;                                                   // four waves arrive per crossing; the counter never wraps within a launch
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (lane == 0) atomicAdd(cnt, 1u);
+  unsigned seen;
+  do {
+    seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
+    if ((int)(seen - target) < 0) __builtin_amdgcn_s_sleep(1);
+  } while ((int)(seen - target) < 0);
+  asm volatile("" ::: "memory");
+}
+template <int W_, bool FREE = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Args a) {
   constexpr int R = 64 / W_ > 0 ? 64 / W_ : 1;                 // image rows per 64-pixel chunk (W_ = 16, 32 or 64)
   constexpr int PR = R + 2, PC = W_ + 2, PS = PR * PC;          // x patch positions
@@ -3893,7 +3909,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   constexpr int XV = 16 * PSP, XVP = (XV + 63) / 64 * 64, DV = (16 * DSP + 63) / 64 * 64, IMG = XVP + DV;      // vectors: 8 groups x 2 terms x positions
   constexpr int NXI = XVP / 64, NXS = (NXI + 3) / 4, NDS = 4;   // DMA instructions per wave: x patch, dy (16 planes / 4 waves)
   static_assert(W_ == 16 || W_ == 32 || W_ == 64, "plane widths of this path");
-  static_assert(2 * IMG * 16 <= 160 * 1024, "two operand images");
+  static_assert(2 * IMG * 16 + 64 <= 160 * 1024, "two operand images (+ the halves' arrival counters)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   uint4* xs = reinterpret_cast<uint4*>(smem_raw) + half * IMG;  // this half's image: [ci group 8][term 2][PS]
@@ -3999,6 +4015,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
   };
   // step st: half A multiplies its chunk st while half B loads its chunk st; then half B multiplies while half A loads chunk
   // st + 1 (nA >= nB: the loop runs over half A's chunks; a half past its range idles through the barriers)
+  if constexpr (FREE) {
+    unsigned* hcnt = reinterpret_cast<unsigned*>(smem_raw + (size_t)2 * IMG * 16) + half * 8;      // one counter per half, 32 bytes apart
+    if (tid == 0) *hcnt = 0u;
+    __syncthreads();
+    unsigned target = 0u;
+    for (int st = 0; st < nmine; ++st) {
+      load(u0 + st);                                              // (returns with this wave's pieces landed)
+      half_barrier(hcnt, target, lane);                           // the half's image is complete
+      multiply();
+      half_barrier(hcnt, target, lane);                           // every wave of the half is past the image
+    }
+    __syncthreads();
+  } else {
   if (half == 0 && nmine > 0) load(u0);
   __syncthreads();
   for (int st = 0; st < nA; ++st) {
@@ -4006,6 +4035,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
     __syncthreads();
     if (half == 1) { if (st < nmine) multiply(); } else if (st + 1 < nmine) load(u0 + st + 1);
     __syncthreads();
+  }
   }
   // half B's accumulators into half A's, through LDS (both images are dead): 9 taps x 1024 floats per wave = 147 KB per half,
   // handed over in three rounds of three taps
@@ -4051,12 +4081,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_p16_pp_kernel(WgradP16Ar
 // 16-wide 52 -> 50 us, and the slab reduction 16.5 -> 10.8 us; 32-wide 70 -> 98 us (its 34 KB x patch per 64 pixels makes the
 // load phase longer than the multiply phase, and strict alternation then idles the matrix pipe more than chance did).
 static int wgrad_pp_mode() { static int v = -1; if (v < 0) { v = GR_KNOB("GR_WGRAD_PP", 1); } return v; }
-static bool wgrad_pp(int W) { const int m = wgrad_pp_mode(); return m == 2 || (m == 1 && W == 16); }
+// GR_WGRAD_FREE (ablation build): planes at least this wide take the free-running halves (default 32: the 32- and 64-wide layers); 0 = never (rounds 3-4)
+static int wgrad_free_from() { static const int v = GR_KNOB("GR_WGRAD_FREE", 32); return v; }
+static bool wgrad_free(int W) { return wgrad_free_from() > 0 && W >= wgrad_free_from() && wgrad_pp_mode() != 2; }
+static bool wgrad_pp(int W) { const int m = wgrad_pp_mode(); return m == 2 || (m == 1 && W == 16) || wgrad_free(W); }
 template <int W_>
 static void launch_wgrad_p16_pp_t(const WgradP16Args& a, int grid, size_t lds, hipStream_t s) {
   static bool st = false;
-  if (!st) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_p16_pp_kernel<W_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); st = true; }
-  hipLaunchKernelGGL(conv3x3_wgrad_p16_pp_kernel<W_>, dim3(grid), dim3(512), lds, s, a);
+  if (!st) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_p16_pp_kernel<W_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_p16_pp_kernel<W_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 64);
+    st = true;
+  }
+  if (wgrad_free(W_)) hipLaunchKernelGGL((conv3x3_wgrad_p16_pp_kernel<W_, true>), dim3(grid), dim3(512), lds + 64, s, a);
+  else hipLaunchKernelGGL((conv3x3_wgrad_p16_pp_kernel<W_, false>), dim3(grid), dim3(512), lds, s, a);
 }
 
 static bool wgrad_use_vec(int W) { return W >= 16 && W % 4 == 0; }
@@ -4143,7 +4181,7 @@ void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, 
     const int R = 64 / W > 0 ? 64 / W : 1, PS = (R + 2) * (W + 2), PSP = PS + (10 - PS % 8) % 8;
     const size_t lds = 16 * (size_t)((16 * PSP + 63) / 64 * 64 + (16 * 66 + 63) / 64 * 64);
     const std::string nm = "conv3x3_wgrad_p16_kernel<" + std::to_string(W) + ">";
-    const std::string nm2 = "conv3x3_wgrad_p16_pp_kernel<" + std::to_string(W) + ">";
+    const std::string nm2 = "conv3x3_wgrad_p16_pp_kernel<" + std::to_string(W) + (wgrad_free(W) ? ", true>" : ">");      // as rocprofv3 prints them (FREE = true: free-running halves)
     KtScope kt(wgrad_pp(W) ? nm2.c_str() : nm.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
     if (wgrad_pp(W)) {
       if (W == 16) launch_wgrad_p16_pp_t<16>(a, grid, 2 * lds, s); else if (W == 32) launch_wgrad_p16_pp_t<32>(a, grid, 2 * lds, s); else launch_wgrad_p16_pp_t<64>(a, grid, 2 * lds, s);
