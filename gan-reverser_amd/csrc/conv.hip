@@ -1927,6 +1927,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
         if (o < a.Cout) a.stat_part[((size_t)o * a.stat_tiles + e_tile) * 2 + wh] = t;
       }
       lds_only_barrier();
+      if (GR_DBG(a.wt != nullptr)) {      // ablation build, GR_K32_FENCE_PROBE=1: what a release + arrival per unit would cost (a BatchNorm finalisation by the last arriver needs it)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (tid == 0) atomicAdd(reinterpret_cast<unsigned*>(const_cast<float*>(a.wt)) + (e_o0 / CT) * 32, 1u);
+      }
     }
     // output stores through the per-wave LDS transpose of the kernel above: [channel][pixel of the wave's 64] -> four consecutive pixels of a channel per lane
     float omax = 0.f;
@@ -2784,6 +2788,9 @@ static int launch_conv_p16_k32(ConvArgs a, const void* wsplit, const void* xin, 
   // two resident workgroups per CU walk the units (a multiple of 8 workgroups: blockIdx.x & 7 = the XCD, and xcd_remap keys the unit's place on that);
   // GR_K32_PERSIST=0 (ablation build): one workgroup per unit, as in rounds 3-4
   static const int persist = GR_KNOB("GR_K32_PERSIST", 1);
+#ifdef GR_ABLATE
+  { static unsigned* probe = nullptr; if (GR_KNOB("GR_K32_FENCE_PROBE", 0)) { if (!probe) { (void)hipMalloc((void**)&probe, 4096); (void)hipMemset(probe, 0, 4096); } a.wt = reinterpret_cast<const float*>(probe); } }
+#endif
   const int grid = (persist && a.n_tiles > 512) ? 512 : a.n_tiles;
   hipLaunchKernelGGL(conv3x3_p16_k32_kernel<TW>, dim3(grid), dim3(256), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
   return a.stat_tiles;
