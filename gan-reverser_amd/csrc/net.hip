@@ -475,6 +475,7 @@ struct gr_net {
   uint64_t prepped_version[3] = {0, 0, 0};
   unsigned* amax = nullptr;          // f16x3 scale tracking, groups of [nst] slots: x xt y | kb dy dz | w  (AG_*, AMAX_GROUPS)
   bool dy_slots_zeroed = false, w_slots_zeroed = false;   // set by forward_impl's single fill, consumed by backward / weight prep
+  bool last_fwd_training = true;     // mode of the last forward (a backward after an evaluate()-mode forward is checked against THAT, not against the current mode)
   bool head_fused = false;           // gr_train_r_step: this forward stops after fc1's GEMM and this backward starts at fc1's GEMMs - the head kernel does what lies between
   int begun_B = 0;                   // > 0: forward_begin has already run for the next forward of this batch size (gr_train_r_step ran it on the side stream)
   int amax_prezeroed_groups = 0;     // > 0: the caller (gr_train_r_step's one fill per step) has just zeroed that many slot groups: the next forward skips its own fill
@@ -1066,6 +1067,7 @@ static int forward_stages(gr_net* n, const float* in_dev, int B) {
   int r = GR_OK;
   if (n->begun_B != B) { r = forward_begin(n, B); if (r) { n->begun_B = 0; return r; } }
   n->begun_B = 0;
+  n->last_fwd_training = n->training;
   const float* x = in_dev;
   const bool f16 = c->conv_mode == 2;
   const size_t nst = n->st.size();
@@ -1424,7 +1426,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
   gr_ctx* c = n->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   if (B != n->lastB) return fail(c, GR_ERR_STATE, "backward batch %d does not match the last forward (%d)", B, n->lastB);
-  if (!n->training)       // an evaluate()-mode forward may have handed stage outputs over operand-ready only (forward_stages: po / post_p16)
+  if (!n->last_fwd_training)       // an evaluate()-mode forward may have handed stage outputs over operand-ready only (forward_stages: po / post_p16); m:training() in between does not bring the tensors back
     for (auto& s : n->st)
       if (s.out_skipped) return fail(c, GR_ERR_STATE, "backward after an evaluate()-mode forward that kept stage outputs operand-ready only (gr_set_tuning \"eval_p16\" 0 keeps the fp32 tensors)");
   reduce = reduce && have_peers(c);

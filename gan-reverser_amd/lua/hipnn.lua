@@ -45,6 +45,7 @@ int gr_cosine_assign_host(gr_ctx*, const float* x, int64_t n, int d, const float
 int gr_set_conv_mode(gr_ctx*, int mode);   /* 0 exact fp32 MFMA, 1 bf16x6, 2 f16x3 (default) */
 int gr_set_tuning(gr_ctx*, const char* key, int value);                    /* "range_guard" 0|1 ... (include/ganrev.h) */
 int gr_range_guard_stats(gr_ctx*, int64_t* scans, int64_t* fallbacks);     /* f16x3 passes the range guard sent to bf16x6 */
+int gr_range_guard_scan_params(gr_net* net, int* tripped_out);                  /* synchronous scan of a net's weights / BatchNorm scales (device-pointer loops) */
 int gr_search_stats(gr_ctx*, int64_t* reruns);
 /* fast mode: everything resident on the GPU (INTEGRATION.md section 2) */
 int gr_malloc(gr_ctx*, int64_t bytes, void** out_dev);  int gr_free(gr_ctx*, void* dev);
@@ -277,6 +278,12 @@ function hipnn.embed(G, Rs, N, batchSize, noiseMethod, seed)
       local o = ffi.new('int[3]'); C.gr_net_out_dim(R.net, o, o + 1, o + 2)
       dims[i] = o[0] * o[1] * o[2]; nets[i-1] = R.net; outs[i-1] = dev(4 * N * dims[i])
    end
+   -- the device-pointer calls inside gr_embed_dev are not range-guarded (include/ganrev.h): scan every net's weights and BatchNorm scales once,
+   -- as ganrev.apply_r.embed_dev does - a hostile spread keeps the context on bf16x6 for the whole pipeline.  (gr_net_set_training(net, 0) above
+   -- leaves R_FIXER's always-on first Dropout active: GR_DROPOUT_ALWAYS_ON layers ignore the mode, models.lua:399-406.)
+   local tripped = ffi.new('int[1]')
+   check(C.gr_range_guard_scan_params(G.net, tripped), 'gr_range_guard_scan_params')
+   for i = 1, #Rs do check(C.gr_range_guard_scan_params(Rs[i].net, tripped), 'gr_range_guard_scan_params') end
    check(C.gr_embed_dev(G.net, nets, #Rs, noise, N, batchSize, nil, outs), 'gr_embed_dev')
    local emb = {N = N, noise = noise, tables = outs, dims = dims}
    function emb:attributes(i)
