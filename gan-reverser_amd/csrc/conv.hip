@@ -4188,7 +4188,7 @@ void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, 
     const int R = 64 / W > 0 ? 64 / W : 1, PS = (R + 2) * (W + 2), PSP = PS + (10 - PS % 8) % 8;
     const size_t lds = 16 * (size_t)((16 * PSP + 63) / 64 * 64 + (16 * 66 + 63) / 64 * 64);
     const std::string nm = "conv3x3_wgrad_p16_kernel<" + std::to_string(W) + ">";
-    const std::string nm2 = "conv3x3_wgrad_p16_pp_kernel<" + std::to_string(W) + (wgrad_free(W) ? ", true>" : ">");      // as rocprofv3 prints them (FREE = true: free-running halves)
+    const std::string nm2 = "conv3x3_wgrad_p16_pp_kernel<" + std::to_string(W) + (wgrad_free(W) ? ", true>" : ", false>");      // as rocprofv3 prints them (FREE = true: free-running halves)
     KtScope kt(wgrad_pp(W) ? nm2.c_str() : nm.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
     if (wgrad_pp(W)) {
       if (W == 16) launch_wgrad_p16_pp_t<16>(a, grid, 2 * lds, s); else if (W == 32) launch_wgrad_p16_pp_t<32>(a, grid, 2 * lds, s); else launch_wgrad_p16_pp_t<64>(a, grid, 2 * lds, s);

@@ -557,15 +557,24 @@ def test_side_stream_weight_gradients_change_nothing(ctx):
         R.training(); R.forward(synth.uniform((2,) + dims, 2, 0, 1)); R.push_params()
         theta0 = R._net.get_params()
         res = []
-        for side in (0, 1):
+        # (third arm, round 5: side stream AND a one-rank RCCL communicator - at cfg3's sizes the side stream is on by default, so under data parallelism the
+        #  bucketed all-reduce on the comm stream has to wait for weight gradients that finish on the side stream)
+        for side, comm in ((0, False), (1, False), (1, True)):
             ctx.set_tuning("side_wgrad", side)
             R._net.set_params(theta0); R._net.adam_reset(); R._net.set_seed(7)
-            tr = DeviceTrainer(ctx, G._net, R._net, L.Hyper(), B)
-            for i in range(3):
-                tr.new_noise(i + 1); tr.step()
-            ctx.synchronize()
-            res.append((R._net.get_params(), R._net.get_grads()))
-        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+            if comm:
+                ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+            try:
+                tr = DeviceTrainer(ctx, G._net, R._net, L.Hyper(), B)
+                for i in range(3):
+                    tr.new_noise(i + 1); tr.step()
+                ctx.synchronize()
+                res.append((R._net.get_params(), R._net.get_grads()))
+            finally:
+                if comm:
+                    ctx.comm_destroy()
+        for other in res[1:]:
+            assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1])
     finally:
         ctx.set_tuning("side_wgrad", -1)     # the library default: by stage size
         ctx.set_conv_mode(prev)
