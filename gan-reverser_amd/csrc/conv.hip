@@ -2940,7 +2940,16 @@ __global__ __launch_bounds__(256) void conv_weight_absmax_batch_kernel(const Pre
   const long nv = (n - head) >> 2, tail = head + 4 * nv;
   const float4* wv = reinterpret_cast<const float4*>(w + head);
   float m = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) m = absmax4(m, wv[i]);
+  {     // eight 16-byte loads in flight per thread (fc1's 4.2 M weights are 16 vectors per thread: one at a time they were 12 us of launch per step)
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x; i0 < nv; i0 += 8 * stride) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const long i = i0 + u * stride; v[u] = wv[i < nv ? i : nv - 1]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = absmax4(m, v[u]);       // (a clamped duplicate of the last vector changes no maximum)
+    }
+  }
   if (blockIdx.x == 0) {
     if ((long)threadIdx.x < head) m = fmaxf(m, fabsf(w[threadIdx.x]));
     if (tail + threadIdx.x < n) m = fmaxf(m, fabsf(w[tail + threadIdx.x]));
