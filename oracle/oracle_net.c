@@ -306,7 +306,8 @@ int go_net_forward(go_net* net, const float* in, int B, float* out_host) {
         }
         break;
       case GO_ELU:      /* THNN ELU.c: x <= 0 ? (exp(x)-1)*alpha : x */
-        for (int64_t k = 0; k < nin; ++k) y[k] = x[k] <= 0 ? (expf(x[k]) - 1.f) * 1.f : x[k];
+        /* (real = float, exp() is the double function and alpha a double literal-typed accreal there: the expression is evaluated in double and rounded once) */
+        for (int64_t k = 0; k < nin; ++k) y[k] = x[k] <= 0 ? (float)((exp((double)x[k]) - 1.0) * 1.0) : x[k];
         break;
       case GO_RELU:
         for (int64_t k = 0; k < nin; ++k) y[k] = x[k] > 0 ? x[k] : 0.f;
@@ -322,10 +323,10 @@ int go_net_forward(go_net* net, const float* in, int B, float* out_host) {
         for (int64_t k = 0; k < nin; ++k) y[k] = x[k] > 0 ? x[k] : w0 * x[k];
         break; }
       case GO_SIGMOID:
-        for (int64_t k = 0; k < nin; ++k) y[k] = 1.f / (1.f + expf(-x[k]));
+        for (int64_t k = 0; k < nin; ++k) y[k] = (float)(1.0 / (1.0 + exp(-(double)x[k])));      /* THNN Sigmoid.c: 1./(1.+ exp(-x)) - double literals, one rounding */
         break;
       case GO_TANH:
-        for (int64_t k = 0; k < nin; ++k) y[k] = tanhf(x[k]);
+        for (int64_t k = 0; k < nin; ++k) y[k] = (float)tanh((double)x[k]);      /* THNN Tanh.c: tanh(*input) - the double function, one rounding */
         break;
       case GO_DROPOUT: {
         /* nn.Dropout: train: noise~Bernoulli(1-p) [v2: /(1-p)], out = in*noise ; eval: v1 out=in*(1-p), v2 identity */
