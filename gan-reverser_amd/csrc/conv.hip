@@ -2480,10 +2480,14 @@ template <int TW, int NI>
 static void launch_conv_up2_t(const ConvArgs& a, const void* wup, hipStream_t s) {
   constexpr int IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), PSL = (PS + 15) / 16 * 16;
   constexpr bool FITS = 2 * 16 * (2 * 2 * PSL + 2 * 2 * 8 * 2 * 32) + 5 * 32 * 4 <= 160 * 1024;    // two LDS images where they fit (not the 8-wide tile)
+#ifdef GR_ABLATE      // GR_UP2_DB=0: one LDS image where two fit (the A/B control; the shipping library instantiates the kernel it launches)
   static int db = -1;
   if (db < 0) { db = GR_KNOB("GR_UP2_DB", 1); }
   if (FITS && db) launch_conv_up2_db<TW, NI, FITS>(a, wup, s);
   else launch_conv_up2_db<TW, NI, false>(a, wup, s);
+#else
+  launch_conv_up2_db<TW, NI, FITS>(a, wup, s);
+#endif
 }
 template <int TW, int NI>
 static void launch_conv_up2q(ConvArgs a, const void* wup, hipStream_t s) {
@@ -2626,10 +2630,15 @@ static void launch_conv_split_wide_db(ConvArgs a, const void* wsplit, hipStream_
 template <int TW, int NI, int NTERM>
 static void launch_conv_split_wide(const ConvArgs& a, const void* wsplit, hipStream_t s) {
   // two f16x3 images fit the 160 KB LDS (152-157 KB): double-buffered; three-term bf16 images do not
+#ifdef GR_ABLATE      // GR_CONV_DB=0: single-buffered f16x3 images (the A/B control)
   static int db = -1;
   if (db < 0) { db = GR_KNOB("GR_CONV_DB", 1); }
   if (NTERM == 2 && db) launch_conv_split_wide_db<TW, NI, 2, true>(a, wsplit, s);
   else launch_conv_split_wide_db<TW, NI, NTERM, false>(a, wsplit, s);
+#else
+  if constexpr (NTERM == 2) launch_conv_split_wide_db<TW, NI, 2, true>(a, wsplit, s);
+  else launch_conv_split_wide_db<TW, NI, NTERM, false>(a, wsplit, s);
+#endif
 }
 
 // returns the number of statistics tiles written per channel (0: the chosen kernel does not produce them)
@@ -2753,6 +2762,9 @@ static int launch_conv_p16_quad(ConvArgs a, const void* wsplit, const void* xin,
 }
 template <int TW, int NI>
 static int launch_conv_p16_t(ConvArgs a, const void* wsplit, const void* xin, hipStream_t s) {
+#ifndef GR_ABLATE      // the eight-wave persistent kernel (conv3x3_p16_wide_kernel, round 2) lost to the four-wave one: ablation build only ("p16_variant" 0)
+  return launch_conv_p16_quad<TW, NI>(a, wsplit, xin, s);
+#else
   if (g_p16_variant == 1) return launch_conv_p16_quad<TW, NI>(a, wsplit, xin, s);
   constexpr int TR = 512 / TW, IH = 512 / (NI * TW), PS = NI * (IH + 2) * (TW + 2), CT = 64;
   constexpr int PVP = (4 * PS + P16_PAD - 1) / P16_PAD * P16_PAD, LBUF = PVP + 36 * CT;
@@ -2769,6 +2781,7 @@ static int launch_conv_p16_t(ConvArgs a, const void* wsplit, const void* xin, hi
   KtScope kt(name.c_str(), 2.0 * px * a.Cout * a.Cin * 9.0, 4.0 * (px * a.Cin + px * a.Cout + 9.0 * a.Cin * a.Cout), s);
   hipLaunchKernelGGL((conv3x3_p16_wide_kernel<TW, NI>), dim3(grid), dim3(512), lds, s, a, reinterpret_cast<const uint4*>(wsplit), reinterpret_cast<const uint4*>(xin));
   return a.stat_tiles;
+#endif
 }
 bool conv_p16_out_supported(int Cout) { return g_p16_variant == 1 && Cout % 8 == 0; }
 // 256-pixel x 32-channel tiles, 32-channel chunks on v_mfma_f32_16x16x32_f16 (conv3x3_p16_k32_kernel): training-mode output only
@@ -4101,16 +4114,19 @@ static int wgrad_pp_mode() { static int v = -1; if (v < 0) { v = GR_KNOB("GR_WGR
 static int wgrad_free_from() { static const int v = GR_KNOB("GR_WGRAD_FREE", 32); return v; }
 static bool wgrad_free(int W) { return wgrad_free_from() > 0 && W >= wgrad_free_from() && wgrad_pp_mode() != 2; }
 static bool wgrad_pp(int W) { const int m = wgrad_pp_mode(); return m == 2 || (m == 1 && W == 16) || wgrad_free(W); }
+template <int W_, bool FREE_>
+static void launch_wgrad_p16_pp_tf(const WgradP16Args& a, int grid, size_t lds, hipStream_t s) {
+  static bool st = false;
+  if (!st) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_p16_pp_kernel<W_, FREE_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 64); st = true; }
+  hipLaunchKernelGGL((conv3x3_wgrad_p16_pp_kernel<W_, FREE_>), dim3(grid), dim3(512), lds + (FREE_ ? 64 : 0), s, a);
+}
 template <int W_>
 static void launch_wgrad_p16_pp_t(const WgradP16Args& a, int grid, size_t lds, hipStream_t s) {
-  static bool st = false;
-  if (!st) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_p16_pp_kernel<W_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 64);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_p16_pp_kernel<W_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + 64);
-    st = true;
-  }
-  if (wgrad_free(W_)) hipLaunchKernelGGL((conv3x3_wgrad_p16_pp_kernel<W_, true>), dim3(grid), dim3(512), lds + 64, s, a);
-  else hipLaunchKernelGGL((conv3x3_wgrad_p16_pp_kernel<W_, false>), dim3(grid), dim3(512), lds, s, a);
+#ifdef GR_ABLATE      // every (width, variant) pair exists in the ablation build only; the shipping library instantiates what it launches: <16, false>, <32, true>, <64, true>
+  if (wgrad_free(W_)) launch_wgrad_p16_pp_tf<W_, true>(a, grid, lds, s); else launch_wgrad_p16_pp_tf<W_, false>(a, grid, lds, s);
+#else
+  launch_wgrad_p16_pp_tf<W_, (W_ >= 32)>(a, grid, lds, s);
+#endif
 }
 
 static bool wgrad_use_vec(int W) { return W >= 16 && W % 4 == 0; }
@@ -4201,8 +4217,10 @@ void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, 
     KtScope kt(wgrad_pp(W) ? nm2.c_str() : nm.c_str(), 2.0 * px * Cout * Cin * 9.0, 4.0 * (px * Cin + px * Cout + 9.0 * Cin * Cout), s);
     if (wgrad_pp(W)) {
       if (W == 16) launch_wgrad_p16_pp_t<16>(a, grid, 2 * lds, s); else if (W == 32) launch_wgrad_p16_pp_t<32>(a, grid, 2 * lds, s); else launch_wgrad_p16_pp_t<64>(a, grid, 2 * lds, s);
-    } else
-    if (W == 16) launch_wgrad_p16_t<16>(a, grid, lds, s); else if (W == 32) launch_wgrad_p16_t<32>(a, grid, lds, s); else launch_wgrad_p16_t<64>(a, grid, lds, s);
+    }
+#ifdef GR_ABLATE      // two four-wave workgroups per CU (rounds 2-4): an A/B control now
+    else if (W == 16) launch_wgrad_p16_t<16>(a, grid, lds, s); else if (W == 32) launch_wgrad_p16_t<32>(a, grid, lds, s); else launch_wgrad_p16_t<64>(a, grid, lds, s);
+#endif
   }
   const long n_ = (long)9 * Cout * a.cinp;
   KtScope kt("conv3x3_wgrad_reduce_tiled_kernel", (double)n_ * a.nsplit, 4.0 * n_ * (a.nsplit + 2.0), s);

@@ -421,7 +421,9 @@ void launch_post_forward(const PostArgs& a0, hipStream_t s) {
       blocks *= 4; if (blocks > 8192) blocks = 8192;
       if (a.pool) with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<true, 256, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
       else with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<false, 256, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
-    } else if (g8_half_tiles() && hwo % 512 == 0) {
+    }
+#ifdef GR_ABLATE      // GR_G8_HALF_TILES=1 / 0: 512- and 1024-pixel LDS tiles (round 2's measurements; the shipping library runs 256-pixel tiles everywhere)
+    else if (g8_half_tiles() && hwo % 512 == 0) {
       blocks *= 2; if (blocks > 8192) blocks = 8192;
       if (a.pool) with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<true, 512, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
       else with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<false, 512, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
@@ -429,6 +431,7 @@ void launch_post_forward(const PostArgs& a0, hipStream_t s) {
       if (a.pool) with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<true, 1024, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
       else with_combo(post_combo(a), [&](auto cb) { hipLaunchKernelGGL((post_forward_g8_kernel<false, 1024, decltype(cb)::value>), dim3((unsigned)blocks), dim3(256), 0, s, a); });
     }
+#endif
     return;
   }
   const bool vec = (a.pool ? (a.W % 8 == 0 && a.H % 2 == 0) : (a.W % 4 == 0)) && (long)a.B * a.C * a.H * a.W < (1l << 32);
@@ -1082,8 +1085,10 @@ void launch_post_backward(const PostBwdArgs& a0, hipStream_t s, BiasJobs* defer,
     { const int per = (f.B + slices - 1) / slices; slices = (f.B + per - 1) / per; }
     if (f.H * f.W <= 256) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, psplits, slices, nb, g_p16_debug); });
     else if (g8_half_tiles() == 2) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<256, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, psplits, slices, nb, g_p16_debug); });
+#ifdef GR_ABLATE
     else if (g8_half_tiles() && (f.H * f.W) % 512 == 0) with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<512, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, psplits, slices, nb, g_p16_debug); });
     else with_combo(post_combo(f), [&](auto cb) { hipLaunchKernelGGL((post_backward_b_g8_kernel<1024, decltype(cb)::value>), dim3(f.C / 8, slices), dim3(256), 0, s, aB, psplits, slices, nb, g_p16_debug); });
+#endif
     if (a.gbias) {
       BiasJobs one{}; one.n = 0;
       BiasJobs* q = defer ? defer : &one;
