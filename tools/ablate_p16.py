@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NEEDS THE ABLATION BUILD: make -C gan-reverser_amd/csrc ablate, then GANREV_LIB=$PWD/gan-reverser_amd/ganrev/libganrev_ablate.so python tools/ablate_p16.py ...
+# (the shipping library does not answer the gr_set_tuning keys / GR_* switches this script flips: they make kernels compute wrong results by design)
 """Ablation of conv3x3_p16_wide_kernel (cdna_hip_programming.md section 7, diagnostic loop step 2): the same launch with parts
 switched off (gr_set_tuning "p16_debug": 1 no output stores, 2 no statistics, 4 no DMA, 8 no MFMA), interleaved rounds in one
 process, median of the rounds.  Outputs are wrong by design when anything is off: only the times matter."""

@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NEEDS THE ABLATION BUILD: make -C gan-reverser_amd/csrc ablate, then GANREV_LIB=$PWD/gan-reverser_amd/ganrev/libganrev_ablate.so python tools/stagger_p16.py ...
+# (the shipping library does not answer the gr_set_tuning keys / GR_* switches this script flips: they make kernels compute wrong results by design)
 """Sweep of the start delay of the second-dispatched workgroups in conv3x3_p16_quad_kernel (interleaved rounds, one process)."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

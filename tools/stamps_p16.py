@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# NEEDS THE ABLATION BUILD: make -C gan-reverser_amd/csrc ablate, then GANREV_LIB=$PWD/gan-reverser_amd/ganrev/libganrev_ablate.so python tools/stamps_p16.py ...
+# (the shipping library does not answer the gr_set_tuning keys / GR_* switches this script flips: they make kernels compute wrong results by design)
 """In-kernel time stamps of conv3x3_p16_quad_kernel (cdna_hip_programming.md section 7): per workgroup, wave 0 records
 s_memtime at the start, after every 'chunk landed' barrier, after every 'chunk consumed' barrier and at the end, plus HW_ID.
 Prints, for a few CUs, the timeline of the workgroups that ran there."""
