@@ -775,8 +775,9 @@ __global__ __launch_bounds__(256) void post_backward_a_vec_kernel(PostBwdArgs a,
     // four float4 groups per thread and round: all their loads are issued before the first is used (a block owns only ~1024
     // groups - four per thread - so without this every thread waits out one memory round trip per group); post_bwd_load4 /
     // post_bwd_dz_of are the two halves of post_bwd_dz4, same operations in the same order
-    // Round 5: a block may own several rounds of 1024 groups (launcher: fewer, longer blocks on tensors the Infinity Cache holds); round k + 1 is requested
-    // before round k is worked on, so a thread's memory latency hides behind its own arithmetic as well as behind the other waves'
+    // A block owns several rounds of 1024 groups whenever its batch slice holds more than 4096 elements per channel (cfg3: 8 images of 64 x 64 = 8 rounds;
+    // cfg2: one round); round k + 1 is requested before round k is worked on.  (The ablation launcher GR_PASSA_SPLIT_DIV, which MAKES blocks longer at
+    // cfg2, measured no gain: profiles/r05_ab_passa_prefetch_cfg2.txt - the second buffer set is for the naturally long blocks.)
     BwdRaw r[4], rn[4]; unsigned ee[4], een[4];
     auto request = [&](unsigned j0, BwdRaw* rr, unsigned* e_) {
 #pragma unroll
@@ -1227,20 +1228,26 @@ struct HeadArgs {
   float* gW2; float* gb2; float* ggamma; float* gbeta; float* gb1;
   unsigned* amax_dy;
   unsigned* bar; unsigned bar_base;
+  unsigned* fault; int spin_limit; // sticky device word a timed-out barrier sets (penalty_clamp_adam_kernel skips its update while it is set; the host turns it into GR_ERR_STATE)
   unsigned long long* stamps;      // ablation build: [workgroup][8] wall-clock stamps of the phases (tools/debug/debug_head.py)
 };
 constexpr int HEAD_FW = 8, HEAD_RG = 32, HEAD_RMAX = 16;
-__device__ __forceinline__ bool head_grid_barrier(unsigned* ctr, unsigned target) {
+// Bounded: a launch that cannot become resident as a whole (a partitioned device, CUs held by other work for seconds) does not hang the GPU.  ANY workgroup
+// that gives up sets the sticky fault word: the phases after it then run on incomplete data, so the step's update must not happen - penalty_clamp_adam_kernel
+// reads the word and leaves theta / g / m / v untouched, and the host reports GR_ERR_STATE from the next call that synchronises (net.hip head_fault_check).
+// Every workgroup still adds its arrival to the counter, so the counter stays in step with the host's running base whatever happened.
+__device__ __forceinline__ bool head_grid_barrier(unsigned* ctr, unsigned target, unsigned* fault, int spin_limit) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   __shared__ int ok_;
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 0;
-    for (int spin = 0; spin < (1 << 22); ++spin) {               // bounded: a launch that cannot become resident as a whole ends with a NaN loss, not a hung GPU
+    for (int spin = 0; spin < spin_limit; ++spin) {
       if ((int)(__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { ok = 1; break; }
       __builtin_amdgcn_s_sleep(4);
     }
+    if (!ok) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     ok_ = ok;
   }
   __syncthreads();
@@ -1309,7 +1316,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
   HEAD_STAMP(1)
-  alive = head_grid_barrier(a.bar, a.bar_base + (unsigned)NW) && alive;
+  alive = head_grid_barrier(a.bar, a.bar_base + (unsigned)NW, a.fault, a.spin_limit) && alive;
   HEAD_STAMP(2)
   // ---------------------------------------------------------------- phase 2: rows r0 .. r0 + nrows - 1, all features
   // Every global load of the phase that does not depend on its own arithmetic goes out at its top - the slice's out1 rows, the first eight W2 rows of each
@@ -1472,7 +1479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
   HEAD_STAMP(4)
-  alive = head_grid_barrier(a.bar, a.bar_base + 2u * (unsigned)NW) && alive;
+  alive = head_grid_barrier(a.bar, a.bar_base + 2u * (unsigned)NW, a.fault, a.spin_limit) && alive;
   HEAD_STAMP(5)
   // ---------------------------------------------------------------- phase 3: features f0 .. f0 + 7, all rows
   {
@@ -1562,7 +1569,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (wg == 0 && tid == 0) {
       double t = 0;
       for (int k = 0; k < NW; ++k) t += a.loss_part[k];
-      *a.loss = alive ? t * a.inv_n : (double)NAN;
+      // (another workgroup may still time out after this one has passed: the sticky word, not this NaN, is what the host and the optimiser go by)
+      const bool faulted = !alive || __hip_atomic_load(a.fault, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      *a.loss = faulted ? (double)NAN : t * a.inv_n;
     }
   }
 }
@@ -1590,7 +1599,7 @@ void launch_head_fwd_bwd(const HeadLaunch& h, hipStream_t s) {
   a.target = h.target; a.inv_n = 1.0 / (double)h.n_global; a.norm = (float)(2.0 / (double)h.n_global); a.loss = h.loss; a.loss_part = h.loss_part;
   a.gout = h.gout; a.gy2 = h.gy2; a.dy1 = h.dy1;
   a.gW2 = h.gW2; a.gb2 = h.gb2; a.ggamma = h.ggamma; a.gbeta = h.gbeta; a.gb1 = h.gb1;
-  a.amax_dy = h.amax_dy; a.bar = h.bar; a.bar_base = h.bar_base; a.stamps = reinterpret_cast<unsigned long long*>(g_p16_stamps);
+  a.amax_dy = h.amax_dy; a.bar = h.bar; a.bar_base = h.bar_base; a.fault = h.fault; a.spin_limit = h.spin_limit > 0 ? h.spin_limit : (1 << 22); a.stamps = reinterpret_cast<unsigned long long*>(g_p16_stamps);
   const size_t lds = head_lds_bytes(h.B, h.C1, h.nd, 4);      // (head_supported: at most 4 rows per workgroup)
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fwd_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
@@ -1644,7 +1653,10 @@ __device__ __forceinline__ void adam_one(float& th, float& gv, float& mv, float&
 // four entries per thread as one 16-byte access per array (the flat vectors are hipMalloc'ed: 256-byte aligned); the last
 // n % 4 entries go through the scalar path of the thread that would own the next vector
 __global__ __launch_bounds__(256) void penalty_clamp_adam_kernel(float* __restrict__ theta, float* __restrict__ g, float* __restrict__ m,
-                                                                 float* __restrict__ v, long n, AdamConsts c) {
+                                                                 float* __restrict__ v, long n, AdamConsts c, const unsigned* __restrict__ skip) {
+  // skip: the context's sticky fault word (a grid barrier of head_fwd_bwd_kernel timed out: the gradients of that step are incomplete).  A uniform scalar
+  // load; while it is set no step changes theta, g, m or v - the host reports GR_ERR_STATE at its next synchronising call and clears it.
+  if (skip != nullptr && *skip != 0u) return;
   const long n4 = n >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i <= n4; i += (long)gridDim.x * blockDim.x) {
     if (i < n4) {
@@ -1663,12 +1675,12 @@ __global__ __launch_bounds__(256) void penalty_clamp_adam_kernel(float* __restri
     }
   }
 }
-void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long n, const AdamConsts& c, hipStream_t s) {
+void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long n, const AdamConsts& c, hipStream_t s, const unsigned* skip) {
   long blocks = ((n >> 2) + 1 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   KtScope kt("penalty_clamp_adam_kernel", 0.0, 32.0 * (double)n, s);   // read theta,g,m,v + write theta,g,m,v
-  hipLaunchKernelGGL(penalty_clamp_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, theta, g, m, v, n, c);
+  hipLaunchKernelGGL(penalty_clamp_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, theta, g, m, v, n, c, skip);
 }
 
 // ------------------------------------------------------------------ counter-based RNG (Philox4x32-10)

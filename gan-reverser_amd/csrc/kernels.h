@@ -7,7 +7,7 @@
 #include <stdlib.h>
 
 // ---------------------------------------------------------------- knobs
-// The SHIPPING library (make: libganrev.so) reads three environment variables (GR_CONV_MODE, GR_RANGE_GUARD, GR_SIDE_WGRAD: net.hip, gr_init) and
+// The SHIPPING library (make: libganrev.so) reads four environment variables (GR_CONV_MODE, GR_RANGE_GUARD, GR_SIDE_WGRAD, GR_FUSED_HEAD: net.hip, gr_init) and
 // answers the gr_set_tuning keys include/ganrev.h documents; nothing else selects kernels at run time.  Every other switch - A/B controls of
 // variants that lost their measurement, and ablation bits that make kernels compute WRONG results by design (no stores, no MFMA, no DMA ...) - exists
 // only in the ablation build (make ablate: libganrev_ablate.so, -DGR_ABLATE), where GR_KNOB reads the environment; in the shipping build it is its
@@ -367,13 +367,14 @@ struct HeadLaunch {
   float *gW2, *gb2, *ggamma, *gbeta, *gb1;                       // accumulated into (accGradParameters)
   unsigned* amax_dy;                                             // f16x3: max|dy1| slot of fc1's backward GEMMs (nullable)
   unsigned* bar; unsigned bar_base;                              // grid-barrier arrival counter (monotonic; the launch adds 2 x C1 / 8) and its value before this launch
+  unsigned* fault; int spin_limit;                               // sticky fault word a timed-out barrier sets; polls per barrier before giving up (0 = the default 2^22, ~5 s)
 };
 bool head_supported(int B, int C1, int nd);
 void launch_head_fwd_bwd(const HeadLaunch& h, hipStream_t s);
 void launch_add_inplace(float* y, const float* x, long n, hipStream_t s);        // y += x
 void launch_bce(const float* x, const float* t, long n, double* loss_dev, float* grad, hipStream_t s);      // nn.BCECriterion (sizeAverage)
 struct AdamConsts { float b1, b2, c1, c2, eps, step, l1, l2, clamp; int use_penalty, use_clamp; };
-void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long n, const AdamConsts& c, hipStream_t s);
+void launch_penalty_clamp_adam(float* theta, float* g, float* m, float* v, long n, const AdamConsts& c, hipStream_t s, const unsigned* skip = nullptr);
 void launch_gen_mask(uint32_t* words, long n_elems, float p_drop, uint64_t seed, uint64_t counter, uint32_t layer, hipStream_t s);
 // all masks of one forward in one launch (jobs travel in the kernel argument block)
 struct MaskJob { uint32_t* words; long nwords; uint32_t thresh; int half; uint32_t layer; };

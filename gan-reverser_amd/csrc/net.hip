@@ -38,6 +38,9 @@ struct gr_ctx {
   hipEvent_t ev_dy_ready = nullptr, ev_wgrad_done[2] = {nullptr, nullptr};
   // R's head in one launch (gr_train_r_step, elem.hip head_fwd_bwd_kernel): grid-barrier counter (monotonic) and per-workgroup loss partials
   unsigned* head_bar = nullptr; unsigned head_bar_count = 0; double* head_loss_part = nullptr;
+  bool head_unchecked = false;         // a head kernel has been launched since the sticky fault word (d_loss + 48) was last read: head_fault_check
+  int head_fault_inject = 0;           // gr_set_tuning "head_fault_inject" (test hook): the NEXT head launch waits at its barriers for an arrival count that never comes
+  int cu_count = 0;                    // the grid barrier needs every workgroup of the head kernel resident at once: head_plan refuses devices with fewer CUs than workgroups
   int fused_head = 1;                  // gr_set_tuning "fused_head" (1 default; 0 = the stage-by-stage path: the A/B control and what every other entry point runs)
   hipEvent_t ev_prep_go = nullptr, ev_prep_done = nullptr;    // ablation build: R's per-step preparation on the side stream beside G's forward (GR_PREP_OVERLAP=1; it lost its A/B)
   int side_wgrad = -1;                 // gr_set_tuning "side_wgrad" / GR_SIDE_WGRAD: 1 on, 0 off, -1 (default) by size.  The MFMA kernels take the whole register file of a
@@ -46,7 +49,7 @@ struct gr_ctx {
                                        // cost an event hand-over per stage), cfg3 12.005 -> 11.875 ms (faster: the slab write + reduction tail of a 0.3 ms launch hides
                                        // behind the data gradient).  Auto = on for stages of >= 2^26 activations (cfg3's layers; cfg2's have 2^24).  Bit-identical
                                        // either way.  Per-kernel timing (gr_set_timing 2) forces it off, so that kernel durations are not inflated by overlap.
-  double* d_loss = nullptr;     // device scalar (64-byte block: +0 the loss, +16 the range guard's alarm word, +32 the search's arrival counter)
+  double* d_loss = nullptr;     // device scalar (64-byte block: +0 the loss, +16 the range guard's alarm word, +32 the search's arrival counter, +48 the head kernel's sticky fault word)
   double* h_loss = nullptr;     // pinned host scalar
   bool timing = false;
   int conv_mode = 2;            // 2 = f16x3 split (fp32-accurate, f16 MFMA; default), 1 = bf16x6 split (fp32-accurate, bf16 MFMA), 0 = exact fp32 MFMA
@@ -167,6 +170,9 @@ static int small_allreduce(gr_ctx* c, void* buf, long count, int kind) {
 // true here by construction, but never run with a peer on this pool, so it is not relied on.
 static int ensure_stat_comm(gr_ctx* c) {
   if (!c->comm || c->stat_comm || !c->sync_bn) return GR_OK;
+  // a split with operations still outstanding on the parent is not supported: gradient buckets / the loss all-reduce of the previous step may be in flight
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
   NCCLCHK(c, ncclCommSplit(c->comm, 0, c->rank, &c->stat_comm, nullptr));
   return GR_OK;
 }
@@ -212,6 +218,27 @@ static int ensure_ws2(gr_ctx* c, size_t bytes) {
   return GR_OK;
 }
 
+// The head kernel's sticky fault word (elem.hip head_grid_barrier).  Read - one 4-byte copy, only when a head kernel has run since the last look - by every
+// call that synchronises the stream anyway: gr_train_r_step with a loss_out, gr_synchronize, gr_net_get_params / gr_net_get_grads.  Set means: a grid
+// barrier timed out in some step since then, that step and every later one skipped its optimiser update (penalty_clamp_adam_kernel), so the parameters and
+// Adam's moments are those of the last good step (BatchNorm running statistics and the gradient vector are not rolled back).  Reported ONCE as GR_ERR_STATE;
+// the barrier state is reset so that training can go on.
+static unsigned* head_fault_dev(gr_ctx* c) { return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(c->d_loss) + 48); }
+static int head_fault_check(gr_ctx* c) {
+  if (!c->head_unchecked) return GR_OK;
+  unsigned w = 0;
+  HIPCHK(c, hipMemcpyAsync(&w, head_fault_dev(c), sizeof w, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->head_unchecked = false;
+  if (!w) return GR_OK;
+  HIPCHK(c, hipMemsetAsync(head_fault_dev(c), 0, sizeof(unsigned), c->stream));
+  if (c->head_bar) HIPCHK(c, hipMemsetAsync(c->head_bar, 0, 256, c->stream));
+  c->head_bar_count = 0;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return fail(c, GR_ERR_STATE, "head kernel: a grid barrier timed out (its workgroups were not resident together); every optimiser update since then was skipped - "
+              "parameters and Adam state are those of the last good step.  gr_set_tuning \"fused_head\" 0 selects the stage-by-stage path");
+}
+
 extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.4 (round 4)"; }
 
 extern "C" int gr_init(int device, gr_ctx** out) {
@@ -225,6 +252,7 @@ extern "C" int gr_init(int device, gr_ctx** out) {
   if (strncmp(p.gcnArchName, "gfx950", 6) != 0) return GR_ERR_NO_DEVICE;  // kernels are built for gfx950 only
   gr_ctx* c = new gr_ctx();
   c->device = device;
+  c->cu_count = p.multiProcessorCount;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void**)&c->d_loss, 64) != hipSuccess || hipMalloc((void**)&c->amax, sizeof(unsigned) * 4 * AMAX_WORDS) != hipSuccess || hipHostMalloc((void**)&c->h_loss, 64) != hipSuccess) {
     delete c; return GR_ERR_HIP;
@@ -253,6 +281,7 @@ extern "C" int gr_shutdown(gr_ctx* c) {
   if (!c) return GR_ERR_INVALID;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);      // gradient buckets in flight: before the communicators go
   if (c->stat_comm) { ncclCommDestroy(c->stat_comm); c->stat_comm = nullptr; }
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
   if (c->ws) (void)hipFree(c->ws);
@@ -282,7 +311,7 @@ extern "C" int gr_shutdown(gr_ctx* c) {
 }
 extern "C" const char* gr_last_error(gr_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 extern "C" void* gr_stream(gr_ctx* c) { return c ? (void*)c->stream : nullptr; }
-extern "C" int gr_synchronize(gr_ctx* c) { if (!c) return GR_ERR_INVALID; HIPCHK(c, hipStreamSynchronize(c->stream)); return GR_OK; }
+extern "C" int gr_synchronize(gr_ctx* c) { if (!c) return GR_ERR_INVALID; HIPCHK(c, hipStreamSynchronize(c->stream)); return head_fault_check(c); }
 extern "C" int gr_device_info(gr_ctx* c, char* buf, int n) {
   if (!c || !buf) return GR_ERR_INVALID;
   hipDeviceProp_t p; HIPCHK(c, hipGetDeviceProperties(&p, c->device));
@@ -315,6 +344,7 @@ extern "C" int gr_set_tuning(gr_ctx* c, const char* key, int value) {
   if (!strcmp(key, "eval_p16")) { g_eval_p16 = value; return GR_OK; }           // evaluate()-mode stages hand their output over operand-ready (1, default) or as fp32 (0: the A/B control)
   if (!strcmp(key, "side_wgrad")) { c->side_wgrad = value; return GR_OK; }
   if (!strcmp(key, "fused_head")) { c->fused_head = value != 0; return GR_OK; }   // gr_train_r_step: R's last two stages + the criterion, forward and backward, in one launch
+  if (!strcmp(key, "head_fault_inject")) { c->head_fault_inject = value != 0; return GR_OK; }   // test hook: the next head launch's grid barriers time out (after 2^10 polls), as on a device that cannot hold its workgroups together
   // synchronised BatchNorm under data parallelism: per-channel batch sums are all-reduced, fwd and bwd (include/ganrev.h)
   if (!strcmp(key, "sync_bn")) { c->sync_bn = value != 0; return ensure_stat_comm(c); }   // (collective when a communicator exists: every rank sets it at the same point)
   // f16x3 range guard on / off.  Off also clears a tripped trainer guard AND drops a verdict still in flight: that verdict is about the
@@ -697,9 +727,9 @@ static int copy_flat(gr_net* n, float* dev, float* host_out, const float* host_i
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GR_OK;
 }
-extern "C" int gr_net_get_params(gr_net* n, float* h) { if (!n || !h) return GR_ERR_INVALID; return copy_flat(n, n->params, h, nullptr); }
+extern "C" int gr_net_get_params(gr_net* n, float* h) { if (!n || !h) return GR_ERR_INVALID; const int r = copy_flat(n, n->params, h, nullptr); return r ? r : head_fault_check(n->ctx); }
 extern "C" int gr_net_set_params(gr_net* n, const float* h) { if (!n || !h) return GR_ERR_INVALID; n->params_version++; return copy_flat(n, n->params, nullptr, h); }
-extern "C" int gr_net_get_grads(gr_net* n, float* h) { if (!n || !h) return GR_ERR_INVALID; return copy_flat(n, n->grads, h, nullptr); }
+extern "C" int gr_net_get_grads(gr_net* n, float* h) { if (!n || !h) return GR_ERR_INVALID; const int r = copy_flat(n, n->grads, h, nullptr); return r ? r : head_fault_check(n->ctx); }
 extern "C" int gr_net_set_grads(gr_net* n, const float* h) { if (!n || !h) return GR_ERR_INVALID; return copy_flat(n, n->grads, nullptr, h); }
 extern "C" int gr_net_zero_grads(gr_net* n) { if (!n) return GR_ERR_INVALID; HIPCHK(n->ctx, hipMemsetAsync(n->grads, 0, sizeof(float) * (size_t)n->n_params, n->ctx->stream)); return GR_OK; }
 extern "C" int gr_adam_reset(gr_net* n) {
@@ -1290,6 +1320,7 @@ extern "C" float* gr_net_output_dev(gr_net* n) { return (n && !n->st.empty()) ? 
 
 extern "C" int gr_net_forward_dev(gr_net* n, const float* in_dev, int B, float* out_dev) {
   if (!n || !in_dev || B <= 0) return GR_ERR_INVALID;
+  n->head_fused = false;
   n->keep_fp32 = false; n->last_fwd_fell_back = false;      // device-resident callers: no stream synchronisation, so no range guard here (gr_train_r_step samples one)
   return forward_impl(n, in_dev, B, out_dev);
 }
@@ -1607,6 +1638,7 @@ static int backward_impl(gr_net* n, const float* in_dev, const float* gout_dev, 
 
 extern "C" int gr_net_backward_dev(gr_net* n, const float* in_dev, const float* gout_dev, int B, float* gin_dev) {
   if (!n || !in_dev || !gout_dev || B <= 0) return GR_ERR_INVALID;
+  n->head_fused = false;
   return backward_impl(n, in_dev, gout_dev, B, gin_dev);
 }
 
@@ -1715,7 +1747,7 @@ static AdamConsts adam_consts(const gr_hyper* h, int t) {
 extern "C" int gr_adam_step(gr_net* n, const gr_hyper* h, int t) {
   if (!n || !h || t < 1) return GR_ERR_INVALID;
   gr_ctx* c = n->ctx;
-  launch_penalty_clamp_adam(n->params, n->grads, n->adam_m, n->adam_v, n->n_params, adam_consts(h, t), c->stream);
+  launch_penalty_clamp_adam(n->params, n->grads, n->adam_m, n->adam_v, n->n_params, adam_consts(h, t), c->stream, head_fault_dev(c));
   LAUNCHCHK(c);
   n->params_version++;
   return GR_OK;
@@ -1805,6 +1837,7 @@ static bool head_plan(gr_net* n, int B, HeadLaunch& h) {
   if (s1.kind != ST_LINEAR || s2.kind != ST_LINEAR || !s1.has_post || !s1.has_bn || s1.pool || s1.m2 >= 0 || s1.H != 1 || s1.W != 1) return false;
   if (s1.act == ACT_PRELU || s2.has_bn || s2.pool || s2.m1 >= 0 || s2.m2 >= 0 || !(s2.act == ACT_NONE || s2.act == ACT_TANH)) return false;
   if (s2.Cin != s1.Cout || !head_supported(B, s1.Cout, s2.Cout) || B > n->capB) return false;      // (gr_train_r_step has sized the buffers: ensure_batch)
+  if (c->cu_count < s1.Cout / 8) return false;                 // the grid barrier needs its C1 / 8 workgroups (one per CU: 256 threads at one wave per SIMD) resident together - not on a partition with fewer CUs
   bool need = false;
   const MaskRef m1 = mask_ref(n, s1.m1, need);
   if (!(m1.kind == MASK_NONE || m1.kind == MASK_ELEM)) return false;
@@ -1831,6 +1864,9 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
     return fail(c, GR_ERR_INVALID, "synchronised BatchNorm needs equal shards: batch %d x %d ranks != global batch %d", B, c->nranks, GB);
   const bool tm = c->timing;
   int r;
+  // Per-step state of the two nets that must not outlive this call on ANY exit (an early error return used to leave head_fused set: a later gr_net_forward_* /
+  // gr_net_backward_* on the same net then skipped its last two stages silently; likewise the 'slots already zeroed' and 'forward already begun' notes)
+  struct StepState { gr_net* g; gr_net* rn; ~StepState() { rn->head_fused = false; g->amax_prezeroed_groups = rn->amax_prezeroed_groups = 0; rn->begun_B = 0; } } step_state{g, rn};
   // Range guard of the device-resident loop: no synchronisation is allowed here, so the parameter scans (weights, BatchNorm
   // scales of G and R) run every GUARD_PERIOD-th step and their verdict is read, without waiting, by a later call.  Once a
   // hostile spread shows, the context stays on bf16x6 (gr_set_tuning "range_guard" 0 clears it).  Latency: under 2 periods.
@@ -1905,15 +1941,20 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
   if (rn->head_fused) {
     // fc1's BatchNorm / activation / Dropout, fc2, the criterion (:147,150) and their backward down to fc1's dy: one launch (elem.hip, head_fwd_bwd_kernel)
     if (!c->head_bar) {
-      if (hipMalloc((void**)&c->head_bar, 256) != hipSuccess || hipMalloc((void**)&c->head_loss_part, sizeof(double) * 512) != hipSuccess) { rn->head_fused = false; return fail(c, GR_ERR_HIP, "head kernel: allocation failed"); }
+      unsigned* bar = nullptr; double* part = nullptr;           // both or neither: a half-made pair would launch the kernel with a null loss_part next time
+      if (hipMalloc((void**)&bar, 256) != hipSuccess || hipMalloc((void**)&part, sizeof(double) * 512) != hipSuccess) { if (bar) (void)hipFree(bar); return fail(c, GR_ERR_HIP, "head kernel: allocation failed"); }
+      c->head_bar = bar; c->head_loss_part = part;
       HIPCHK(c, hipMemsetAsync(c->head_bar, 0, 256, c->stream));
       c->head_bar_count = 0;
     }
     if (!head_plan(rn, B, hl)) { rn->head_fused = false; return fail(c, GR_ERR_STATE, "head kernel: the plan changed during the forward"); }   // (again: the forward may have re-allocated the Dropout bits)
     hl.n_global = (long)GB * nd; hl.target = noise_dev; hl.loss = c->d_loss; hl.loss_part = c->head_loss_part;
     hl.bar = c->head_bar; hl.bar_base = c->head_bar_count;
+    hl.fault = head_fault_dev(c); hl.spin_limit = 0;
     c->head_bar_count += 2u * (unsigned)(hl.C1 / 8);
+    if (c->head_fault_inject) { hl.bar_base += 1u << 30; hl.spin_limit = 1 << 10; c->head_fault_inject = 0; }      // (test hook: targets no arrival count reaches)
     launch_head_fwd_bwd(hl, c->stream);
+    c->head_unchecked = true;
   } else
   launch_mse(rn->st.back().out, noise_dev, (long)B * nd, (long)GB * nd, c->d_loss, rn->gout_buf, c->stream);  // :147,150
   LAUNCHCHK(c);
@@ -1942,6 +1983,7 @@ extern "C" int gr_train_r_step(gr_net* g, gr_net* rn, const float* noise_dev, in
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (loss_out) *loss_out = *c->h_loss;
     if (tm) for (int i = 0; i < 6; ++i) HIPCHK(c, hipEventElapsedTime(&c->times[i], c->ev[i], c->ev[i + 1]));
+    return head_fault_check(c);       // (this call has waited for the stream anyway: a timed-out grid barrier of this or an earlier step surfaces here)
   }
   return GR_OK;
 }

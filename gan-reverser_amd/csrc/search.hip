@@ -499,7 +499,8 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
       // stores: ~300 cycles each, one after the other, 5000 cycles per tile against 900 for its 28 MFMAs (243 TFLOP/s = 0.098 of the bf16 peak).  Now a
       // position with a hit costs a wave vote, a prefix count and ONE fire-and-forget 8-byte LDS write into the wave's own queue (no atomic, no wait: the
       // position is scalar base + mbcnt); the queue is drained once per tile, one entry per lane, so the atomics and stores of all ~20 entries overlap.
-      // An entry that does not fit the queue takes the old path on the spot: nothing is dropped here that round 4 kept.
+      // An entry that does not fit the wave's queue IS dropped - and raises wg_ovf, which forces this workgroup's counts past BSLOT: the whole call then
+      // reruns unbatched (gr_search_stats counts it), so the result stays exact; a queue sized for ~3x the expected hits makes that a rare path.
       unsigned qn = 0u;                                          // wave-uniform: passing values so far (may exceed qcap: see below)
       const unsigned lo_base = ((unsigned)(64 * wave + l31) << 8) | (unsigned)(4 * h);
 #pragma unroll

@@ -191,7 +191,13 @@ int gr_get_conv_mode(gr_ctx* ctx);
  *                    the criterion (train_r.lua:147-151) and their backward in ONE launch where that wins (at most 4 rows per workgroup of 8 features:
  *                    batch <= 256 at 512 features, and nd <= 32); same operations per value as the stage-by-stage path, sums in another order (1e-6 on the
  *                    loss, 1e-4 of a module's largest entry on the gradients: tests/test_gpu_parity.py::test_head_kernel_equals_the_stage_by_stage_step).
- *                    0 = stage by stage: what gr_net_forward_* / gr_net_backward_* compute, bit for bit
+ *                    0 = stage by stage: what gr_net_forward_* / gr_net_backward_* compute, bit for bit.  The launch synchronises its C1 / 8 workgroups with
+ *                    two grid barriers, so it is only taken on a device with at least that many CUs; a barrier that still times out (~5 s: the CUs were held
+ *                    by other work) sets a sticky device word - the optimiser update of that step and of every later one is skipped (parameters and Adam
+ *                    state stay those of the last good step) and the next call that synchronises (gr_train_r_step with loss_out, gr_synchronize,
+ *                    gr_net_get_params / gr_net_get_grads) returns GR_ERR_STATE once and re-arms the barrier
+ *   "head_fault_inject" (default 0; test hook) 1 = the NEXT head launch waits at its barriers for an arrival count that never comes and gives up after 2^10
+ *                    polls: the failure path above, on demand (tests/test_gpu_abi_behaviour.py)
  *   "sync_bn"        (default 0) synchronised BatchNorm under data parallelism - see below
  *   "range_guard"    (default 1) the f16x3 range guard - see below */
 int gr_set_tuning(gr_ctx* ctx, const char* key, int value);
