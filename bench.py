@@ -851,7 +851,10 @@ def main():
             dist.all_gather_object(seen, (rank, local_rank))
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": sorted(seen)}))
+            wl = WORKLOADS["cfg2" if args.workload == "both" else args.workload]
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": sorted(seen), "scaling": "weak",
+                              "config": {"workload": wl["name"], "per_gpu_batch": wl["batch"], "global_batch": wl["batch"] * world,
+                                         "parallelism": f"dp{world}"}}))
         return
 
     head = "cfg2" if args.workload == "both" else args.workload

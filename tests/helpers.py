@@ -341,3 +341,41 @@ class OracleGraph:
             gin = gi if gin is None else gin + gi
             lo += k
         return gin
+
+
+# ------------------------------------------------------------------ sharded search, all ranks in one process
+def tied_corpus(N, d, seed, needle, bounds):
+    """A corpus whose exact-tie groups straddle shard boundaries (the merge order - score descending, GLOBAL row ascending - decides):
+    * four bit-identical rows, one in each of the first four shards, nearly parallel to the needle row -> one tie group across THREE boundaries;
+    * a duplicate of the needle row itself in the last shard (score ties with the needle's own hit);
+    * a pair of identical rows in two middle shards.
+    Returns (emb, rows of the 4-fold group)."""
+    from ganrev import synth
+    emb = synth.normal((N, d), seed)
+    near = (emb[needle] + 0.05 * synth.normal((d,), seed + 1)).astype(np.float32)
+    group = [lo + (hi - lo) // 3 for lo, hi in bounds[:4]]
+    for r in group:
+        emb[r] = near
+    emb[bounds[-1][0] + 7] = emb[needle]
+    emb[bounds[len(bounds) // 2][0] + 11] = emb[bounds[len(bounds) // 2 - 1][0] + 5]
+    return emb, group
+
+
+def sharded_search_in_process(local_topk, emb, bounds, needles, k):
+    """ganrev.parallel.sharded_cosine_topk for every shard of `bounds`, one after the other in this process: each rank's candidate lists are caught at its
+    all-gather and merged afterwards exactly as the ranks would (merge_candidates).  The needle exchange (sum all-reduce) returns what the sum over the
+    ranks is: the needle rows."""
+    from ganrev.parallel import merge_candidates, sharded_cosine_topk
+    vec = emb[list(needles)].copy()
+
+    class Comm:
+        def __init__(self, r): self.rank, self.world, self.got = r, len(bounds), []
+        def allreduce_sum(self, arr): return vec.copy()
+        def allgather(self, arr):
+            self.got.append(arr); return [arr]
+    ci, cs = [], []
+    for r, (lo, hi) in enumerate(bounds):
+        c = Comm(r)
+        sharded_cosine_topk(local_topk, emb[lo:hi], lo, needles, k, c)
+        ci.append(c.got[0]); cs.append(c.got[1])
+    return merge_candidates(ci, cs, k)

@@ -51,16 +51,17 @@ def _check_against_oracle(oracle, R, ref, loss, raw_sum, grads, theta, m2, v2, f
     assert_close(m2, ref["m"], 1e-5, "adam m"); assert_close(v2, ref["v"], 1e-5, "adam v")
 
 
-@pytest.mark.parametrize("name,dims,nd,B", [pytest.param(*c, id=c[0]) for c in D.CASES])
-def test_dp_two_shards_in_process_vs_grouped_oracle(ctx, oracle, conv_mode, name, dims, nd, B):
+@pytest.mark.parametrize("world,name,dims,nd,B", [pytest.param(*c, id=c[1]) for c in D.WORLD_CASES])
+def test_dp_two_shards_in_process_vs_grouped_oracle(ctx, oracle, conv_mode, world, name, dims, nd, B):
+    """`world` shards (2, and 8 = cfg4's rank count) of one global batch through the HIP path, one after the other in this process."""
     import ganrev._lib as L
     G, R = D.make_models(dims, nd)
     oG, oR = oracle.from_model(G, (nd, 1, 1)), oracle.from_model(R, dims)
     _compile(G, R, dims, nd)
     gnet, rnet = G._net, R._net
     theta0 = oR.params.copy()
-    noise, masks = D.global_inputs(R, _layer_of(R, oR), oR.mask_size, dims, nd, B)
-    GB = B * D.WORLD
+    noise, masks = D.global_inputs(R, _layer_of(R, oR), oR.mask_size, dims, nd, B, world=world)
+    GB = B * world
     hyper, free = L.Hyper(), L.Hyper(l1=0.0, l2=0.0, clamp=0.0)          # `free`: no penalty, no clamp -> the step leaves the raw gradient
     zeros = np.zeros_like(theta0)
     pooled = _pooled_convs(R, oR)
@@ -69,18 +70,20 @@ def test_dp_two_shards_in_process_vs_grouped_oracle(ctx, oracle, conv_mode, name
     dloss = ctx.malloc(64)
     raw, losses, images, preds = [], [], [], []
     idx = {li: [] for li in pooled}; ys = {cl: [] for cl in pooled.values()}
-    for r in range(D.WORLD):
+    def shard(a, r):
+        return D.shard(a, r, world)
+    for r in range(world):
         rnet.set_params(theta0); rnet.set_adam_state(zeros, zeros)
-        ctx.upload(D.shard(noise, r), dn)
+        ctx.upload(shard(noise, r), dn)
         for li, k in masks.items():
-            rnet.set_mask(li, D.shard(k.reshape(GB, -1), r).ravel())
+            rnet.set_mask(li, shard(k.reshape(GB, -1), r).ravel())
         # (a0) the fused entry point as it ships (round 5: R's head - fc1's pipeline, fc2, the criterion and their backward - in ONE launch,
         #      head_fwd_bwd_kernel): same operations per value as the stage-by-stage path, sums in another order -> compared at the gradient bar, not bit for bit
         loss_head = L.train_r_step(gnet, rnet, dn, B, GB, free, D.T_STEP)
         raw_head = rnet.get_grads()
         rnet.set_params(theta0); rnet.set_adam_state(zeros, zeros)
         for li, k in masks.items():
-            rnet.set_mask(li, D.shard(k.reshape(GB, -1), r).ravel())
+            rnet.set_mask(li, shard(k.reshape(GB, -1), r).ravel())
         # (a) the fused entry point with the GLOBAL normaliser; no communicator: its Adam sees the local gradient only, so the
         #     penalty-free hyper-parameters keep the raw local gradient readable afterwards.  Stage by stage (fused_head 0): (b) below must reproduce it bit for bit
         ctx.set_tuning("fused_head", 0)
@@ -100,7 +103,7 @@ def test_dp_two_shards_in_process_vs_grouped_oracle(ctx, oracle, conv_mode, name
         #     bit-identical raw gradient and partial loss
         rnet.set_params(theta0)
         for li, k in masks.items():
-            rnet.set_mask(li, D.shard(k.reshape(GB, -1), r).ravel())
+            rnet.set_mask(li, shard(k.reshape(GB, -1), r).ravel())
         gnet.set_training(False); img_dev = gnet.forward_dev(dn, B)
         rnet.set_training(True); rnet.zero_grads()
         pred_dev = rnet.forward_dev(img_dev, B)
@@ -111,7 +114,9 @@ def test_dp_two_shards_in_process_vs_grouped_oracle(ctx, oracle, conv_mode, name
     for p in (dn, dfdo, dloss):
         ctx.free(p)
     # SUM on the host (what ncclAllReduce(sum) does between the ranks), then the non-linear part on the reduced gradient
-    raw_sum = raw[0] + raw[1]
+    raw_sum = raw[0].copy()
+    for g in raw[1:]:                                                    # rank order, fp32: what a ring / tree all-reduce may re-associate (inside the gradient bar)
+        raw_sum += g
     rnet.set_params(theta0); rnet.set_adam_state(zeros, zeros)
     rnet.set_grads(raw_sum)
     rnet.adam_step(hyper, D.T_STEP)                                      # gr_adam_step = penalty + clamp + Adam (train_r.lua:153-170)
@@ -121,17 +126,17 @@ def test_dp_two_shards_in_process_vs_grouped_oracle(ctx, oracle, conv_mode, name
     dev_index = {li: np.concatenate(v) for li, v in idx.items()}
     dev_y = {cl: np.concatenate(v) for cl, v in ys.items()}
     rep = {}
-    ref = D.oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, oracle.GoHyper(), dev_index, dev_y, R, max_flips=16, report=rep)
-    assert_close(np.concatenate(images), ref["images"], TOL, "G images of both shards")
-    assert_close(np.concatenate(preds), ref["preds"], TOL, "recovered noise of both shards (per-shard BatchNorm statistics)")
-    _check_against_oracle(oracle, R, ref, losses[0] + losses[1], raw_sum, grads, theta, m2, v2, f"(argmax flips {rep.get('flips')})")
+    ref = D.oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, oracle.GoHyper(), dev_index, dev_y, R, max_flips=16, report=rep, groups=world)
+    assert_close(np.concatenate(images), ref["images"], TOL, "G images of all shards")
+    assert_close(np.concatenate(preds), ref["preds"], TOL, "recovered noise of all shards (per-shard BatchNorm statistics)")
+    _check_against_oracle(oracle, R, ref, float(np.sum(losses)), raw_sum, grads, theta, m2, v2, f"(world {world}, argmax flips {rep.get('flips')})")
     # and the control: ONE batch-statistics group over the 2B batch is a different computation (per-rank BatchNorm is what DP means here)
     oR.set_bn_groups(1)
     oR.params[...] = theta0
     for li, k in masks.items():
         oR.set_mask(li, k)
     single = oR.forward(ref["images"])
-    oR.set_bn_groups(D.WORLD)
+    oR.set_bn_groups(world)
     assert maxdiff(single, ref["preds"]) > 10 * TOL, "grouped and ungrouped BatchNorm agree: the case does not separate them"
 
 

@@ -1394,6 +1394,26 @@ def test_sharded_search_merge_equals_unsharded(ctx):
     assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
 
 
+def test_sharded_search_eight_shards_with_ties_across_three_boundaries(ctx, oracle):
+    """cfg4's rank count for the search leg: EIGHT unequal shards of a 160 003 x 100 table searched by the HIP search (every shard large enough
+    for the filtered small-needle path and small enough for the plain one: both run), candidates merged as the ranks would; one exact-tie group spread over
+    four shards, a duplicate of the needle in the last shard, the cut inside the tie group at k = 4.  Bit-identical to the unsharded device search and to
+    the oracle."""
+    from helpers import sharded_search_in_process, tied_corpus
+    N, d = 160003, 100
+    cuts = [0, 9000, 21000, 40000, 40001, 75000, 100000, 131100, N]
+    bounds = list(zip(cuts[:-1], cuts[1:]))
+    needles = [100, 40000, N - 1]
+    emb, group = tied_corpus(N, d, 88, needles[0], bounds)
+    for k in (4, 50):
+        idx, sc = sharded_search_in_process(ctx.cosine_topk, emb, bounds, needles, k)
+        ridx, rsc = ctx.cosine_topk(emb, needles, k)
+        assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
+        oidx, osc = oracle.cosine_topk(emb, needles, k)
+        assert np.array_equal(idx, oidx) and np.array_equal(sc, osc)
+    assert ridx[0][2:6].tolist() == group
+
+
 def test_train_r_reads_and_writes_torch7_checkpoints(ctx, tmp_path):
     """train_r.lua:68-75 (G and the geometry come from a Torch7 checkpoint {G=..., opt=...}) and :227-235 (torch.save {R=..., opt=...})
     through ganrev/t7.py: G's images from the loaded model equal the original's, and the saved R reloads to the trained parameters."""

@@ -289,6 +289,43 @@ def test_bench_launches_its_own_ranks():
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
 
 
+def test_bench_gpus_8_dry_run_forms_eight_ranks():
+    """cfg4's launch shape (BASELINE configs[3]: 8 ranks): `python bench.py --gpus 8` spawns eight rank processes that meet in the gloo control group, each
+    bound to its LOCAL_RANK's device, and rank 0 relays ONE line with n_gpus = 8 and the eight (rank, device) pairs; per-rank batch and global batch are the
+    weak-scaling ones (256 per GPU at cfg2, 512 at cfg3 = cfg4's 4096).  The dry-run hook stops each rank after the rendezvous: this box has no GPU and the
+    8-GPU run itself is the driver's (SCALE_rNN.json)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GANREV_BENCH_DRY_RUN"] = "1"
+    for wl, per, glob in (("cfg2", 256, 2048), ("cfg3", 512, 4096)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--workload", wl], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 8 and line["ranks"] == [[i, i] for i in range(8)], line
+        assert line["scaling"] == "weak" and line["config"]["per_gpu_batch"] == per and line["config"]["global_batch"] == glob, line
+
+
+def test_sharded_search_eight_ranks_with_ties_across_three_boundaries(oracle):
+    """SURVEY 8e at cfg4's rank count: the corpus split over EIGHT unequal shards, local top-k, candidate gather, merge - bit-identical to the unsharded
+    search, with one exact-tie group spread over four shards (three boundaries), a duplicate of the needle row in the last shard, and k chosen so that the
+    cut falls INSIDE the tie group (global row order decides who is in).  Oracle as the local search (the HIP variant: tests/test_gpu_parity.py)."""
+    from helpers import sharded_search_in_process, tied_corpus
+    N, d = 4003, 32
+    cuts = [0, 300, 811, 1500, 1501, 2400, 3000, 3777, N]            # unequal shards, one of a single row
+    bounds = list(zip(cuts[:-1], cuts[1:]))
+    needles = [99, 1500, 4002]
+    emb, group = tied_corpus(N, d, 77, needles[0], bounds)
+    for k in (4, 50):                                                 # k = 4: needle, its duplicate, then 2 of the 4 tied rows
+        idx, sc = sharded_search_in_process(oracle.cosine_topk, emb, bounds, needles, k)
+        ridx, rsc = oracle.cosine_topk(emb, needles, k)
+        assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
+    ridx, rsc = oracle.cosine_topk(emb, needles, 6)
+    assert sorted(ridx[0][:2].tolist()) == [99, bounds[-1][0] + 7] and ridx[0][2:6].tolist() == group      # the case is what it claims to be
+    assert len(set(rsc[0][2:6].tolist())) == 1
+
+
 def test_bench_headline_is_compact_strict_json():
     """the LAST stdout line of bench.py must be a compact (< 4 KB), strictly valid JSON object carrying the contract's keys,
     `roofline` and `cpu_baseline`; the tables go to a side file.  Built here from a canned full result (a committed copy of round 4's 23 KB line) and from the
