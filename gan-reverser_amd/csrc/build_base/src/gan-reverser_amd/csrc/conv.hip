@@ -1802,29 +1802,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
   const int ktot = f16_scale_exp(absmax_read(a.amax_in)) + f16_scale_exp(absmax_read(a.amax_w));
   int voff[NPS], woff[NWS];
   int tile, y0, x0, o0, b;
-  // WHOLE (TW = 16: the launcher takes this kernel on 16 x 16 planes only): a unit's pixel tile is one whole image, so the per-lane DMA offsets are the same for
-  // every unit - computed ONCE per workgroup for image 0 / output block 0; the unit's image and output block travel in the SCALAR offset of the DMA
-  // instructions (round 6: the per-unit recomputation was ~600 VALU instructions - six patch slots and five weight slots with two integer divisions each -
-  // between a unit's last multiply and the next unit's first request; the PMC pass counted 2.1 VALU per MFMA over the kernel, the chunk loop itself has 7 per
-  // 216.  Same box, interleaved: 0.2681 -> 0.2650 ms for the six launches of a cfg2 step, profiles/r06_ab_k32_geometry_cfg2.txt)
-  constexpr bool WHOLE = TW == 16;
-  int psbase = 0, wsbase = 0;                                     // scalar byte offsets of the unit's image / output-channel block (WHOLE)
-  auto lane_offsets = [&](int bb, int oo0) {
-#pragma unroll
-    for (int j = 0; j < NPS; ++j) {
-      const int e = 64 * (wave + NW * j) + lane;
-      const int p8 = e / PS, pos = e - p8 * PS, t = p8 >> 2, grp = p8 & 3;      // plane p8 = term * 4 + group
-      const int rr = pos / PC, c = pos - rr * PC;
-      const int yy = y0 + rr - 1, xx = x0 + c - 1;
-      const bool inb = e < PV && pos < PS0 && yy >= 0 && yy < H && xx >= 0 && xx < W && bb < a.B;
-      voff[j] = inb ? (((bb * G + grp) * 2 + t) * HW + yy * W + xx) * 16 : (int)0x7FFFF000;
-    }
-#pragma unroll
-    for (int j = 0; j < NWS; ++j) {          // weight vector f of the [2 sub-chunks][36 rows][32 o] image
-      const int f = 64 * (wave + NW * j) + lane, cc = f / (WR16 * CT), rem = f - cc * (WR16 * CT), r = rem / CT, col = rem - r * CT;
-      woff[j] = f < WV ? ((cc * WR16 + r) * a.cout_pad + oo0 + col) * 16 : (int)0x7FFFF000;
-    }
-  };
   auto unit_geometry = [&](int u) {                               // unit u -> tile / channel block, and the per-lane DMA offsets of its operand image
     int bid = xcd_remap(u, a.n_tiles);
     tile = bid / a.n_otiles;
@@ -1832,13 +1809,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y; b = bid / a.tiles_y;
     y0 = ty * TR; x0 = tx * TW; o0 = ot * CT;
-    if (WHOLE) { psbase = b * G * 2 * HW * 16; wsbase = o0 * 16; }     // (u < n_tiles = B x n_otiles: b < B)
-    else lane_offsets(b, o0);
+#pragma unroll
+    for (int j = 0; j < NPS; ++j) {
+      const int e = 64 * (wave + NW * j) + lane;
+      const int p8 = e / PS, pos = e - p8 * PS, t = p8 >> 2, grp = p8 & 3;      // plane p8 = term * 4 + group
+      const int rr = pos / PC, c = pos - rr * PC;
+      const int yy = y0 + rr - 1, xx = x0 + c - 1;
+      const bool inb = e < PV && pos < PS0 && yy >= 0 && yy < H && xx >= 0 && xx < W && b < a.B;
+      voff[j] = inb ? (((b * G + grp) * 2 + t) * HW + yy * W + xx) * 16 : (int)0x7FFFF000;
+    }
+#pragma unroll
+    for (int j = 0; j < NWS; ++j) {          // weight vector f of the [2 sub-chunks][36 rows][32 o] image
+      const int f = 64 * (wave + NW * j) + lane, cc = f / (WR16 * CT), rem = f - cc * (WR16 * CT), r = rem / CT, col = rem - r * CT;
+      woff[j] = f < WV ? ((cc * WR16 + r) * a.cout_pad + o0 + col) * 16 : (int)0x7FFFF000;
+    }
   };
-  if (WHOLE) { y0 = 0; x0 = 0; lane_offsets(0, 0); }
 #define GR_K32_DMA_PATCH(ch_)                                                                             \
   {                                                                                                       \
-    const int psoff_ = psbase + (ch_) * HW * 128;                      /* 4 groups x 2 terms x HW vectors */ \
+    const int psoff_ = (ch_) * HW * 128;                               /* 4 groups x 2 terms x HW vectors */ \
     _Pragma("unroll") for (int j = 0; j < NPS; ++j) {                                                     \
       const int i_ = wave + NW * j;                                                                       \
       if (i_ < NPI) lds_dma16(rin, lds + 64 * i_, voff[j], psoff_);                                       \
@@ -1846,7 +1834,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
   }
 #define GR_K32_DMA_WEIGHTS(ch_)                                                                           \
   {                                                                                                       \
-    const int wsoff_ = wsbase + (ch_) * 2 * WR16 * a.cout_pad * 16;                                       \
+    const int wsoff_ = (ch_) * 2 * WR16 * a.cout_pad * 16;                                                \
     _Pragma("unroll") for (int j = 0; j < NWS; ++j) {                                                     \
       const int r_ = wave + NW * j;                                                                       \
       if (r_ < NWI) lds_dma16(rwt, lds + PVP + 64 * r_, woff[j], wsoff_);                                 \
@@ -1903,11 +1891,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_p16_k32_kernel(ConvArgs a, con
     const int un = u + (int)gridDim.x;
     const bool more = un < a.n_tiles;
     if (more) { unit_geometry(un); GR_K32_DMA_PATCH(0) }          // lands in the patch half while the epilogue works in the weight half
-    // (Round 6, measured and removed - git history, profiles/r06_ab_k32_register_transpose_cfg2.txt: an epilogue that transposes in registers - 4 x 4 quad_perm
-    //  exchanges, 16 VALU per four values - needs no LDS staging, so the next unit's WEIGHTS can be requested here too and nothing is waited for at a unit start.
-    //  A timing-only probe of that request order promised -11 % (r06_ab_k32_early_weights_bound_cfg2.txt) - on an operand image the staging had overwritten, i.e.
-    //  on garbage: the real kernel measured +0.5 ... +0.8 % (0.2598 -> 0.2620 ms for the six launches).  The unit-start wait is hidden by the CU's other workgroup;
-    //  what the probe showed was the clock the chip holds on trivial operands - MI355X_MICROARCH.md, DVFS give-back - not a schedule.)
     // scale back + bias: lane holds channel chl = 16 mb + 4 q + i of pixel l15 of block nb
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
