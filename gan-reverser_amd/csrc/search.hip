@@ -301,12 +301,17 @@ __global__ void topk_decode_kernel(const unsigned long long* __restrict__ keys, 
 // For Q >= BATCH_MIN_Q needles the exact pass above is compute-bound (N * d * Q fp32 products with fp64 sums on the VALU: 16 ms
 // for 1024 needles over 10^6 x 100).  The batched path (north_star: "one MFMA GEMM + top-k") keeps the RESULT exact and uses the
 // matrix pipe only to decide which rows can matter:
-//   1. approximate cosines  emb x needles^T  on v_mfma_f32_32x32x16_bf16 (both operands rounded to bf16 while staged, row norms
-//      from the bf16 values): the approximate score is the cosine of the ROUNDED vectors a^ = a + da, |da| <= u |a| with
-//      u = 2^-8 (bf16 keeps 8 significant bits, round to nearest), so each vector turns by at most asin(u) and
-//      |approximate - exact| <= 2 u + O(u^2) = 2^-7 (1 + 2^-9 ..) - SLIGHTLY ABOVE 2^-7 - plus the fp32
-//      accumulation of d <= 128 products (< 1e-5) and the 1e-12 in the denominators.  BERR = 2^-7 + 2^-10 bounds all of it
-//      with a margin of 9.8e-4, so the two cuts below are proven, not merely comfortable in practice;
+//   1. approximate cosines  emb x needles^T  on v_mfma_f32_32x32x16_f16 (round 6; bf16 until then): both operands rounded to fp16 while staged, row
+//      norms from the fp16 values.  The approximate score is the cosine of the ROUNDED vectors a^ = a + da.  fp16 keeps 11 significant bits (round to
+//      nearest: relative error 2^-11 per NORMAL element) and has a narrow exponent range, so a vector is only taken when its squared norm (of the rounded
+//      values) lies in [2^-10, 65504^2]: no element overflows (|a_i| <= |a|), and elements in the subnormal range are off by at most 2^-25 each, together
+//      sqrt(128) 2^-25 = 2^-21.5 <= 2^-16.5 |a|.  Then |da| <= u |a| with u = 2^-11 + 2^-16.5, each vector turns by at most asin(u) and
+//      |approximate - exact| <= 2 u + O(u^2) < 2^-10 + 2^-15; the products of two fp16 values are exact in fp32, their accumulation over d <= 128 columns
+//      adds <= 128 x 2^-24 = 2^-17, the fp32 steps behind the sums and the 1e-12 in the denominators ~1e-7.  BERR = 2^-10 + 2^-13 bounds all of it with
+//      a margin of 8e-5.  A row outside the norm range (or a zero row) raises the overflow status like an overflowing list - the call reruns
+//      unbatched, exact as ever - and a needle outside it gets the threshold -inf, which overflows every list: same rerun.  bf16 (u = 2^-8) needed
+//      BERR = 2^-7 + 2^-10: the cuts are eight times tighter now, an eighth of the candidates reach the queues, the lists and the exact re-score
+//      (same box, 1024 needles over 1 M x 100: kernels 0.603 -> 0.562 ms, profiles/r06_ab_search_fp16_candidates.txt);
 //   2. a strided sample of SAMPLE_ROWS rows first: tau_q = (k-th largest approximate sample score) - 2 BERR is a lower bound
 //      of every approximate score whose exact score can reach the true k-th largest one;
 //   3. the pass over the table keeps (row, approximate score) pairs >= tau_q, each workgroup in its own BSLOT entries per needle;
@@ -322,11 +327,14 @@ constexpr int BQ_MAX = 2048;          // needles per call of the batched path (L
 constexpr long BSAMPLE_ROWS = 65536;  // the batched path's sample: 256 workgroups of 256 rows, ONE value per (workgroup, needle) - their maximum - leaves the kernel
 constexpr int BSLOT = 16;             // (row, score) entries per workgroup (256 rows) and needle: expected 1.2 at cfg5, P(> 16) ~ 1e-14
 constexpr int BD_MAX = 128;           // widest row the batched kernel stages whole
-#define GR_BERR 0.0087890625f      /* 2^-7 + 2^-10: see the bound above */
-typedef short bf16x8s __attribute__((ext_vector_type(8)));
+#define GR_BERR 0.0010986328125f   /* 2^-10 + 2^-13: see the bound above */
+#define GR_BNRM_MIN 9.765625e-4f   /* 2^-10: smallest squared norm a vector may have on the fp16 candidate pass */
+#define GR_BNRM_MAX 4.2907e9f      /* < 65504^2: largest */
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
 typedef float f32x16s __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ unsigned short to_bf16(float x) { const __bf16 h = (__bf16)x; return __builtin_bit_cast(unsigned short, h); }
-__device__ __forceinline__ float from_bf16(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+// (the names keep their round-2 spelling: the staged 16-bit image was bf16 until round 6; it is IEEE fp16 now, round to nearest even)
+__device__ __forceinline__ unsigned short to_bf16(float x) { const _Float16 h = (_Float16)x; return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ float from_bf16(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
 
 // lane i of a 16-lane DPP row receives lane i - n's value (row_shr:n = 0x110 + n); lanes without a source keep their own
 template <int CTRL>
@@ -424,7 +432,12 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const float a = from_bf16((unsigned short)(w[j] & 0xffffu)), b = from_bf16((unsigned short)(w[j] >> 16)); nrm += a * a; nrm += b * b; }
     }
-    sw32s[tid] = sqrtf(1.f / (nrm + 1e-12f));
+    // a row the fp16 image cannot carry within the proven bound (see the head of this section): its scale becomes NaN - it passes no threshold and enters
+    // no maximum - and in the pass over the table it marks the workgroup overflowed, so that the call reruns unbatched
+    const bool in_table = r0 + tid < N;
+    const bool good = nrm >= GR_BNRM_MIN && nrm <= GR_BNRM_MAX;
+    sw32s[tid] = (in_table && good) ? sqrtf(1.f / (nrm + 1e-12f)) : NAN;
+    if (MODE == 1 && in_table && !good) *wg_ovf = 1u;             // (its zeroing at the top of the kernel is behind the staging barrier)
   }
   uint4 bop[2][NK];                                             // this lane's B operands: rows 64 wave + 32 rb + l31, k octet h of every k-step
 #pragma unroll
@@ -476,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
-          acc[nb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, a[nb]), __builtin_bit_cast(bf16x8s, bop[rb][kk]), acc[nb][rb], 0, 0, 0);
+          acc[nb][rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, a[nb]), __builtin_bit_cast(f16x8s, bop[rb][kk]), acc[nb][rb], 0, 0, 0);
     }
     // this lane's 32 needles of the tile are 8 runs of 4 (accumulator register r <-> needle 32 nb + 8 (r >> 2) + 4 h + (r & 3)):
     // their thresholds (MODE 1: tau / sqrt(w22), so that one multiply per value decides) or scales (MODE 0) come in as 8
@@ -557,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
           const float4 p4 = pv[nb][r >> 2];
           const float pq = (r & 3) == 0 ? p4.x : ((r & 3) == 1 ? p4.y : ((r & 3) == 2 ? p4.z : p4.w));
           const float v = acc[nb][rb][r] * s32[rb];
-          if (MODE == 0) { if (i < N) vmax0[nb][r] = rb == 0 ? v : fmaxf(vmax0[nb][r], v); else if (rb == 0) vmax0[nb][r] = -INFINITY; }
+          if (MODE == 0) { if (i < N && s32[rb] == s32[rb]) vmax0[nb][r] = rb == 0 ? v : fmaxf(vmax0[nb][r], v); else if (rb == 0) vmax0[nb][r] = -INFINITY; }      // (a row past the table or outside the fp16 norm range - NaN scale - enters no maximum: leaving rows out only lowers the threshold)
           else if (v >= pq) {                                   // (the threshold is +inf past Q; rows past N carry a NaN scale: never true)
             const unsigned pos = atomicAdd(&lds_cnt[q], 1u);
             if (pos < (unsigned)BSLOT) { const long at2 = ((long)q * gridDim.x + blockIdx.x) * BSLOT + pos; cand_idx[at2] = (unsigned)i; cand_sc[at2] = v * sw22t[cur * 64 + ql]; }
@@ -613,19 +626,21 @@ __device__ __forceinline__ unsigned kth_of_maxima(unsigned mine, unsigned* list,
   return r;
 }
 // tau[q] from the approximate sample scores [Q][S]
-__global__ __launch_bounds__(1024) void batched_tau_kernel(const float* __restrict__ samp, long S, int k, const float* __restrict__ sw22s, float* __restrict__ tau) {
+// (a needle whose squared norm 1 / w22 - 1e-12 lies outside the fp16 pass's range gets -inf: every row passes, every list overflows, the call reruns unbatched)
+__device__ __forceinline__ bool batched_needle_ok(float w22q) { const float n2 = 1.f / w22q; return n2 >= GR_BNRM_MIN && n2 <= GR_BNRM_MAX; }
+__global__ __launch_bounds__(1024) void batched_tau_kernel(const float* __restrict__ samp, long S, int k, const float* __restrict__ sw22s, float* __restrict__ tau, const float* __restrict__ w22) {
   __shared__ unsigned list[1024];
   const int q = blockIdx.x;
   unsigned mine = 0u;
   for (long i = threadIdx.x; i < S; i += 1024) { const unsigned o = orderable(samp[(long)q * S + i]); mine = o > mine ? o : mine; }
   const unsigned kth = kth_of_maxima(mine, list, k);
   // stored divided by sqrt(w22): cos_mfma_kernel compares (dot * sqrt(w32)) with it; the rounding of the division is far inside the 2 BERR slack
-  if (threadIdx.x == 0) tau[q] = kth ? (unorderable(kth) - 2.f * GR_BERR) / sw22s[q] : -INFINITY;
+  if (threadIdx.x == 0) tau[q] = (kth && batched_needle_ok(w22[q])) ? (unorderable(kth) - 2.f * GR_BERR) / sw22s[q] : -INFINITY;
 }
 // the same threshold by ONE wave per needle (four needles per workgroup): the <= 256 sample maxima as orderable bit patterns, four per lane, and the exact
 // k-th largest built bit by bit from the top (res |= bit while at least k patterns are >= the trial value) - no LDS, no block barriers (the 1024-thread
 // bitonic sort above took 23 us for 1024 needles)
-__global__ __launch_bounds__(256) void batched_tau_wave_kernel(const float* __restrict__ samp, int S, int Q, int k, const float* __restrict__ sw22s, float* __restrict__ tau) {
+__global__ __launch_bounds__(256) void batched_tau_wave_kernel(const float* __restrict__ samp, int S, int Q, int k, const float* __restrict__ sw22s, float* __restrict__ tau, const float* __restrict__ w22) {
   const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Q) return;
   unsigned ov[4];
@@ -638,7 +653,7 @@ __global__ __launch_bounds__(256) void batched_tau_wave_kernel(const float* __re
     const int c = __popcll(__ballot(ov[0] >= t)) + __popcll(__ballot(ov[1] >= t)) + __popcll(__ballot(ov[2] >= t)) + __popcll(__ballot(ov[3] >= t));
     if (c >= k) res = t;
   }
-  if (lane == 0) tau[q] = res ? (unorderable(res) - 2.f * GR_BERR) / sw22s[q] : -INFINITY;
+  if (lane == 0) tau[q] = (res && batched_needle_ok(w22[q])) ? (unorderable(res) - 2.f * GR_BERR) / sw22s[q] : -INFINITY;
 }
 // per needle: second cut on the approximate scores, exact re-score of what is left, sort, decode
 template <bool ACCF>
@@ -1324,10 +1339,10 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
     static const bool old_tail = GR_KNOB_SET("GR_BATCHED_OLD_TAIL");      // A/B: round 4's first threshold and selection kernels (bitonic sorts of 1024 per-thread maxima)
     if (old_tail || swg > 256) {
       KtScope kt("batched_tau_kernel", 0.0, 4.0 * swg * Q, s);
-      hipLaunchKernelGGL(batched_tau_kernel, dim3(Q), dim3(1024), 0, s, samp, swg, k, sw22s, tau);
+      hipLaunchKernelGGL(batched_tau_kernel, dim3(Q), dim3(1024), 0, s, samp, swg, k, sw22s, tau, w22);
     } else {
       KtScope kt("batched_tau_wave_kernel", 0.0, 4.0 * swg * Q, s);
-      hipLaunchKernelGGL(batched_tau_wave_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s, samp, (int)swg, Q, k, sw22s, tau);
+      hipLaunchKernelGGL(batched_tau_wave_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, s, samp, (int)swg, Q, k, sw22s, tau, w22);
     }
     {
       KtScope kt("cos_mfma_kernel", 2.0 * N * d * Q, 4.0 * N * d, s);

@@ -1031,8 +1031,8 @@ def test_search_1024_needles_bit_exact(ctx, oracle):
 
 
 def test_search_batched_mfma_path_bit_exact_and_its_rerun(ctx, oracle):
-    """Q >= 32 needles on a table of >= 2^17 rows take the batched path: approximate cosines on the bf16 MFMA select candidates
-    (two cuts with a 2^-6 safety margin around a 2^-7 error bound), the exact op order re-scores them.  (1) 1M x 100, 48
+    """Q >= 32 needles on a table of >= 2^17 rows take the batched path: approximate cosines on the fp16 MFMA (bf16 until round 6) select candidates
+    (two cuts with a margin of twice the proven error bound 2^-10 + 2^-13), the exact op order re-scores them.  (1) 1M x 100, 48
     needles incl. a duplicated row and a parallel vector: indices and scores bit-exact vs the oracle, no rerun; (2) d = 30 (not
     a multiple of 4: scalar staging, k padding); (3) a table built against the sample overflows the per-workgroup entries:
     rerun on the unbatched path, still exact."""
@@ -1063,6 +1063,44 @@ def test_search_batched_mfma_path_bit_exact_and_its_rerun(ctx, oracle):
     ridx, rsc = oracle.cosine_topk(hostile, q, k)
     assert ctx.search_reruns() == r0 + 1, "the overflow must be detected and the search rerun unbatched"
     assert np.array_equal(idx, ridx) and np.array_equal(sc, rsc)
+
+
+def test_search_batched_fp16_candidate_pass_bound_and_range_guard(ctx, oracle):
+    """Round 6: the batched path's candidate pass runs on the fp16 MFMA (rows and needles rounded to fp16 while staged, error bound 2^-10 + 2^-13 instead of
+    bf16's 2^-7 + 2^-10 - search.hip).  (1) a cluster of 300 rows within 2e-4 of each other in cosine around the needle, scattered over a 200 000 x 64
+    table: fp16 rounding (up to 1e-3) reorders them at will, the two cuts must keep every one of them and the exact re-score must order them as the oracle
+    does - no rerun; (2) the same table scaled by 2^9 (norms inside the fp16 range: still no rerun); (3) tables fp16 cannot carry within the proven bound -
+    rows scaled up past 65504 (norm^2 > 65504^2), scaled down into the subnormal range (norm^2 < 2^-10), ONE zero row in an ordinary table, and one needle
+    of huge norm among ordinary rows - must be noticed and rerun on the unbatched path, exact."""
+    import os
+    from ganrev import synth
+    oracle.set_threads(max(1, min(32, os.cpu_count() or 1)))
+    N, d, k = 200_000, 64, 50
+    emb = synth.normal((N, d), 606)
+    needle = 777
+    cluster = (np.arange(300, dtype=np.int64) * 661 + 13) % N
+    emb[cluster] = emb[needle][None, :] + np.float32(0.02) * synth.normal((300, d), 607)
+    q = np.concatenate([np.array([needle], dtype=np.int64), (np.arange(39, dtype=np.int64) * 4999 + 11) % N])
+    ridx, rsc = oracle.cosine_topk(emb, q, k)
+    assert np.isin(ridx[0][1:], cluster).all() and float(rsc[0][1] - rsc[0][k - 1]) < 3e-4, "the case: the needle's top k is the tight cluster"
+    r0 = ctx.search_reruns()
+    for scale in (1.0, 512.0):
+        idx, sc = ctx.cosine_topk(emb * np.float32(scale), q, k)
+        oidx, osc = (ridx, rsc) if scale == 1.0 else oracle.cosine_topk(emb * np.float32(scale), q, k)
+        assert np.array_equal(idx, oidx) and np.array_equal(sc, osc), f"fp16 candidate pass, scale {scale}"
+    assert ctx.search_reruns() == r0, "tables inside the fp16 range must not rerun"
+    hostile = []
+    hostile.append(("rows past 65504", emb * np.float32(1e5)))
+    hostile.append(("rows in the subnormal range", emb * np.float32(2.0 ** -20)))
+    z = emb.copy(); z[5] = 0.0
+    hostile.append(("one zero row", z))
+    h = emb.copy(); h[q[3]] *= np.float32(1e6)
+    hostile.append(("one needle of huge norm", h))
+    for i, (what, tab) in enumerate(hostile):
+        idx, sc = ctx.cosine_topk(tab, q, k)
+        oidx, osc = oracle.cosine_topk(tab, q, k)
+        assert ctx.search_reruns() == r0 + i + 1, f"{what}: the fp16 range guard must send the call to the unbatched path"
+        assert np.array_equal(idx, oidx) and np.array_equal(sc, osc), what
 
 
 def test_search_filter_bound_and_its_overflow_rerun(ctx, oracle):

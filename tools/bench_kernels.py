@@ -9,7 +9,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 which_names = {0: "fwd", 1: "dgrad", 2: "wgrad", 3: "up2fwd", 4: "p16fwd", 5: "p16fwd+stats"}
 shapes = [("R.conv2/3", 64, 64, 32, 32), ("R.conv4", 64, 128, 16, 16), ("R.conv5/6", 128, 128, 16, 16),
           ("G.convA", 512, 256, 16, 16), ("G.convB", 256, 128, 32, 32), ("R.conv1", 1, 64, 32, 32), ("G.convC", 128, 1, 32, 32),
-          ("G2.convA", 128, 256, 16, 16), ("G2.convB", 256, 128, 32, 32)]      # G2: G at cfg2 (gray 32x32)
+          ("G2.convA", 128, 256, 16, 16), ("G2.convB", 256, 128, 32, 32),      # G2: G at cfg2 (gray 32x32)
+          ("G3.convC", 128, 3, 64, 64)]                                        # G's last convolution at cfg3 (64x64 RGB; run with B = 512)
 sel = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 for name, cin, cout, h, w in shapes:
     if sel and not any(s in name for s in sel):
