@@ -244,7 +244,7 @@ def search_cfg5(ctx):
         idx, sc = ctx.cosine_topk(None, needles, k, emb_dev=dev, n=N, d=d)
     ctx.event_record(60001)
     ms = ctx.event_elapsed_ms(60000, 60001) / reps
-    # many needles at once (the batched path: bf16 MFMA candidates + exact re-score): 1024 needles, the five above among them
+    # many needles at once (the batched path: fp16 MFMA candidates + exact re-score): 1024 needles, the five above among them
     many = np.concatenate([needles, (np.arange(1019, dtype=np.int64) * 977 + 13) % N])
     ctx.cosine_topk(None, many, k, emb_dev=dev, n=N, d=d)
     r0 = ctx.search_reruns()
@@ -256,7 +256,7 @@ def search_cfg5(ctx):
     batched = dict(needles=int(many.size), ms=round(ms_many, 4), mfma_tflops=round(2.0 * N * d * many.size / ms_many / 1e9, 1),
                    us_per_needle=round(ms_many * 1e3 / many.size, 3), reruns_unbatched=int(ctx.search_reruns() - r0),
                    first5_equal_single_path=bool(np.array_equal(midx[:5], idx) and np.array_equal(msc[:5], sc)),
-                   note="approximate cosines on v_mfma_f32_32x32x16_bf16 pick candidates, the exact TH-order re-score decides: bit-identical results")
+                   note="approximate cosines on v_mfma_f32_32x32x16_f16 (error bound 2^-10 + 2^-13) pick candidates, the exact TH-order re-score decides: bit-identical results")
     emb = ctx.download(dev, (N, d)); ctx.free(dev)
     oracle.set_threads(min(32, os.cpu_count() or 1))
     t0 = time.perf_counter(); ridx, rsc = oracle.cosine_topk(emb, needles, k); t_cpu = time.perf_counter() - t0
@@ -754,7 +754,7 @@ def headline(out, conv_mode="f16x3"):
     g = out.get("gan_step")
     if g:
         line["gan_step"] = {"error": str(g["error"])[:120]} if "error" in g else {b: (g.get(b) or {}).get("ms_per_batch") for b in ("batch32", "batch256")}
-    line["detail"] = "gpurun_out/bench_detail.json: mode tables, per-kernel tables, notes (a copy of the builder's run: profiles/r05_bench_default.json)"
+    line["detail"] = "gpurun_out/bench_detail.json: mode tables, per-kernel tables, notes (a copy of the builder's run: profiles/r06_bench_default.json)"
     return line
 
 

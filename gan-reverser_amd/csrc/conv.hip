@@ -269,6 +269,11 @@ __global__ __launch_bounds__(256, (TW == 64 && CO <= 3) ? 4 : 3) void conv3x3_fe
   constexpr int WS = (CO * 9 + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float patch[CK * PS];
   __shared__ __attribute__((aligned(16))) float wsh[CK * WS];
+  // the two halo columns of every patch row in an array of their own, [row][left, right]: read as single dwords by the edge strips of a row (two lanes in
+  // eight / sixteen); inside the patch rows (stride 48 / 72 floats) the rows a 32-lane group covers put them on ONE bank - a 4-way (TW = 32) / 2-way (TW = 64)
+  // conflict per halo read, which is where the conflicts went when the float4 reads became conflict-free (counters of the first attempt:
+  // profiles/r06_pmc_step_conv_cfg2_first.txt, 39.5 -> 36.1 %); here consecutive rows sit two banks apart
+  __shared__ float halo[NROWS * 2];
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   const int tx = bid % a.tiles_x; bid /= a.tiles_x;
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256, (TW == 64 && CO <= 3) ? 4 : 3) void conv3x3_fe
 #pragma unroll
     for (int i = 0; i < NHL; ++i) {
       const int e = tid + 256 * i, side = e & 1, rr = (e >> 1) % PR, cil = (e >> 1) / PR;
-      if (cil < CK) patch[cil * PS + rr * PCS + (side ? TW + 4 : 3)] = hv[i];
+      if (cil < CK) halo[(cil * PR + rr) * 2 + side] = hv[i];
     }
     if (wl_c < CK) wsh[wl_c * WS + wl_e] = wreg[0];
     if (wl_c2 < CK) wsh[wl_c2 * WS + wl_e2] = wreg[1];
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256, (TW == 64 && CO <= 3) ? 4 : 3) void conv3x3_fe
           // from LDS, in one instruction.  (Both neighbours as single-dword LDS reads: 64 lanes on 16 banks, 59 % of this kernel's
           // LDS cycles were bank conflicts on the counters.)
           float lf = dpp_take<0x111, 0xF>(m.w), rt = dpp_take<0x101, 0xF>(m.x);      // row_shr:1 / row_shl:1
-          if (strip == 0 || strip == SPR - 1) { const float hv = pr[strip == 0 ? 3 : 8]; if (strip == 0) lf = hv; else rt = hv; }
+          if (strip == 0 || strip == SPR - 1) { const float hv = halo[(cil * PR + row + ky) * 2 + (strip == 0 ? 0 : 1)]; if (strip == 0) lf = hv; else rt = hv; }
           const fo_f2 p01 = {lf, m.x}, p12 = {m.x, m.y}, p23 = {m.y, m.z}, p34 = {m.z, m.w}, p45 = {m.w, rt};
 #pragma unroll
           for (int o = 0; o < CO; ++o) {

@@ -507,6 +507,11 @@ __global__ __launch_bounds__(256, 2) void cos_mfma_kernel(const float* __restric
     }
     if (MODE == 1 && (dbg & 1)) {
     } else if (MODE == 1 && qcap > 0) {
+      // (Round 6, measured and removed - git history, profiles/r06_ab_search_block_prefilter.txt: testing a 16-register block as a whole - d = value - threshold
+      //  by one fma per register, their maximum by v_max3, ONE vote per block, and only lanes with a hit walking their registers into LDS atomics - was
+      //  bit-identical and SLOWER: main pass 415 -> 495 us for 1024 needles.  The ablation of this epilogue (r06_ablate_search_batched.txt: 167 of the pass's
+      //  422 us with the fp16 bound) is therefore not its multiplies and votes as such: the queue version's work overlaps the CU partner's MFMAs, the
+      //  16-deep predicated hit walk with its dependent atomics did not.)
       // Round 5.  0.5 % of the 64 x 64 values of a wave's tile pass their threshold, so ~17 of the 64 (needle block, row block, register) positions have a
       // passing lane somewhere in the wave.  Round 4 entered the hit path at each of them - an LDS atomic WITH return, a wait, an LDS read, two scattered
       // stores: ~300 cycles each, one after the other, 5000 cycles per tile against 900 for its 28 MFMAs (243 TFLOP/s = 0.098 of the bf16 peak).  Now a

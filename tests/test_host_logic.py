@@ -326,6 +326,52 @@ def test_sharded_search_eight_ranks_with_ties_across_three_boundaries(oracle):
     assert len(set(rsc[0][2:6].tolist())) == 1
 
 
+def test_design_quotes_the_tracked_bench_summary():
+    """VERDICT round 5, item 2 (the mis-filed r05 summary: DESIGN quoted 136.4 k img/s while the tracked file held a 3-step run at 50.6 k).  The tracked
+    summary of the round - profiles/r06_bench_default.json, the --detail file of an UNPROFILED `python bench.py` - must be a real run (>= 20 timed steps,
+    >= 5 warm-up, the headline workload, the arithmetic the line names), and every number DESIGN.md's current-round table quotes must be the number in that
+    file (the table is generated from it by tools/update_design_table.py: equal to the printed precision, not merely within a box-to-box spread)."""
+    import json, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "profiles", "r06_bench_default.json")
+    assert os.path.exists(path), "profiles/r06_bench_default.json is missing"
+    d = json.load(open(path))
+    assert d["steps"] >= 20 and d["warmup"] >= 5, (d["steps"], d["warmup"])
+    assert d["n_gpus"] == 1 and "batch=256" in d["config"]["workload"] and d["dtype"].startswith("f32 via f16x3")
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - d["config"]["per_gpu_batch"]) < 0.01 * d["config"]["per_gpu_batch"]      # images/s x s/step = batch
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 5e-4 and abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_ms"]) < 0.02 * r["achieved"]
+    assert r["avg_launch_ms"] * r["launches_per_step"] < d["ms_per_step"]
+    assert "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port" and "cfg3" in d and d["search_cfg5"]["exact_match"] is True
+    text = open(os.path.join(root, "DESIGN.md")).read()
+    m = re.search(r"<!-- bench-table:begin -->\n(.*?)\n<!-- bench-table:end -->", text, flags=re.S)
+    assert m, "DESIGN.md has no bench table"
+    rows = [l for l in m.group(1).splitlines() if l.startswith("|") and "`" in l]
+    assert len(rows) >= 15, rows
+
+    def lookup(o, dotted):
+        for k in dotted.split("."):
+            o = o[k]
+        return o
+    checked = 0
+    for l in rows:
+        keys = re.search(r"\| `([^`]+)` \|", l).group(1).split(";")          # (a row may carry two keys, "a;b", its value cell then reads "x / y")
+        shown = [v.strip() for v in l.rstrip("|").rsplit("|", 1)[1].split(" / ")]
+        assert len(keys) == len(shown), l
+        for key, txt in zip(keys, shown):
+            want = lookup(d, key)
+            if isinstance(want, bool) or isinstance(want, str):
+                assert txt == str(want), (key, txt, want)
+            else:
+                digits = len(txt.split(".")[1]) if "." in txt else 0
+                assert abs(float(txt) - float(want)) <= 0.5 * 10 ** (-digits) + 1e-12, (key, txt, want)
+            checked += 1
+    assert checked >= 20
+    # the headline quoted in the prose around the table must be the file's too (no second source of truth)
+    for k_img in re.findall(r"\*\*(\d{3}\.\d) k img/s", text):
+        assert abs(float(k_img) * 1e3 - d["value"]) <= 60, (k_img, d["value"])
+
+
 def test_bench_headline_is_compact_strict_json():
     """the LAST stdout line of bench.py must be a compact (< 4 KB), strictly valid JSON object carrying the contract's keys,
     `roofline` and `cpu_baseline`; the tables go to a side file.  Built here from a canned full result (a committed copy of round 4's 23 KB line) and from the

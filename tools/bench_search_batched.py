@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The batched search (Q >= 32 needles: bf16 MFMA candidates + exact re-score) at cfg5's table: N = 1M x d = 100, top-50, Q = 1024 (and 48, 256).
+"""The batched search (Q >= 32 needles: fp16 MFMA candidates + exact re-score) at cfg5's table: N = 1M x d = 100, top-50, Q = 1024 (and 48, 256).
 Per-kernel HIP-event times of one gr_cosine_topk_dev call and the whole call; first rows checked against the five-needle path."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
