@@ -3560,10 +3560,17 @@ __global__ __launch_bounds__(256, TW == 32 ? 2 : 1) void conv3x3_wgrad_split_rol
 template <int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_small_kernel(WgradArgs a) {
   constexpr int PT = 64, TR = PT / TW, PR = TR + 2, PC = TW + 2, PSR = PR * PC, DYS = PT + 1, MAXC = 3;
+  // Round 6 (37-39 % of this kernel's LDS cycles were bank conflicts).  Lane l31 of the B operand reads the patch at the offset
+  // of ITS (input channel, tap): ci * plane + ky * row + kx.  With the geometric strides (row = TW + 2 = 34 = 2 mod 32, plane = 136 = 8 mod 32) taps
+  // (0, 2) / (1, 0) and (1, 2) / (2, 0) share a bank.  LDS strides of their own - row = 3 (mod 32), plane = 9 (mod 32) - put the 27 (ci, ky, kx) on banks
+  // 9 ci + 3 ky + kx: all distinct (ds_read_b32 serves 32 lanes per cycle on 32 banks).
+  constexpr int PCS = PC + ((3 - PC % 32) + 32) % 32;              // 35 (TW = 32), 35 (TW = 16: 18 -> 35)
+  constexpr int PSS = PR * PCS + ((9 - (PR * PCS) % 32) + 32) % 32;
+  static_assert(PCS % 32 == 3 && PSS % 32 == 9, "conflict-free tap offsets");
   constexpr int NDV = 64 * PT / 4 / 256;
   constexpr int NXS = (MAXC * PSR + 255) / 256;
   __shared__ float dyT[64 * DYS];
-  __shared__ float xp[MAXC * PSR + 64];
+  __shared__ float xp[MAXC * PSS + 64];
   __shared__ float red[2][32 * 33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int mt = wave & 1, kh = wave >> 1;
@@ -3573,7 +3580,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_small_kernel(WgradArgs a
   const size_t HW = (size_t)H * W;
   // column j of the MFMA tile = (ci, tap); unused columns read offset 0 (their results are dropped by the reduce)
   int boff = 0;
-  if (l31 < 9 * Cin) { const int ci = l31 / 9, tap = l31 - ci * 9, ky = tap / 3, kx = tap - ky * 3; boff = ci * PSR + ky * PC + kx; }
+  if (l31 < 9 * Cin) { const int ci = l31 / 9, tap = l31 - ci * 9, ky = tap / 3, kx = tap - ky * 3; boff = ci * PSS + ky * PCS + kx; }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -3604,7 +3611,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_small_kernel(WgradArgs a
   if (have) GR_WS_LOAD(tile)
   while (have) {
 #pragma unroll
-    for (int i = 0; i < NXS; ++i) { const int e = tid + 256 * i; if (e < MAXC * PSR) xp[e] = xs[i]; }
+    for (int i = 0; i < NXS; ++i) { const int e = tid + 256 * i, ci = e / PSR, rem = e - ci * PSR, r = rem / PC, c = rem - r * PC; if (e < MAXC * PSR) xp[ci * PSS + r * PCS + c] = xs[i]; }
 #pragma unroll
     for (int i = 0; i < NDV; ++i) {
       const int f = tid + 256 * i, q = f % (PT / 4), o = f / (PT / 4);
@@ -3621,7 +3628,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_small_kernel(WgradArgs a
     for (int s = 0; s < PT / 4; ++s) {
       const int p0 = kh * (PT / 2) + 2 * s;     // kh is wave-uniform; pr/pc below are computed at run time from it
       const int pr = p0 / TW, pc = p0 - pr * TW;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[pr * PC + pc], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[pr * PCS + pc], acc, 0, 0, 0);
     }
     __syncthreads();
     tile = next; have = have_next;

@@ -239,7 +239,7 @@ static int head_fault_check(gr_ctx* c) {
               "parameters and Adam state are those of the last good step.  gr_set_tuning \"fused_head\" 0 selects the stage-by-stage path");
 }
 
-extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.4 (round 4)"; }
+extern "C" const char* gr_version(void) { return "ganrev-gfx950 0.6 (round 6)"; }
 
 extern "C" int gr_init(int device, gr_ctx** out) {
   if (!out) return GR_ERR_INVALID;
