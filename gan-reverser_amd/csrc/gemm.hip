@@ -358,6 +358,11 @@ struct BigTileLoader {
     }
   }
 };
+// Row stride (16-byte vectors) of a k-group plane of the 128-tile operand images.  K-contiguous staging stores, per 8-lane group of a ds_write_b128, the four
+// k-groups of two consecutive rows: vectors g * BIG_RS + r, g = 0..3, r = 0, 1.  They fall on distinct 16-byte slots of the 128-byte bank row iff BIG_RS = 2
+// (mod 8): 130.  (132 until round 6 - "the four k-groups of a row in distinct banks" held for g = 0, 1 only: slots 0, 4, 0, 4 - and the counters showed
+// 20-31 % of these kernels' LDS cycles as bank conflicts, profiles/r06_pmc_gemm_cfg3.txt.)  The MFMA operand reads are 32 consecutive vectors: any stride.
+constexpr int BIG_RS = 130;
 template <bool KCONTIG>
 __device__ __forceinline__ void tile_store8_big(uint4* T, float sc, const float (&v)[2][8], int tid) {
 #pragma unroll
@@ -366,14 +371,14 @@ __device__ __forceinline__ void tile_store8_big(uint4* T, float sc, const float 
     const int r = KCONTIG ? e >> 2 : e & 127, g = KCONTIG ? e & 3 : e >> 7;
     uint4 t0, t1;
     split8_f16(v[u], sc, t0, t1);
-    T[(0 * 4 + g) * 132 + r] = t0; T[(1 * 4 + g) * 132 + r] = t1;   // 132: the four k-groups of a row land in distinct banks
+    T[(0 * 4 + g) * BIG_RS + r] = t0; T[(1 * 4 + g) * BIG_RS + r] = t1;
   }
 }
 
 template <bool AK, bool BK>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_big_kernel(GemmArgs a) {
-  __shared__ uint4 As[2 * 2 * 4 * 132];
-  __shared__ uint4 Bs[2 * 2 * 4 * 132];
+  __shared__ uint4 As[2 * 2 * 4 * BIG_RS];
+  __shared__ uint4 Bs[2 * 2 * 4 * BIG_RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
@@ -402,11 +407,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_big_kernel(GemmArgs a) {
   __syncthreads();
   int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += 32, cur ^= 1) {
-    const uint4* Ac = As + cur * (2 * 4 * 132);
-    const uint4* Bc = Bs + cur * (2 * 4 * 132);
+    const uint4* Ac = As + cur * (2 * 4 * BIG_RS);
+    const uint4* Bc = Bs + cur * (2 * 4 * BIG_RS);
     if (k0 + 32 < kend) {
-      tile_store8_big<AK>(As + (cur ^ 1) * (2 * 4 * 132), sa, av, tid);
-      tile_store8_big<BK>(Bs + (cur ^ 1) * (2 * 4 * 132), sb, bv, tid);
+      tile_store8_big<AK>(As + (cur ^ 1) * (2 * 4 * BIG_RS), sa, av, tid);
+      tile_store8_big<BK>(Bs + (cur ^ 1) * (2 * 4 * BIG_RS), sb, bv, tid);
       if (k0 + 64 < kend) { la.load(k0 + 64 - kbeg, kend - k0 - 64, av); lb.load(k0 + 64 - kbeg, kend - k0 - 64, bv); }
     }
 #pragma unroll
@@ -416,8 +421,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_big_kernel(GemmArgs a) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          x[i][t] = Ac[(t * 4 + 2 * kk + h) * 132 + wm * 64 + i * 32 + l31];
-          y[i][t] = Bc[(t * 4 + 2 * kk + h) * 132 + wn * 64 + i * 32 + l31];
+          x[i][t] = Ac[(t * 4 + 2 * kk + h) * BIG_RS + wm * 64 + i * 32 + l31];
+          y[i][t] = Bc[(t * 4 + 2 * kk + h) * BIG_RS + wn * 64 + i * 32 + l31];
         }
       // term-major: consecutive MFMAs go to different accumulators (the per-accumulator order lo*hi, hi*lo, hi*hi is the 64-tile kernel's)
 #pragma unroll
@@ -475,8 +480,12 @@ static void gemm_plan(int M, int N, int K, int& nsplit, int& klen, int tile = 64
   const long tiles = (long)((M + tile - 1) / tile) * ((N + tile - 1) / tile);
   nsplit = 1;
   if (tiles < 256 && K >= 256) {
-    long want = (512 + tiles - 1) / tiles;
-    const long maxs = K / 128;
+    // (Round 6, profiles/r06_gemm_plan_sweep.txt: R.fc1's three GEMMs take 26-28 us at cfg2 and 86 us at cfg3 under EVERY plan - 256 ... 2048 workgroups, K runs of
+    //  64 ... 512, 64- or 128-wide tiles - and an XCD-aware tile order that keeps a split's tiles on one L2 changed nothing either (r06_ab_gemm_xcd_order.txt):
+    //  the kernels are bound by splitting their operands while staging, 9-12 VALU instructions per MFMA on the counters (r06_pmc_gemm_cfg3.txt), not by the plan.)
+    static const int wgs_want = GR_KNOB("GR_GEMM_WGS", 512), min_klen = GR_KNOB("GR_GEMM_MIN_KLEN", 128);      // (ablation build: workgroups aimed for, shortest K run per split)
+    long want = (wgs_want + tiles - 1) / tiles;
+    const long maxs = K / min_klen;
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     nsplit = (int)want;
