@@ -25,6 +25,8 @@ CONV_SHAPES = [
     (2, 128, 128, 16, 16),   # R.conv5/6
     (3, 128, 3, 32, 32),     # G.convC RGB
     (2, 128, 1, 32, 32),     # G.convC gray
+    (2, 24, 3, 40, 40),      # few output channels on a plane that is neither small nor a multiple of 64 wide: the generic 32-row tiles of conv3x3_fewout_kernel (ragged last tile column and row)
+    (1, 16, 2, 96, 96),      # ... with 3 x 3 whole tiles
     (2, 16, 40, 8, 8),       # ragged: Cout not a multiple of 32
     (9, 32, 40, 8, 8),       # 8x8 planes, four images stacked per tile (conv3x3_split_kernel<8, 1, *, 4>), ragged last tile, ragged Cout
     (8, 48, 128, 8, 8),      # ... and the 64-channel workgroups (<8, 2, *, 4>): the D network's deep tower (models.lua:304-317)
