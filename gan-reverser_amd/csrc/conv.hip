@@ -3750,6 +3750,30 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_tiled_kernel(const f
   }
 }
 
+#ifdef GR_ABLATE
+// Probe (ablation build, GR_WGRAD_REDUCE_PROBE=1): what "the LAST ARRIVER of an (output block, channel block) tile sums its tile's
+// splits" costs - ONE workgroup per tile walks the tile's 9 x 64 x 64 / 4 float4 positions and adds the nsplit slabs in split order, exactly the reads the
+// folded epilogue would issue from the last workgroup of the producer (a lower bound: the real thing also waits for the slowest split).  Result discarded
+// (written to the slab's first split, which nobody reads afterwards).  Timed by the kernel timer as "wgrad_reduce_one_wg_probe".
+__global__ __launch_bounds__(512) void conv3x3_wgrad_reduce_one_wg_probe_kernel(float4* __restrict__ slab, int n_ob, int n_cb, int nsplit, long n4) {
+  const int tile = blockIdx.x;                                    // (tap-major slab: tile t owns positions [tap][t][1024 float4] for the 9 taps)
+  for (int i = threadIdx.x; i < 9 * 1024; i += 512) {
+    const int tap = i >> 10, w = i & 1023;
+    const long f = ((long)tap * n_ob * n_cb + tile) * 1024 + w;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(k + u) * n4 + f];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < nsplit; ++k) { const float4 v = slab[(size_t)k * n4 + f]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    slab[f] = s;
+  }
+}
+#endif
 __global__ void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gw,
                                             int Cin, int Cout, int cinp, int coutp, int nsplit) {
   const long n = (long)9 * Cout * cinp;
@@ -4266,6 +4290,13 @@ void launch_conv3x3_wgrad_p16(const void* x_p16, const void* dy_p16, float* gw, 
   KtScope kt("conv3x3_wgrad_reduce_tiled_kernel", (double)n_ * a.nsplit, 4.0 * n_ * (a.nsplit + 2.0), s);
   hipLaunchKernelGGL(conv3x3_wgrad_reduce_tiled_kernel, dim3((unsigned)((n_ / 4 + 31) / 32)), dim3(256), 0, s, reinterpret_cast<const float4*>(a.slab), gw,
                      Cin, Cout, a.n_ob, a.n_cb, a.nsplit);
+#ifdef GR_ABLATE
+  { static const int probe = GR_KNOB("GR_WGRAD_REDUCE_PROBE", 0);
+    if (probe) {
+      KtScope kt2("wgrad_reduce_one_wg_probe", (double)n_ * a.nsplit, 4.0 * n_ * a.nsplit, s);
+      hipLaunchKernelGGL(conv3x3_wgrad_reduce_one_wg_probe_kernel, dim3(a.n_ob * a.n_cb), dim3(512), 0, s, reinterpret_cast<float4*>(a.slab), a.n_ob, a.n_cb, a.nsplit, n_ / 4);
+    } }
+#endif
 }
 
 void launch_conv3x3_wgrad(const float* x, const float* dy, float* gw, void* workspace,
