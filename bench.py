@@ -783,6 +783,24 @@ def _finite(o):
     return o
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """torch's gloo transport prints "[Gloo] Rank r is connected to ..." on the process's STDOUT (file descriptor 1, from C++) when a group forms: the contract is ONE
+    JSON line on stdout, so fd 1 points at stderr while the group is being set up."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def emit(out, args):
     out = _finite(out)
     detail = json.dumps(out, allow_nan=False)
@@ -846,10 +864,11 @@ def main():
         seen = [(rank, local_rank)]
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            seen = [None] * world
-            dist.all_gather_object(seen, (rank, local_rank))
-            dist.destroy_process_group()
+            with _stdout_to_stderr():
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                seen = [None] * world
+                dist.all_gather_object(seen, (rank, local_rank))
+                dist.destroy_process_group()
         if rank == 0:
             wl = WORKLOADS["cfg2" if args.workload == "both" else args.workload]
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": sorted(seen), "scaling": "weak",
@@ -883,7 +902,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only; gradients go over RCCL
+        with _stdout_to_stderr():
+            dist.init_process_group("gloo", rank=rank, world_size=world)     # control plane only; gradients go over RCCL
+            dist.barrier()                                                   # (the transport connects lazily: its chatter belongs to this block too)
     os.environ["LOCAL_RANK"] = str(local_rank)
     ctx = L.default_context()          # THE context of this process: the side legs' modules (default_context()) launch on the stream the timers watch
     ctx.set_conv_mode(args.conv_mode)

@@ -284,6 +284,15 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks"] == [[0, 0], [1, 1]]
+    # the contract is ONE JSON line on stdout: torch's gloo transport prints "[Gloo] Rank r is connected to ..." on fd 1 when the group forms - bench.py keeps
+    # that off stdout (round 6: found with the driver-style launch on the GPU box)
+    assert [l for l in r.stdout.splitlines() if l.strip()] == [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout[:500]
+    # ... and the same when the driver starts the ranks itself (python -m torch.distributed.run ... bench.py --gpus 2)
+    d = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert d.returncode == 0, d.stderr[-2000:]
+    out_lines = [l for l in d.stdout.splitlines() if l.strip()]
+    assert len(out_lines) == 1 and json.loads(out_lines[0])["n_gpus"] == 2, d.stdout[:500]
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
