@@ -151,6 +151,77 @@ def test_sync_bn_two_ranks_equal_one_device_on_the_global_batch(oracle, mode, wo
     assert maxdiff(grouped, preds) > 10 * TOL, "per-rank and synchronised BatchNorm agree: the case does not separate them"
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
+@pytest.mark.parametrize("world,name,dims,nd,B", [pytest.param(*c, id=c[1]) for c in D.WORLD_CASES])
+def test_dp_ranks_as_threads_reduce_their_gradients_through_the_hook(oracle, mode, world, name, dims, nd, B):
+    """The DEFAULT data-parallel step (per-rank BatchNorm statistics) with `world` ranks (2, and 8 = cfg4's rank count) as threads of this process, one gr_ctx
+    each on GPU 0: every rank runs the real gr_train_r_step, whose gradient buckets and loss all-reduce go through gr_comm_set_host_exchange (tests/test_gpu_dp.py
+    sums the shards' gradients on the host itself; here the library's own reduction points are exercised: fc1's bucket first, the loss, the tail).  Replicas must
+    end bit-identical; loss, reduced raw gradient, penalised + clamped gradient, parameters and Adam state against the oracle run ONCE on the global batch with
+    BatchNorm in `world` groups."""
+    import ganrev._lib as L
+    GB = B * world
+    G0, R0 = D.make_models(dims, nd)
+    oG, oR = oracle.from_model(G0, (nd, 1, 1)), oracle.from_model(R0, dims)
+    theta0 = oR.params.copy()
+    noise, masks = D.global_inputs(R0, _layer_of(R0, oR), oR.mask_size, dims, nd, B, world=world)
+    pooled = _pooled_convs(R0, oR)
+    zeros = np.zeros_like(theta0)
+    xch = HostExchange(world)
+    out, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            ctx = L.Context(0)
+            ctx.set_conv_mode(mode)
+            G, R = D.make_models(dims, nd)
+            G._ctx = R._ctx = ctx
+            _compile(G, R, dims, nd)
+            gnet, rnet = G._net, R._net
+            ctx.set_host_exchange(world, r, xch.fn(r, ctx))
+            dn = ctx.upload(D.shard(noise, r, world))
+            res = {}
+            for tag, hyper in (("raw", L.Hyper(l1=0.0, l2=0.0, clamp=0.0)), ("step", L.Hyper())):
+                rnet.set_params(theta0); rnet.set_adam_state(zeros, zeros)
+                for li, k in masks.items():
+                    rnet.set_mask(li, D.shard(k.reshape(GB, -1), r, world).ravel())
+                res[tag + "_loss"] = L.train_r_step(gnet, rnet, dn, B, GB, hyper, D.T_STEP)
+                res[tag + "_grads"] = rnet.get_grads()
+            res["theta"] = rnet.get_params()
+            res["m"], res["v"] = rnet.adam_state()
+            res["preds"] = ctx.download(rnet.lib.gr_net_output_dev(rnet.h), (B, nd))
+            for m, li, (c, h, w) in pool_layers(R0, oR):
+                res[f"pool{li}"] = rnet.pool_index(li, B * c * (h // 2) * (w // 2))
+                res[f"y{pooled[li]}"] = rnet.layer_output(pooled[li], (B * c * h * w,))
+            ctx.set_host_exchange(1, 0, None)
+            ctx.free(dn)
+            gnet.close(); rnet.close(); ctx.close()
+            out[r] = res
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((r, e))
+            xch.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, f"rank failures: {errors}"
+    a = out[0]
+    for rk, b in enumerate(out[1:], 1):
+        for k in ("raw_grads", "step_grads", "theta", "m", "v"):
+            assert np.array_equal(a[k], b[k]), f"replicas 0 and {rk} differ in {k}"
+        assert a["raw_loss"] == b["raw_loss"] == a["step_loss"] == b["step_loss"]
+    # per step and rank: the loss + at least two gradient buckets (fc1's >= 1 M floats first, the rest behind it); no BatchNorm exchange without sync_bn
+    assert len(set(xch.calls)) == 1 and 2 * 2 <= xch.calls[0] <= 2 * 8, xch.calls
+    dev_index = {li: np.concatenate([rk[f"pool{li}"] for rk in out]) for li in pooled}
+    dev_y = {cl: np.concatenate([rk[f"y{cl}"] for rk in out]) for cl in pooled.values()}
+    rep = {}
+    ref = D.oracle_grouped_step(oracle, oG, oR, noise, masks, theta0, oracle.GoHyper(), dev_index, dev_y, R0, max_flips=16, report=rep, mode=mode, groups=world)
+    assert_close(np.concatenate([rk["preds"] for rk in out]), ref["preds"], TOL, "recovered noise: per-rank BatchNorm statistics")
+    _check_against_oracle(oracle, R0, ref, a["step_loss"], a["raw_grads"], a["step_grads"], a["theta"], a["m"], a["v"], f"[hook DP world {world} {mode}, argmax flips {rep.get('flips')}]")
+
+
 def test_sync_bn_through_a_one_rank_rccl_communicator_changes_no_bit(ctx, oracle):
     """The RCCL side of the same code (ncclAllReduce of doubles on the compute stream, and of the uint32 max|dz| words): with a ONE-rank
     communicator on the context the synchronised path - compacted per-channel sums -> all-reduce -> statistics - must reproduce the plain
