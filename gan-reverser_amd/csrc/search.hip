@@ -1356,7 +1356,8 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
 #undef GR_MFMA
     // (the histogram-cut selection kernel of the small path, instantiated for these lists - small_select_kernel<ACCF, 512, BSLOT, false>, tau scaled by sqrt(w22) -
     // was measured here: 109 us against this kernel's 101 for 1024 needles.  Both read 3907 sixty-four-byte lists per needle, 70 % of them non-empty, one DRAM
-    // line each: 256 MB of scattered reads set the time, not the barriers of the sort; not used)
+    // line each: 256 MB of scattered reads set the time, not the barriers of the sort; not used.  Round 6, again with the fp16 bound's eight times fewer
+    // candidates (profiles/r06_ab_search_hist_select.txt): 87 us against 84-88 for 1024 needles, 26 against 36 for 256 - still the lists' scattered lines)
     KtScope kt("batched_select_kernel", 0.0, 0.0, s);
     if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev, BSLOT, 2.f * GR_BERR, SmallQ{}, 0);
     else hipLaunchKernelGGL(batched_select_kernel<false>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev, BSLOT, 2.f * GR_BERR, SmallQ{}, 0);
