@@ -1357,7 +1357,11 @@ int launch_cosine_topk(const float* emb, long N, int d, const long* query_rows_d
     // (the histogram-cut selection kernel of the small path, instantiated for these lists - small_select_kernel<ACCF, 512, BSLOT, false>, tau scaled by sqrt(w22) -
     // was measured here: 109 us against this kernel's 101 for 1024 needles.  Both read 3907 sixty-four-byte lists per needle, 70 % of them non-empty, one DRAM
     // line each: 256 MB of scattered reads set the time, not the barriers of the sort; not used.  Round 6, again with the fp16 bound's eight times fewer
-    // candidates (profiles/r06_ab_search_hist_select.txt): 87 us against 84-88 for 1024 needles, 26 against 36 for 256 - still the lists' scattered lines)
+    // candidates (profiles/r06_ab_search_hist_select.txt): 87 us against 84-88 for 1024 needles, 26 against 36 for 256 - still the lists' scattered lines.
+    // Also round 6, built, bit-identical, removed (git history; profiles/r06_ab_search_compact_lists.txt): ONE compact list per needle, filled at the end of the
+    // main pass from wave queues that live as long as the workgroup (one global atomic add with return per entry) - the selection drops to 49-52 us, but the
+    // 0.6 M returning atomics cost the main pass more than the per-tile drain and the 4 M count stores they replace: 411 -> 437 us at 1024 needles (the call
+    // -2 %), 98 -> 179 us at 48 needles (3907 workgroups x 4 waves on 48 counters).  Device-scope atomics are performed at the memory side.)
     KtScope kt("batched_select_kernel", 0.0, 0.0, s);
     if (accf) hipLaunchKernelGGL(batched_select_kernel<true>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev, BSLOT, 2.f * GR_BERR, SmallQ{}, 0);
     else hipLaunchKernelGGL(batched_select_kernel<false>, dim3(Q), dim3(1024), 0, s, emb, d, needles, w22, cidx, csc, wcnt, nwg, k, idx_out, score_out, status_dev, BSLOT, 2.f * GR_BERR, SmallQ{}, 0);
