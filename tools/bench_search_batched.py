@@ -10,7 +10,7 @@ ctx = L.default_context()
 N, d, k = 1_000_000, 100, 50
 dev = ctx.malloc(4 * N * d)
 ctx.fill_normal(dev, N * d, 42)
-for Q in (48, 256, 1024):
+for Q in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (48, 256, 1024)):      # python tools/bench_search_batched.py [Q,Q,...]
     q = (np.arange(Q, dtype=np.int64) * 977 + 100) % N
     q[:5] = np.arange(1, 6) * 100
     r0 = ctx.search_reruns()

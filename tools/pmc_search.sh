@@ -1,11 +1,11 @@
 #!/bin/bash
-# PMC passes over tools/bench_search_batched.py (run on the GPU box): per-kernel counters of the batched search (48, 256, 1024 needles mixed in the averages).  usage: tools/pmc_search.sh [kernel-substring]  (the same counter passes over tools/bench_search_batched.py)
+# PMC passes over tools/bench_search_batched.py (run on the GPU box): per-kernel counters of the batched search (48, 256, 1024 needles mixed in the averages).  usage: tools/pmc_search.sh [kernel-substring] [Q,Q,...]  (the same counter passes over tools/bench_search_batched.py)
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
 F=${1:-conv3x3}; WL=${2:-cfg2}
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmcs_$tag
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_$tag -- python3 $R/tools/bench_search_batched.py > $R/gpurun_out/pmcs_$tag.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcs_$tag -- python3 $R/tools/bench_search_batched.py ${2:-48,256,1024} > $R/gpurun_out/pmcs_$tag.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
